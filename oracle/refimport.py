@@ -1,0 +1,72 @@
+"""TEST INFRASTRUCTURE ONLY — imports the *reference* (read-only checkout at /root/reference).
+
+Only `oracle/gen_golden.py` (run in the build container, where /root/reference exists) uses this
+file.  Nothing in the product package, `bench.py`, `smoke()` or the `-m gpu` tests may import it:
+/root/reference does not exist on the GPU box.
+
+The reference's hot-path modules import four off-path third-party packages at module scope
+(SURVEY.md §8c).  They are stubbed in ``sys.modules`` so that the in-scope code imports unchanged:
+  torchaudio(.transforms.Resample)  — autoencoders.py:9, pretransforms.py:4
+  alias_free_torch.Activation1d     — autoencoders.py:10 (only used if antialias_activation)
+  k_diffusion                       — inference/sampling.py:6 (only used by sample_k)
+  einops_exts.rearrange_many        — adp.py:14
+"""
+import importlib.util
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("SAT_REFERENCE_ROOT", "/root/reference")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import torch
+
+    class _Unavailable(torch.nn.Module):
+        def __init__(self, *a, **k):
+            raise RuntimeError("stubbed third-party module (off the hot path)")
+
+    if "torchaudio" not in sys.modules:
+        ta = _stub("torchaudio")
+        ta.transforms = _stub("torchaudio.transforms", Resample=_Unavailable)
+        ta.functional = _stub("torchaudio.functional")
+    if "alias_free_torch" not in sys.modules:
+        _stub("alias_free_torch", Activation1d=_Unavailable)
+    if "k_diffusion" not in sys.modules:
+        kd = _stub("k_diffusion")
+        kd.external = _stub("k_diffusion.external")
+        kd.sampling = _stub("k_diffusion.sampling")
+    if "einops_exts" not in sys.modules:
+        _stub("einops_exts", rearrange_many=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stub")))
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, "stable_audio_tools"))
+
+
+def import_reference():
+    """Returns the reference `stable_audio_tools` package (models only)."""
+    if not available():
+        raise RuntimeError(f"reference checkout not found at {REF_ROOT}")
+    install_stubs()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    import stable_audio_tools  # noqa: F401
+    return stable_audio_tools
+
+
+def import_auraloss():
+    """training/losses/auraloss.py must be loaded by file path: the package __init__ chain pulls in
+    torchaudio / pytorch_lightning."""
+    path = os.path.join(REF_ROOT, "stable_audio_tools", "training", "losses", "auraloss.py")
+    spec = importlib.util.spec_from_file_location("ref_auraloss", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,76 @@
+"""ctypes binding of the C-ABI in include/sat_amd.h.
+
+The product path loads exactly one library: ``csrc/libsat_amd.so`` (hipcc, gfx950).  If it is
+missing or cannot be loaded this module raises — there is NO CPU or PyTorch fallback for the
+kernels.  (The CPU test-suite binds the same signatures onto the host-side *simulator* build of the
+kernel sources, tests/emu/libsat_emu.so, through :func:`bind`; :func:`load` refuses that library.)
+"""
+import ctypes
+import os
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_longlong
+_F = ctypes.c_float
+
+# name -> (restype, argtypes).  Must match include/sat_amd.h (tests/test_abi.py checks both ways).
+SIGNATURES = {
+    "sat_abi_version": (_I, []),
+    "sat_is_simulator": (_I, []),
+    "sat_last_error": (ctypes.c_char_p, []),
+    # conv1d.hip
+    "sat_conv1d": (_I, [_P] * 12 + [_I] * 10 + [_P]),
+    "sat_conv1d_partial_rows": (_I, [_I, _I]),
+    # convtr1d.hip
+    "sat_convtr1d": (_I, [_P] * 12 + [_I] * 9 + [_P]),
+    "sat_convtr1d_partial_rows": (_I, [_I, _I, _I, _I]),
+    # conv_wgrad.hip
+    "sat_conv_wgrad": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _L] + [_I] * 9 + [_P]),
+    "sat_conv_wgrad_nsplit": (_I, [_I] * 7),
+    "sat_reduce_splits": (_I, [_P, _P, _L, _I, _F, _I, _P]),
+    "sat_rowsum": (_I, [_P, _P, _I, _I, _I, _P]),
+    "sat_rowsum_nsplit": (_I, [_I]),
+    # elementwise.hip
+    "sat_wn_fold": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "sat_wn_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sat_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sat_vae_nblocks": (_I, [_L]),
+    "sat_vae_sample_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "sat_vae_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sat_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsat_amd.so")
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every C-ABI symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def load():
+    """Load the gfx950 library (once).  Fails loudly; never substitutes anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"stable_audio_tools_amd: HIP library not built: {LIB_PATH} is missing. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    try:
+        cdll = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. no ROCm runtime on this machine
+        raise RuntimeError(f"stable_audio_tools_amd: cannot load {LIB_PATH}: {e}. There is no CPU fallback.") from e
+    bind(cdll)
+    if cdll.sat_is_simulator():
+        raise RuntimeError("stable_audio_tools_amd: refusing to use a simulator build as the product library")
+    _lib = cdll
+    return _lib

@@ -1,0 +1,257 @@
+// elementwise.hip — HBM-bound helpers of the Oobleck path: weight-norm fold/grad, weight packing,
+// VAE bottleneck sample/KL, fused AdamW on flat parameter buffers, status plumbing.
+#include "sat_device.h"
+
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------
+// status plumbing (C-ABI contract: int status, last-error string, never throw)
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_sat_err[512] = "";
+void sat_set_error(const char* msg) {
+    strncpy(g_sat_err, msg, sizeof(g_sat_err) - 1);
+    g_sat_err[sizeof(g_sat_err) - 1] = 0;
+}
+int sat_check_launch(const char* what) {
+    const auto e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        sat_set_error(buf);
+        return 2;
+    }
+    return 0;
+}
+extern "C" const char* sat_last_error() { return g_sat_err; }
+extern "C" int sat_abi_version() { return 1; }
+extern "C" int sat_is_simulator() {
+#if defined(SAT_HIPEMU)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight norm  (torch.nn.utils.weight_norm, dim=0: w = g * v / ||v||, norm over all dims but 0;
+// reference call sites autoencoders.py:23-27.  For ConvTranspose1d dim 0 is the INPUT channel.)
+// ---------------------------------------------------------------------------------------------
+struct SatWnParams {
+    const float* v;     // (D0, R)
+    const float* g;     // (D0)
+    const float* dw;    // (D0, R)   (grad only)
+    float* w;           // (D0, R)   (fold)  |  dv (grad)
+    float* norm;        // (D0)      (fold: out) | (grad: in)
+    float* dg;          // (D0)      (grad)
+    int D0, R;
+};
+
+SAT_DEVICE float sat_block_sum_256(float s, float* red) {
+    s = sat_wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) sat_wn_fold_kernel(SatWnParams p) {
+    __shared__ float red[4];
+    const int d = blockIdx.x;
+    const float* v = p.v + (size_t)d * p.R;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < p.R; i += 256) s += v[i] * v[i];
+    s = sat_block_sum_256(s, red);
+    const float nrm = sqrtf(s);
+    const float sc = p.g[d] / nrm;
+    float* w = p.w + (size_t)d * p.R;
+    for (int i = threadIdx.x; i < p.R; i += 256) w[i] = v[i] * sc;
+    if (threadIdx.x == 0) p.norm[d] = nrm;
+}
+
+__global__ void __launch_bounds__(256) sat_wn_grad_kernel(SatWnParams p) {
+    __shared__ float red[4];
+    const int d = blockIdx.x;
+    const float* v = p.v + (size_t)d * p.R;
+    const float* dw = p.dw + (size_t)d * p.R;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < p.R; i += 256) s += v[i] * dw[i];
+    s = sat_block_sum_256(s, red);
+    const float nrm = p.norm[d];
+    const float g = p.g[d];
+    const float dgv = s / nrm;
+    const float c1 = g / nrm, c2 = g * s / (nrm * nrm * nrm);
+    float* dv = p.w + (size_t)d * p.R;
+    for (int i = threadIdx.x; i < p.R; i += 256) dv[i] = c1 * dw[i] - c2 * v[i];
+    if (threadIdx.x == 0) p.dg[d] = dgv;
+}
+
+extern "C" int sat_wn_fold(const float* v, const float* g, float* w, float* norm, int D0, int R, void* stream) {
+    if (D0 <= 0 || R <= 0) { sat_set_error("sat_wn_fold: empty shape"); return 1; }
+    SatWnParams p{v, g, nullptr, w, norm, nullptr, D0, R};
+    SAT_LAUNCH(sat_wn_fold_kernel, dim3(D0), dim3(256), stream, p);
+    return sat_check_launch("sat_wn_fold");
+}
+extern "C" int sat_wn_grad(const float* v, const float* g, const float* norm, const float* dw, float* dv, float* dg,
+                           int D0, int R, void* stream) {
+    if (D0 <= 0 || R <= 0) { sat_set_error("sat_wn_grad: empty shape"); return 1; }
+    SatWnParams p{v, g, dw, dv, const_cast<float*>(norm), dg, D0, R};
+    SAT_LAUNCH(sat_wn_grad_kernel, dim3(D0), dim3(256), stream, p);
+    return sat_check_launch("sat_wn_grad");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: torch layout w[d0][d1][K]  ->  GEMM-side layouts (see sat_amd.h)
+//   mode 0: out[d1][k][d0]                       (conv fwd; convT dgrad)
+//   mode 1: out[d0][K-1-k][d1]                   (stride-1 conv dgrad: flipped, transposed)
+//   mode 2: out[r][j][d0][d1], k = r + j*S       (polyphase: convT fwd; down-conv dgrad)
+// ---------------------------------------------------------------------------------------------
+struct SatPackParams {
+    const float* w;
+    float* out;
+    int D0, D1, K, S, mode;
+    long long total;
+};
+__global__ void __launch_bounds__(256) sat_pack_kernel(SatPackParams p) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.total) return;
+    int i0, i1, k;
+    if (p.mode == 0) {
+        i0 = (int)(o % p.D0);
+        const long long q = o / p.D0;
+        k = (int)(q % p.K);
+        i1 = (int)(q / p.K);
+    } else if (p.mode == 1) {
+        i1 = (int)(o % p.D1);
+        const long long q = o / p.D1;
+        k = p.K - 1 - (int)(q % p.K);
+        i0 = (int)(q / p.K);
+    } else {
+        i1 = (int)(o % p.D1);
+        long long q = o / p.D1;
+        i0 = (int)(q % p.D0);
+        q /= p.D0;
+        const int j = (int)(q % 2), r = (int)(q / 2);
+        k = r + j * p.S;
+    }
+    p.out[o] = p.w[((size_t)i0 * p.D1 + i1) * p.K + k];
+}
+extern "C" int sat_pack_weights(const float* w, float* out, int D0, int D1, int K, int S, int mode, void* stream) {
+    if (D0 <= 0 || D1 <= 0 || K <= 0) { sat_set_error("sat_pack_weights: empty shape"); return 1; }
+    if (mode < 0 || mode > 2) { sat_set_error("sat_pack_weights: bad mode"); return 1; }
+    if (mode == 2 && K != 2 * S) { sat_set_error("sat_pack_weights: polyphase packing needs K == 2*S"); return 1; }
+    SatPackParams p{w, out, D0, D1, K, S, mode, (long long)D0 * D1 * K};
+    SAT_LAUNCH(sat_pack_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
+    return sat_check_launch("sat_pack_weights");
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAE bottleneck (reference: models/bottleneck.py:105-113 vae_sample, :119-133 VAEBottleneck.encode)
+//   mean, scale = chunk(pre, 2, dim=1); stdev = softplus(scale) + 1e-4; z = noise*stdev + mean
+//   kl = (mean^2 + var - log var - 1).sum(1).mean()
+// The N(0,1) draw is an INPUT (torch.randn_like on the caller side) so results are reproducible.
+// ---------------------------------------------------------------------------------------------
+struct SatVaeParams {
+    const float* pre;    // (B, 2C, T)
+    const float* noise;  // (B, C, T)
+    const float* dz;     // (B, C, T) (bwd)
+    float* z;            // (B, C, T) fwd out | d_pre (B, 2C, T) bwd out
+    float* kl_partial;   // [gridDim.x] fwd
+    const float* dkl;    // bwd: device scalar dL/dkl (or null)
+    float inv_bt;        // bwd: 1 / (B*T)
+    int B, C, T;
+};
+SAT_DEVICE float sat_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // torch threshold = 20
+
+__global__ void __launch_bounds__(256) sat_vae_fwd_kernel(SatVaeParams p) {
+    __shared__ float red[4];
+    const long long n = (long long)p.B * p.C * p.T;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % p.T);
+        const long long q = i / p.T;
+        const int c = (int)(q % p.C), b = (int)(q / p.C);
+        const float mean = p.pre[((size_t)b * 2 * p.C + c) * p.T + t];
+        const float scale = p.pre[((size_t)b * 2 * p.C + p.C + c) * p.T + t];
+        const float stdev = sat_softplus(scale) + 1e-4f;
+        const float var = stdev * stdev;
+        p.z[i] = p.noise[i] * stdev + mean;
+        s += mean * mean + var - logf(var) - 1.0f;
+    }
+    s = sat_block_sum_256(s, red);
+    if (threadIdx.x == 0) p.kl_partial[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) sat_vae_bwd_kernel(SatVaeParams p) {
+    const long long n = (long long)p.B * p.C * p.T;
+    const float gkl = p.dkl ? p.dkl[0] * p.inv_bt : 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % p.T);
+        const long long q = i / p.T;
+        const int c = (int)(q % p.C), b = (int)(q / p.C);
+        const size_t im = ((size_t)b * 2 * p.C + c) * p.T + t;
+        const size_t is = ((size_t)b * 2 * p.C + p.C + c) * p.T + t;
+        const float mean = p.pre[im], scale = p.pre[is];
+        const float stdev = sat_softplus(scale) + 1e-4f;
+        const float sig = scale > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-scale));
+        const float dz = p.dz ? p.dz[i] : 0.0f;
+        p.z[im] = dz + gkl * 2.0f * mean;
+        p.z[is] = (dz * p.noise[i] + gkl * (2.0f * stdev - 2.0f / stdev)) * sig;
+    }
+}
+extern "C" int sat_vae_nblocks(long long n) {
+    long long b = sat_cdivll(n, 256);
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+extern "C" int sat_vae_sample_fwd(const float* pre, const float* noise, float* z, float* kl_partial, int B, int C,
+                                  int T, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0) { sat_set_error("sat_vae_sample_fwd: empty shape"); return 1; }
+    SatVaeParams p{pre, noise, nullptr, z, kl_partial, nullptr, 0.f, B, C, T};
+    SAT_LAUNCH(sat_vae_fwd_kernel, dim3(sat_vae_nblocks((long long)B * C * T)), dim3(256), stream, p);
+    return sat_check_launch("sat_vae_sample_fwd");
+}
+extern "C" int sat_vae_sample_bwd(const float* pre, const float* noise, const float* dz, const float* dkl,
+                                  float* dpre, int B, int C, int T, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0) { sat_set_error("sat_vae_sample_bwd: empty shape"); return 1; }
+    SatVaeParams p{pre, noise, dz, dpre, nullptr, dkl, 1.0f / ((float)B * (float)T), B, C, T};
+    SAT_LAUNCH(sat_vae_bwd_kernel, dim3(sat_vae_nblocks((long long)B * C * T)), dim3(256), stream, p);
+    return sat_check_launch("sat_vae_sample_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW semantics, the optimizer the
+// reference configures: configs/model_configs/autoencoders/stable_audio_2_0_vae.json:41-49;
+// training/utils.py:60-79).  One launch per optimizer step instead of one per tensor.
+// ---------------------------------------------------------------------------------------------
+struct SatAdamParams {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+    float lr, b1, b2, eps, wd, bc1, bc2s;  // bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
+    float gscale;
+};
+__global__ void __launch_bounds__(256) sat_adamw_kernel(SatAdamParams a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        const float g = a.g[i] * a.gscale;
+        float p = a.p[i];
+        p *= (1.0f - a.lr * a.wd);
+        const float m = a.b1 * a.m[i] + (1.0f - a.b1) * g;
+        const float v = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / a.bc2s + a.eps;
+        p -= (a.lr / a.bc1) * (m / denom);
+        a.p[i] = p;
+    }
+}
+extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (n <= 0 || step < 1) { sat_set_error("sat_adamw_step: empty buffer or step < 1"); return 1; }
+    SatAdamParams a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                    1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), grad_scale};
+    long long nb = sat_cdivll(n, 256);
+    if (nb > 4096) nb = 4096;
+    SAT_LAUNCH(sat_adamw_kernel, dim3((unsigned)nb), dim3(256), stream, a);
+    return sat_check_launch("sat_adamw_step");
+}

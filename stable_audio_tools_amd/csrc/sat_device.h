@@ -1,0 +1,160 @@
+// sat_device.h — common device-side vocabulary for the gfx950 (MI355X / CDNA4) kernels.
+//
+// The kernels are written for wave64 + MFMA + LDS directly; there is no other backend.  The only
+// alternative consumer of these sources is the host-side *simulator* used by the CPU test-suite
+// (tests/emu/, -DSAT_HIPEMU), which executes the same kernel bodies with fibers so that indexing
+// and fragment layouts can be checked against the oracle without a GPU.  It is never shipped.
+#pragma once
+
+#if defined(SAT_HIPEMU)
+#include "hipemu.h"
+#define SAT_DEVICE static inline
+#else
+#include <hip/hip_runtime.h>
+#define SAT_DEVICE __device__ __forceinline__
+#endif
+
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define SAT_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers.  Fragment layouts (cdna_hip_programming.md §3):
+//   32x32x2 f32 : A lane l -> A[i=l&31][k=l>>5]; B lane l -> B[k=l>>5][j=l&31];
+//                 D reg r  -> D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
+//   32x32x16 bf16: A lane l -> A[i=l&31][k=8*(l>>5)+e], e=0..7; B lane l -> B[k=8*(l>>5)+e][j=l&31];
+//                 D as above.
+//   16x16x32 bf16: A lane l -> A[i=l&15][k=8*(l>>4)+e]; B lane l -> B[k=8*(l>>4)+e][j=l&15];
+//                 D reg r -> D[row=4*(l>>4)+r][col=l&15]
+// ---------------------------------------------------------------------------------------------
+#if defined(SAT_HIPEMU)
+static inline float hipemu_bf16_to_f32(short s) {
+    uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline f32x16 sat_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    struct { float a, b; } mine = {a, b};
+    const char* all = hipemu::wave_exchange(&mine, sizeof(mine));
+    const int l = hipemu::lane_id();
+    const int col = l & 31, hi = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, all + (size_t)(row + 32 * k) * hipemu::kSlotBytes, 4);
+            memcpy(&bv, all + (size_t)(col + 32 * k) * hipemu::kSlotBytes + 4, 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+static inline f32x16 sat_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    struct { bf16x8 a, b; } mine = {a, b};
+    const char* all = hipemu::wave_exchange(&mine, sizeof(mine));
+    const int l = hipemu::lane_id();
+    const int col = l & 31, hi = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 av, bv;
+            memcpy(&av, all + (size_t)(row + 32 * g) * hipemu::kSlotBytes, 16);
+            memcpy(&bv, all + (size_t)(col + 32 * g) * hipemu::kSlotBytes + 16, 16);
+            for (int e = 0; e < 8; ++e) acc += hipemu_bf16_to_f32(av[e]) * hipemu_bf16_to_f32(bv[e]);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+static inline f32x4 sat_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    struct { bf16x8 a, b; } mine = {a, b};
+    const char* all = hipemu::wave_exchange(&mine, sizeof(mine));
+    const int l = hipemu::lane_id();
+    const int col = l & 15, grp = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * grp + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 av, bv;
+            memcpy(&av, all + (size_t)(row + 16 * g) * hipemu::kSlotBytes, 16);
+            memcpy(&bv, all + (size_t)(col + 16 * g) * hipemu::kSlotBytes + 16, 16);
+            for (int e = 0; e < 8; ++e) acc += hipemu_bf16_to_f32(av[e]) * hipemu_bf16_to_f32(bv[e]);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#else
+SAT_DEVICE f32x16 sat_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+SAT_DEVICE f32x16 sat_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+SAT_DEVICE f32x4 sat_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+#endif
+
+// round-to-nearest-even fp32 -> bf16 bits
+SAT_DEVICE short sat_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (short)0x7fc0;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+SAT_DEVICE float sat_bf16_to_f32(short s) {
+    uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// wave64 all-lane sum
+SAT_DEVICE float sat_wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+// sum inside each 32-lane half
+SAT_DEVICE float sat_half_sum(float v) {
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// SnakeBeta activation (reference: stable_audio_tools/models/blocks.py:291-292, :321-329).
+// a = exp(alpha_log), ib = 1/(exp(beta_log) + 1e-9) are prepared once per channel by the caller.
+SAT_DEVICE float sat_snake(float x, float a, float ib) {
+    const float s = sinf(x * a);
+    return x + ib * s * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch + status plumbing shared by every C-ABI entry point.
+// ---------------------------------------------------------------------------------------------
+void sat_set_error(const char* msg);
+int sat_check_launch(const char* what);
+
+#if defined(SAT_HIPEMU)
+#define SAT_LAUNCH(kernel, grid, block, stream, params) \
+    hipemu::launch((grid), (block), [=]() { kernel(params); })
+#else
+#define SAT_LAUNCH(kernel, grid, block, stream, params) \
+    hipLaunchKernelGGL(kernel, (grid), (block), 0, (hipStream_t)(stream), params)
+#endif
+
+static inline int sat_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long sat_cdivll(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,0 +1,190 @@
+"""Autograd boundary of the Oobleck conv stack.
+
+Each ``torch.autograd.Function`` is one *fusion unit* of the reference graph
+(stable_audio_tools/models/autoencoders.py):
+
+  WeightNormFn       weight_norm reparametrisation  (:23-27)
+  SnakeConv1dFn      SnakeBeta -> WNConv1d [-> +residual] [-> tanh]   (:58-83, :233-250, :298-312, :333-354)
+  SnakeConvTr1dFn    SnakeBeta -> WNConvTranspose1d                   (:266-271)
+  ResidualUnitFn     x + conv1(snake(conv7_dil(snake(x))))            (:58-83)
+  VaeSampleFn        VAEBottleneck.encode                             (models/bottleneck.py:105-133)
+
+Forward and backward both run on the HIP kernels (ops.SatOps); the SnakeBeta activations are never
+materialised — backward recomputes them inside the wgrad / dgrad kernels from the saved
+pre-activation.  Where the reference wraps ResidualUnit in torch.utils.checkpoint
+(autoencoders.py:78-79) we instead keep the one intermediate (h) resident: 288 GB of HBM makes
+recompute the worse trade on MI355X.
+"""
+import torch
+
+from . import ops as _ops_mod
+from .ops import PACK_CONV_DGRAD, PACK_CONV_FWD, PACK_POLYPHASE
+
+
+def _ops(ops):
+    return ops if ops is not None else _ops_mod.get_ops()
+
+
+class WeightNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g, ops=None):
+        ops = _ops(ops)
+        v = v.contiguous()
+        gf = g.contiguous().view(-1)
+        w, norm = ops.wn_fold(v, gf)
+        ctx.save_for_backward(v, gf, norm)
+        ctx.ops = ops
+        ctx.g_shape = g.shape
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, gf, norm = ctx.saved_tensors
+        dv, dg = ctx.ops.wn_grad(v, gf, norm, dw.contiguous())
+        return dv, dg.view(ctx.g_shape), None
+
+
+def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
+    """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K)."""
+    if stride == 1:
+        wpb = ops.pack(w, PACK_CONV_DGRAD)
+        return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res)
+    wpb = ops.pack(w, PACK_POLYPHASE, stride)
+    return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
+
+
+class SnakeConv1dFn(torch.autograd.Function):
+    """y = tanh?( conv1d(snake(x; alpha, beta), w, bias, stride, dil, pad) + res )."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None):
+        ops = _ops(ops)
+        x = x.contiguous()
+        w = w.contiguous()
+        cout, cin, k = w.shape
+        snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
+        wp = ops.pack(w, PACK_CONV_FWD)
+        y = ops.conv1d(x, wp, cout, k, stride, dil, pad, bias=bias, snake=snake,
+                       res=res.contiguous() if res is not None else None, tanh_out=tanh_out)
+        ctx.ops = ops
+        ctx.cfg = (stride, dil, pad, tanh_out, bias is not None, res is not None, alpha is not None)
+        ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        stride, dil, pad, tanh_out, has_bias, has_res, has_snake = ctx.cfg
+        x, alpha, beta, w, y = ctx.saved_tensors
+        cout, cin, k = w.shape
+        dy = dy.contiguous()
+        if tanh_out:
+            dy = dy * (1.0 - y * y)
+        snake = (alpha, beta) if has_snake else None
+        dres = dy if has_res else None
+        dbias = ops.rowsum(dy) if has_bias else None
+        dw = None
+        if ctx.needs_input_grad[3]:
+            dw = ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
+        dx = da = db = None
+        if has_snake:
+            dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
+        elif ctx.needs_input_grad[0]:
+            dx = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], None)
+        return dx, da, db, dw, dbias, dres, None, None, None, None, None
+
+
+class SnakeConvTr1dFn(torch.autograd.Function):
+    """y = conv_transpose1d(snake(x), w (Cin, Cout, K=2*stride), bias, stride, pad)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta, w, bias, stride, pad, ops=None):
+        ops = _ops(ops)
+        x = x.contiguous()
+        w = w.contiguous()
+        cin, cout, k = w.shape
+        snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
+        wp = ops.pack(w, PACK_POLYPHASE, stride)
+        y = ops.convtr1d(x, wp, cout, k, stride, pad, bias=bias, snake=snake)
+        ctx.ops = ops
+        ctx.cfg = (stride, pad, bias is not None, alpha is not None)
+        ctx.save_for_backward(x, alpha, beta, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        stride, pad, has_bias, has_snake = ctx.cfg
+        x, alpha, beta, w = ctx.saved_tensors
+        cin, cout, k = w.shape
+        dy = dy.contiguous()
+        snake = (alpha, beta) if has_snake else None
+        dbias = ops.rowsum(dy) if has_bias else None
+        dw = ops.conv_wgrad(x, dy, k, stride, 1, pad, snake=snake, snake_on=1)
+        # dgrad of a transposed conv is the strided conv with in=Cout, out=Cin: packed [co][k][ci]
+        wpb = ops.pack(w, PACK_CONV_FWD)
+        dx = da = db = None
+        if has_snake:
+            dx, da, db = ops.conv1d(dy, wpb, cin, k, stride, 1, pad, tout=x.shape[2], dsnake=(x, alpha, beta))
+        elif ctx.needs_input_grad[0]:
+            dx = ops.conv1d(dy, wpb, cin, k, stride, 1, pad, tout=x.shape[2])
+        return dx, da, db, dw, dbias, None, None, None
+
+
+class ResidualUnitFn(torch.autograd.Function):
+    """y = x + conv1x1(snake2(conv7_dil(snake1(x))))  — one unit, one saved intermediate."""
+
+    @staticmethod
+    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None):
+        ops = _ops(ops)
+        x = x.contiguous()
+        w1 = w1.contiguous()
+        w2 = w2.contiguous()
+        c = x.shape[1]
+        k1 = w1.shape[2]
+        pad = dil * (k1 - 1) // 2
+        h = ops.conv1d(x, ops.pack(w1, PACK_CONV_FWD), c, k1, 1, dil, pad, bias=bias1, snake=(a1, b1))
+        y = ops.conv1d(h, ops.pack(w2, PACK_CONV_FWD), c, w2.shape[2], 1, 1, 0, bias=bias2, snake=(a2, b2), res=x)
+        ctx.ops = ops
+        ctx.dil = dil
+        ctx.save_for_backward(x, h, a1, b1, w1, a2, b2, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        x, h, a1, b1, w1, a2, b2, w2 = ctx.saved_tensors
+        dil = ctx.dil
+        c = x.shape[1]
+        k1, k2 = w1.shape[2], w2.shape[2]
+        pad1 = dil * (k1 - 1) // 2
+        t = x.shape[2]
+        dy = dy.contiguous()
+        dbias2 = ops.rowsum(dy)
+        dw2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2)
+        dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2))
+        dbias1 = ops.rowsum(dh)
+        dw1 = ops.conv_wgrad(dh, x, k1, 1, dil, pad1, snake=(a1, b1), snake_on=2)
+        dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
+        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None
+
+
+class VaeSampleFn(torch.autograd.Function):
+    """(z, kl) = vae_sample(chunk(pre, 2, dim=1)) with the N(0,1) draw supplied by the caller."""
+
+    @staticmethod
+    def forward(ctx, pre, noise, ops=None):
+        ops = _ops(ops)
+        pre = pre.contiguous()
+        noise = noise.contiguous()
+        z, kl = ops.vae_sample_fwd(pre, noise)
+        ctx.ops = ops
+        ctx.save_for_backward(pre, noise)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        pre, noise = ctx.saved_tensors
+        dpre = ctx.ops.vae_sample_bwd(pre, noise, dz.contiguous() if dz is not None else None,
+                                      dkl.contiguous() if dkl is not None else None)
+        return dpre, None, None

@@ -1,0 +1,201 @@
+"""Python mirror of the C-ABI (include/sat_amd.h): torch tensors in, torch tensors out.
+
+PyTorch is used here only as the device allocator / stream provider.  Every function hands raw
+device pointers + shapes to the HIP library on ``torch.cuda.current_stream()``; the caller (the
+PyTorch caching allocator) owns all buffers including workspaces.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+PACK_CONV_FWD = 0      # w[d0][d1][K] -> [d1][k][d0]
+PACK_CONV_DGRAD = 1    # w[d0][d1][K] -> [d0][K-1-k][d1]
+PACK_POLYPHASE = 2     # w[d0][d1][2S] -> [r][j][d0][d1]
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class SatOps:
+    def __init__(self, cdll):
+        self.lib = cdll
+        self.simulator = bool(cdll.sat_is_simulator())
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self, t):
+        if self.simulator:
+            return None
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def _chk(self, status):
+        if status != 0:
+            raise RuntimeError(self.lib.sat_last_error().decode())
+
+    def _f32(self, *tensors):
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dtype != torch.float32:
+                raise TypeError(f"expected float32 tensor, got {t.dtype}")
+            if not t.is_contiguous():
+                raise ValueError("expected contiguous tensor")
+            if not self.simulator and not t.is_cuda:
+                raise RuntimeError("stable_audio_tools_amd kernels need CUDA(HIP) tensors; there is no CPU path")
+
+    # ------------------------------------------------------------------ weight norm / packing
+    def wn_fold(self, v, g):
+        """w = g * v / ||v||  (norm over all dims but 0) -> (w like v, norm (D0,))"""
+        self._f32(v, g)
+        d0 = v.shape[0]
+        r = v.numel() // d0
+        w = torch.empty_like(v)
+        norm = torch.empty(d0, dtype=torch.float32, device=v.device)
+        self._chk(self.lib.sat_wn_fold(_ptr(v), _ptr(g), _ptr(w), _ptr(norm), d0, r, self._stream(v)))
+        return w, norm
+
+    def wn_grad(self, v, g, norm, dw):
+        self._f32(v, g, norm, dw)
+        d0 = v.shape[0]
+        r = v.numel() // d0
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        self._chk(self.lib.sat_wn_grad(_ptr(v), _ptr(g), _ptr(norm), _ptr(dw), _ptr(dv), _ptr(dg), d0, r, self._stream(v)))
+        return dv, dg
+
+    def pack(self, w, mode, stride=1):
+        self._f32(w)
+        d0, d1, k = w.shape
+        out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        self._chk(self.lib.sat_pack_weights(_ptr(w), _ptr(out), d0, d1, k, stride, mode, self._stream(w)))
+        return out
+
+    # ------------------------------------------------------------------ convs
+    def _reduce_rows(self, partial, rows, count, scale=1.0):
+        out = torch.empty(count, dtype=torch.float32, device=partial.device)
+        self._chk(self.lib.sat_reduce_splits(_ptr(partial), _ptr(out), count, rows, scale, 0, self._stream(partial)))
+        return out
+
+    def conv1d(self, x, w_packed, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
+               tanh_out=False, dsnake=None):
+        """y = conv(snake(x)) [+bias] [+res] ; or, with dsnake=(x2, alpha2, beta2):
+        y = conv(x) * dsnake(x2) + res and returns (y, dlog_alpha2, dlog_beta2)."""
+        b, cin, tin = x.shape
+        if tout is None:
+            tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(x, w_packed, bias, alpha, beta, res)
+        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        x2 = a2 = b2 = pda = pdb = None
+        rows = 0
+        if dsnake is not None:
+            x2, a2, b2 = dsnake
+            self._f32(x2, a2, b2)
+            rows = self.lib.sat_conv1d_partial_rows(b, tout)
+            pda = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+            pdb = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_conv1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
+                                      _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
+                                      b, cin, cout, tin, tout, k, stride, dil, pad, int(tanh_out), self._stream(x)))
+        if dsnake is not None:
+            return y, self._reduce_rows(pda, rows, cout), self._reduce_rows(pdb, rows, cout)
+        return y
+
+    def convtr1d(self, x, w_packed, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
+                 tanh_out=False, dsnake=None):
+        b, cin, tin = x.shape
+        if tout is None:
+            tout = (tin - 1) * stride - 2 * pad + k
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(x, w_packed, bias, alpha, beta, res)
+        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        x2 = a2 = b2 = pda = pdb = None
+        rows = 0
+        if dsnake is not None:
+            x2, a2, b2 = dsnake
+            self._f32(x2, a2, b2)
+            rows = self.lib.sat_convtr1d_partial_rows(b, tout, stride, pad)
+            if rows < 0:
+                raise RuntimeError("sat_convtr1d: unsupported stride")
+            pda = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+            pdb = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_convtr1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
+                                        _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
+                                        b, cin, cout, tin, tout, k, stride, pad, int(tanh_out), self._stream(x)))
+        if dsnake is not None:
+            return y, self._reduce_rows(pda, rows, cout), self._reduce_rows(pdb, rows, cout)
+        return y
+
+    def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False):
+        """dW[m][n][k] = sum_{b,t} actA(lo[b,m,t]) * actB(hi[b,n,t*s + k*d - pad]).
+        Returns (M, N, K); with transposed_out=True returns it laid out as (N, M, K)."""
+        bsz, m, tlo = lo.shape
+        _, n, thi = hi.shape
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(lo, hi, alpha, beta)
+        nsplit = self.lib.sat_conv_wgrad_nsplit(bsz, m, n, tlo, k, stride, dil)
+        if nsplit < 0:
+            raise RuntimeError("sat_conv_wgrad: receptive field too large")
+        partial = torch.empty(nsplit, m * n * k, dtype=torch.float32, device=lo.device)
+        if transposed_out:
+            so_m, so_n, so_k = k, m * k, 1
+            shape = (n, m, k)
+        else:
+            so_m, so_n, so_k = n * k, k, 1
+            shape = (m, n, k)
+        self._chk(self.lib.sat_conv_wgrad(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta), snake_on if snake is not None else 0,
+                                          _ptr(partial), so_m, so_n, so_k, bsz, m, n, tlo, thi, k, stride, dil, pad,
+                                          self._stream(lo)))
+        return self._reduce_rows(partial, nsplit, m * n * k).view(shape)
+
+    def rowsum(self, x):
+        """(B, C, T) -> (C,) sum over batch and time."""
+        self._f32(x)
+        b, c, t = x.shape
+        ns = self.lib.sat_rowsum_nsplit(t)
+        partial = torch.empty(ns, c, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_rowsum(_ptr(x), _ptr(partial), b, c, t, self._stream(x)))
+        return self._reduce_rows(partial, ns, c)
+
+    # ------------------------------------------------------------------ VAE bottleneck
+    def vae_sample_fwd(self, pre, noise):
+        self._f32(pre, noise)
+        b, c2, t = pre.shape
+        c = c2 // 2
+        z = torch.empty(b, c, t, dtype=torch.float32, device=pre.device)
+        nb = self.lib.sat_vae_nblocks(b * c * t)
+        klp = torch.empty(nb, dtype=torch.float32, device=pre.device)
+        self._chk(self.lib.sat_vae_sample_fwd(_ptr(pre), _ptr(noise), _ptr(z), _ptr(klp), b, c, t, self._stream(pre)))
+        kl = self._reduce_rows(klp, nb, 1, 1.0 / (b * t)).view(())
+        return z, kl
+
+    def vae_sample_bwd(self, pre, noise, dz, dkl):
+        """dz: (B, C, T) or None; dkl: 0-dim device tensor (dL/dkl) or None."""
+        self._f32(pre, noise, dz, dkl)
+        b, c2, t = pre.shape
+        c = c2 // 2
+        dpre = torch.empty_like(pre)
+        self._chk(self.lib.sat_vae_sample_bwd(_ptr(pre), _ptr(noise), _ptr(dz), _ptr(dkl), _ptr(dpre), b, c, t,
+                                              self._stream(pre)))
+        return dpre
+
+    # ------------------------------------------------------------------ optimizer
+    def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        self._f32(p, g, m, v)
+        self._chk(self.lib.sat_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                          weight_decay, step, grad_scale, self._stream(p)))
+
+
+_ops = None
+
+
+def get_ops():
+    """The product singleton: bound to the gfx950 library, or raises."""
+    global _ops
+    if _ops is None:
+        _ops = SatOps(_lib.load())
+    return _ops
