@@ -1,0 +1,347 @@
+"""MI355X-native Oobleck audio autoencoder — drop-in for the reference's hot-path classes.
+
+Mirrors (same class names, constructor kwargs, module tree and therefore state_dict keys):
+  stable_audio_tools/models/autoencoders.py
+    WNConv1d :23, WNConvTranspose1d :26, ResidualUnit :58, EncoderBlock :233, DecoderBlock :252,
+    OobleckEncoder :285, OobleckDecoder :320, AudioAutoencoder :401 (encode :446, decode :493)
+  stable_audio_tools/models/blocks.py  SnakeBeta :301
+so a reference checkpoint loads unchanged (weight_g / weight_v / bias / alpha / beta).
+
+What is different is the execution: the module tree is only a parameter container.  Forward walks
+it in *fusion units* (functional.py) so SnakeBeta, bias, residual add and tanh never make their own
+trip through HBM, and both forward and backward run on the HIP kernels of csrc/.  There is no
+PyTorch conv fallback: without the gfx950 library these modules raise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from .bottleneck import VAEBottleneck  # noqa: F401  (re-export, mirrors reference import surface)
+
+
+class SnakeBeta(nn.Module):
+    """Parameter holder for SnakeBeta (blocks.py:301-329): log-scale alpha/beta, zero-init.
+    Standalone forward exists for API parity; inside the Oobleck stack it is always fused into the
+    following convolution's prologue."""
+
+    def __init__(self, in_features, alpha=1.0, alpha_trainable=True, alpha_logscale=True):
+        super().__init__()
+        if not alpha_logscale:
+            raise NotImplementedError("only alpha_logscale=True (the reference default used by Oobleck) is implemented")
+        self.in_features = in_features
+        self.alpha_logscale = alpha_logscale
+        self.alpha = nn.Parameter(torch.zeros(in_features) * alpha)
+        self.beta = nn.Parameter(torch.zeros(in_features) * alpha)
+        self.alpha.requires_grad = alpha_trainable
+        self.beta.requires_grad = alpha_trainable
+        self.no_div_by_zero = 0.000000001
+
+    def forward(self, x):
+        # identity 1x1 "conv" with the snake prologue: keeps the standalone call on the HIP path
+        c = x.shape[1]
+        eye = torch.eye(c, device=x.device, dtype=x.dtype).unsqueeze(-1)
+        return Fn.SnakeConv1dFn.apply(x, self.alpha, self.beta, eye, None, None, 1, 1, 0, False)
+
+
+class _WNConvBase(nn.Module):
+    """Old-style torch.nn.utils.weight_norm parametrisation (dim=0): parameters weight_g, weight_v
+    (+ bias) — the names the reference checkpoints carry (autoencoders.py:8, :23-27)."""
+
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        if self.transposed:
+            wshape = (in_channels, out_channels, kernel_size)
+        else:
+            wshape = (out_channels, in_channels, kernel_size)
+        # nn.Conv1d default init (kaiming_uniform a=sqrt(5)), then g = ||v|| as weight_norm does
+        v = torch.empty(wshape)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+        self.weight_v = nn.Parameter(v)
+        if bias:
+            # fan_in as torch computes it for the (possibly transposed) weight tensor: size(1) * K
+            fan_in = wshape[1] * kernel_size
+            bound = 1.0 / math.sqrt(fan_in)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def folded_weight(self):
+        return Fn.WeightNormFn.apply(self.weight_v, self.weight_g)
+
+
+class WNConv1d(_WNConvBase):
+    def forward(self, x, snake=None, res=None, tanh_out=False):
+        a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
+        return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias, res, self.stride, self.dilation,
+                                      self.padding, tanh_out)
+
+
+class WNConvTranspose1d(_WNConvBase):
+    transposed = True
+
+    def forward(self, x, snake=None):
+        a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
+        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias, self.stride, self.padding)
+
+
+def _require_snake(use_snake, antialias_activation=False):
+    if not use_snake:
+        raise NotImplementedError("only use_snake=True (SnakeBeta, the Stable Audio Open / 2.0 VAE configuration) is "
+                                  "implemented on the HIP path; the ELU variant is out of scope (SURVEY.md §8a V3)")
+    if antialias_activation:
+        raise NotImplementedError("antialias_activation (alias_free_torch) is out of scope")
+
+
+class ResidualUnit(nn.Module):
+    def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
+        super().__init__()
+        _require_snake(use_snake, antialias_activation)
+        self.dilation = dilation
+        padding = (dilation * (7 - 1)) // 2
+        self.layers = nn.Sequential(
+            SnakeBeta(out_channels),
+            WNConv1d(in_channels, out_channels, kernel_size=7, dilation=dilation, padding=padding),
+            SnakeBeta(out_channels),
+            WNConv1d(out_channels, out_channels, kernel_size=1),
+        )
+
+    def forward(self, x):
+        s1, c1, s2, c2 = self.layers
+        return Fn.ResidualUnitFn.apply(x, s1.alpha, s1.beta, c1.folded_weight(), c1.bias,
+                                       s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation)
+
+
+class EncoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False):
+        super().__init__()
+        _require_snake(use_snake, antialias_activation)
+        self.layers = nn.Sequential(
+            ResidualUnit(in_channels, in_channels, dilation=1, use_snake=use_snake),
+            ResidualUnit(in_channels, in_channels, dilation=3, use_snake=use_snake),
+            ResidualUnit(in_channels, in_channels, dilation=9, use_snake=use_snake),
+            SnakeBeta(in_channels),
+            WNConv1d(in_channels, out_channels, kernel_size=2 * stride, stride=stride, padding=math.ceil(stride / 2)),
+        )
+
+    def forward(self, x):
+        r1, r2, r3, snake, down = self.layers
+        return down(r3(r2(r1(x))), snake=snake)
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False,
+                 use_nearest_upsample=False):
+        super().__init__()
+        _require_snake(use_snake, antialias_activation)
+        if use_nearest_upsample:
+            raise NotImplementedError("use_nearest_upsample is out of scope (no in-repo Oobleck config enables it)")
+        self.layers = nn.Sequential(
+            SnakeBeta(in_channels),
+            WNConvTranspose1d(in_channels, out_channels, kernel_size=2 * stride, stride=stride,
+                              padding=math.ceil(stride / 2)),
+            ResidualUnit(out_channels, out_channels, dilation=1, use_snake=use_snake),
+            ResidualUnit(out_channels, out_channels, dilation=3, use_snake=use_snake),
+            ResidualUnit(out_channels, out_channels, dilation=9, use_snake=use_snake),
+        )
+
+    def forward(self, x):
+        snake, up, r1, r2, r3 = self.layers
+        return r3(r2(r1(up(x, snake=snake))))
+
+
+class OobleckEncoder(nn.Module):
+    def __init__(self, in_channels=2, channels=128, latent_dim=32, c_mults=[1, 2, 4, 8], strides=[2, 4, 8, 8],
+                 use_snake=False, antialias_activation=False):
+        super().__init__()
+        _require_snake(use_snake, antialias_activation)
+        self.in_channels = in_channels
+        c_mults = [1] + list(c_mults)
+        self.depth = len(c_mults)
+        layers = [WNConv1d(in_channels, c_mults[0] * channels, kernel_size=7, padding=3)]
+        for i in range(self.depth - 1):
+            layers += [EncoderBlock(c_mults[i] * channels, c_mults[i + 1] * channels, stride=strides[i], use_snake=use_snake)]
+        layers += [SnakeBeta(c_mults[-1] * channels),
+                   WNConv1d(c_mults[-1] * channels, latent_dim, kernel_size=3, padding=1)]
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, x):
+        mods = list(self.layers)
+        x = mods[0](x)
+        for blk in mods[1:-2]:
+            x = blk(x)
+        return mods[-1](x, snake=mods[-2])
+
+
+class OobleckDecoder(nn.Module):
+    def __init__(self, out_channels=2, channels=128, latent_dim=32, c_mults=[1, 2, 4, 8], strides=[2, 4, 8, 8],
+                 use_snake=False, antialias_activation=False, use_nearest_upsample=False, final_tanh=True):
+        super().__init__()
+        _require_snake(use_snake, antialias_activation)
+        self.out_channels = out_channels
+        c_mults = [1] + list(c_mults)
+        self.depth = len(c_mults)
+        layers = [WNConv1d(latent_dim, c_mults[-1] * channels, kernel_size=7, padding=3)]
+        for i in range(self.depth - 1, 0, -1):
+            layers += [DecoderBlock(c_mults[i] * channels, c_mults[i - 1] * channels, stride=strides[i - 1],
+                                    use_snake=use_snake, antialias_activation=antialias_activation,
+                                    use_nearest_upsample=use_nearest_upsample)]
+        layers += [SnakeBeta(c_mults[0] * channels),
+                   WNConv1d(c_mults[0] * channels, out_channels, kernel_size=7, padding=3, bias=False),
+                   nn.Tanh() if final_tanh else nn.Identity()]
+        self.final_tanh = final_tanh
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, x):
+        mods = list(self.layers)
+        x = mods[0](x)
+        for blk in mods[1:-3]:
+            x = blk(x)
+        return mods[-2](x, snake=mods[-3], tanh_out=self.final_tanh)
+
+
+class AudioAutoencoder(nn.Module):
+    """Encoder / bottleneck / decoder orchestration (autoencoders.py:401-534, :601-732).
+    Inner `pretransform` (wavelet/PQMF front-ends) is out of scope and must be None."""
+
+    def __init__(self, encoder, decoder, latent_dim, downsampling_ratio, sample_rate, io_channels=2, bottleneck=None,
+                 pretransform=None, in_channels=None, out_channels=None, soft_clip=False):
+        super().__init__()
+        if pretransform is not None:
+            raise NotImplementedError("AudioAutoencoder(pretransform=...) is out of scope for the HIP path")
+        self.downsampling_ratio = downsampling_ratio
+        self.sample_rate = sample_rate
+        self.latent_dim = latent_dim
+        self.io_channels = io_channels
+        self.in_channels = io_channels if in_channels is None else in_channels
+        self.out_channels = io_channels if out_channels is None else out_channels
+        self.min_length = self.downsampling_ratio
+        self.bottleneck = bottleneck
+        self.encoder = encoder
+        self.decoder = decoder
+        self.pretransform = None
+        self.soft_clip = soft_clip
+        self.is_discrete = self.bottleneck is not None and self.bottleneck.is_discrete
+
+    def encode(self, audio, skip_bottleneck=False, return_info=False, skip_pretransform=False, iterate_batch=False, **kwargs):
+        info = {}
+        if iterate_batch:
+            latents = torch.cat([self.encoder(audio[i:i + 1]) for i in range(audio.shape[0])], dim=0)
+        else:
+            latents = self.encoder(audio)
+        info["pre_bottleneck_latents"] = latents
+        if self.bottleneck is not None and not skip_bottleneck:
+            latents, binfo = self.bottleneck.encode(latents, return_info=True, **kwargs)
+            info.update(binfo)
+        if return_info:
+            return latents, info
+        return latents
+
+    def decode(self, latents, skip_bottleneck=False, iterate_batch=False, **kwargs):
+        if self.bottleneck is not None and not skip_bottleneck:
+            latents = self.bottleneck.decode(latents)
+        if iterate_batch:
+            decoded = torch.cat([self.decoder(latents[i:i + 1]) for i in range(latents.shape[0])], dim=0)
+        else:
+            decoded = self.decoder(latents, **kwargs)
+        if self.soft_clip:
+            decoded = torch.tanh(decoded)
+        return decoded
+
+    # -- chunked overlap-and-paste orchestration (autoencoders.py:601-732) --------------------
+    def encode_audio(self, audio, chunked=False, overlap=32, chunk_size=128, **kwargs):
+        """`overlap` / `chunk_size` are in latent frames (autoencoders.py:601-669)."""
+        if not chunked:
+            return self.encode(audio, **kwargs)
+        r = int(self.downsampling_ratio)
+        out = torch.zeros((audio.shape[0], self.latent_dim, audio.shape[2] // r), device=audio.device, dtype=audio.dtype)
+        for win in _chunk_windows(audio.shape[2] // r, chunk_size, overlap):
+            y = self.encode(audio[:, :, win.src0 * r:win.src1 * r])
+            out[:, :, win.dst0:win.dst1] = y[:, :, win.keep0:win.keep1]
+        return out
+
+    def decode_audio(self, latents, chunked=False, overlap=32, chunk_size=128, **kwargs):
+        """Chunked decode: keep the centre of every chunk, last chunk right-aligned (autoencoders.py:671-732)."""
+        if not chunked:
+            return self.decode(latents, **kwargs)
+        r = int(self.downsampling_ratio)
+        out = torch.zeros((latents.shape[0], self.out_channels, latents.shape[2] * r), device=latents.device,
+                          dtype=latents.dtype)
+        for win in _chunk_windows(latents.shape[2], chunk_size, overlap):
+            y = self.decode(latents[:, :, win.src0:win.src1])
+            out[:, :, win.dst0 * r:win.dst1 * r] = y[:, :, win.keep0 * r:win.keep1 * r]
+        return out
+
+
+class _Win:
+    __slots__ = ("src0", "src1", "dst0", "dst1", "keep0", "keep1")
+
+
+def _chunk_windows(total, chunk, overlap):
+    """Windows (all in latent frames) of the reference's overlap-and-paste scheme
+    (autoencoders.py:626-668 / :689-731): chunks of `chunk` frames every `chunk - overlap` frames, a
+    final right-aligned chunk if the grid does not end exactly at `total`; from every chunk the
+    half-overlap at each interior edge is discarded."""
+    hop = chunk - overlap
+    starts = list(range(0, total - chunk + 1, hop))
+    if not starts:
+        raise ValueError("chunked encode/decode needs at least chunk_size latent frames")
+    if starts[-1] + chunk != total:
+        starts.append(total - chunk)
+    half = overlap // 2
+    wins = []
+    for n, s0 in enumerate(starts):
+        w = _Win()
+        last = n == len(starts) - 1
+        w.src0, w.src1 = s0, s0 + chunk
+        # nominal destination of a grid chunk is n*hop; the last one is pasted at the very end
+        d0 = (total - chunk) if last else n * hop
+        w.keep0 = half if n > 0 else 0
+        w.keep1 = chunk if last else chunk - half
+        w.dst0, w.dst1 = d0 + w.keep0, d0 + w.keep1
+        wins.append(w)
+    return wins
+
+
+def create_encoder_from_config(cfg):
+    if cfg.get("type") != "oobleck":
+        raise NotImplementedError(f"encoder type {cfg.get('type')!r} is out of scope (only 'oobleck' is on the hot path)")
+    enc = OobleckEncoder(**cfg["config"])
+    if not cfg.get("requires_grad", True):
+        for p in enc.parameters():
+            p.requires_grad = False
+    return enc
+
+
+def create_decoder_from_config(cfg):
+    if cfg.get("type") != "oobleck":
+        raise NotImplementedError(f"decoder type {cfg.get('type')!r} is out of scope (only 'oobleck' is on the hot path)")
+    dec = OobleckDecoder(**cfg["config"])
+    if not cfg.get("requires_grad", True):
+        for p in dec.parameters():
+            p.requires_grad = False
+    return dec
+
+
+def create_autoencoder_from_config(config):
+    """Same JSON surface as autoencoders.py:867-910 for the in-scope types."""
+    ae = config["model"]
+    if ae.get("pretransform") is not None:
+        raise NotImplementedError("autoencoder-level pretransform is out of scope")
+    encoder = create_encoder_from_config(ae["encoder"])
+    decoder = create_decoder_from_config(ae["decoder"])
+    bottleneck = None
+    if ae.get("bottleneck") is not None:
+        if ae["bottleneck"]["type"] != "vae":
+            raise NotImplementedError("only the 'vae' bottleneck is on the hot path")
+        bottleneck = VAEBottleneck()
+    return AudioAutoencoder(encoder, decoder, latent_dim=ae["latent_dim"], downsampling_ratio=ae["downsampling_ratio"],
+                            sample_rate=config["sample_rate"], io_channels=ae["io_channels"], bottleneck=bottleneck,
+                            in_channels=ae.get("in_channels"), out_channels=ae.get("out_channels"),
+                            soft_clip=ae["decoder"].get("soft_clip", False))

@@ -21,8 +21,18 @@ from . import ops as _ops_mod
 from .ops import PACK_CONV_DGRAD, PACK_CONV_FWD, PACK_POLYPHASE
 
 
+# Test seam: the CPU test-suite points this at a SatOps bound to the host-side *simulator* build of
+# the kernel sources (tests/emu).  Product code never sets it; with it unset every call goes to the
+# gfx950 library or raises (ops.get_ops()).
+_TEST_OPS = None
+
+
 def _ops(ops):
-    return ops if ops is not None else _ops_mod.get_ops()
+    if ops is not None:
+        return ops
+    if _TEST_OPS is not None:
+        return _TEST_OPS
+    return _ops_mod.get_ops()
 
 
 class WeightNormFn(torch.autograd.Function):
