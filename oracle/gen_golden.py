@@ -91,9 +91,12 @@ def gen_chunked(name, seed):
         dec = model.decode_audio(lat, chunked=True, overlap=4, chunk_size=16)
         dec_full = model.decode_audio(lat, chunked=False)
         audio = torch.from_numpy(seeded.seeded_array((1, cfg["model"]["io_channels"], 44 * ratio), seed + 6, scale=0.5))
-        enc_pre = model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16, skip_bottleneck=True)
+        # the reference's chunked encode drops kwargs and samples the VAE per chunk (autoencoders.py:646):
+        # fix the CPU generator so the per-chunk randn_like draws are reproducible
+        torch.manual_seed(4242)
+        enc = model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16)
     np.savez_compressed(os.path.join(OUT, f"vae_chunked_{name}.npz"), decoded_chunked=dec.numpy(), decoded_full=dec_full.numpy(),
-                        encoded_chunked_pre=enc_pre.numpy())
+                        encoded_chunked=enc.numpy())
     print(f"vae_chunked_{name}: {tuple(dec.shape)} chunk-vs-full maxdiff {float((dec - dec_full).abs().max()):.3e}")
 
 

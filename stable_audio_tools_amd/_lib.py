@@ -38,6 +38,11 @@ SIGNATURES = {
     "sat_vae_sample_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sat_vae_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sat_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    # stft.hip
+    "sat_fir": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sat_stft_tiles": (_I, [_I, _I, _I]),
+    "sat_stft_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sat_stft_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsat_amd.so")

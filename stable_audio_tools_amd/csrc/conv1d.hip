@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
     __shared__ float w_lds[SAT_W_ROWS][SAT_CO_T];  // [(c, tap)][co]
     __shared__ float a_lds[SAT_A_FLOATS];          // [c][...] activation slab
     __shared__ float red_lds[2][2][SAT_CO_T];      // [quantity][t-wave][co] (backward epilogue)
+    __shared__ float ep_lds[3][SAT_CO_T];          // per-row epilogue constants: bias, e^alpha2, e^beta2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -59,6 +60,15 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (tid < SAT_CO_T) {
+        const int co = co0 + tid;
+        const bool ok = co < p.Cout;
+        ep_lds[0][tid] = (ok && p.bias) ? p.bias[co] : 0.0f;
+        ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[co]) : 1.0f;
+        ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[co]) : 1.0f;
+    }
+    // (visibility of ep_lds is ordered by the barriers of the K loop; Cin >= 1 guarantees one pass)
 
     // fixed staging channel per thread
     const int tpc = 256 / CI_T;
@@ -163,12 +173,8 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
                 const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int co = co0 + col;
                 const bool co_ok = co < p.Cout;
-                const float bias = (co_ok && p.bias) ? p.bias[co] : 0.0f;
-                float a2 = 1.f, b2 = 1.f;
-                if (bwd && co_ok) {
-                    a2 = expf(p.alpha2[co]);
-                    b2 = expf(p.beta2[co]);
-                }
+                const float bias = ep_lds[0][col];
+                const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
                 float pda = 0.f, pdb = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {

@@ -9,7 +9,7 @@
 #define SAT_CO_T 128
 #define SAT_T_T 128
 #define SAT_W_ROWS 64      // max (ci, tap) rows of the weight slab staged per K-chunk
-#define SAT_A_FLOATS 4608  // activation slab capacity (floats)
+#define SAT_A_FLOATS 4352  // activation slab capacity (floats)
 
 struct SatConvParams {
     const float* x;       // (B, Cin, Tin)   conv input (pre-activation)

@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
     __shared__ float w_lds[SAT_W_ROWS][SAT_CO_T];  // [(r*2+j)*CI_T + c][co]
     __shared__ float a_lds[32][QB + 4];            // [c][q - Q0 + 1]
     __shared__ float red_lds[2][2][SAT_CO_T];
+    __shared__ float ep_lds[3][SAT_CO_T];  // per-row epilogue constants: bias, e^alpha2, e^beta2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -50,6 +51,14 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.0f;
+
+    if (tid < SAT_CO_T) {
+        const int co = co0 + tid;
+        const bool ok = co < p.Cout;
+        ep_lds[0][tid] = (ok && p.bias) ? p.bias[co] : 0.0f;
+        ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[co]) : 1.0f;
+        ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[co]) : 1.0f;
+    }
 
     const int tpc = 256 / CI_T;
     const int sc = tid / tpc, sj0 = tid - sc * tpc;
@@ -146,12 +155,8 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
                 const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int co = co0 + col;
                 const bool co_ok = co < p.Cout;
-                const float bias = (co_ok && p.bias) ? p.bias[co] : 0.0f;
-                float a2 = 1.f, b2 = 1.f;
-                if (bwd && co_ok) {
-                    a2 = expf(p.alpha2[co]);
-                    b2 = expf(p.beta2[co]);
-                }
+                const float bias = ep_lds[0][col];
+                const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
                 float pda = 0.f, pdb = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {

@@ -1,0 +1,375 @@
+// stft.hip — auraloss multi-resolution STFT loss, forward and backward, without ever materialising
+// a spectrogram (reference: stable_audio_tools/training/losses/auraloss.py — FIRFilter :76-169,
+// STFTLoss.stft :368-395, SpectralConvergenceLoss :171-181, STFTMagnitudeLoss :183-223,
+// STFTLoss.forward :397-449; stereo assembly training/autoencoders.py:142-146,:186-194).
+//
+//   sat_fir         A-weighting FIR (101-tap cross-correlation, zero pad) and its adjoint.
+//   sat_stft_fwd    per resolution: frames (reflect pad, periodic Hann) -> LDS radix-2 FFT ->
+//                   |X|,|Y| -> per-(item, view) sums  S1 = sum (|Y|-|X|)^2, S2 = sum |Y|^2,
+//                   S3 = sum |log|X| - log|Y||.
+//   sat_stft_bwd    recomputes the FFT, forms dL/dY per bin from the three sums' coefficients,
+//                   runs the adjoint DFT in LDS, applies the window, overlap-adds a block's frames in
+//                   LDS and scatters into dL/d(filtered y) with one atomic per sample.
+//
+// Two real signals ride in one complex FFT (z = x + i y), so one transform yields both spectra.
+// A "view" is a linear combination of an item's channels (sum / difference / left / right of a
+// stereo pair — SumAndDifference, auraloss.py:43-73); the FIR is linear, so it is applied once per
+// channel and the views are formed while frames are loaded.
+#include "sat_device.h"
+
+#define SAT_FFT_MAX 2048
+#define SAT_STFT_NG 8  // frame groups per workgroup (consecutive frames share the LDS overlap-add buffer)
+#define SAT_STFT_OBUF (7 * 512 + 2048)
+
+#if defined(SAT_HIPEMU)
+static inline unsigned sat_brev(unsigned v) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+static inline void sat_sincospi(float x, float* s, float* c) {
+    *s = (float)sin(3.14159265358979323846 * (double)x);
+    *c = (float)cos(3.14159265358979323846 * (double)x);
+}
+#else
+SAT_DEVICE unsigned sat_brev(unsigned v) { return __brev(v); }
+SAT_DEVICE void sat_sincospi(float x, float* s, float* c) { sincospif(x, s, c); }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// FIR
+// ---------------------------------------------------------------------------------------------
+struct SatFirParams {
+    const float* x;     // (N, T)
+    const float* taps;  // (ntaps)
+    float* y;           // (N, T)
+    int N, T, ntaps, adjoint;
+};
+#define SAT_FIR_TILE 1024
+#define SAT_FIR_MAXTAPS 257
+__global__ void __launch_bounds__(256) sat_fir_kernel(SatFirParams p) {
+    __shared__ float xs[SAT_FIR_TILE + SAT_FIR_MAXTAPS];
+    __shared__ float ts[SAT_FIR_MAXTAPS];
+    const int row = blockIdx.y;
+    const int t0 = blockIdx.x * SAT_FIR_TILE;
+    const int P = p.ntaps / 2;
+    const float* xr = p.x + (size_t)row * p.T;
+    for (int i = threadIdx.x; i < p.ntaps; i += 256) ts[i] = p.adjoint ? p.taps[p.ntaps - 1 - i] : p.taps[i];
+    for (int i = threadIdx.x; i < SAT_FIR_TILE + p.ntaps - 1; i += 256) {
+        const int t = t0 - P + i;
+        xs[i] = (t >= 0 && t < p.T) ? xr[t] : 0.0f;
+    }
+    __syncthreads();
+    for (int u = 0; u < SAT_FIR_TILE / 256; ++u) {
+        const int o = threadIdx.x + u * 256;
+        const int t = t0 + o;
+        if (t < p.T) {
+            float acc = 0.f;
+            for (int k = 0; k < p.ntaps; ++k) acc = fmaf(ts[k], xs[o + k], acc);
+            p.y[(size_t)row * p.T + t] = acc;
+        }
+    }
+}
+extern "C" int sat_fir(const float* x, const float* taps, float* y, int N, int T, int ntaps, int adjoint, void* stream) {
+    if (N <= 0 || T <= 0) { sat_set_error("sat_fir: empty shape"); return 1; }
+    if (ntaps < 1 || ntaps > SAT_FIR_MAXTAPS || (ntaps & 1) == 0) { sat_set_error("sat_fir: ntaps must be odd and <= 257"); return 1; }
+    SatFirParams p{x, taps, y, N, T, ntaps, adjoint};
+    SAT_LAUNCH(sat_fir_kernel, dim3(sat_cdiv(T, SAT_FIR_TILE), N), dim3(256), stream, p);
+    return sat_check_launch("sat_fir");
+}
+
+// ---------------------------------------------------------------------------------------------
+// STFT loss
+// ---------------------------------------------------------------------------------------------
+struct SatStftParams {
+    const float* x;       // (NI, C, T) first loss argument  ("input" in auraloss naming)
+    const float* y;       // (NI, C, T) second argument ("target"); gradients flow to this one
+    const float* views;   // (NV, 2) channel weights
+    float* partial;       // fwd: [tiles][NI][NV][3]
+    const float* coef;    // bwd: [NI][NV][3]  (c1, c2, c3)
+    float* dy;            // bwd: (NI, C, T) accumulated with atomics (caller zero-fills)
+    int NI, C, T, NV;
+    int n, log2n, hop, nframes;
+    int fb;               // frames transformed concurrently
+    int wrt_x;            // bwd: 0 = gradient w.r.t. y (second argument), 1 = w.r.t. x (first argument)
+};
+
+SAT_DEVICE int sat_reflect(int t, int T) {
+    if (t < 0) t = -t;
+    if (t >= T) t = 2 * (T - 1) - t;
+    return t;
+}
+
+struct SatFftLds {
+    float* re;
+    float* im;
+    float* twr;
+    float* twi;
+};
+
+// twiddles tw[j] = exp(-2 pi i j / n), j < n/2
+SAT_DEVICE void sat_fft_init_twiddles(const SatFftLds& L, int n) {
+    for (int j = threadIdx.x; j < n / 2; j += 256) {
+        float s, c;
+        sat_sincospi(-2.0f * (float)j / (float)n, &s, &c);
+        L.twr[j] = c;
+        L.twi[j] = s;
+    }
+}
+SAT_DEVICE float sat_hann(const SatFftLds& L, int j, int n) {
+    const int h = n >> 1;
+    const float c = (j < h) ? L.twr[j] : -L.twr[j - h];
+    return 0.5f - 0.5f * c;
+}
+// in-place radix-2 DIT over `fb` frames of length n stored bit-reversed; ends with a barrier
+SAT_DEVICE void sat_fft_run(const SatFftLds& L, int n, int log2n, int fb) {
+    const int halfn = n >> 1;
+    for (int s = 1; s <= log2n; ++s) {
+        const int half = 1 << (s - 1);
+        for (int i = threadIdx.x; i < fb * halfn; i += 256) {
+            const int fi = i >> (log2n - 1);
+            const int bi = i & (halfn - 1);
+            const int grp = bi >> (s - 1), pos = bi & (half - 1);
+            const int i0 = fi * n + (grp << s) + pos, i1 = i0 + half;
+            const int tw = pos << (log2n - s);
+            const float wr = L.twr[tw], wi = L.twi[tw];
+            const float br = L.re[i1], bim = L.im[i1];
+            const float tr = br * wr - bim * wi, ti = br * wi + bim * wr;
+            const float ar = L.re[i0], ai = L.im[i0];
+            L.re[i0] = ar + tr;
+            L.im[i0] = ai + ti;
+            L.re[i1] = ar - tr;
+            L.im[i1] = ai - ti;
+        }
+        __syncthreads();
+    }
+}
+
+SAT_DEVICE void sat_stft_load_frames(const SatStftParams& p, const SatFftLds& L, int item, int view, int f0) {
+    const int n = p.n, log2n = p.log2n;
+    const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
+    const float* x0 = p.x + (size_t)item * p.C * p.T;
+    const float* y0 = p.y + (size_t)item * p.C * p.T;
+    for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+        const int fi = i >> log2n, j = i & (n - 1);
+        const int f = f0 + fi;
+        float xv = 0.f, yv = 0.f;
+        if (f < p.nframes) {
+            const int t = sat_reflect(f * p.hop + j - (n >> 1), p.T);
+            xv = va * x0[t];
+            yv = va * y0[t];
+            if (p.C > 1) {
+                xv += vb * x0[p.T + t];
+                yv += vb * y0[p.T + t];
+            }
+            const float w = sat_hann(L, j, n);
+            xv *= w;
+            yv *= w;
+        }
+        const int jr = (int)(sat_brev((unsigned)j) >> (32 - log2n));
+        L.re[fi * n + jr] = xv;
+        L.im[fi * n + jr] = yv;
+    }
+}
+
+// spectra of the two packed real signals at bin k of frame fi
+SAT_DEVICE void sat_unpack_bins(const SatFftLds& L, int n, int fi, int k, float* xr, float* xi, float* yr, float* yi) {
+    const int k2 = (n - k) & (n - 1);
+    const float ar = L.re[fi * n + k], ai = L.im[fi * n + k];
+    const float br = L.re[fi * n + k2], bi = L.im[fi * n + k2];
+    *xr = 0.5f * (ar + br);
+    *xi = 0.5f * (ai - bi);
+    *yr = 0.5f * (ai + bi);
+    *yi = -0.5f * (ar - br);
+}
+
+__global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
+    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
+    __shared__ float red[3][4];
+    const SatFftLds L{re, im, twr, twi};
+    const int n = p.n, nb = (n >> 1) + 1;
+    const int item = blockIdx.y, view = blockIdx.z;
+    sat_fft_init_twiddles(L, n);
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int g = 0; g < SAT_STFT_NG; ++g) {
+        const int f0 = (blockIdx.x * SAT_STFT_NG + g) * p.fb;
+        if (f0 >= p.nframes) break;  // block-uniform
+        sat_stft_load_frames(p, L, item, view, f0);
+        __syncthreads();
+        sat_fft_run(L, n, p.log2n, p.fb);
+        for (int i = threadIdx.x; i < p.fb * nb; i += 256) {
+            const int fi = i / nb, k = i - fi * nb;
+            if (f0 + fi < p.nframes) {
+                float xr, xi, yr, yi;
+                sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
+                const float xm = sqrtf(fmaxf(xr * xr + xi * xi, 1e-8f));
+                const float ym = sqrtf(fmaxf(yr * yr + yi * yi, 1e-8f));
+                const float d = ym - xm;
+                s1 += d * d;
+                s2 += ym * ym;
+                s3 += fabsf(logf(xm) - logf(ym));
+            }
+        }
+        __syncthreads();
+    }
+    s1 = sat_wave_sum(s1);
+    s2 = sat_wave_sum(s2);
+    s3 = sat_wave_sum(s3);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+        red[2][threadIdx.x >> 6] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float* o = p.partial + (((size_t)blockIdx.x * p.NI + item) * p.NV + view) * 3;
+        o[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    }
+}
+
+__global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
+    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
+    __shared__ float obuf[SAT_STFT_OBUF];
+    const SatFftLds L{re, im, twr, twi};
+    const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
+    const int item = blockIdx.y, view = blockIdx.z;
+    const float c1 = p.coef[(item * p.NV + view) * 3 + 0];
+    const float c2 = p.coef[(item * p.NV + view) * 3 + 1];
+    const float c3 = p.coef[(item * p.NV + view) * 3 + 2];
+    sat_fft_init_twiddles(L, n);
+    const int fpb = SAT_STFT_NG * p.fb;
+    const int olen = (fpb - 1) * p.hop + n;
+    for (int i = threadIdx.x; i < olen; i += 256) obuf[i] = 0.f;
+    __syncthreads();
+    const int fbase = blockIdx.x * fpb;
+    for (int g = 0; g < SAT_STFT_NG; ++g) {
+        const int f0 = fbase + g * p.fb;
+        if (f0 >= p.nframes) break;
+        sat_stft_load_frames(p, L, item, view, f0);
+        __syncthreads();
+        sat_fft_run(L, n, log2n, p.fb);
+        // dL/dY per bin, kept in registers while the LDS frame buffer is recycled
+        float gr[5], gi[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            gr[u] = 0.f;
+            gi[u] = 0.f;
+            const int i = threadIdx.x + u * 256;
+            if (i < p.fb * nb) {
+                const int fi = i / nb, k = i - fi * nb;
+                if (f0 + fi < p.nframes) {
+                    float xr, xi, yr, yi;
+                    sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
+                    const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
+                    const float xm = sqrtf(fmaxf(px, 1e-8f)), ym = sqrtf(fmaxf(py, 1e-8f));
+                    const float dl = logf(ym) - logf(xm);
+                    const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+                    // clamp(min=eps) passes no gradient below eps (auraloss.py:385-387)
+                    if (!p.wrt_x) {
+                        if (py > 1e-8f) {
+                            const float gm = c1 * ((ym - xm) - c2 * ym) + c3 * sg / ym;
+                            gr[u] = gm * yr / ym;
+                            gi[u] = gm * yi / ym;
+                        }
+                    } else if (px > 1e-8f) {
+                        const float gm = -c1 * (ym - xm) - c3 * sg / xm;
+                        gr[u] = gm * xr / xm;
+                        gi[u] = gm * xi / xm;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+            re[i] = 0.f;
+            im[i] = 0.f;
+        }
+        __syncthreads();
+        // adjoint DFT: Re(sum_k G[k] e^{+2 pi i jk/n}) = Re(DFT(conj G))[j]
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int i = threadIdx.x + u * 256;
+            if (i < p.fb * nb) {
+                const int fi = i / nb, k = i - fi * nb;
+                const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
+                if (k < n) {  // k == n/2 < n always; guard keeps the index in range for n == 1 corner
+                    re[fi * n + kr] = gr[u];
+                    im[fi * n + kr] = -gi[u];
+                }
+            }
+        }
+        __syncthreads();
+        sat_fft_run(L, n, log2n, p.fb);
+        for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+            const int fi = i >> log2n, j = i & (n - 1);
+            if (f0 + fi < p.nframes) {
+                const float v = re[i] * sat_hann(L, j, n);
+                atomicAdd(&obuf[(g * p.fb + fi) * p.hop + j], v);
+            }
+        }
+        __syncthreads();
+    }
+    // scatter: obuf[i] belongs to padded-signal index fbase*hop + i  ->  sample (.. - n/2), reflected
+    const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
+    float* d0 = p.dy + (size_t)item * p.C * p.T;
+    const int last = (p.nframes - 1) * p.hop + n;  // one past the last padded index any frame touches
+    for (int i = threadIdx.x; i < olen; i += 256) {
+        const int pidx = fbase * p.hop + i;
+        if (pidx < last) {
+            const float v = obuf[i];
+            if (v != 0.f) {
+                const int t = sat_reflect(pidx - (n >> 1), p.T);
+                atomicAdd(&d0[t], va * v);
+                if (p.C > 1) atomicAdd(&d0[p.T + t], vb * v);
+            }
+        }
+    }
+}
+
+static int sat_stft_plan(int n, int hop, int T, SatStftParams* p) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    if ((1 << l) != n || n < 8 || n > SAT_FFT_MAX) return 1;
+    if (hop < 1 || hop > n) return 1;
+    if (T <= n / 2) return 1;  // reflect padding needs n/2 < T (torch.stft raises as well)
+    p->n = n;
+    p->log2n = l;
+    p->hop = hop;
+    p->nframes = 1 + T / hop;
+    p->fb = (n >= 512) ? 1 : 512 / n;
+    const int fpb = SAT_STFT_NG * p->fb;
+    if ((fpb - 1) * hop + n > SAT_STFT_OBUF) return 1;
+    if (p->fb * (n / 2 + 1) > 5 * 256) return 1;
+    return 0;
+}
+
+extern "C" int sat_stft_tiles(int n, int hop, int T) {
+    SatStftParams p;
+    if (sat_stft_plan(n, hop, T, &p)) return -1;
+    return sat_cdiv(p.nframes, SAT_STFT_NG * p.fb);
+}
+
+extern "C" int sat_stft_fwd(const float* x, const float* y, const float* views, float* partial, int NI, int C, int T,
+                            int NV, int n_fft, int hop, void* stream) {
+    SatStftParams p;
+    if (NI <= 0 || T <= 0 || NV <= 0 || (C != 1 && C != 2)) { sat_set_error("sat_stft_fwd: bad shape (C must be 1 or 2)"); return 1; }
+    if (sat_stft_plan(n_fft, hop, T, &p)) { sat_set_error("sat_stft_fwd: unsupported n_fft/hop/T (n_fft power of two in [8, 2048], hop <= n_fft, T > n_fft/2)"); return 1; }
+    p.x = x; p.y = y; p.views = views; p.partial = partial; p.coef = nullptr; p.dy = nullptr;
+    p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = 0;
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
+    SAT_LAUNCH(sat_stft_fwd_kernel, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_stft_fwd");
+}
+
+extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, const float* coef, float* dy, int NI,
+                            int C, int T, int NV, int n_fft, int hop, int wrt_x, void* stream) {
+    SatStftParams p;
+    if (NI <= 0 || T <= 0 || NV <= 0 || (C != 1 && C != 2)) { sat_set_error("sat_stft_bwd: bad shape (C must be 1 or 2)"); return 1; }
+    if (sat_stft_plan(n_fft, hop, T, &p)) { sat_set_error("sat_stft_bwd: unsupported n_fft/hop/T"); return 1; }
+    p.x = x; p.y = y; p.views = views; p.partial = nullptr; p.coef = coef; p.dy = dy;
+    p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = wrt_x;
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
+    SAT_LAUNCH(sat_stft_bwd_kernel, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_stft_bwd");
+}

@@ -183,6 +183,36 @@ class SatOps:
                                               self._stream(pre)))
         return dpre
 
+    # ------------------------------------------------------------------ MR-STFT loss
+    def fir(self, x, taps, adjoint=False):
+        """x: (N, T) -> cross-correlation with `taps` (zero pad ntaps//2); adjoint=True applies the transpose."""
+        self._f32(x, taps)
+        n, t = x.shape
+        y = torch.empty_like(x)
+        self._chk(self.lib.sat_fir(_ptr(x), _ptr(taps), _ptr(y), n, t, taps.numel(), int(adjoint), self._stream(x)))
+        return y
+
+    def stft_sums(self, x, y, views, n_fft, hop):
+        """x, y: (NI, C, T); views: (NV, 2).  Returns (NI, NV, 3) = [sum(|Y|-|X|)^2, sum|Y|^2, sum|log|X|-log|Y||]."""
+        self._f32(x, y, views)
+        ni, c, t = x.shape
+        nv = views.shape[0]
+        tiles = self.lib.sat_stft_tiles(n_fft, hop, t)
+        if tiles < 0:
+            raise RuntimeError(f"sat_stft: unsupported n_fft={n_fft} hop={hop} T={t}")
+        partial = torch.empty(tiles, ni * nv * 3, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_stft_fwd(_ptr(x), _ptr(y), _ptr(views), _ptr(partial), ni, c, t, nv, n_fft, hop, self._stream(x)))
+        return self._reduce_rows(partial, tiles, ni * nv * 3).view(ni, nv, 3)
+
+    def stft_backward(self, x, y, views, coef, dy, n_fft, hop, wrt_x=False):
+        """Accumulates dL/dy (or dL/dx with wrt_x) into `dy` (caller zero-initialised) for one resolution.
+        coef: (NI, NV, 3) = (c1, c2, c3) — see csrc/stft.hip."""
+        self._f32(x, y, views, coef, dy)
+        ni, c, t = x.shape
+        nv = views.shape[0]
+        self._chk(self.lib.sat_stft_bwd(_ptr(x), _ptr(y), _ptr(views), _ptr(coef), _ptr(dy), ni, c, t, nv, n_fft, hop,
+                                        int(wrt_x), self._stream(x)))
+
     # ------------------------------------------------------------------ optimizer
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         self._f32(p, g, m, v)

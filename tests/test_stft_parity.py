@@ -1,0 +1,129 @@
+"""Parity of the HIP multi-resolution STFT loss (csrc/stft.hip via stable_audio_tools_amd.auraloss)
+against golden values produced by the reference's auraloss and against the oracle.
+
+Loss VALUES are held to the 1e-3 bar of BASELINE.json (they agree to ~1e-5).  The loss GRADIENT
+w.r.t. the decoded signal is ill-conditioned in fp32 (log of A-weighted magnitudes near the 1e-4
+clamp): the reference's own fp32 gradient sits 2e-3 (relative L2) from the float64 result on the
+golden signal (tests/test_oracle_golden.py), so gradient parity is measured against the float64
+oracle and must be no further from it than 2x the reference's own distance.
+"""
+import pytest
+import torch
+
+import seeded
+import stft_oracle
+from golden_util import load_golden, rel_err
+
+CFG = seeded.STFT_CFG
+SR = 44100
+
+
+def _signals(device):
+    reals = torch.from_numpy(seeded.seeded_array((2, 2, 6000), 500, scale=0.1)).to(device)
+    decoded = (reals + torch.from_numpy(seeded.seeded_array((2, 2, 6000), 501, scale=0.01)).to(device))
+    return reals, decoded
+
+
+def _values(device):
+    from stable_audio_tools_amd import auraloss as al
+    g = load_golden("mrstft")
+    reals, decoded = _signals(device)
+    mx, my = reals[:, 0:1].contiguous(), decoded[:, 0:1].contiguous()
+    for n, h, w in zip(CFG["fft_sizes"], CFG["hop_sizes"], CFG["win_lengths"]):
+        assert rel_err(al.STFTLoss(n, h, w)(mx, my), g[f"stft_plain_{n}"]) < 1e-3, n
+        assert rel_err(al.STFTLoss(n, h, w, perceptual_weighting=True, sample_rate=SR).to(device)(mx, my), g[f"stft_aw_{n}"]) < 1e-3, n
+    mr = al.MultiResolutionSTFTLoss(sample_rate=SR, **CFG).to(device)
+    sd = al.SumAndDifferenceSTFTLoss(sample_rate=SR, **CFG).to(device)
+    assert rel_err(mr(mx, my), g["loss_mono"]) < 1e-3
+    assert rel_err(sd(reals, decoded), g["loss_sd"]) < 1e-3
+    assert rel_err(mr(reals[:, 0:1].contiguous(), decoded[:, 0:1].contiguous()), g["loss_left"]) < 1e-3
+    assert rel_err(mr(reals[:, 1:2].contiguous(), decoded[:, 1:2].contiguous()), g["loss_right"]) < 1e-3
+    fused = al.AutoencoderSpectralLoss(SR, **CFG).to(device)
+    assert rel_err(fused(reals, decoded), g["total"]) < 1e-3
+
+
+def _gradients(device):
+    from stable_audio_tools_amd import auraloss as al
+    g = load_golden("mrstft")
+    reals, decoded = _signals(device)
+    d = decoded.clone().requires_grad_(True)
+    fused = al.AutoencoderSpectralLoss(SR, **CFG).to(device)
+    (gr,) = torch.autograd.grad(fused(reals, d), d)
+    # three separate reference-style modules must give the same gradient as the fused form
+    sd = al.SumAndDifferenceSTFTLoss(sample_rate=SR, **CFG).to(device)
+    mr = al.MultiResolutionSTFTLoss(sample_rate=SR, **CFG).to(device)
+    d2 = decoded.clone().requires_grad_(True)
+    tot = sd(reals, d2) + 0.5 * mr(reals[:, 0:1], d2[:, 0:1]) + 0.5 * mr(reals[:, 1:2], d2[:, 1:2])
+    (gr2,) = torch.autograd.grad(tot, d2)
+    assert float((gr - gr2).norm() / gr.norm()) < 2e-3
+    # float64 truth from the oracle
+    r64 = reals.detach().cpu().double()
+    d64 = decoded.detach().cpu().double().requires_grad_(True)
+    (g64,) = torch.autograd.grad(stft_oracle.autoencoder_spectral_loss(r64, d64, CFG, SR), d64)
+    ref = torch.from_numpy(g["grad_decoded"]).double()
+    floor_ref = float((ref - g64).norm() / g64.norm())
+    err = float((gr.detach().cpu().double() - g64).norm() / g64.norm())
+    assert err < max(2 * floor_ref, 5e-3), (err, floor_ref)
+    # swapped order: gradient w.r.t. the FIRST argument
+    x = decoded.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(sd(x, reals), x)
+    x64 = decoded.detach().cpu().double().requires_grad_(True)
+    (gx64,) = torch.autograd.grad(stft_oracle.sum_and_difference_loss(
+        x64, r64, CFG["fft_sizes"], CFG["hop_sizes"], CFG["win_lengths"], stft_oracle.aweighting_fir_taps(SR)), x64)
+    assert float((gx.detach().cpu().double() - gx64).norm() / gx64.norm()) < 1e-2
+
+
+def test_fir_and_adjoint_simulator(emu):
+    taps = stft_oracle.aweighting_fir_taps(SR)
+    x = torch.from_numpy(seeded.seeded_array((3, 2500), 7))
+    y = emu.fir(x, taps)
+    assert rel_err(y, stft_oracle.fir_filter(x, taps)) < 1e-5
+    # <FIR x, z> == <x, FIR^T z>
+    z = torch.from_numpy(seeded.seeded_array((3, 2500), 8))
+    lhs = float((y.double() * z.double()).sum())
+    rhs = float((x.double() * emu.fir(z, taps, adjoint=True).double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+def test_stft_loss_values_simulator(emu_modules):
+    _values("cpu")
+
+
+def test_stft_loss_gradients_simulator(emu_modules):
+    _gradients("cpu")
+
+
+def test_unsupported_configurations_raise():
+    from stable_audio_tools_amd import auraloss as al
+    with pytest.raises(NotImplementedError):
+        al.STFTLoss(1024, 256, 600)
+    with pytest.raises(NotImplementedError):
+        al.MultiResolutionSTFTLoss(w_lin_mag=1.0, fft_sizes=[64], hop_sizes=[16], win_lengths=[64])
+    with pytest.raises(ValueError):
+        al.STFTLoss(64, 16, 64, perceptual_weighting=True)
+
+
+@pytest.mark.gpu
+def test_stft_loss_values_gpu(hip):
+    _values("cuda")
+
+
+@pytest.mark.gpu
+def test_stft_loss_gradients_gpu(hip):
+    _gradients("cuda")
+
+
+@pytest.mark.gpu
+def test_stft_linearity_property_full_size_gpu(hip):
+    """Size-independent property at BASELINE.json's full length (T = 2097152): the sums are homogeneous —
+    scaling both signals by a scales S1, S2 by a^2 and leaves S3 unchanged."""
+    t = 2097152
+    x = torch.randn(1, 2, t, device="cuda") * 0.1
+    y = x + 0.01 * torch.randn_like(x)
+    views = torch.tensor([[1.0, 1.0], [1.0, -1.0], [1.0, 0.0], [0.0, 1.0]], device="cuda")
+    for n, h in ((2048, 512), (32, 8)):
+        s = hip.stft_sums(x, y, views, n, h)
+        s2 = hip.stft_sums(2 * x, 2 * y, views, n, h)
+        assert rel_err(s2[..., 0], 4 * s[..., 0]) < 1e-4
+        assert rel_err(s2[..., 1], 4 * s[..., 1]) < 1e-4
+        assert rel_err(s2[..., 2], s[..., 2]) < 1e-3
