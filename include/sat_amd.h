@@ -1,0 +1,126 @@
+/* sat_amd.h — C-ABI of libsat_amd.so, the MI355X (gfx950) implementation of stable-audio-tools'
+ * denoising hot path.
+ *
+ * The reference (Stability-AI/stable-audio-tools) is pure Python: it has no FFI, and its boundary
+ * for this path is the nn.Module API.  This header is therefore the boundary a
+ * maintainer binds ONCE (ctypes; stable_audio_tools_amd/_lib.py is that binding)
+ * underneath module shims that keep the reference's class names and state_dict keys.  Each entry
+ * point cites the reference code whose device work it replaces (paths relative to
+ * stable_audio_tools/ in the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller (the PyTorch caching allocator),
+ *     including workspaces and partial-sum buffers; the library allocates nothing and keeps no state
+ *     besides a thread-local last-error string;
+ *   - tensors are fp32, contiguous, (B, C, T) with T fastest unless stated otherwise;
+ *   - `stream` is a hipStream_t; every call is asynchronous and stream-ordered, no hidden syncs;
+ *   - return value: 0 = ok, non-zero = error (sat_last_error() describes it); nothing throws;
+ *   - re-entrant; one process per GPU.
+ */
+#ifndef SAT_AMD_H
+#define SAT_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sat_abi_version(void);
+int sat_is_simulator(void);          /* 0 for the gfx950 library; 1 only for the CPU test-suite's simulator build */
+const char* sat_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Oobleck conv stack — models/autoencoders.py:23-27 (WNConv1d / WNConvTranspose1d), :58-83
+ * (ResidualUnit), :233-283 (Encoder/DecoderBlock), :285-362 (OobleckEncoder/Decoder);
+ * SnakeBeta models/blocks.py:291-329.  Replaces F.conv1d / F.conv_transpose1d / snake_beta and
+ * their autograd.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y = [tanh]( conv1d(snake(x; alpha, beta), W, stride, dil, pad) + bias + res )
+ * or, when x2 != NULL (backward epilogue of the conv that consumed snake(x2)):
+ *   y = conv1d(x, W) * dsnake(x2)/dx2 + res, and per-tile partial sums of dL/dlog-alpha2,
+ *   dL/dlog-beta2 in part_da / part_db ([sat_conv1d_partial_rows(B,Tout)][Cout], reduce with
+ *   sat_reduce_splits).
+ * w_packed: [Cin][K][Cout]  (sat_pack_weights mode 0; mode 1 of the forward weight for the
+ * stride-1 data-gradient).  alpha/beta, bias, res may be NULL.  stride > 1 requires dil == 1. */
+int sat_conv1d(const float* x, const float* w_packed, const float* bias, const float* alpha, const float* beta,
+               const float* res, float* y, const float* x2, const float* alpha2, const float* beta2,
+               float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride,
+               int dil, int pad, int tanh_out, void* stream);
+int sat_conv1d_partial_rows(int B, int Tout);
+
+/* Transposed conv, K == 2*stride (the Oobleck resampler, autoencoders.py:266-268), polyphase form.
+ * Also the data-gradient of the strided down-conv (:245-247).  w_packed: [r][j][Cin][Cout]
+ * (sat_pack_weights mode 2).  Same prologue/epilogue options as sat_conv1d. stride in [2, 8]. */
+int sat_convtr1d(const float* x, const float* w_packed, const float* bias, const float* alpha, const float* beta,
+                 const float* res, float* y, const float* x2, const float* alpha2, const float* beta2,
+                 float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride,
+                 int pad, int tanh_out, void* stream);
+int sat_convtr1d_partial_rows(int B, int Tout, int stride, int pad);
+
+/* Weight gradient of any of the above as a split-K GEMM over (batch, time):
+ *   dW[m][n][k] = sum_{b,t} actA(lo[b][m][t]) * actB(hi[b][n][t*stride + k*dil - pad])
+ * snake_on: 0 none, 1 snake on `lo` rows (ConvTranspose input), 2 on `hi` rows (Conv1d input).
+ * Writes sat_conv_wgrad_nsplit(...) slabs of M*N*K floats into `partial`, element (m,n,k) at
+ * m*so_m + n*so_n + k*so_k; sum the slabs with sat_reduce_splits. */
+int sat_conv_wgrad(const float* lo, const float* hi, const float* alpha, const float* beta, int snake_on,
+                   float* partial, long long so_m, long long so_n, long long so_k, int B, int M, int N, int Tlo,
+                   int Thi, int K, int stride, int dil, int pad, void* stream);
+int sat_conv_wgrad_nsplit(int B, int M, int N, int Tlo, int K, int stride, int dil);
+
+/* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */
+int sat_reduce_splits(const float* partial, float* out, long long count, int nsplit, float scale, int accumulate,
+                      void* stream);
+/* bias gradient: partial[z][c] = sum over the z-th time slice and all b of x[b][c][t]; z < sat_rowsum_nsplit(T) */
+int sat_rowsum(const float* x, float* partial, int B, int C, int T, void* stream);
+int sat_rowsum_nsplit(int T);
+
+/* torch.nn.utils.weight_norm (dim 0) fold and its gradient — autoencoders.py:23-27.
+ * v: (D0, R) g: (D0).  fold: w = g*v/||v||, norm[d] = ||v[d]||.  grad: dv, dg from dw. */
+int sat_wn_fold(const float* v, const float* g, float* w, float* norm, int D0, int R, void* stream);
+int sat_wn_grad(const float* v, const float* g, const float* norm, const float* dw, float* dv, float* dg, int D0,
+                int R, void* stream);
+/* torch weight w[D0][D1][K] -> GEMM-side layout.  mode 0: [D1][k][D0]; 1: [D0][K-1-k][D1]; 2: [r][j][D0][D1], k=r+j*S */
+int sat_pack_weights(const float* w, float* out, int D0, int D1, int K, int S, int mode, void* stream);
+
+/* VAEBottleneck — models/bottleneck.py:105-133.  pre: (B, 2C, T) = [mean | scale]; noise: (B, C, T)
+ * N(0,1) draw supplied by the caller.  fwd: z = noise*(softplus(scale)+1e-4)+mean and kl partial sums
+ * (sat_vae_nblocks(B*C*T) floats; kl = sum / (B*T)).  bwd: dpre from dz (may be NULL) and the device
+ * scalar dkl (may be NULL). */
+int sat_vae_nblocks(long long n);
+int sat_vae_sample_fwd(const float* pre, const float* noise, float* z, float* kl_partial, int B, int C, int T,
+                       void* stream);
+int sat_vae_sample_bwd(const float* pre, const float* noise, const float* dz, const float* dkl, float* dpre, int B,
+                       int C, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-resolution STFT loss — training/losses/auraloss.py: FIRFilter :76-169, STFTLoss :226-449,
+ * MultiResolutionSTFTLoss :451-539, SumAndDifferenceSTFTLoss :542-615.  Replaces F.conv1d (FIR),
+ * torch.stft, the magnitude/log/norm reductions and their autograd.
+ * ---------------------------------------------------------------------------------------------- */
+/* y[n][t] = sum_k taps[k] * x[n][t + k - ntaps/2] (zero padded); adjoint != 0 applies the transpose. x: (N, T) */
+int sat_fir(const float* x, const float* taps, float* y, int N, int T, int ntaps, int adjoint, void* stream);
+/* One resolution. x, y: (NI, C, T), C in {1,2}; views: (NV, 2) channel weights (sum/diff/left/right).
+ * fwd writes partial[tile][NI][NV][3] = {sum(|Y|-|X|)^2, sum|Y|^2, sum|log|X|-log|Y||}, tile < sat_stft_tiles().
+ * bwd accumulates (atomics; caller zero-fills) dL/dy — or dL/dx if wrt_x — given coef[NI][NV][3] =
+ * {c1, c2, c3}: dL/d|Y| = c1*((|Y|-|X|) - c2*|Y|) + c3*sign(log|Y|-log|X|)/|Y|.
+ * Periodic Hann window of length n_fft, centre/reflect padding, hop, one-sided, unnormalised, power clamped at 1e-8. */
+int sat_stft_tiles(int n_fft, int hop, int T);
+int sat_stft_fwd(const float* x, const float* y, const float* views, float* partial, int NI, int C, int T, int NV,
+                 int n_fft, int hop, void* stream);
+int sat_stft_bwd(const float* x, const float* y, const float* views, const float* coef, float* dy, int NI, int C,
+                 int T, int NV, int n_fft, int hop, int wrt_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer — torch.optim.AdamW as configured by training/utils.py:60-79 and
+ * configs/model_configs/autoencoders/stable_audio_2_0_vae.json:41-49, over ONE flat buffer; optional
+ * EMA shadow (ema_pytorch.EMA, training/autoencoders.py:262-270) updated from the pre-step parameters.
+ * grad_scale folds the 1/world_size of the data-parallel mean into the same pass.
+ * ---------------------------------------------------------------------------------------------- */
+int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, float* ema, float ema_decay,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAT_AMD_H */

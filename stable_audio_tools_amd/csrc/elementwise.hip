@@ -230,11 +230,15 @@ struct SatAdamParams {
     long long n;
     float lr, b1, b2, eps, wd, bc1, bc2s;  // bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
     float gscale;
+    float* ema;       // optional EMA shadow of the parameters (null = none)
+    float ema_decay;  // ema = decay*ema + (1-decay)*p_before_step  (the wrapper calls ema.update()
+                      // BEFORE optimizer.step(): training/autoencoders.py:504-515)
 };
 __global__ void __launch_bounds__(256) sat_adamw_kernel(SatAdamParams a) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         const float g = a.g[i] * a.gscale;
         float p = a.p[i];
+        if (a.ema) a.ema[i] = a.ema_decay * a.ema[i] + (1.0f - a.ema_decay) * p;
         p *= (1.0f - a.lr * a.wd);
         const float m = a.b1 * a.m[i] + (1.0f - a.b1) * g;
         const float v = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
@@ -246,10 +250,11 @@ __global__ void __launch_bounds__(256) sat_adamw_kernel(SatAdamParams a) {
     }
 }
 extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, float* ema,
+                              float ema_decay, void* stream) {
     if (n <= 0 || step < 1) { sat_set_error("sat_adamw_step: empty buffer or step < 1"); return 1; }
     SatAdamParams a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                    1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), grad_scale};
+                    1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), grad_scale, ema, ema_decay};
     long long nb = sat_cdivll(n, 256);
     if (nb > 4096) nb = 4096;
     SAT_LAUNCH(sat_adamw_kernel, dim3((unsigned)nb), dim3(256), stream, a);

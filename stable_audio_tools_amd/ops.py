@@ -214,10 +214,10 @@ class SatOps:
                                         int(wrt_x), self._stream(x)))
 
     # ------------------------------------------------------------------ optimizer
-    def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-        self._f32(p, g, m, v)
+    def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
+        self._f32(p, g, m, v, ema)
         self._chk(self.lib.sat_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
-                                          weight_decay, step, grad_scale, self._stream(p)))
+                                          weight_decay, step, grad_scale, _ptr(ema), ema_decay, self._stream(p)))
 
 
 _ops = None
