@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="items per GPU per step")
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-samples", type=int, default=65536)
+    ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
     return ap.parse_args()
 
 
@@ -44,38 +44,31 @@ class ConvProfiler:
     and tallies its ALGORITHMIC flops (2 * Cin * Cout * K * Tout * B per launch — DESIGN.md §Kernels)."""
 
     def __init__(self, ops):
-        self.ops = ops
         self.records = []
         self.enabled = False
-        self._orig = ops.conv1d
+        orig = ops.lib.sat_conv1d   # the C-ABI entry point: exactly one sat_conv1d_kernel launch per call
 
-        def timed(x, w_packed, cout, k, stride=1, dil=1, pad=0, tout=None, **kw):
+        def timed(*a):
             if not self.enabled:
-                return self._orig(x, w_packed, cout, k, stride, dil, pad, tout, **kw)
-            b, cin, tin = x.shape
-            to = tout if tout is not None else (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+                return orig(*a)
+            b, cin, cout, _tin, tout, k = a[12:18]
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = self._orig(x, w_packed, cout, k, stride, dil, pad, tout, **kw)
-            # the wrapper launches reductions after the conv when dsnake is given; bracket only the conv
+            s.record()          # torch's current stream == the stream handed to the C-ABI (ops._stream)
+            rc = orig(*a)
             e.record()
-            self.records.append((s, e, 2.0 * cin * cout * k * to * b, kw.get("dsnake") is not None))
-            return out
+            self.records.append((s, e, 2.0 * b * cin * cout * k * tout))
+            return rc
 
-        ops.conv1d = timed
+        ops.lib.sat_conv1d = timed
 
     def summary(self):
         torch.cuda.synchronize()
         ms = fl = 0.0
-        n = 0
-        for s, e, f, bwd in self.records:
-            if bwd:
-                continue  # dsnake launches are followed by two small reduce kernels inside the bracket; keep the pure ones
+        for s, e, f in self.records:
             ms += s.elapsed_time(e)
             fl += f
-            n += 1
-        return n, ms, fl
+        return len(self.records), ms, fl
 
 
 def cpu_baseline(cfg, nsamples):
@@ -87,7 +80,9 @@ def cpu_baseline(cfg, nsamples):
     import stft_oracle
     import vae_oracle
     from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
-    cores = os.cpu_count() or 1
+    # torch's CPU conv path degrades badly when oversubscribed (measured: 256 threads on the GPU box's host
+    # took 700 s for what 8 threads do in ~25 s) — use a bounded pool and report the threads actually used
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     # same random-init recipe as the GPU replica (reference-format state_dict consumed by the oracle)
     torch.manual_seed(1234)
@@ -184,8 +179,9 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "sat_conv1d_kernel", "launches": nlaunch,
                          "avg_launch_ms": (ms / nlaunch) if nlaunch else None,
-                         "note": "algorithmic flops 2*Cin*Cout*K*Tout*B per launch over HIP-event time of the forward/"
-                                 "plain-dgrad launches in the timed region; fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak"},
+                         "note": "algorithmic flops 2*Cin*Cout*K*Tout*B per launch over HIP-event time of EVERY sat_conv1d_kernel "
+                                 "launch in the timed region (forward convs and data-gradients, incl. the dsnake epilogue "
+                                 "variant); peak = fp32 MFMA (v_mfma_f32_32x32x2_f32) dense"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)

@@ -38,8 +38,8 @@ const char* sat_last_error(void);
 /* y = [tanh]( conv1d(snake(x; alpha, beta), W, stride, dil, pad) + bias + res )
  * or, when x2 != NULL (backward epilogue of the conv that consumed snake(x2)):
  *   y = conv1d(x, W) * dsnake(x2)/dx2 + res, and per-tile partial sums of dL/dlog-alpha2,
- *   dL/dlog-beta2 in part_da / part_db ([sat_conv1d_partial_rows(B,Tout)][Cout], reduce with
- *   sat_reduce_splits).
+ *   dL/dlog-beta2 in part_da / part_db ([Cout][sat_conv1d_partial_rows(B,Tout)], reduce with
+ *   sat_rowsum).
  * w_packed: [Cin][K][Cout]  (sat_pack_weights mode 0; mode 1 of the forward weight for the
  * stride-1 data-gradient).  alpha/beta, bias, res may be NULL.  stride > 1 requires dil == 1. */
 int sat_conv1d(const float* x, const float* w_packed, const float* bias, const float* alpha, const float* beta,
@@ -100,7 +100,7 @@ int sat_vae_sample_bwd(const float* pre, const float* noise, const float* dz, co
 /* y[n][t] = sum_k taps[k] * x[n][t + k - ntaps/2] (zero padded); adjoint != 0 applies the transpose. x: (N, T) */
 int sat_fir(const float* x, const float* taps, float* y, int N, int T, int ntaps, int adjoint, void* stream);
 /* One resolution. x, y: (NI, C, T), C in {1,2}; views: (NV, 2) channel weights (sum/diff/left/right).
- * fwd writes partial[tile][NI][NV][3] = {sum(|Y|-|X|)^2, sum|Y|^2, sum|log|X|-log|Y||}, tile < sat_stft_tiles().
+ * fwd writes partial[NI][NV][3][tile] = {sum(|Y|-|X|)^2, sum|Y|^2, sum|log|X|-log|Y||}, tile < sat_stft_tiles()  (sum over tiles: sat_rowsum).
  * bwd accumulates (atomics; caller zero-fills) dL/dy — or dL/dx if wrt_x — given coef[NI][NV][3] =
  * {c1, c2, c3}: dL/d|Y| = c1*((|Y|-|X|) - c2*|Y|) + c3*sign(log|Y|-log|X|)/|Y|.
  * Periodic Hann window of length n_fft, centre/reflect padding, hop, one-sided, unnormalised, power clamped at 1e-8. */

@@ -194,8 +194,9 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
         __syncthreads();
         if (tid < SAT_CO_T && co0 + tid < p.Cout) {
             const size_t row = (size_t)b * gridDim.x + blockIdx.x;
-            p.part_da[row * p.Cout + co0 + tid] = red_lds[0][0][tid] + red_lds[0][1][tid];
-            p.part_db[row * p.Cout + co0 + tid] = red_lds[1][0][tid] + red_lds[1][1][tid];
+            const size_t nrows = (size_t)p.B * gridDim.x;  // layout [Cout][rows]: reduced by sat_rowsum
+            p.part_da[(size_t)(co0 + tid) * nrows + row] = red_lds[0][0][tid] + red_lds[0][1][tid];
+            p.part_db[(size_t)(co0 + tid) * nrows + row] = red_lds[1][0][tid] + red_lds[1][1][tid];
         }
     }
 }

@@ -85,7 +85,7 @@ struct SatStftParams {
     const float* x;       // (NI, C, T) first loss argument  ("input" in auraloss naming)
     const float* y;       // (NI, C, T) second argument ("target"); gradients flow to this one
     const float* views;   // (NV, 2) channel weights
-    float* partial;       // fwd: [tiles][NI][NV][3]
+    float* partial;       // fwd: [NI][NV][3][tiles]
     const float* coef;    // bwd: [NI][NV][3]  (c1, c2, c3)
     float* dy;            // bwd: (NI, C, T) accumulated with atomics (caller zero-fills)
     int NI, C, T, NV;
@@ -223,8 +223,9 @@ __global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
     }
     __syncthreads();
     if (threadIdx.x < 3) {
-        float* o = p.partial + (((size_t)blockIdx.x * p.NI + item) * p.NV + view) * 3;
-        o[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        // layout [(item, view, q)][tile]: reduced over tiles by sat_rowsum
+        float* o = p.partial + ((((size_t)item * p.NV + view) * 3 + threadIdx.x) * gridDim.x + blockIdx.x);
+        *o = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
     }
 }
 

@@ -80,6 +80,11 @@ class SatOps:
         self._chk(self.lib.sat_reduce_splits(_ptr(partial), _ptr(out), count, rows, scale, 0, self._stream(partial)))
         return out
 
+    def _sum_last(self, partial):
+        """(C, R) -> (C,): bandwidth-efficient reduction of per-tile partial sums (sat_rowsum)."""
+        c, r = partial.shape
+        return self.rowsum(partial.view(1, c, r))
+
     def conv1d(self, x, w_packed, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
                tanh_out=False, dsnake=None):
         """y = conv(snake(x)) [+bias] [+res] ; or, with dsnake=(x2, alpha2, beta2):
@@ -96,13 +101,13 @@ class SatOps:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
             rows = self.lib.sat_conv1d_partial_rows(b, tout)
-            pda = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
-            pdb = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+            pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
+            pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
         self._chk(self.lib.sat_conv1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
                                       _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                                       b, cin, cout, tin, tout, k, stride, dil, pad, int(tanh_out), self._stream(x)))
         if dsnake is not None:
-            return y, self._reduce_rows(pda, rows, cout), self._reduce_rows(pdb, rows, cout)
+            return y, self._sum_last(pda), self._sum_last(pdb)
         return y
 
     def convtr1d(self, x, w_packed, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
@@ -121,13 +126,13 @@ class SatOps:
             rows = self.lib.sat_convtr1d_partial_rows(b, tout, stride, pad)
             if rows < 0:
                 raise RuntimeError("sat_convtr1d: unsupported stride")
-            pda = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
-            pdb = torch.empty(rows, cout, dtype=torch.float32, device=x.device)
+            pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
+            pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
         self._chk(self.lib.sat_convtr1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
                                         _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                                         b, cin, cout, tin, tout, k, stride, pad, int(tanh_out), self._stream(x)))
         if dsnake is not None:
-            return y, self._reduce_rows(pda, rows, cout), self._reduce_rows(pdb, rows, cout)
+            return y, self._sum_last(pda), self._sum_last(pdb)
         return y
 
     def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False):
@@ -170,7 +175,7 @@ class SatOps:
         nb = self.lib.sat_vae_nblocks(b * c * t)
         klp = torch.empty(nb, dtype=torch.float32, device=pre.device)
         self._chk(self.lib.sat_vae_sample_fwd(_ptr(pre), _ptr(noise), _ptr(z), _ptr(klp), b, c, t, self._stream(pre)))
-        kl = self._reduce_rows(klp, nb, 1, 1.0 / (b * t)).view(())
+        kl = (self._sum_last(klp.view(1, nb)) * (1.0 / (b * t))).view(())
         return z, kl
 
     def vae_sample_bwd(self, pre, noise, dz, dkl):
@@ -200,9 +205,9 @@ class SatOps:
         tiles = self.lib.sat_stft_tiles(n_fft, hop, t)
         if tiles < 0:
             raise RuntimeError(f"sat_stft: unsupported n_fft={n_fft} hop={hop} T={t}")
-        partial = torch.empty(tiles, ni * nv * 3, dtype=torch.float32, device=x.device)
+        partial = torch.empty(ni * nv * 3, tiles, dtype=torch.float32, device=x.device)
         self._chk(self.lib.sat_stft_fwd(_ptr(x), _ptr(y), _ptr(views), _ptr(partial), ni, c, t, nv, n_fft, hop, self._stream(x)))
-        return self._reduce_rows(partial, tiles, ni * nv * 3).view(ni, nv, 3)
+        return self._sum_last(partial).view(ni, nv, 3)
 
     def stft_backward(self, x, y, views, coef, dy, n_fft, hop, wrt_x=False):
         """Accumulates dL/dy (or dL/dx with wrt_x) into `dy` (caller zero-initialised) for one resolution.
