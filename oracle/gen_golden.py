@@ -130,10 +130,51 @@ def gen_stft(seed, batch=2, length=6000):
     print(f"mrstft: total {total.item():.6f} |grad| {g.norm().item():.4e}")
 
 
+def dit_inputs(name, batch=2, length=37, ctx_len=11, seed=600):
+    """Seeded DiT inputs shared with the tests (also imported by tests/test_dit_parity.py)."""
+    cfg = seeded.DIT_CONFIGS[name]
+    rs = np.random.RandomState(seed)
+    out = {
+        "x": torch.from_numpy(seeded.seeded_array((batch, cfg["io_channels"], length), seed + 1)),
+        "t": torch.from_numpy(rs.uniform(0.05, 0.95, size=(batch,)).astype(np.float32)),
+        "cross_attn_cond": torch.from_numpy(seeded.seeded_array((batch, ctx_len, cfg["cond_token_dim"]), seed + 2)),
+        "global_embed": torch.from_numpy(seeded.seeded_array((batch, cfg["global_cond_dim"]), seed + 3)),
+    }
+    if cfg.get("prepend_cond_dim", 0) > 0:
+        out["prepend_cond"] = torch.from_numpy(seeded.seeded_array((batch, 3, cfg["prepend_cond_dim"]), seed + 4))
+        # the reference concatenates prepend masks unconditionally (dit.py:188) -> a mask must be supplied
+        out["prepend_cond_mask"] = torch.ones(batch, 3, dtype=torch.bool)
+    return out
+
+
+def gen_dit(name, seed):
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    cfg = seeded.DIT_CONFIGS[name]
+    model = DiffusionTransformer(**cfg).float()
+    model.train(False)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith("inv_freq")}
+    sd = seeded.seeded_state_dict(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    inp = dit_inputs(name)
+    with torch.no_grad():
+        plain = model(inp["x"], inp["t"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"],
+                      prepend_cond=inp.get("prepend_cond"), prepend_cond_mask=inp.get("prepend_cond_mask"),cfg_scale=1.0)
+        guided = model(inp["x"], inp["t"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"],
+                       prepend_cond=inp.get("prepend_cond"), prepend_cond_mask=inp.get("prepend_cond_mask"),cfg_scale=6.0, scale_phi=0.75)
+        hidden = model(inp["x"], inp["t"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"],
+                       prepend_cond=inp.get("prepend_cond"), prepend_cond_mask=inp.get("prepend_cond_mask"),return_info=True)[1]["hidden_states"]
+    out = {"plain": plain.numpy(), "guided": guided.numpy(), "hidden_first": hidden[0].numpy(), "hidden_last": hidden[-1].numpy(),
+           "keys": np.array(sorted(model.state_dict().keys()))}
+    np.savez_compressed(os.path.join(OUT, f"dit_{name}.npz"), **out)
+    print(f"dit_{name}: out {tuple(plain.shape)} |plain| {plain.abs().max():.3f} |guided| {guided.abs().max():.3f} params {sum(p.numel() for p in model.parameters())}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refimport.import_reference()
     torch.set_num_threads(8)
+    for i, name in enumerate(seeded.DIT_CONFIGS):
+        gen_dit(name, seed=700 + 10 * i)
     gen_vae("tiny", batch=2, in_len=512, seed=100)
     gen_vae("mid", batch=1, in_len=1536, seed=200)
     gen_vae("mono", batch=2, in_len=320, seed=300)

@@ -49,6 +49,21 @@ STFT_CFG = {
 }
 
 
+# DiffusionTransformer kwargs (the `model.diffusion.config` JSON block).  BASELINE.json configs[0]:
+# tiny DiT, 4 layers, d=256, 4 heads of 64, 64-d context -> GQA 4 q-heads / 1 kv-head, run with both
+# global-conditioning modes.
+DIT_CONFIGS = {
+    "tiny_prepend": dict(io_channels=4, embed_dim=256, depth=4, num_heads=4, cond_token_dim=64, global_cond_dim=64,
+                         project_cond_tokens=False, global_cond_type="prepend"),
+    "tiny_adaln": dict(io_channels=4, embed_dim=256, depth=4, num_heads=4, cond_token_dim=64, global_cond_dim=64,
+                       project_cond_tokens=False, global_cond_type="adaLN"),
+    # projected context (full multi-head cross attention), rectified-flow objective, prepend conditioning tokens
+    "small_rf": dict(io_channels=6, embed_dim=128, depth=2, num_heads=2, cond_token_dim=48, global_cond_dim=32,
+                     prepend_cond_dim=24, project_cond_tokens=True, global_cond_type="prepend",
+                     diffusion_objective="rectified_flow"),
+}
+
+
 def seeded_array(shape, seed, scale=1.0):
     rs = np.random.RandomState(seed)
     return (rs.standard_normal(size=shape) * scale).astype(np.float32)
@@ -68,6 +83,16 @@ def seeded_state_dict(shapes, seed):
             a = 0.1 * rs.standard_normal(size=shape)
         elif key.endswith("alpha") or key.endswith("beta"):
             a = 0.3 * rs.standard_normal(size=shape)
+        elif key.endswith("gamma"):
+            a = 1.0 + 0.1 * rs.standard_normal(size=shape)
+        elif key.endswith("to_scale_shift_gate"):
+            a = rs.standard_normal(size=shape) / np.sqrt(shape[0] / 6)
+        elif key.endswith("timestep_features.weight"):
+            a = rs.standard_normal(size=shape)
+        elif key.endswith(".weight") and len(shape) >= 2:
+            # nn.Linear / 1x1 Conv1d: includes the branches the reference zero-initialises (to_out, ff.2,
+            # pre/postprocess_conv) so that parity tests are not vacuous
+            a = rs.standard_normal(size=shape) / np.sqrt(int(np.prod(shape[1:])))
         else:
             a = rs.standard_normal(size=shape)
         out[key] = a.astype(np.float32)

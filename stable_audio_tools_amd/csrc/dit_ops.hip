@@ -1,0 +1,320 @@
+// dit_ops.hip — the HBM-bound operators of the DiT block (stable_audio_tools/models/transformer.py):
+//   sat_layernorm_fwd/bwd   LayerNorm.forward :236-241 (gamma, zero beta buffer, eps 1e-5, fp32 math) fused with
+//                           the adaLN modulation x*(1+scale)+shift of TransformerBlock.forward :682, :697
+//   sat_rope_tables / sat_rope_apply   RotaryEmbedding.forward :125-138 + apply_rotary_pos_emb :155-174
+//                           (fp32, first rot_dim dims of every head, NeoX half rotation), applied in place
+//                           on the q and k slices of the fused qkv projection
+//   sat_swiglu_fwd/bwd      GLU.forward :274-275  (x * silu(gate))
+//   sat_gate_residual       x * sigmoid(1 - gate) + residual   :684-686, :699-701
+// One wave per token row, wavefront-shuffle reductions, 16-byte accesses where the layout allows.
+// dtype: 0 = fp32, 1 = bf16 tensors (statistics and math always fp32).
+#include "sat_device.h"
+
+template <typename T> struct SatIO;
+template <> struct SatIO<float> {
+    static SAT_DEVICE float ld(const void* p, long long i) { return ((const float*)p)[i]; }
+    static SAT_DEVICE void st(void* p, long long i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct SatIO<short> {
+    static SAT_DEVICE float ld(const void* p, long long i) { return sat_bf16_to_f32(((const short*)p)[i]); }
+    static SAT_DEVICE void st(void* p, long long i, float v) { ((short*)p)[i] = sat_f32_to_bf16(v); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (+ adaLN modulate)
+// ------------------------------------------------------------------------------------------------
+struct SatLnParams {
+    const void* x;        // (rows, D)
+    const float* gamma;   // (D) fp32 master
+    const float* beta;    // (D) or null
+    const void* scale;    // (B, D) or null : y = ln * (1 + scale[b]) + shift[b]
+    const void* shift;    // (B, D)
+    void* y;              // (rows, D)
+    float* mean;          // (rows) saved for backward (may be null)
+    float* rstd;          // (rows)
+    // backward
+    const void* dy;       // (rows, D)
+    void* dx;             // (rows, D)
+    float* part;          // [3][nblocks_y][D] partial column sums: d_gamma, d_scale(per batch), d_shift(per batch)
+    long long mod_stride; // element stride between batches in scale/shift (>= D)
+    int rows, D, rows_per_batch;
+    float eps;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_fwd_kernel(SatLnParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;   // whole wave exits together; no block barrier below
+    const long long base = (long long)row * p.D;
+    float s = 0.f;
+    for (int i = lane; i < p.D; i += 64) s += SatIO<T>::ld(p.x, base + i);
+    const float mean = sat_wave_sum(s) / (float)p.D;
+    float v = 0.f;
+    for (int i = lane; i < p.D; i += 64) {
+        const float d = SatIO<T>::ld(p.x, base + i) - mean;
+        v += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(sat_wave_sum(v) / (float)p.D + p.eps);
+    const long long mb = p.scale ? (long long)(row / p.rows_per_batch) * p.mod_stride : 0;
+    for (int i = lane; i < p.D; i += 64) {
+        float o = (SatIO<T>::ld(p.x, base + i) - mean) * rstd * p.gamma[i];
+        if (p.beta) o += p.beta[i];
+        if (p.scale) o = o * (1.0f + SatIO<T>::ld(p.scale, mb + i)) + SatIO<T>::ld(p.shift, mb + i);
+        SatIO<T>::st(p.y, base + i, o);
+    }
+    if (lane == 0 && p.mean) {
+        p.mean[row] = mean;
+        p.rstd[row] = rstd;
+    }
+}
+
+// dx: one wave per row.
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_kernel(SatLnParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const long long base = (long long)row * p.D;
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    const long long mb = p.scale ? (long long)(row / p.rows_per_batch) * p.mod_stride : 0;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < p.D; i += 64) {
+        float g = SatIO<T>::ld(p.dy, base + i);
+        if (p.scale) g *= 1.0f + SatIO<T>::ld(p.scale, mb + i);
+        g *= p.gamma[i];
+        const float xh = (SatIO<T>::ld(p.x, base + i) - mean) * rstd;
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = sat_wave_sum(s1) / (float)p.D;
+    s2 = sat_wave_sum(s2) / (float)p.D;
+    for (int i = lane; i < p.D; i += 64) {
+        float g = SatIO<T>::ld(p.dy, base + i);
+        if (p.scale) g *= 1.0f + SatIO<T>::ld(p.scale, mb + i);
+        g *= p.gamma[i];
+        const float xh = (SatIO<T>::ld(p.x, base + i) - mean) * rstd;
+        SatIO<T>::st(p.dx, base + i, rstd * (g - s1 - xh * s2));
+    }
+}
+
+// parameter / modulation gradients: thread per column, a workgroup walks a slab of rows of ONE batch item.
+//   part[0] : d_gamma  = sum dy*(1+scale) * xhat
+//   part[1] : d_scale  = sum dy * ln   (ln = xhat*gamma + beta)        (adaLN only)
+//   part[2] : d_shift  = sum dy                                       (adaLN only)
+#define SAT_LN_ROWS_PER_BLOCK 64
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_bwd_param_kernel(SatLnParams p) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    const int r0 = b * p.rows_per_batch + blockIdx.y * SAT_LN_ROWS_PER_BLOCK;
+    int r1 = r0 + SAT_LN_ROWS_PER_BLOCK;
+    const int rend = (b + 1) * p.rows_per_batch;
+    if (r1 > rend) r1 = rend;
+    if (col >= p.D) return;
+    const float gam = p.gamma[col], bet = p.beta ? p.beta[col] : 0.0f;
+    const float sc = p.scale ? 1.0f + SatIO<T>::ld(p.scale, (long long)b * p.mod_stride + col) : 1.0f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float dy = SatIO<T>::ld(p.dy, (long long)r * p.D + col);
+        const float xh = (SatIO<T>::ld(p.x, (long long)r * p.D + col) - p.mean[r]) * p.rstd[r];
+        a0 += dy * sc * xh;
+        a1 += dy * (xh * gam + bet);
+        a2 += dy;
+    }
+    const int nby = gridDim.y * gridDim.z;
+    const int by = b * gridDim.y + blockIdx.y;
+    p.part[((size_t)0 * nby + by) * p.D + col] = a0;
+    p.part[((size_t)1 * nby + by) * p.D + col] = a1;
+    p.part[((size_t)2 * nby + by) * p.D + col] = a2;
+}
+
+static int sat_ln_check(int rows, int D, int rows_per_batch, int dtype, const char* who) {
+    if (rows <= 0 || D <= 0 || rows_per_batch <= 0 || rows % rows_per_batch != 0) { sat_set_error(who); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("layernorm: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    return 0;
+}
+
+extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* scale,
+                                 const void* shift, long long mod_stride, void* y, float* mean, float* rstd, int rows,
+                                 int D, int rows_per_batch, float eps, int dtype, void* stream) {
+    if (sat_ln_check(rows, D, rows_per_batch, dtype, "sat_layernorm_fwd: bad shape")) return 1;
+    if ((scale == nullptr) != (shift == nullptr)) { sat_set_error("sat_layernorm_fwd: scale/shift must both be given"); return 1; }
+    SatLnParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.y = y; p.mean = mean; p.rstd = rstd;
+    p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch; p.eps = eps;
+    dim3 grid(sat_cdiv(rows, 4));
+    if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_layernorm_fwd_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_layernorm_fwd");
+}
+
+extern "C" int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch) {
+    return (rows / rows_per_batch) * sat_cdiv(rows_per_batch, SAT_LN_ROWS_PER_BLOCK);
+}
+
+extern "C" int sat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                                 const void* scale, long long mod_stride, const float* mean, const float* rstd,
+                                 void* dx, float* part, int rows, int D, int rows_per_batch, int dtype, void* stream) {
+    if (sat_ln_check(rows, D, rows_per_batch, dtype, "sat_layernorm_bwd: bad shape")) return 1;
+    SatLnParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.dy = dy; p.dx = dx; p.part = part;
+    p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+    p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch;
+    dim3 g1(sat_cdiv(rows, 4));
+    dim3 g2(sat_cdiv(D, 256), sat_cdiv(rows_per_batch, SAT_LN_ROWS_PER_BLOCK), rows / rows_per_batch);
+    if (dtype == 0) {
+        SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<float>, g1, dim3(256), stream, p);
+        SAT_LAUNCH(sat_layernorm_bwd_param_kernel<float>, g2, dim3(256), stream, p);
+    } else {
+        SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<short>, g1, dim3(256), stream, p);
+        SAT_LAUNCH(sat_layernorm_bwd_param_kernel<short>, g2, dim3(256), stream, p);
+    }
+    return sat_check_launch("sat_layernorm_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rotary position embedding
+// ------------------------------------------------------------------------------------------------
+struct SatRopeTabParams {
+    const float* inv_freq;  // (R/2)
+    float* cs;              // (N, R/2, 2) = cos, sin
+    int N, half;
+    float pos_scale;        // positions are pos_scale * n (the q/k length ratio of transformer.py:498-503)
+};
+__global__ void __launch_bounds__(256) sat_rope_tables_kernel(SatRopeTabParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.N * p.half) return;
+    const int n = i / p.half, j = i - n * p.half;
+    // freqs = t * inv_freq in fp32 (einsum), then optionally * ratio, then cos/sin in fp32
+    const float ang = ((float)n * p.inv_freq[j]) * p.pos_scale;
+    p.cs[2 * i + 0] = cosf(ang);
+    p.cs[2 * i + 1] = sinf(ang);
+}
+extern "C" int sat_rope_tables(const float* inv_freq, float* cs, int N, int half, float pos_scale, void* stream) {
+    if (N <= 0 || half <= 0) { sat_set_error("sat_rope_tables: empty shape"); return 1; }
+    SatRopeTabParams p{inv_freq, cs, N, half, pos_scale};
+    SAT_LAUNCH(sat_rope_tables_kernel, dim3(sat_cdiv(N * half, 256)), dim3(256), stream, p);
+    return sat_check_launch("sat_rope_tables");
+}
+
+struct SatRopeParams {
+    void* t;          // element (b, n, h, d) at b*sb + n*sn + h*sh + d
+    const float* cs;  // (Ntab, half, 2)
+    long long sb, sn, sh;
+    int B, N, H, half, tab_off;  // table row = tab_off + n  (freqs[-seq_len:], transformer.py:162)
+    float sign;                  // +1 forward, -1 transpose (backward)
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_rope_apply_kernel(SatRopeParams p) {
+    const long long total = (long long)p.B * p.N * p.H * p.half;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % p.half);
+        long long q = i / p.half;
+        const int h = (int)(q % p.H);
+        q /= p.H;
+        const int n = (int)(q % p.N), b = (int)(q / p.N);
+        const long long base = (long long)b * p.sb + (long long)n * p.sn + (long long)h * p.sh;
+        const float c = p.cs[2 * ((long long)(p.tab_off + n) * p.half + j) + 0];
+        const float s = p.sign * p.cs[2 * ((long long)(p.tab_off + n) * p.half + j) + 1];
+        const float x1 = SatIO<T>::ld(p.t, base + j), x2 = SatIO<T>::ld(p.t, base + p.half + j);
+        // t*cos + rotate_half(t)*sin with rotate_half = (-x2, x1)   (transformer.py:149-152, :170)
+        SatIO<T>::st(p.t, base + j, x1 * c - x2 * s);
+        SatIO<T>::st(p.t, base + p.half + j, x2 * c + x1 * s);
+    }
+}
+extern "C" int sat_rope_apply(void* t, const float* cs, long long sb, long long sn, long long sh, int B, int N, int H,
+                              int half, int tab_off, int transpose, int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0 || half <= 0 || tab_off < 0) { sat_set_error("sat_rope_apply: bad shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_rope_apply: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    SatRopeParams p{t, cs, sb, sn, sh, B, N, H, half, tab_off, transpose ? -1.0f : 1.0f};
+    long long nb = sat_cdivll((long long)B * N * H * half, 256);
+    if (nb > 8192) nb = 8192;
+    if (dtype == 0) SAT_LAUNCH(sat_rope_apply_kernel<float>, dim3((unsigned)nb), dim3(256), stream, p);
+    else SAT_LAUNCH(sat_rope_apply_kernel<short>, dim3((unsigned)nb), dim3(256), stream, p);
+    return sat_check_launch("sat_rope_apply");
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU and gate/residual
+// ------------------------------------------------------------------------------------------------
+struct SatGluParams {
+    const void* xin;   // (rows, 2F): [x | gate]
+    void* out;         // fwd: (rows, F) ;  bwd: d_xin (rows, 2F)
+    const void* dout;  // bwd: (rows, F)
+    long long rows;
+    int F;
+};
+SAT_DEVICE float sat_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) sat_swiglu_fwd_kernel(SatGluParams p) {
+    const long long total = p.rows * p.F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / p.F;
+        const int c = (int)(i - r * p.F);
+        const float x = SatIO<T>::ld(p.xin, r * 2 * p.F + c), g = SatIO<T>::ld(p.xin, r * 2 * p.F + p.F + c);
+        SatIO<T>::st(p.out, i, x * (g * sat_sigmoid(g)));
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) sat_swiglu_bwd_kernel(SatGluParams p) {
+    const long long total = p.rows * p.F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / p.F;
+        const int c = (int)(i - r * p.F);
+        const float x = SatIO<T>::ld(p.xin, r * 2 * p.F + c), g = SatIO<T>::ld(p.xin, r * 2 * p.F + p.F + c);
+        const float d = SatIO<T>::ld(p.dout, i);
+        const float sg = sat_sigmoid(g);
+        SatIO<T>::st(p.out, r * 2 * p.F + c, d * g * sg);
+        SatIO<T>::st(p.out, r * 2 * p.F + p.F + c, d * x * (sg * (1.0f + g * (1.0f - sg))));
+    }
+}
+extern "C" int sat_swiglu(const void* xin, const void* dout, void* out, long long rows, int F, int backward, int dtype,
+                          void* stream) {
+    if (rows <= 0 || F <= 0) { sat_set_error("sat_swiglu: empty shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_swiglu: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    SatGluParams p{xin, out, dout, rows, F};
+    long long nb = sat_cdivll(rows * F, 256);
+    if (nb > 8192) nb = 8192;
+    dim3 grid((unsigned)nb);
+    if (!backward) {
+        if (dtype == 0) SAT_LAUNCH(sat_swiglu_fwd_kernel<float>, grid, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_swiglu_fwd_kernel<short>, grid, dim3(256), stream, p);
+    } else {
+        if (dtype == 0) SAT_LAUNCH(sat_swiglu_bwd_kernel<float>, grid, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_swiglu_bwd_kernel<short>, grid, dim3(256), stream, p);
+    }
+    return sat_check_launch("sat_swiglu");
+}
+
+struct SatGateParams {
+    const void* x;     // (B, N, D) branch output
+    const void* gate;  // (B, D) with batch stride gstride
+    const void* res;   // (B, N, D)
+    void* y;
+    long long gstride;
+    int B, N, D;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_gate_residual_kernel(SatGateParams p) {
+    const long long total = (long long)p.B * p.N * p.D;
+    const long long per_b = (long long)p.N * p.D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / per_b);
+        const int c = (int)(i % p.D);
+        const float g = SatIO<T>::ld(p.gate, (long long)b * p.gstride + c);
+        SatIO<T>::st(p.y, i, SatIO<T>::ld(p.x, i) * sat_sigmoid(1.0f - g) + SatIO<T>::ld(p.res, i));
+    }
+}
+extern "C" int sat_gate_residual(const void* x, const void* gate, long long gstride, const void* res, void* y, int B,
+                                 int N, int D, int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || D <= 0) { sat_set_error("sat_gate_residual: empty shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_gate_residual: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    SatGateParams p{x, gate, res, y, gstride, B, N, D};
+    long long nb = sat_cdivll((long long)B * N * D, 256);
+    if (nb > 8192) nb = 8192;
+    if (dtype == 0) SAT_LAUNCH(sat_gate_residual_kernel<float>, dim3((unsigned)nb), dim3(256), stream, p);
+    else SAT_LAUNCH(sat_gate_residual_kernel<short>, dim3((unsigned)nb), dim3(256), stream, p);
+    return sat_check_launch("sat_gate_residual");
+}

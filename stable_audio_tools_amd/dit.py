@@ -1,0 +1,207 @@
+"""MI355X-native DiffusionTransformer — drop-in mirror of stable_audio_tools/models/dit.py
+(DiffusionTransformer.__init__ :13, _forward :125, forward :231) with the reference's constructor
+kwargs (the `model.diffusion.config` JSON block), forward signature and state_dict keys
+(timestep_features.weight, to_timestep_embed.{0,2}, to_cond_embed.{0,2}, to_global_embed.{0,2},
+to_prepend_embed.{0,2}, transformer.*, preprocess_conv.weight, postprocess_conv.weight).
+
+The block stack runs on the HIP kernels (transformer.py); what is left here is the thin glue the
+reference also keeps in Python: conditioning projections on (B, D) vectors, the 1x1 pre/post convs
+on the 64-channel latent, classifier-free-guidance batching and the CFG combine/rescale.
+"""
+import math
+import typing as tp
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .transformer import ContinuousTransformer
+
+
+class FourierFeatures(nn.Module):
+    """models/blocks.py:85-94: cat(cos(2 pi x W^T), sin(2 pi x W^T))."""
+
+    def __init__(self, in_features, out_features, std=1.):
+        super().__init__()
+        assert out_features % 2 == 0
+        self.weight = nn.Parameter(torch.randn([out_features // 2, in_features]) * std)
+
+    def forward(self, input):
+        f = 2 * math.pi * input @ self.weight.T
+        return torch.cat([f.cos(), f.sin()], dim=-1)
+
+
+class DiffusionTransformer(nn.Module):
+    def __init__(self, io_channels=32, patch_size=1, embed_dim=768, cond_token_dim=0, project_cond_tokens=True,
+                 global_cond_dim=0, project_global_cond=True, input_concat_dim=0, prepend_cond_dim=0, depth=12,
+                 num_heads=8, transformer_type: tp.Literal["continuous_transformer"] = "continuous_transformer",
+                 global_cond_type: tp.Literal["prepend", "adaLN"] = "prepend",
+                 timestep_cond_type: tp.Literal["global", "input_concat"] = "global", timestep_embed_dim=None,
+                 diffusion_objective: tp.Literal["v", "rectified_flow", "rf_denoiser"] = "v", **kwargs):
+        super().__init__()
+        self.cond_token_dim = cond_token_dim
+        self.timestep_cond_type = timestep_cond_type
+        timestep_features_dim = 256
+        self.timestep_features = FourierFeatures(1, timestep_features_dim)
+        if timestep_cond_type == "global":
+            timestep_embed_dim = embed_dim
+        elif timestep_cond_type == "input_concat":
+            assert timestep_embed_dim is not None, "timestep_embed_dim must be specified if timestep_cond_type is input_concat"
+            input_concat_dim += timestep_embed_dim
+        self.to_timestep_embed = nn.Sequential(nn.Linear(timestep_features_dim, timestep_embed_dim, bias=True), nn.SiLU(),
+                                               nn.Linear(timestep_embed_dim, timestep_embed_dim, bias=True))
+        self.diffusion_objective = diffusion_objective
+        if cond_token_dim > 0:
+            cond_embed_dim = cond_token_dim if not project_cond_tokens else embed_dim
+            self.to_cond_embed = nn.Sequential(nn.Linear(cond_token_dim, cond_embed_dim, bias=False), nn.SiLU(),
+                                               nn.Linear(cond_embed_dim, cond_embed_dim, bias=False))
+        else:
+            cond_embed_dim = 0
+        if global_cond_dim > 0:
+            global_embed_dim = global_cond_dim if not project_global_cond else embed_dim
+            self.to_global_embed = nn.Sequential(nn.Linear(global_cond_dim, global_embed_dim, bias=False), nn.SiLU(),
+                                                 nn.Linear(global_embed_dim, global_embed_dim, bias=False))
+        if prepend_cond_dim > 0:
+            self.to_prepend_embed = nn.Sequential(nn.Linear(prepend_cond_dim, embed_dim, bias=False), nn.SiLU(),
+                                                  nn.Linear(embed_dim, embed_dim, bias=False))
+        self.input_concat_dim = input_concat_dim
+        dim_in = io_channels + self.input_concat_dim
+        self.patch_size = patch_size
+        self.transformer_type = transformer_type
+        self.global_cond_type = global_cond_type
+        if transformer_type != "continuous_transformer":
+            raise ValueError(f"Unknown transformer type: {transformer_type}")
+        global_dim = embed_dim if global_cond_type == "adaLN" else None
+        self.transformer = ContinuousTransformer(dim=embed_dim, depth=depth, dim_heads=embed_dim // num_heads,
+                                                 dim_in=dim_in * patch_size, dim_out=io_channels * patch_size,
+                                                 cross_attend=cond_token_dim > 0, cond_token_dim=cond_embed_dim,
+                                                 global_cond_dim=global_dim, **kwargs)
+        self.preprocess_conv = nn.Conv1d(dim_in, dim_in, 1, bias=False)
+        nn.init.zeros_(self.preprocess_conv.weight)
+        self.postprocess_conv = nn.Conv1d(io_channels, io_channels, 1, bias=False)
+        nn.init.zeros_(self.postprocess_conv.weight)
+
+    @staticmethod
+    def _conv1x1_residual(conv, x):
+        # Conv1d(k=1, bias=False)(x) + x on a (B, C<=64+, T) latent: one small GEMM (dit.py:193, :224)
+        return torch.einsum("oc,bct->bot", conv.weight[:, :, 0], x) + x
+
+    def _forward(self, x, t, mask=None, cross_attn_cond=None, cross_attn_cond_mask=None, input_concat_cond=None,
+                 global_embed=None, prepend_cond=None, prepend_cond_mask=None, return_info=False, exit_layer_ix=None,
+                 **kwargs):
+        if cross_attn_cond is not None:
+            cross_attn_cond = self.to_cond_embed(cross_attn_cond)
+        if global_embed is not None:
+            global_embed = self.to_global_embed(global_embed)
+        prepend_inputs = None
+        prepend_length = 0
+        if prepend_cond is not None:
+            prepend_inputs = self.to_prepend_embed(prepend_cond)
+            prepend_length = prepend_inputs.shape[1]
+        if input_concat_cond is not None:
+            if input_concat_cond.shape[2] != x.shape[2]:
+                input_concat_cond = F.interpolate(input_concat_cond, (x.shape[2],), mode="nearest")
+            x = torch.cat([x, input_concat_cond], dim=1)
+        timestep_embed = self.to_timestep_embed(self.timestep_features(t[:, None]))
+        if self.timestep_cond_type == "global":
+            global_embed = global_embed + timestep_embed if global_embed is not None else timestep_embed
+        elif self.timestep_cond_type == "input_concat":
+            x = torch.cat([x, timestep_embed.unsqueeze(1).expand(-1, -1, x.shape[2])], dim=1)
+        if self.global_cond_type == "prepend" and global_embed is not None:
+            g = global_embed.unsqueeze(1)
+            prepend_inputs = g if prepend_inputs is None else torch.cat([prepend_inputs, g], dim=1)
+            prepend_length = prepend_inputs.shape[1]
+        x = self._conv1x1_residual(self.preprocess_conv, x)
+        x = x.transpose(1, 2)                                       # b c t -> b t c
+        extra_args = {}
+        if self.global_cond_type == "adaLN":
+            extra_args["global_cond"] = global_embed
+        if self.patch_size > 1:
+            b, tp_, c = x.shape
+            x = x.reshape(b, tp_ // self.patch_size, self.patch_size, c).transpose(2, 3).reshape(b, tp_ // self.patch_size, c * self.patch_size)
+        output = self.transformer(x, prepend_embeds=prepend_inputs, context=cross_attn_cond, return_info=return_info,
+                                  exit_layer_ix=exit_layer_ix, **extra_args, **kwargs)
+        info = None
+        if return_info:
+            output, info = output
+        if exit_layer_ix is not None:
+            return (output, info) if return_info else output
+        output = output.transpose(1, 2)[:, :, prepend_length:]      # b t c -> b c t, drop prepended tokens
+        if self.patch_size > 1:
+            b, cp, tt = output.shape
+            output = output.reshape(b, cp // self.patch_size, self.patch_size, tt).transpose(2, 3).reshape(b, cp // self.patch_size, tt * self.patch_size)
+        output = self._conv1x1_residual(self.postprocess_conv, output)
+        return (output, info) if return_info else output
+
+    def forward(self, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
+                negative_cross_attn_mask=None, input_concat_cond=None, global_embed=None, negative_global_embed=None,
+                prepend_cond=None, prepend_cond_mask=None, cfg_scale=1.0, cfg_dropout_prob=0.0, cfg_interval=(0, 1),
+                causal=False, scale_phi=0.0, mask=None, return_info=False, exit_layer_ix=None, **kwargs):
+        assert causal is False, "Causal mode is not supported for DiffusionTransformer"
+        dt = next(self.parameters()).dtype
+
+        def cast(a):
+            return a.to(dt) if a is not None else None
+        x, t = x.to(dt), t.to(dt)
+        cross_attn_cond, negative_cross_attn_cond = cast(cross_attn_cond), cast(negative_cross_attn_cond)
+        input_concat_cond, global_embed, prepend_cond = cast(input_concat_cond), cast(global_embed), cast(prepend_cond)
+        cross_attn_cond_mask = None      # conditioning masks are disabled in the reference (dit.py:283)
+        if prepend_cond_mask is not None:
+            prepend_cond_mask = prepend_cond_mask.bool()
+        common = dict(input_concat_cond=input_concat_cond, mask=mask, return_info=return_info, **kwargs)
+
+        if exit_layer_ix is not None:    # early exit bypasses CFG (dit.py:289-305)
+            return self._forward(x, t, cross_attn_cond=cross_attn_cond, global_embed=global_embed, prepend_cond=prepend_cond,
+                                 prepend_cond_mask=prepend_cond_mask, exit_layer_ix=exit_layer_ix, **common)
+
+        if cfg_dropout_prob > 0.0 and cfg_scale == 1.0:     # CFG dropout only fires at cfg_scale == 1 (dit.py:307)
+            if cross_attn_cond is not None:
+                drop = torch.bernoulli(torch.full((cross_attn_cond.shape[0], 1, 1), cfg_dropout_prob, device=cross_attn_cond.device)).to(torch.bool)
+                cross_attn_cond = torch.where(drop, torch.zeros_like(cross_attn_cond), cross_attn_cond)
+            if prepend_cond is not None:
+                drop = torch.bernoulli(torch.full((prepend_cond.shape[0], 1, 1), cfg_dropout_prob, device=prepend_cond.device)).to(torch.bool)
+                prepend_cond = torch.where(drop, torch.zeros_like(prepend_cond), prepend_cond)
+
+        if self.diffusion_objective == "v":
+            sigma = torch.sin(t * math.pi / 2)
+        else:
+            sigma = t
+
+        use_cfg = cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None) \
+            and bool(cfg_interval[0] <= sigma[0] <= cfg_interval[1])   # reads sigma[0] only (dit.py:324)
+        if not use_cfg:
+            return self._forward(x, t, cross_attn_cond=cross_attn_cond, global_embed=global_embed, prepend_cond=prepend_cond,
+                                 prepend_cond_mask=prepend_cond_mask, **common)
+
+        # classifier-free guidance: conditioned and unconditioned halves in one batch (dit.py:328-395)
+        def twice(a):
+            return torch.cat([a, a], dim=0) if a is not None else None
+        batch_cond = None
+        if cross_attn_cond is not None:
+            null = torch.zeros_like(cross_attn_cond)
+            if negative_cross_attn_cond is not None:
+                if negative_cross_attn_mask is not None:
+                    negative_cross_attn_cond = torch.where(negative_cross_attn_mask.to(torch.bool).unsqueeze(2), negative_cross_attn_cond, null)
+                batch_cond = torch.cat([cross_attn_cond, negative_cross_attn_cond], dim=0)
+            else:
+                batch_cond = torch.cat([cross_attn_cond, null], dim=0)
+        batch_prepend = torch.cat([prepend_cond, torch.zeros_like(prepend_cond)], dim=0) if prepend_cond is not None else None
+        out = self._forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), cross_attn_cond=batch_cond,
+                            mask=twice(mask), input_concat_cond=twice(input_concat_cond), global_embed=twice(global_embed),
+                            prepend_cond=batch_prepend, prepend_cond_mask=twice(prepend_cond_mask), return_info=return_info,
+                            **kwargs)
+        info = None
+        if return_info:
+            out, info = out
+        cond_output, uncond_output = torch.chunk(out, 2, dim=0)
+        cfg_output = uncond_output + (cond_output - uncond_output) * cfg_scale
+        if scale_phi != 0.0:    # CFG rescale over the channel dim (dit.py:405-408)
+            cond_std = cond_output.std(dim=1, keepdim=True)
+            cfg_std = cfg_output.std(dim=1, keepdim=True)
+            output = scale_phi * (cfg_output * (cond_std / cfg_std)) + (1 - scale_phi) * cfg_output
+        else:
+            output = cfg_output
+        if return_info:
+            info["uncond_output"] = uncond_output
+            return output, info
+        return output

@@ -218,6 +218,117 @@ class SatOps:
         self._chk(self.lib.sat_stft_bwd(_ptr(x), _ptr(y), _ptr(views), _ptr(coef), _ptr(dy), ni, c, t, nv, n_fft, hop,
                                         int(wrt_x), self._stream(x)))
 
+    # ------------------------------------------------------------------ DiT operators
+    def _dt(self, *tensors):
+        """dtype code for the DiT kernels: 0 = fp32, 1 = bf16 (all given tensors must agree)."""
+        dt = None
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError(f"DiT kernels take float32 or bfloat16 tensors, got {t.dtype}")
+            if dt is not None and t.dtype != dt:
+                raise TypeError("mixed dtypes")
+            dt = t.dtype
+            if not self.simulator and not t.is_cuda:
+                raise RuntimeError("stable_audio_tools_amd kernels need CUDA(HIP) tensors; there is no CPU path")
+        return 0 if dt == torch.float32 else 1
+
+    def attention(self, q, k, v, scale, need_lse=False):
+        """q: (B, H, Nq, 64) k, v: (B, Hkv, Nk, 64) — any strides with the head dim contiguous.
+        Returns o: (B, Nq, H*64) [, lse (B, H, Nq) fp32]."""
+        dt = self._dt(q, k, v)
+        b, h, nq, d = q.shape
+        _, hk, nk, _ = k.shape
+        for t in (q, k, v):
+            if t.stride(3) != 1:
+                raise ValueError("head dim must be contiguous")
+        o = torch.empty(b, nq, h * d, dtype=q.dtype, device=q.device)
+        lse = torch.empty(b, h, nq, dtype=torch.float32, device=q.device) if need_lse else None
+        self._chk(self.lib.sat_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse),
+                                             q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                             v.stride(0), v.stride(1), v.stride(2), b, h, hk, nq, nk, d, float(scale), dt,
+                                             self._stream(q)))
+        return (o, lse) if need_lse else o
+
+    def layernorm(self, x, gamma, beta=None, scale=None, shift=None, eps=1e-5, save_stats=False):
+        """x: (B, N, D) contiguous; gamma/beta fp32 (D,); scale/shift: (B, D) views (last dim contiguous) for adaLN."""
+        dt = self._dt(x, scale, shift)
+        self._f32(gamma, beta)
+        if not x.is_contiguous():
+            raise ValueError("expected contiguous x")
+        b, n, d = x.shape
+        y = torch.empty_like(x)
+        mean = rstd = None
+        if save_stats:
+            mean = torch.empty(b * n, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(b * n, dtype=torch.float32, device=x.device)
+        ms = scale.stride(0) if scale is not None else 0
+        self._chk(self.lib.sat_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), ms, _ptr(y),
+                                             _ptr(mean), _ptr(rstd), b * n, d, n, eps, dt, self._stream(x)))
+        return (y, mean, rstd) if save_stats else y
+
+    def layernorm_bwd(self, dy, x, gamma, beta, scale, mean, rstd):
+        """Returns dx, dgamma (D,), dscale (B, D) or None, dshift (B, D) or None."""
+        dt = self._dt(dy, x, scale)
+        b, n, d = x.shape
+        dx = torch.empty_like(x)
+        nby = self.lib.sat_layernorm_bwd_nblocks(b * n, n)
+        part = torch.empty(3, nby, d, dtype=torch.float32, device=x.device)
+        ms = scale.stride(0) if scale is not None else 0
+        self._chk(self.lib.sat_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), ms, _ptr(mean),
+                                             _ptr(rstd), _ptr(dx), _ptr(part), b * n, d, n, dt, self._stream(x)))
+        per_b = nby // b
+        dgamma = self._reduce_rows(part[0].contiguous(), nby, d)
+        if scale is None:
+            return dx, dgamma, None, None
+        dscale = torch.stack([self._reduce_rows(part[1, i * per_b:(i + 1) * per_b].contiguous(), per_b, d) for i in range(b)])
+        dshift = torch.stack([self._reduce_rows(part[2, i * per_b:(i + 1) * per_b].contiguous(), per_b, d) for i in range(b)])
+        return dx, dgamma, dscale, dshift
+
+    def rope_tables(self, inv_freq, n, pos_scale=1.0):
+        self._f32(inv_freq)
+        half = inv_freq.numel()
+        cs = torch.empty(n, half, 2, dtype=torch.float32, device=inv_freq.device)
+        self._chk(self.lib.sat_rope_tables(_ptr(inv_freq), _ptr(cs), n, half, float(pos_scale), self._stream(inv_freq)))
+        return cs
+
+    def rope_apply_(self, t, cs, transpose=False):
+        """In place on t: (B, N, H, dh) view (dh contiguous); rotates the first 2*half dims of every head."""
+        dt = self._dt(t)
+        b, n, h, dh = t.shape
+        half = cs.shape[1]
+        if t.stride(3) != 1 or 2 * half > dh:
+            raise ValueError("bad rotary layout")
+        self._chk(self.lib.sat_rope_apply(_ptr(t), _ptr(cs), t.stride(0), t.stride(1), t.stride(2), b, n, h, half,
+                                          cs.shape[0] - n, int(transpose), dt, self._stream(t)))
+        return t
+
+    def swiglu(self, xin):
+        dt = self._dt(xin)
+        f = xin.shape[-1] // 2
+        rows = xin.numel() // (2 * f)
+        out = torch.empty(*xin.shape[:-1], f, dtype=xin.dtype, device=xin.device)
+        self._chk(self.lib.sat_swiglu(_ptr(xin), None, _ptr(out), rows, f, 0, dt, self._stream(xin)))
+        return out
+
+    def swiglu_bwd(self, xin, dout):
+        dt = self._dt(xin, dout)
+        f = xin.shape[-1] // 2
+        rows = xin.numel() // (2 * f)
+        dxin = torch.empty_like(xin)
+        self._chk(self.lib.sat_swiglu(_ptr(xin), _ptr(dout), _ptr(dxin), rows, f, 1, dt, self._stream(xin)))
+        return dxin
+
+    def gate_residual(self, x, gate, res):
+        """x * sigmoid(1 - gate[b]) + res;  x, res: (B, N, D) contiguous; gate: (B, D) view."""
+        dt = self._dt(x, gate, res)
+        b, n, d = x.shape
+        y = torch.empty_like(x)
+        self._chk(self.lib.sat_gate_residual(_ptr(x), _ptr(gate), gate.stride(0), _ptr(res), _ptr(y), b, n, d, dt,
+                                             self._stream(x)))
+        return y
+
     # ------------------------------------------------------------------ optimizer
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)

@@ -1,0 +1,333 @@
+"""MI355X-native ContinuousTransformer — drop-in mirror of
+stable_audio_tools/models/transformer.py (LayerNorm :215, RotaryEmbedding :92, GLU :252,
+FeedForward :277, Attention :328, TransformerBlock :582, ContinuousTransformer :715): same class
+names, constructor kwargs and state_dict keys (gamma/beta, to_qkv / to_q / to_kv / to_out,
+ff.ff.0.proj / ff.ff.2, to_scale_shift_gate, project_in/out, rotary_pos_emb.inv_freq,
+global_cond_embedder).
+
+Execution: LayerNorm(+adaLN modulate), partial rotary, attention (self and GQA cross), SwiGLU and the
+gate/residual epilogue are HIP kernels (csrc/dit_ops.hip, csrc/attention.hip); the plain bias-free /
+biased projections are nn.Linear (hipBLASLt — "plain library GEMMs").  Options of the reference that
+the Stable Audio DiT configs never enable (qk_norm, differential attention, conformer, layer_scale,
+memory tokens, sliding window, causal, flex-attention masks, abs/sinusoidal position embeddings)
+raise NotImplementedError.
+
+Round-1 status: forward path (sampling) complete and parity-tested; LayerNorm / rotary / SwiGLU have
+HIP backward kernels, the attention backward kernel is not written yet, so autograd through
+Attention raises NotImplementedError instead of falling back to a PyTorch implementation.
+"""
+import torch
+from torch import nn
+
+from . import functional as _fn
+
+
+def _ops():
+    return _fn._ops(None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, eps):
+        ops = _ops()
+        x = x.contiguous()
+        g32 = gamma.float().contiguous()
+        b32 = beta.float().contiguous() if beta is not None else None
+        if any(ctx.needs_input_grad):   # (torch.is_grad_enabled() is always False inside Function.forward)
+            y, mean, rstd = ops.layernorm(x, g32, b32, scale, shift, eps, save_stats=True)
+            ctx.save_for_backward(x, g32, b32, scale, mean, rstd)
+            ctx.ops = ops
+            ctx.gdtype = gamma.dtype
+        else:
+            y = ops.layernorm(x, g32, b32, scale, shift, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, b32, scale, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dscale, dshift = ctx.ops.layernorm_bwd(dy.contiguous(), x, g32, b32, scale, mean, rstd)
+        if dscale is not None:
+            dscale, dshift = dscale.to(scale.dtype), dshift.to(scale.dtype)
+        return dx, dgamma.to(ctx.gdtype), None, dscale, dshift, None
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, bias=False, fix_scale=False, force_fp32=False, eps=1e-5):
+        super().__init__()
+        if fix_scale:
+            self.register_buffer("gamma", torch.ones(dim))
+        else:
+            self.gamma = nn.Parameter(torch.ones(dim))
+        if bias:
+            self.beta = nn.Parameter(torch.zeros(dim))
+        else:
+            self.register_buffer("beta", torch.zeros(dim))
+        self.eps = eps
+        self.force_fp32 = force_fp32   # statistics are always fp32 in the HIP kernel
+
+    def forward(self, x, scale=None, shift=None):
+        """scale/shift: optional (B, D) adaLN modulation fused into the same pass: LN(x)*(1+scale)+shift."""
+        return LayerNormFn.apply(x, self.gamma, self.beta, scale, shift, self.eps)
+
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, dim, use_xpos=False, scale_base=512, interpolation_factor=1., base=10000, base_rescale_factor=1.):
+        super().__init__()
+        if use_xpos:
+            raise NotImplementedError("use_xpos is dead code in the reference (transformer.py:143) and not implemented")
+        base *= base_rescale_factor ** (dim / (dim - 2))
+        inv_freq = 1. / (base ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq)
+        assert interpolation_factor >= 1.
+        self.interpolation_factor = interpolation_factor
+        self.register_buffer("scale", None)
+
+    def tables(self, seq_len):
+        """(seq_len, dim/2, 2) fp32 cos/sin table (csrc/dit_ops.hip sat_rope_tables)."""
+        inv = self.inv_freq.float().contiguous()
+        if self.interpolation_factor != 1.:
+            inv = inv / self.interpolation_factor
+        return _ops().rope_tables(inv, seq_len)
+
+    def forward_from_seq_len(self, seq_len):
+        return self.tables(seq_len), 1.
+
+
+class _RopeQKFn(torch.autograd.Function):
+    """In-place rotary on the q and k slices of a fused (B, N, 3*H*dh) projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, cs, heads, dh):
+        ops = _ops()
+        b, n, _ = qkv.shape
+        hd = heads * dh
+        ops.rope_apply_(qkv[..., 0:hd].unflatten(-1, (heads, dh)), cs)
+        ops.rope_apply_(qkv[..., hd:2 * hd].unflatten(-1, (heads, dh)), cs)
+        ctx.mark_dirty(qkv)
+        ctx.save_for_backward(cs)
+        ctx.meta = (heads, dh, ops)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, g):
+        (cs,) = ctx.saved_tensors
+        heads, dh, ops = ctx.meta
+        g = g.clone()
+        hd = heads * dh
+        ops.rope_apply_(g[..., 0:hd].unflatten(-1, (heads, dh)), cs, transpose=True)
+        ops.rope_apply_(g[..., hd:2 * hd].unflatten(-1, (heads, dh)), cs, transpose=True)
+        return g, None, None, None
+
+
+class _AttentionCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        return _ops().attention(q, k, v, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("stable_audio_tools_amd: the HIP attention backward kernel is not written yet "
+                                  "(round-1 scope is the DiT forward / sampling path); there is no PyTorch fallback")
+
+
+class _SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xin):
+        xin = xin.contiguous()
+        ctx.save_for_backward(xin)
+        ctx.ops = _ops()
+        return ctx.ops.swiglu(xin)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xin,) = ctx.saved_tensors
+        return ctx.ops.swiglu_bwd(xin, g.contiguous())
+
+
+class _GateResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate, res):
+        return _ops().gate_residual(x.contiguous(), gate, res.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("stable_audio_tools_amd: gate/residual backward lands with the attention backward")
+
+
+class GLU(nn.Module):
+    def __init__(self, dim_in, dim_out, activation=None, use_conv=False, conv_kernel_size=3):
+        super().__init__()
+        if use_conv:
+            raise NotImplementedError("GLU(use_conv=True) is not used by the DiT and not implemented")
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        return _SwiGLUFn.apply(self.proj(x))     # x * silu(gate), transformer.py:274-275
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, no_bias=False, glu=True, use_conv=False, conv_kernel_size=3,
+                 zero_init_output=True):
+        super().__init__()
+        if not glu or use_conv:
+            raise NotImplementedError("only the SwiGLU feed-forward (glu=True, use_conv=False) is implemented")
+        inner_dim = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        linear_in = GLU(dim, inner_dim)
+        linear_out = nn.Linear(inner_dim, dim_out, bias=not no_bias)
+        if zero_init_output:
+            nn.init.zeros_(linear_out.weight)
+            if not no_bias:
+                nn.init.zeros_(linear_out.bias)
+        self.ff = nn.Sequential(linear_in, nn.Identity(), linear_out, nn.Identity())
+
+    def forward(self, x):
+        return self.ff(x)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, dim_heads=64, dim_context=None, causal=False, zero_init_output=True, qk_norm="none",
+                 differential=False, feat_scale=False):
+        super().__init__()
+        if causal or qk_norm != "none" or differential or feat_scale:
+            raise NotImplementedError("causal / qk_norm / differential / feat_scale attention are not on the HIP path")
+        if dim_heads != 64:
+            raise NotImplementedError("the HIP attention kernel is specialised for head dim 64 (every Stable Audio DiT config)")
+        self.dim, self.dim_heads = dim, dim_heads
+        dim_kv = dim_context if dim_context is not None else dim
+        self.num_heads = dim // dim_heads
+        self.kv_heads = dim_kv // dim_heads
+        if dim_context is not None:
+            self.to_q = nn.Linear(dim, dim, bias=False)
+            self.to_kv = nn.Linear(dim_kv, dim_kv * 2, bias=False)
+        else:
+            self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.to_out = nn.Linear(dim, dim, bias=False)
+        if zero_init_output:
+            nn.init.zeros_(self.to_out.weight)
+        self.causal = False
+        self.scale = dim_heads ** -0.5
+
+    def forward(self, x, context=None, rotary_pos_emb=None, causal=None, **unsupported):
+        for k, v in unsupported.items():
+            if v is not None:
+                raise NotImplementedError(f"Attention.forward({k}=...) is not on the HIP path")
+        h, kv_h, dh = self.num_heads, self.kv_heads, self.dim_heads
+        b, n, _ = x.shape
+        if hasattr(self, "to_q"):
+            kv_input = context if context is not None else x
+            q = self.to_q(x).view(b, n, h, dh).permute(0, 2, 1, 3)
+            kv = self.to_kv(kv_input)
+            m = kv.shape[1]
+            k = kv[..., :kv_h * dh].unflatten(-1, (kv_h, dh)).permute(0, 2, 1, 3)
+            v = kv[..., kv_h * dh:].unflatten(-1, (kv_h, dh)).permute(0, 2, 1, 3)
+            if rotary_pos_emb is not None:
+                raise NotImplementedError("rotary on a separate-projection attention is never used by the DiT")
+        else:
+            qkv = self.to_qkv(x)
+            if rotary_pos_emb is not None:
+                cs, _ = rotary_pos_emb
+                qkv = _RopeQKFn.apply(qkv, cs, h, dh)
+            hd = h * dh
+            q = qkv[..., 0:hd].unflatten(-1, (h, dh)).permute(0, 2, 1, 3)
+            k = qkv[..., hd:2 * hd].unflatten(-1, (h, dh)).permute(0, 2, 1, 3)
+            v = qkv[..., 2 * hd:].unflatten(-1, (h, dh)).permute(0, 2, 1, 3)
+        out = _AttentionCoreFn.apply(q, k, v, self.scale)       # (B, N, H*dh): heads already merged
+        return self.to_out(out)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, dim, dim_heads=64, cross_attend=False, dim_context=None, global_cond_dim=None, causal=False,
+                 zero_init_branch_outputs=True, conformer=False, layer_ix=-1, remove_norms=False, add_rope=False,
+                 layer_scale=False, attn_kwargs={}, ff_kwargs={}, norm_kwargs={}):
+        super().__init__()
+        if conformer or remove_norms or add_rope or layer_scale or causal:
+            raise NotImplementedError("conformer / remove_norms / add_rope / layer_scale / causal are not on the HIP path")
+        self.dim = dim
+        self.dim_heads = min(dim_heads, dim)
+        self.cross_attend = cross_attend
+        self.dim_context = dim_context
+        self.pre_norm = LayerNorm(dim, **norm_kwargs)
+        self.self_attn = Attention(dim, dim_heads=self.dim_heads, zero_init_output=zero_init_branch_outputs, **attn_kwargs)
+        if cross_attend:
+            self.cross_attend_norm = LayerNorm(dim, **norm_kwargs)
+            self.cross_attn = Attention(dim, dim_heads=self.dim_heads, dim_context=dim_context,
+                                        zero_init_output=zero_init_branch_outputs, **attn_kwargs)
+        self.ff_norm = LayerNorm(dim, **norm_kwargs)
+        self.ff = FeedForward(dim, zero_init_output=zero_init_branch_outputs, **ff_kwargs)
+        self.layer_ix = layer_ix
+        self.global_cond_dim = global_cond_dim
+        if global_cond_dim is not None:
+            self.to_scale_shift_gate = nn.Parameter(torch.randn(6 * dim) / dim ** 0.5)
+
+    def forward(self, x, context=None, global_cond=None, rotary_pos_emb=None, **unsupported):
+        for k, v in unsupported.items():
+            if v is not None:
+                raise NotImplementedError(f"TransformerBlock.forward({k}=...) is not on the HIP path")
+        d = self.dim
+        if self.global_cond_dim is not None and self.global_cond_dim > 0 and global_cond is not None:
+            # adaLN: (to_scale_shift_gate + global_cond).chunk(6)   (transformer.py:677)
+            mod = (self.to_scale_shift_gate + global_cond).contiguous()          # (B, 6D)
+            scale_self, shift_self, gate_self = mod[:, 0:d], mod[:, d:2 * d], mod[:, 2 * d:3 * d]
+            scale_ff, shift_ff, gate_ff = mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], mod[:, 5 * d:6 * d]
+            h = self.self_attn(self.pre_norm(x, scale_self, shift_self), rotary_pos_emb=rotary_pos_emb)
+            x = _GateResidualFn.apply(h, gate_self, x)                           # h*sigmoid(1-gate)+x  (:684-686)
+            if context is not None and self.cross_attend:
+                x = x + self.cross_attn(self.cross_attend_norm(x), context=context)   # never modulated (:688-689)
+            h = self.ff(self.ff_norm(x, scale_ff, shift_ff))
+            x = _GateResidualFn.apply(h, gate_ff, x)
+        else:
+            x = x + self.self_attn(self.pre_norm(x), rotary_pos_emb=rotary_pos_emb)
+            if context is not None and self.cross_attend:
+                x = x + self.cross_attn(self.cross_attend_norm(x), context=context)
+            x = x + self.ff(self.ff_norm(x))
+        return x
+
+
+class ContinuousTransformer(nn.Module):
+    def __init__(self, dim, depth, *, dim_in=None, dim_out=None, dim_heads=64, cross_attend=False, cond_token_dim=None,
+                 final_cross_attn_ix=-1, global_cond_dim=None, causal=False, rotary_pos_emb=True,
+                 zero_init_branch_outputs=True, conformer=False, use_sinusoidal_emb=False, use_abs_pos_emb=False,
+                 abs_pos_emb_max_length=10000, num_memory_tokens=0, sliding_window=None, **kwargs):
+        super().__init__()
+        if causal or conformer or use_sinusoidal_emb or use_abs_pos_emb or num_memory_tokens or sliding_window is not None:
+            raise NotImplementedError("causal / conformer / abs-pos-emb / memory tokens / sliding window are not on the HIP path")
+        self.dim, self.depth, self.causal = dim, depth, False
+        self.layers = nn.ModuleList([])
+        self.project_in = nn.Linear(dim_in, dim, bias=False) if dim_in is not None else nn.Identity()
+        self.project_out = nn.Linear(dim, dim_out, bias=False) if dim_out is not None else nn.Identity()
+        self.rotary_pos_emb = RotaryEmbedding(max(dim_heads // 2, 32)) if rotary_pos_emb else None
+        self.num_memory_tokens = 0
+        self.global_cond_embedder = None
+        if global_cond_dim is not None:
+            self.global_cond_embedder = nn.Sequential(nn.Linear(global_cond_dim, dim), nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.final_cross_attn_ix = final_cross_attn_ix
+        self.sliding_window = None
+        for i in range(depth):
+            should_cross_attend = cross_attend and (final_cross_attn_ix == -1 or i <= final_cross_attn_ix)
+            self.layers.append(TransformerBlock(dim, dim_heads=dim_heads, cross_attend=should_cross_attend,
+                                                dim_context=cond_token_dim, global_cond_dim=global_cond_dim,
+                                                zero_init_branch_outputs=zero_init_branch_outputs, layer_ix=i, **kwargs))
+
+    def forward(self, x, prepend_embeds=None, global_cond=None, return_info=False, use_checkpointing=True,
+                exit_layer_ix=None, **kwargs):
+        """use_checkpointing is accepted for API parity; activations are kept resident (288 GB HBM)."""
+        model_dtype = next(self.parameters()).dtype
+        x = x.to(model_dtype)
+        info = {"hidden_states": []}
+        x = self.project_in(x)
+        if prepend_embeds is not None:
+            assert prepend_embeds.shape[-1] == x.shape[-1], "prepend dimension must match sequence dimension"
+            x = torch.cat((prepend_embeds, x), dim=-2)
+        rotary = self.rotary_pos_emb.forward_from_seq_len(x.shape[1]) if self.rotary_pos_emb is not None else None
+        if global_cond is not None and self.global_cond_embedder is not None:
+            global_cond = self.global_cond_embedder(global_cond)
+        x = x.contiguous()
+        for layer_ix, layer in enumerate(self.layers):
+            x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, **kwargs)
+            if return_info:
+                info["hidden_states"].append(x)
+            if exit_layer_ix is not None and layer_ix == exit_layer_ix:
+                return (x, info) if return_info else x
+        x = self.project_out(x)
+        return (x, info) if return_info else x

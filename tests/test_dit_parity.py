@@ -1,0 +1,128 @@
+"""Parity of the native DiffusionTransformer (forward / sampling path) against golden vectors produced
+by the reference's DiffusionTransformer and against the oracle (oracle/dit_oracle.py).
+
+fp32 mode: 1e-3 relative (BASELINE.json) — the attention kernel runs its bf16x3 split on fp32 inputs.
+bf16 mode (the perf configuration of configs[2..4]): compared with the fp32 oracle at 3e-2, the
+tolerance of bf16 storage (8-bit mantissa) through 4 residual layers; stated here because the
+north-star's 1e-3 applies to fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+import dit_oracle
+import seeded
+from gen_golden import dit_inputs
+from golden_util import load_golden, rel_err
+
+TOL = 1e-3
+NAMES = list(seeded.DIT_CONFIGS)
+
+
+def _build(name, seed, device, dtype=torch.float32):
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    model = DiffusionTransformer(**seeded.DIT_CONFIGS[name])
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith("inv_freq")}
+    sd = {k: torch.from_numpy(v) for k, v in seeded.seeded_state_dict(shapes, seed).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("inv_freq") for k in missing)
+    full_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.to(device=device, dtype=dtype).train(False), full_sd
+
+
+def _case(name, idx, device):
+    g = load_golden("dit_" + name)
+    model, sd = _build(name, 700 + 10 * idx, device)
+    assert sorted(model.state_dict().keys()) == list(g["keys"]), "state_dict keys differ from the reference"
+    inp = {k: v.to(device) for k, v in dit_inputs(name).items()}
+    kw = dict(cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], prepend_cond=inp.get("prepend_cond"),
+              prepend_cond_mask=inp.get("prepend_cond_mask"))
+    with torch.no_grad():
+        plain = model(inp["x"], inp["t"], cfg_scale=1.0, **kw)
+        guided = model(inp["x"], inp["t"], cfg_scale=6.0, scale_phi=0.75, **kw)
+        _, info = model(inp["x"], inp["t"], return_info=True, **kw)
+    assert rel_err(info["hidden_states"][0], g["hidden_first"]) < TOL
+    assert rel_err(info["hidden_states"][-1], g["hidden_last"]) < TOL
+    assert rel_err(plain, g["plain"]) < TOL
+    assert rel_err(guided, g["guided"]) < TOL
+    # oracle agrees with the reference too (pins oracle/dit_oracle.py)
+    cpu = dit_inputs(name)
+    o_plain = dit_oracle.dit_forward(sd, seeded.DIT_CONFIGS[name], cpu["x"], cpu["t"], cpu["cross_attn_cond"], cpu["global_embed"],
+                                     cpu.get("prepend_cond"))
+    o_guided = dit_oracle.dit_forward(sd, seeded.DIT_CONFIGS[name], cpu["x"], cpu["t"], cpu["cross_attn_cond"], cpu["global_embed"],
+                                      cpu.get("prepend_cond"), cfg_scale=6.0, scale_phi=0.75)
+    assert rel_err(o_plain, g["plain"]) < 1e-4
+    assert rel_err(o_guided, g["guided"]) < 1e-4
+
+
+@pytest.mark.parametrize("idx,name", list(enumerate(NAMES)))
+def test_dit_matches_reference_golden_simulator(emu_modules, idx, name):
+    _case(name, idx, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx,name", list(enumerate(NAMES)))
+def test_dit_matches_reference_golden_gpu(hip, idx, name):
+    _case(name, idx, "cuda")
+
+
+def _bf16(device):
+    name = "tiny_adaln"
+    model, sd = _build(name, 710, device, dtype=torch.bfloat16)
+    inp = dit_inputs(name)
+    kw = dict(cross_attn_cond=inp["cross_attn_cond"].to(device), global_embed=inp["global_embed"].to(device))
+    with torch.no_grad():
+        out = model(inp["x"].to(device), inp["t"].to(device), cfg_scale=1.0, **kw)
+    assert out.dtype == torch.bfloat16
+    # oracle in fp32 on the SAME bf16-rounded weights and inputs: isolates kernel/activation rounding from
+    # weight quantisation (guidance at scale 6 would multiply that rounding noise by 6, so it is compared unguided)
+    def q(a):
+        return a.to(torch.bfloat16).float() if a.is_floating_point() else a
+    sdq = {k: q(v) for k, v in sd.items()}
+    ref = dit_oracle.dit_forward(sdq, seeded.DIT_CONFIGS[name], q(inp["x"]), q(inp["t"]), q(inp["cross_attn_cond"]), q(inp["global_embed"]))
+    assert rel_err(out.float(), ref) < 3e-2
+
+
+def test_dit_bf16_simulator(emu_modules):
+    _bf16("cpu")
+
+
+@pytest.mark.gpu
+def test_dit_bf16_gpu(hip):
+    _bf16("cuda")
+
+
+@pytest.mark.gpu
+def test_attention_full_size_properties_gpu(hip):
+    """Size-independent checks at the BASELINE shapes (N = 1025 self, M = 130 GQA cross, 24 heads):
+    (1) rows of softmax sum to one -> attention of constant V returns the constant;
+    (2) linearity in V; (3) bf16 and fp32-split paths agree to bf16 precision."""
+    torch.manual_seed(0)
+    b, h, n, d = 2, 24, 1025, 64
+    q = torch.randn(b, h, n, d, device="cuda")
+    k = torch.randn(b, h, n, d, device="cuda")
+    v = torch.randn(b, h, n, d, device="cuda")
+    ones = torch.ones_like(v)
+    assert rel_err(hip.attention(q, k, ones, 0.125), torch.ones(b, n, h * d)) < 1e-5
+    o1 = hip.attention(q, k, v, 0.125)
+    o2 = hip.attention(q, k, 2.5 * v, 0.125)
+    assert rel_err(o2, 2.5 * o1) < 1e-5
+    ref = torch.nn.functional.scaled_dot_product_attention(q.double().cpu(), k.double().cpu(), v.double().cpu())
+    ref = ref.permute(0, 2, 1, 3).reshape(b, n, h * d)
+    assert rel_err(o1, ref) < 1e-4
+    ob = hip.attention(q.bfloat16(), k.bfloat16(), v.bfloat16(), 0.125)
+    assert rel_err(ob.float(), ref) < 2e-2
+    kc = torch.randn(b, 12, 130, d, device="cuda")
+    vc = torch.randn(b, 12, 130, d, device="cuda")
+    oc = hip.attention(q, kc, vc, 0.125)
+    refc = torch.nn.functional.scaled_dot_product_attention(q.double().cpu(), kc.double().cpu().repeat_interleave(2, 1),
+                                                            vc.double().cpu().repeat_interleave(2, 1))
+    assert rel_err(oc, refc.permute(0, 2, 1, 3).reshape(b, n, h * d)) < 1e-4
+
+
+def test_training_through_attention_fails_loudly(emu_modules):
+    model, _ = _build("tiny_prepend", 700, "cpu")
+    inp = dit_inputs("tiny_prepend")
+    out = model(inp["x"].requires_grad_(True), inp["t"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"])
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
