@@ -36,7 +36,123 @@ def parse():
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
+    ap.add_argument("--workload", choices=["vae_train", "dit_sample"], default="vae_train",
+                    help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
+                         "dit_sample: configs[2] DiT sampling steps/s (the metric's second half)")
+    ap.add_argument("--dit-dtype", choices=["bf16", "f32"], default="bf16")
     return ap.parse_args()
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+class AttnProfiler:
+    """HIP-event timing + algorithmic flops (4*Nq*Nk*64*H*B) of every sat_attn_fwd_kernel launch."""
+
+    def __init__(self, ops):
+        self.records = []
+        self.enabled = False
+        orig = ops.lib.sat_attention_fwd
+
+        def timed(*a):
+            if not self.enabled:
+                return orig(*a)
+            b, h, _hkv, nq, nk, d = a[14:20]
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig(*a)
+            e.record()
+            self.records.append((s, e, 4.0 * b * h * nq * nk * d))
+            return rc
+
+        ops.lib.sat_attention_fwd = timed
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        return len(self.records), ms, sum(f for _, _, f in self.records)
+
+
+def dit_cpu_baseline(dcfg, latent_len, ctx_len):
+    """Oracle DiT forward (fp32, CFG batch of 2) on <=16 host threads: one model evaluation."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dit_oracle
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    model = DiffusionTransformer(**dcfg)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
+    cross = torch.randn(1, ctx_len, dcfg["cond_token_dim"], generator=g)
+    glob = torch.randn(1, dcfg["global_cond_dim"], generator=g)
+    t = torch.tensor([0.5])
+    with torch.no_grad():
+        dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=6.0)   # warm-up
+        t0 = time.perf_counter()
+        dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=6.0)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 sampler step (oracle DiT forward, fp32, CFG batch 2, N={latent_len + 1}) in {dt:.2f} s"}
+
+
+def run_dit_sample(args):
+    """BASELINE.json configs[2]: Stable-Audio-Open-1.0 DiT, text-conditioned, v-DDIM sampling with CFG
+    (batch doubled inside the model, dit.py:324-410).  One 'step' = one sampler step = one DiT evaluation
+    at batch 2*B plus the DDIM update."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from stable_audio_tools_amd import ops as O
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    from stable_audio_tools_amd.sampling import sample_v_ddim
+    cfg = json.load(open(os.path.join(ROOT, "stable_audio_tools_amd", "configs", "stable_audio_open_dit.json")))
+    dcfg = cfg["diffusion"]["config"]
+    dtype = torch.bfloat16 if args.dit_dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    model = DiffusionTransformer(**dcfg)
+    with torch.no_grad():   # de-zero the branch outputs the reference zero-initialises (SURVEY.md §4)
+        for n_, p in model.named_parameters():
+            if n_.endswith("to_out.weight") or ".ff.ff.2." in n_ or "process_conv" in n_:
+                p.normal_(0.0, 0.02)
+    model = model.to(device=dev, dtype=dtype).train(False)
+    ops = O.get_ops()
+    prof = AttnProfiler(ops)
+    b, tlat, m = args.batch, cfg["latent_length"], cfg["context_length"]
+    g = torch.Generator().manual_seed(0)
+    noise = torch.randn(b, dcfg["io_channels"], tlat, generator=g).to(dev, dtype)
+    cross = torch.randn(b, m, dcfg["cond_token_dim"], generator=g).to(dev, dtype)
+    glob = torch.randn(b, dcfg["global_cond_dim"], generator=g).to(dev, dtype)
+    kw = dict(cross_attn_cond=cross, global_embed=glob, cfg_scale=6.0, scale_phi=0.75)
+    sample_v_ddim(model, noise, max(args.warmup, 1), **kw)
+    torch.cuda.synchronize()
+    prof.enabled = True
+    t0 = time.perf_counter()
+    out = sample_v_ddim(model, noise, args.steps, **kw)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof.enabled = False
+    nl, ms, fl = prof.summary()
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dit_dtype == "bf16" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    n = tlat + 1
+    line = {
+        "metric": "DiT sampling steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dit_dtype, "data": "synthetic",
+        "config": {"workload": "stable_audio_open_1_0 DiT (d=1536, 24 layers, 24x64 heads, GQA cross-attn to 130x768 context), "
+                               "v-DDIM sampler with CFG scale 6 + rescale (model batch 2B), random init",
+                   "latent_frames": tlat, "tokens": n, "context": m, "per_gpu_batch": b, "finite": bool(torch.isfinite(out.float()).all())},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": "sat_attn_fwd_kernel", "launches": nl,
+                     "avg_launch_ms": ms / nl if nl else None,
+                     "note": "algorithmic flops 4*Nq*Nk*64*H*B per launch (self N=1025 and GQA cross M=130) over HIP-event time; "
+                             "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split)"},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = dit_cpu_baseline(dcfg, tlat, m)
+    print(json.dumps(line), flush=True)
 
 
 class ConvProfiler:
@@ -107,6 +223,12 @@ def cpu_baseline(cfg, nsamples):
 
 def main():
     args = parse()
+    if args.workload == "dit_sample":
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            raise SystemExit("dit_sample is replicas-only (independent prompts per GPU, no collective): run it per GPU")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
+        return run_dit_sample(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

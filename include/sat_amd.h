@@ -120,6 +120,49 @@ int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
                    float eps, float weight_decay, int step, float grad_scale, float* ema, float ema_decay,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DiT block operators — models/transformer.py.  dtype: 0 = fp32 tensors, 1 = bf16 tensors
+ * (statistics / softmax / accumulation always fp32).
+ * ---------------------------------------------------------------------------------------------- */
+/* Attention.apply_attn (transformer.py:406-441): o = softmax(q k^T * scale) v, dense, non-causal, no mask;
+ * grouped-query when Hkv < H (replaces repeat_interleave :408-411).  q: element (b,h,n,d) at b*sqb + h*sqh +
+ * n*sqn + d (ELEMENT strides, d contiguous), likewise k, v with Hkv heads.  o: (B, Nq, H*64) — heads merged;
+ * lse: (B, H, Nq) fp32 or NULL.  head_dim must be 64.  fp32 inputs use a bf16x3 split on the matrix cores. */
+int sat_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long long sqb, long long sqh,
+                      long long sqn, long long skb, long long skh, long long skn, long long svb, long long svh,
+                      long long svn, int B, int H, int Hkv, int Nq, int Nk, int head_dim, float scale, int dtype,
+                      void* stream);
+
+/* LayerNorm.forward (transformer.py:236-241: gamma, beta buffer, eps) fused with the adaLN modulation
+ * y = LN(x) * (1 + scale[b]) + shift[b] (TransformerBlock.forward :682, :697).  x, y: (rows, D); gamma/beta fp32;
+ * scale/shift: rows of a (B, ...) tensor with element stride mod_stride between batches, or NULL;
+ * rows_per_batch = N.  mean/rstd (rows) are saved when non-NULL. */
+int sat_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* scale, const void* shift,
+                      long long mod_stride, void* y, float* mean, float* rstd, int rows, int D, int rows_per_batch,
+                      float eps, int dtype, void* stream);
+/* dx plus partial column sums part[3][sat_layernorm_bwd_nblocks()][D] = {d_gamma, d_scale, d_shift} (slabs of one
+ * batch item are contiguous; reduce with sat_reduce_splits). */
+int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch);
+int sat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale,
+                      long long mod_stride, const float* mean, const float* rstd, void* dx, float* part, int rows, int D,
+                      int rows_per_batch, int dtype, void* stream);
+
+/* RotaryEmbedding.forward (transformer.py:125-138): cs[n][j] = {cos, sin}(pos_scale * n * inv_freq[j]), fp32. */
+int sat_rope_tables(const float* inv_freq, float* cs, int N, int half, float pos_scale, void* stream);
+/* apply_rotary_pos_emb (transformer.py:155-174), in place: rotates dims [0, 2*half) of every head of
+ * t: element (b,n,h,d) at b*sb + n*sn + h*sh + d.  Table row = tab_off + n.  transpose != 0 applies the inverse
+ * rotation (the backward pass). */
+int sat_rope_apply(void* t, const float* cs, long long sb, long long sn, long long sh, int B, int N, int H, int half,
+                   int tab_off, int transpose, int dtype, void* stream);
+
+/* GLU.forward (transformer.py:274-275): out = x * silu(gate) for xin = [x | gate] (rows, 2F);
+ * backward != 0: out = d_xin (rows, 2F) from dout (rows, F). */
+int sat_swiglu(const void* xin, const void* dout, void* out, long long rows, int F, int backward, int dtype,
+               void* stream);
+/* y = x * sigmoid(1 - gate[b]) + res   (transformer.py:684-686, :699-701); gate rows at stride gstride. */
+int sat_gate_residual(const void* x, const void* gate, long long gstride, const void* res, void* y, int B, int N, int D,
+                      int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
