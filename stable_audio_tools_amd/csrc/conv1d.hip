@@ -87,32 +87,44 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
             }
             const float* xr = xb + (size_t)ci * p.Tin;
             float* arow = a_lds + sc * cs;
-            for (int j = sj0; j < nj; j += tpc) {
-                const int tin = tin0 + j;
-                float v = 0.0f;
-                if (ch_ok && tin >= 0 && tin < p.Tin) {
-                    v = xr[tin];
-                    if (use_snake) v = sat_snake(v, sa, sib);
+            // loads are issued in batches of 8 per thread BEFORE any of them is consumed, so a chunk costs one
+            // HBM round trip instead of one per element
+            for (int jb = sj0; jb < nj; jb += 8 * tpc) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = jb + u * tpc;
+                    const int tin = tin0 + j;
+                    v[u] = (ch_ok && j < nj && tin >= 0 && tin < p.Tin) ? xr[tin] : 0.0f;
                 }
-                int pos = j;
-                if (S != 1) {
-                    const int q = j / S;
-                    pos = (j - q * S) * L + q;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = jb + u * tpc;
+                    if (j < nj) {
+                        const float o = use_snake ? sat_snake(v[u], sa, sib) : v[u];   // snake(0) == 0: padding stays 0
+                        int pos = j;
+                        if (S != 1) {
+                            const int q = j / S;
+                            pos = (j - q * S) * L + q;
+                        }
+                        arow[pos] = o;
+                    }
                 }
-                arow[pos] = v;
             }
         }
-        // ---- stage weights: rows (c, tap) of the packed [Cin][K][Cout] tensor ----
+        // ---- stage weights: rows (c, tap) of the packed [Cin][K][Cout] tensor (<= 64 rows -> <= 8 float4 per thread) ----
         {
             const int nrows = CI_T * K;
             const float* wbase = p.w + (size_t)ci0 * K * p.Cout;
             const bool vec_ok = ((p.Cout & 3) == 0);
-            for (int idx = tid; idx < nrows * 32; idx += 256) {
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
                 const int r = idx >> 5, c4 = (idx & 31) * 4;
-                const int ci = ci0 + r / K;
                 const int co = co0 + c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < p.Cin) {
+                if (r < nrows && ci0 + r / K < p.Cin) {
                     const float* src = wbase + (size_t)r * p.Cout + co;
                     if (vec_ok && co + 3 < p.Cout) {
                         v = *reinterpret_cast<const float4*>(src);
@@ -123,15 +135,28 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
                         if (co + 3 < p.Cout) v.w = src[3];
                     }
                 }
-                *reinterpret_cast<float4*>(&w_lds[r][c4]) = v;
+                wv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
+                const int r = idx >> 5, c4 = (idx & 31) * 4;
+                if (r < nrows) *reinterpret_cast<float4*>(&w_lds[r][c4]) = wv[u];
             }
         }
         __syncthreads();
 
         if (wave_on) {
+            // Two channel pairs (8 MFMAs) per step; the operands of step i+1 are fetched from LDS before the
+            // MFMAs of step i issue, so the ds_read latency hides under 512 matrix-pipe cycles.  CI_T is a
+            // multiple of 4 and the slabs are zero-filled past Cin, so rounding the pair count up is safe.
             int npairs = (p.Cin - ci0 + 1) >> 1;
             if (npairs > (CI_T >> 1)) npairs = CI_T >> 1;
-            for (int tap = 0; tap < K; ++tap) {
+            const int npr = (npairs + 1) >> 1;       // steps per tap
+            const int nsteps = K * npr;
+            float an[2][2], bn[2][2];                // [pair in step][mi | ni]
+            auto fetch = [&](int step) {
+                const int tap = step / npr, cq = step - tap * npr;
                 int toff;
                 if (S == 1) {
                     toff = tap * dil;
@@ -139,18 +164,35 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
                     const int dq = tap / S;
                     toff = (tap - dq * S) * L + dq;
                 }
-                for (int cp = 0; cp < npairs; ++cp) {
-                    const int c = 2 * cp + hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 2 * (2 * cq + u) + hi;
                     const float* wr = &w_lds[c * K + tap][co_w + l31];
                     const float* ar = a_lds + c * cs + toff + t_w + l31;
-                    const float a0 = wr[0];
-                    const float b0 = ar[0], b1 = ar[32];
-                    acc[0][0] = sat_mfma_32x32x2_f32(a0, b0, acc[0][0]);
-                    acc[0][1] = sat_mfma_32x32x2_f32(a0, b1, acc[0][1]);
+                    an[u][0] = wr[0];
+                    an[u][1] = wr[32];
+                    bn[u][0] = ar[0];
+                    bn[u][1] = ar[32];
+                }
+            };
+            fetch(0);
+            for (int step = 0; step < nsteps; ++step) {
+                float ac[2][2], bc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ac[u][0] = an[u][0];
+                    ac[u][1] = an[u][1];
+                    bc[u][0] = bn[u][0];
+                    bc[u][1] = bn[u][1];
+                }
+                if (step + 1 < nsteps) fetch(step + 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[0][0] = sat_mfma_32x32x2_f32(ac[u][0], bc[u][0], acc[0][0]);
+                    acc[0][1] = sat_mfma_32x32x2_f32(ac[u][0], bc[u][1], acc[0][1]);
                     if (mi1_on) {
-                        const float a1 = wr[32];
-                        acc[1][0] = sat_mfma_32x32x2_f32(a1, b0, acc[1][0]);
-                        acc[1][1] = sat_mfma_32x32x2_f32(a1, b1, acc[1][1]);
+                        acc[1][0] = sat_mfma_32x32x2_f32(ac[u][1], bc[u][0], acc[1][0]);
+                        acc[1][1] = sat_mfma_32x32x2_f32(ac[u][1], bc[u][1], acc[1][1]);
                     }
                 }
             }
@@ -233,9 +275,9 @@ extern "C" int sat_conv1d(const float* x, const float* w_packed, const float* bi
     SatConvLaunch a;
     a.p = SatConvParams{x, w_packed, bias, alpha, beta, res, y, x2, alpha2, beta2, part_da, part_db,
                         B, Cin, Cout, Tin, Tout, K, stride, dil, pad, tanh_out};
-    int ci_t = (SAT_W_ROWS / K) & ~1;
+    int ci_t = (SAT_W_ROWS / K) & ~3;   // multiple of 4: the MFMA loop consumes two channel pairs per step
     if (ci_t > 32) ci_t = 32;
-    if (ci_t < 2) { sat_set_error("sat_conv1d: kernel too wide (K > 32)"); return 1; }
+    if (ci_t < 4) { sat_set_error("sat_conv1d: kernel too wide (K > 16)"); return 1; }
     const int nj = (SAT_T_T - 1) * stride + (K - 1) * dil + 1;
     int cs, L = 0;
     if (stride == 1) {
@@ -249,7 +291,7 @@ extern "C" int sat_conv1d(const float* x, const float* w_packed, const float* bi
         }
         cs = stride * L;
     }
-    while (ci_t > 2 && ci_t * cs > SAT_A_FLOATS) ci_t -= 2;
+    while (ci_t > 4 && ci_t * cs > SAT_A_FLOATS) ci_t -= 4;
     if (ci_t * cs > SAT_A_FLOATS) { sat_set_error("sat_conv1d: receptive field too large for the LDS slab"); return 1; }
     if (256 / ci_t < 1) { sat_set_error("sat_conv1d: internal tiling error"); return 1; }
     a.t = SatConvTile{ci_t, cs, L, nj};

@@ -88,45 +88,73 @@ __global__ void __launch_bounds__(256) sat_conv_wgrad_kernel(SatWgradParams p) {
         const int tt0 = (ch - b * p.nT) * SAT_WG_TT;
         // ---- stage lo: 128 rows x TT ----
         {
+            // all 16 loads of a thread are issued before the first is consumed (one HBM round trip per stage)
             const float* lob = p.lo + (size_t)b * p.M * p.Tlo;
-            for (int idx = tid; idx < SAT_CO_T * SAT_WG_TT; idx += 256) {
+            float v[SAT_CO_T * SAT_WG_TT / 256];
+#pragma unroll
+            for (int u = 0; u < SAT_CO_T * SAT_WG_TT / 256; ++u) {
+                const int idx = tid + u * 256;
                 const int row = idx / SAT_WG_TT, col = idx - row * SAT_WG_TT;
                 const int m = m0 + row, t = tt0 + col;
-                float v = 0.f;
-                if (m < p.M && t < p.Tlo) {
-                    v = lob[(size_t)m * p.Tlo + t];
-                    if (p.snake_on == 1) v = sat_snake(v, sn_a[row], sn_ib[row]);
-                }
-                lo_lds[row][col] = v;
+                v[u] = (m < p.M && t < p.Tlo) ? lob[(size_t)m * p.Tlo + t] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < SAT_CO_T * SAT_WG_TT / 256; ++u) {
+                const int idx = tid + u * 256;
+                const int row = idx / SAT_WG_TT, col = idx - row * SAT_WG_TT;
+                lo_lds[row][col] = (p.snake_on == 1) ? sat_snake(v[u], sn_a[row], sn_ib[row]) : v[u];
             }
         }
-        // ---- stage hi: N_T rows x hi_nj ----
+        // ---- stage hi: N_T rows x hi_nj, in batches of 8 loads per thread ----
         {
             const float* hib = p.hi + (size_t)b * p.N * p.Thi;
             const int th0 = tt0 * S - p.pad + k0 * dil;
             const int nj = p.hi_nj;
-            for (int idx = tid; idx < N_T * nj; idx += 256) {
-                const int row = idx / nj, col = idx - row * nj;
-                const int n = n0 + row, t = th0 + col;
-                float v = 0.f;
-                if (n < p.N && t >= 0 && t < p.Thi) {
-                    v = hib[(size_t)n * p.Thi + t];
-                    if (p.snake_on == 2) v = sat_snake(v, sn_a[row], sn_ib[row]);
+            const int total = N_T * nj;
+            for (int base = tid; base < total; base += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    const int row = idx / nj, col = idx - row * nj;
+                    const int n = n0 + row, t = th0 + col;
+                    v[u] = (idx < total && n < p.N && t >= 0 && t < p.Thi) ? hib[(size_t)n * p.Thi + t] : 0.0f;
                 }
-                hi_lds[row * RLH + col] = v;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total) {
+                        const int row = idx / nj, col = idx - row * nj;
+                        hi_lds[row * RLH + col] = (p.snake_on == 2) ? sat_snake(v[u], sn_a[row], sn_ib[row]) : v[u];
+                    }
+                }
             }
         }
         __syncthreads();
         if (wave_on) {
+            if (kcount == KT) {
+                // branch-free body (a hand-rolled register prefetch here measured 1.7x SLOWER on MI355X:
+                // 47 -> 28 TFLOP/s; the compiler's own schedule of the unrolled loop is kept)
 #pragma unroll 4
-            for (int tp = 0; tp < SAT_WG_TT; tp += 2) {
-                const float av = lo_lds[m_w + l31][tp + hi];
+                for (int tp = 0; tp < SAT_WG_TT; tp += 2) {
+                    const float av = lo_lds[m_w + l31][tp + hi];
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns) {
-                    const float* hr = hi_lds + (ns * 32 + l31) * RLH + (tp + hi) * S;
+                    for (int ns = 0; ns < NSUB; ++ns) {
+                        const float* hr = hi_lds + (ns * 32 + l31) * RLH + (tp + hi) * S;
 #pragma unroll
-                    for (int kk = 0; kk < KT; ++kk) {
-                        if (kk < kcount) acc[ns][kk] = sat_mfma_32x32x2_f32(av, hr[kk * dil], acc[ns][kk]);
+                        for (int kk = 0; kk < KT; ++kk) acc[ns][kk] = sat_mfma_32x32x2_f32(av, hr[kk * dil], acc[ns][kk]);
+                    }
+                }
+            } else {
+                for (int tp = 0; tp < SAT_WG_TT; tp += 2) {
+                    const float av = lo_lds[m_w + l31][tp + hi];
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns) {
+                        const float* hr = hi_lds + (ns * 32 + l31) * RLH + (tp + hi) * S;
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) {
+                            if (kk < kcount) acc[ns][kk] = sat_mfma_32x32x2_f32(av, hr[kk * dil], acc[ns][kk]);
+                        }
                     }
                 }
             }

@@ -86,15 +86,18 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
         }
         {
             // rows: (r*2+j)*CI_T + c  <-  packed[((r*2+j)*Cin + ci0 + c)*Cout + co]
-            const int nrows = 2 * S * CI_T;
+            const int nrows = 2 * S * CI_T;   // <= 64 rows -> <= 8 float4 per thread, all issued before any is stored
             const bool vec_ok = ((p.Cout & 3) == 0);
-            for (int idx = tid; idx < nrows * 32; idx += 256) {
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
                 const int row = idx >> 5, c4 = (idx & 31) * 4;
                 const int rj = row / CI_T, c = row - rj * CI_T;
                 const int ci = ci0 + c;
                 const int co = co0 + c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < p.Cin) {
+                if (row < nrows && ci < p.Cin) {
                     const float* src = p.w + ((size_t)rj * p.Cin + ci) * p.Cout + co;
                     if (vec_ok && co + 3 < p.Cout) {
                         v = *reinterpret_cast<const float4*>(src);
@@ -105,7 +108,13 @@ __global__ void __launch_bounds__(256) sat_convtr1d_kernel(SatConvTrLaunch a) {
                         if (co + 3 < p.Cout) v.w = src[3];
                     }
                 }
-                *reinterpret_cast<float4*>(&w_lds[row][c4]) = v;
+                wv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
+                const int row = idx >> 5, c4 = (idx & 31) * 4;
+                if (row < nrows) *reinterpret_cast<float4*>(&w_lds[row][c4]) = wv[u];
             }
         }
         __syncthreads();
