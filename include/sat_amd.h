@@ -125,12 +125,26 @@ int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
  * (statistics / softmax / accumulation always fp32).
  * ---------------------------------------------------------------------------------------------- */
 /* Attention.apply_attn (transformer.py:406-441): o = softmax(q k^T * scale) v, dense, non-causal, no mask;
- * grouped-query when Hkv < H (replaces repeat_interleave :408-411).  q: element (b,h,n,d) at b*sqb + h*sqh +
- * n*sqn + d (ELEMENT strides, d contiguous), likewise k, v with Hkv heads.  o: (B, Nq, H*64) — heads merged;
- * lse: (B, H, Nq) fp32 or NULL.  head_dim must be 64.  fp32 inputs use a bf16x3 split on the matrix cores. */
-int sat_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long long sqb, long long sqh,
-                      long long sqn, long long skb, long long skh, long long skn, long long svb, long long svh,
-                      long long svn, int B, int H, int Hkv, int Nq, int Nk, int head_dim, float scale, int dtype,
+ * grouped-query when Hkv < H (replaces repeat_interleave :408-411); head_dim must be 64.
+ *
+ * sat_attn_prepare: src element (b,h,n,d) at b*sb + h*sh + n*sn + d (ELEMENT strides, d contiguous, fp32 or
+ * bf16) -> bf16 planes zero-padded to Np = N rounded up to 64: row-major [B][H][Np][64] (rm_*) and/or transposed
+ * [B][H][64][Np] (tr_*); NULL outputs are skipped.  fp32 sources (dtype 0) give hi AND lo planes (x ~ hi + lo)
+ * and the kernels then form every product as three bf16 MFMAs — the fp32-parity mode; bf16 sources use hi only. */
+int sat_attn_prepare(const void* src, long long sb, long long sh, long long sn, short* rm_hi, short* rm_lo,
+                     short* tr_hi, short* tr_lo, int B, int H, int N, int Np, int dtype, void* stream);
+/* forward: q_* row-major planes (B,H,Nqp,64), k_* row-major (B,Hkv,Nkp,64), vt_* TRANSPOSED (B,Hkv,64,Nkp);
+ * o: (B, Nq, H*64) in the model dtype — heads merged; lse: (B, H, Nq) fp32 or NULL. */
+int sat_attention_fwd(const short* q_hi, const short* q_lo, const short* k_hi, const short* k_lo, const short* vt_hi,
+                      const short* vt_lo, void* o, float* lse, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp,
+                      int head_dim, float scale, int dtype, void* stream);
+/* dsum[b][h][q] = sum_d dout[b][q][h*64+d] * out[b][q][h*64+d]   (the softmax-gradient row term) */
+int sat_attention_rowdot(const void* dout, const void* out, float* dsum, int B, int H, int Nq, int dtype, void* stream);
+/* backward (autograd of the above): planes[16] = {q_rm, k_rm, v_rm, k_tr, q_tr, dout_rm, dout_tr, unused} x {hi, lo};
+ * two launches: dQ (wave = 32 queries, key tiles) and dK/dV (wave = 32 keys, query tiles, summed over the query
+ * heads of a kv group); probabilities are recomputed from lse.  dq: (B,H,Nq,64), dk/dv: (B,Hkv,Nk,64), model dtype. */
+int sat_attention_bwd(const short* const* planes, const float* lse, const float* dsum, void* dq, void* dk, void* dv,
+                      int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim, float scale, int dtype,
                       void* stream);
 
 /* LayerNorm.forward (transformer.py:236-241: gamma, beta buffer, eps) fused with the adaLN modulation
@@ -162,6 +176,11 @@ int sat_swiglu(const void* xin, const void* dout, void* out, long long rows, int
 /* y = x * sigmoid(1 - gate[b]) + res   (transformer.py:684-686, :699-701); gate rows at stride gstride. */
 int sat_gate_residual(const void* x, const void* gate, long long gstride, const void* res, void* y, int B, int N, int D,
                       int dtype, void* stream);
+/* its backward: dx = dy * sigmoid(1-gate); part[B][sat_gate_residual_bwd_nchunks(N)][D] partial sums of d_gate
+ * (reduce per batch item with sat_reduce_splits); d_res = dy. */
+int sat_gate_residual_bwd_nchunks(int N);
+int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long long gstride, void* dx, float* part,
+                          int B, int N, int D, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

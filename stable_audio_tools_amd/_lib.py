@@ -44,7 +44,10 @@ SIGNATURES = {
     "sat_stft_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sat_stft_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     # attention.hip
-    "sat_attention_fwd": (_I, [_P] * 5 + [_L] * 9 + [_I] * 6 + [_F, _I, _P]),
+    "sat_attn_prepare": (_I, [_P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sat_attention_fwd": (_I, [_P] * 8 + [_I] * 8 + [_F, _I, _P]),
+    "sat_attention_rowdot": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sat_attention_bwd": (_I, [_P] * 6 + [_I] * 8 + [_F, _I, _P]),
     # dit_ops.hip
     "sat_layernorm_fwd": (_I, [_P] * 5 + [_L] + [_P] * 3 + [_I] * 3 + [_F, _I, _P]),
     "sat_layernorm_bwd_nblocks": (_I, [_I, _I]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "sat_rope_apply": (_I, [_P, _P, _L, _L, _L] + [_I] * 7 + [_P]),
     "sat_swiglu": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "sat_gate_residual": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "sat_gate_residual_bwd_nchunks": (_I, [_I]),
+    "sat_gate_residual_bwd": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsat_amd.so")

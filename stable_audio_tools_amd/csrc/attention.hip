@@ -1,131 +1,211 @@
 // attention.hip — dense non-causal scaled-dot-product attention for the DiT (head dim 64), flash
-// style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), self- and grouped-query cross-attention.
+// style on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): forward, and backward (dQ / dK,dV),
+// self- and grouped-query cross-attention.
 //
 // Replaces Attention.apply_attn (stable_audio_tools/models/transformer.py:406-441): flash_attn_func /
 // F.scaled_dot_product_attention with scale 1/sqrt(d), no mask (masks are disabled by the caller,
-// models/dit.py:283), and the GQA repeat_interleave of k/v (transformer.py:408-411) done by indexing.
+// models/dit.py:283), the GQA repeat_interleave of k/v (transformer.py:408-411) done by indexing, and
+// the autograd of all of it.
 //
-// Structure (one wave = 32 query rows, 4 waves per workgroup, 64-key tiles staged through LDS):
-//   * "swapped" products: S^T = K Q^T and O^T = V^T P^T, so a lane owns ONE query column — its
-//     softmax statistics are lane-local (one lane^32 exchange per tile for the max), the O rescale
-//     is a per-lane scalar, and the P^T accumulator registers feed the second MFMA as its B operand
-//     with no cross-lane traffic: the MFMA k-slot order is simply defined to be the accumulator's
-//     row order, and the V^T fragment is read from LDS in that same order.
-//   * Q fragments live in registers for the whole kernel; K tile row-major (padded rows ->
-//     conflict-free ds_read_b128), V tile transposed in LDS.
-//   * fp32 inputs (the 1e-3 parity mode) are split into bf16 hi + lo parts and every product is
-//     three MFMAs (hi*hi + hi*lo + lo*hi): ~2^-16 relative error per product, fp32 accumulate.
-//     bf16 inputs use one MFMA per product.
-// Outputs O in (B, Nq, H*64) — heads already merged for the to_out projection — and the
-// log-sum-exp per (b, h, q) for the backward pass.
+// Data flow
+//   sat_attn_prepare   (b,h,n,64) strided fp32|bf16  ->  bf16 "planes": row-major [B][H][Np][64] and/or
+//                      transposed [B][H][64][Np], Np = N rounded up to 64, zero padded.  fp32 sources
+//                      are split into hi + lo planes (x ~ hi + lo to ~2^-17): every product in the
+//                      kernels is then three MFMAs (hi*hi + hi*lo + lo*hi) with fp32 accumulation —
+//                      the 1e-3 "rel fp32" parity mode.  bf16 sources give one plane, one MFMA.
+//   kernels            every LDS tile is a straight 16-byte-per-lane copy of a plane tile into padded
+//                      rows (conflict-free ds_read_b128 / b64); no conversion or transposition in the loop.
+//
+// Kernel structure (one wave = 32 rows of its "own" sequence, 4 waves per workgroup, 64-wide tiles of
+// the other sequence staged through LDS): all products are arranged "swapped" so that the softmax row
+// a lane works on is a COLUMN of the accumulator tile — its statistics are lane-local (one lane^32
+// exchange), rescaling O is a per-lane scalar, and accumulator registers feed the next MFMA directly as
+// its B operand: the MFMA k-slot order is defined to be the accumulator row order
+// (slot (hi,e) of step u <-> row 16u + 4hi + (e&3) + 8(e>>2)) and the LDS-side operand is read in that
+// same order.
 #include "sat_device.h"
 
 #define SAT_ATT_D 64
-#define SAT_ATT_KT 64            // keys per tile
-#define SAT_ATT_KROW 72          // bf16 per K row in LDS (64 + 8 pad -> 144 B stride)
-#define SAT_ATT_VROW 72          // bf16 per V^T row in LDS (64 keys + 8 pad)
+#define SAT_ATT_T 64              // tile width (keys in fwd/dQ, queries in dK/dV)
+#define SAT_ATT_ROW 72            // bf16 per LDS row (64 + 8 pad -> 144 B stride, conflict-free b128/b64)
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// prepare: strided source -> bf16 planes
+// ---------------------------------------------------------------------------------------------
+struct SatPrepParams {
+    const void* src;            // element (b,h,n,d) at b*sb + h*sh + n*sn + d
+    long long sb, sh, sn;
+    short* rm_hi; short* rm_lo; // [B][H][Np][64]   (null = skip)
+    short* tr_hi; short* tr_lo; // [B][H][64][Np]
+    int B, H, N, Np;
+};
+
+template <typename T> struct SatSrc;
+template <> struct SatSrc<float> { static SAT_DEVICE float at(const void* p, long long i) { return ((const float*)p)[i]; } };
+template <> struct SatSrc<short> { static SAT_DEVICE float at(const void* p, long long i) { return sat_bf16_to_f32(((const short*)p)[i]); } };
+
+template <typename T>
+__global__ void __launch_bounds__(256) sat_attn_prepare_kernel(SatPrepParams p) {
+    __shared__ short t_hi[SAT_ATT_D][SAT_ATT_T + 2];
+    __shared__ short t_lo[SAT_ATT_D][SAT_ATT_T + 2];
+    const int n0 = blockIdx.x * SAT_ATT_T, h = blockIdx.y, b = blockIdx.z;
+    const long long base = (long long)b * p.sb + (long long)h * p.sh;
+    const size_t plane = ((size_t)b * p.H + h) * (size_t)p.Np * SAT_ATT_D;
+    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D; i += 256) {
+        const int r = i >> 6, d = i & 63;
+        const int n = n0 + r;
+        const float x = (n < p.N) ? SatSrc<T>::at(p.src, base + (long long)n * p.sn + d) : 0.0f;
+        const short hi = sat_f32_to_bf16(x);
+        const short lo = sat_f32_to_bf16(x - sat_bf16_to_f32(hi));
+        if (p.rm_hi) p.rm_hi[plane + (size_t)n * SAT_ATT_D + d] = hi;
+        if (p.rm_lo) p.rm_lo[plane + (size_t)n * SAT_ATT_D + d] = lo;
+        t_hi[d][r] = hi;
+        t_lo[d][r] = lo;
+    }
+    if (p.tr_hi == nullptr && p.tr_lo == nullptr) return;   // block-uniform
+    __syncthreads();
+    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D; i += 256) {
+        const int d = i >> 6, r = i & 63;
+        if (p.tr_hi) p.tr_hi[plane + (size_t)d * p.Np + n0 + r] = t_hi[d][r];
+        if (p.tr_lo) p.tr_lo[plane + (size_t)d * p.Np + n0 + r] = t_lo[d][r];
+    }
+}
+
+extern "C" int sat_attn_prepare(const void* src, long long sb, long long sh, long long sn, short* rm_hi, short* rm_lo,
+                                short* tr_hi, short* tr_lo, int B, int H, int N, int Np, int dtype, void* stream) {
+    if (B <= 0 || H <= 0 || N <= 0) { sat_set_error("sat_attn_prepare: empty shape"); return 1; }
+    if (Np < N || (Np % SAT_ATT_T) != 0) { sat_set_error("sat_attn_prepare: Np must be N rounded up to a multiple of 64"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_attn_prepare: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    SatPrepParams p{src, sb, sh, sn, rm_hi, rm_lo, tr_hi, tr_lo, B, H, N, Np};
+    dim3 grid(Np / SAT_ATT_T, H, B);
+    if (dtype == 0) SAT_LAUNCH(sat_attn_prepare_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_attn_prepare_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_attn_prepare");
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared device helpers
+// ---------------------------------------------------------------------------------------------
+// copy a ROWS x COLS bf16 tile (rows `rstride` elements apart in global) into padded LDS rows; 16 B per lane
+template <int ROWS, int COLS, int LROW>
+SAT_DEVICE void sat_att_stage(short (*dst)[LROW], const short* src, size_t rstride) {
+    constexpr int PARTS = COLS / 8;
+    for (int c = threadIdx.x; c < ROWS * PARTS; c += 256) {
+        const int r = c / PARTS, part = c - r * PARTS;
+        *reinterpret_cast<bf16x8*>(&dst[r][part * 8]) = *reinterpret_cast<const bf16x8*>(src + (size_t)r * rstride + part * 8);
+    }
+}
+// A/B fragment with 8 CONSECUTIVE k (16 B): row-major tile, row = l31 (+32 sub), k offset = 16*s + 8*hi
+template <int LROW>
+SAT_DEVICE bf16x8 sat_att_frag_rm(short (*t)[LROW], int row, int koff) {
+    return *reinterpret_cast<const bf16x8*>(&t[row][koff]);
+}
+// fragment in ACCUMULATOR-ROW order: elements e=0..3 at kofs+{0..3}, e=4..7 at kofs+8+{0..3}
+template <int LROW>
+SAT_DEVICE bf16x8 sat_att_frag_acc(short (*t)[LROW], int row, int kofs) {
+    const s4v a = *reinterpret_cast<const s4v*>(&t[row][kofs]);
+    const s4v b = *reinterpret_cast<const s4v*>(&t[row][kofs + 8]);
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = a[e];
+        v[4 + e] = b[e];
+    }
+    return v;
+}
+template <int NP>
+SAT_DEVICE void sat_att_pack(const f32x16& acc, int u, bf16x8 (&out)[NP]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = acc[8 * u + e];
+        const short hi = sat_f32_to_bf16(x);
+        out[0][e] = hi;
+        if (NP == 2) out[NP - 1][e] = sat_f32_to_bf16(x - sat_bf16_to_f32(hi));
+    }
+}
+// acc += A * B with the 1- or 3-MFMA product
+template <int NP>
+SAT_DEVICE f32x16 sat_att_mma(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 acc) {
+    acc = sat_mfma_32x32x16_bf16(a[0], b[0], acc);
+    if (NP == 2) {
+        acc = sat_mfma_32x32x16_bf16(a[0], b[NP - 1], acc);
+        acc = sat_mfma_32x32x16_bf16(a[NP - 1], b[0], acc);
+    }
+    return acc;
+}
 
 struct SatAttnParams {
-    const void* q;   // element (b, h, n, d) at b*sqb + h*sqh + n*sqn + d   (element strides)
-    const void* k;   // (b, hk, n, d)
-    const void* v;
-    void* o;         // (B, Nq, H*64)
-    float* lse;      // (B, H, Nq) or null
-    long long sqb, sqh, sqn, skb, skh, skn, svb, svh, svn;
-    int B, H, Hkv, Nq, Nk;
+    // planes (hi, lo); lo pointers unused when NP == 1
+    const short* q_rm[2];   // [B][H][Nqp][64]
+    const short* k_rm[2];   // [B][Hkv][Nkp][64]
+    const short* v_rm[2];   // [B][Hkv][Nkp][64]
+    const short* k_tr[2];   // [B][Hkv][64][Nkp]
+    const short* v_tr[2];   // [B][Hkv][64][Nkp]
+    const short* q_tr[2];   // [B][H][64][Nqp]
+    const short* do_rm[2];  // [B][H][Nqp][64]
+    const short* do_tr[2];  // [B][H][64][Nqp]
+    void* o;                // fwd out (B, Nq, H*64), dtype of the model
+    float* lse;             // (B, H, Nq): fwd out / bwd in
+    const float* dsum;      // (B, H, Nq) rowsum(dO * O)   (bwd)
+    void* dq;               // bwd out (B, H, Nq, 64)
+    void* dk;               // bwd out (B, Hkv, Nk, 64)
+    void* dv;
+    int B, H, Hkv, Nq, Nk, Nqp, Nkp;
     float scale;
 };
 
-template <typename T> struct SatLoad;
-template <> struct SatLoad<float> {
-    static SAT_DEVICE float at(const void* p, long long i) { return ((const float*)p)[i]; }
-    static SAT_DEVICE void put(void* p, long long i, float v) { ((float*)p)[i] = v; }
-};
-template <> struct SatLoad<short> {  // bf16 bits
-    static SAT_DEVICE float at(const void* p, long long i) { return sat_bf16_to_f32(((const short*)p)[i]); }
-    static SAT_DEVICE void put(void* p, long long i, float v) { ((short*)p)[i] = sat_f32_to_bf16(v); }
-};
+template <typename T> struct SatOut;
+template <> struct SatOut<float> { static SAT_DEVICE void put(void* p, long long i, float v) { ((float*)p)[i] = v; } };
+template <> struct SatOut<short> { static SAT_DEVICE void put(void* p, long long i, float v) { ((short*)p)[i] = sat_f32_to_bf16(v); } };
 
-SAT_DEVICE void sat_split_bf16(float x, short* hi, short* lo) {
-    const short h = sat_f32_to_bf16(x);
-    *hi = h;
-    *lo = sat_f32_to_bf16(x - sat_bf16_to_f32(h));
-}
-
-template <typename T, bool SPLIT>
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NP>
 __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
-    constexpr int NP = SPLIT ? 2 : 1;  // hi (+ lo) planes
-    __shared__ __attribute__((aligned(16))) short k_lds[NP][SAT_ATT_KT][SAT_ATT_KROW];   // [key][d]
-    __shared__ __attribute__((aligned(16))) short v_lds[NP][SAT_ATT_D][SAT_ATT_VROW];    // [d][key]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) short k_lds[NP][SAT_ATT_T][SAT_ATT_ROW];   // [key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds[NP][SAT_ATT_D][SAT_ATT_ROW];   // [d][key]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int hk = h / (p.H / p.Hkv);
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int qrow = q0 + l31;
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;     // < Nqp (grid covers Nqp in steps of 128 only when present)
+    const bool q_in = qrow < p.Nqp;
     const bool q_ok = qrow < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
 
-    // ---- Q fragments: B operand of S^T = K Q^T : lane (q = l31, hi) holds d = 16*s + 8*hi + e ----
-    bf16x8 qf[NP][4];
-    {
-        const long long base = (long long)b * p.sqb + (long long)h * p.sqh + (long long)qrow * p.sqn;
+    bf16x8 qf[4][NP];   // B operand of S^T = K Q^T: lane (q = l31, hi) holds d = 16 s + 8 hi + e
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = q_ok ? SatLoad<T>::at(p.q, base + 16 * s + 8 * hi + e) : 0.0f;
-                if (SPLIT) {
-                    short a, c;
-                    sat_split_bf16(x, &a, &c);
-                    qf[0][s][e] = a;
-                    qf[NP - 1][s][e] = c;
-                } else {
-                    qf[0][s][e] = sat_f32_to_bf16(x);
-                }
+        for (int pl = 0; pl < NP; ++pl) {
+            if (q_in) qf[s][pl] = *reinterpret_cast<const bf16x8*>(p.q_rm[pl] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[s][pl][e] = 0;
             }
         }
-    }
 
-    f32x16 oacc[2];   // O^T: rows d (2 tiles of 32), cols q
+    f32x16 oacc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
-    float m_run = -INFINITY;   // running max of raw scores (this lane's query)
-    float l_run = 0.0f;        // running sum over THIS half's keys (combined with lane^32 at the end)
-    const float sl2 = p.scale * 1.4426950408889634f;   // scale * log2(e)
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float sl2 = p.scale * 1.4426950408889634f;
 
-    const long long kbase = (long long)b * p.skb + (long long)hk * p.skh;
-    const long long vbase = (long long)b * p.svb + (long long)hk * p.svh;
-
-    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_KT) {
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage K [key][d] and V^T [d][key] (zero beyond Nk) ----
-        for (int i = tid; i < SAT_ATT_KT * (SAT_ATT_D / 4); i += 256) {
-            const int key = i >> 4, d4 = (i & 15) * 4;
-            const bool ok = (k0 + key) < p.Nk;
+    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T) {
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float kx = ok ? SatLoad<T>::at(p.k, kbase + (long long)(k0 + key) * p.skn + d4 + e) : 0.0f;
-                const float vx = ok ? SatLoad<T>::at(p.v, vbase + (long long)(k0 + key) * p.svn + d4 + e) : 0.0f;
-                if (SPLIT) {
-                    short a, c;
-                    sat_split_bf16(kx, &a, &c);
-                    k_lds[0][key][d4 + e] = a;
-                    k_lds[NP - 1][key][d4 + e] = c;
-                    sat_split_bf16(vx, &a, &c);
-                    v_lds[0][d4 + e][key] = a;
-                    v_lds[NP - 1][d4 + e][key] = c;
-                } else {
-                    k_lds[0][key][d4 + e] = sat_f32_to_bf16(kx);
-                    v_lds[0][d4 + e][key] = sat_f32_to_bf16(vx);
-                }
-            }
+        for (int pl = 0; pl < NP; ++pl) {
+            sat_att_stage<64, 64, SAT_ATT_ROW>(k_lds[pl], p.k_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
+            sat_att_stage<64, 64, SAT_ATT_ROW>(v_lds[pl], p.v_tr[pl] + kplane + k0, (size_t)p.Nkp);
         }
         __syncthreads();
 
-        // ---- S^T = K Q^T for the two 32-key sub-tiles ----
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -133,17 +213,12 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                // A operand: K[key = kb*32 + l31][d = 16 s + 8 hi + e]
-                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(&k_lds[0][kb * 32 + l31][16 * s + 8 * hi]);
-                sacc[kb] = sat_mfma_32x32x16_bf16(ka, qf[0][s], sacc[kb]);
-                if (SPLIT) {
-                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(&k_lds[NP - 1][kb * 32 + l31][16 * s + 8 * hi]);
-                    sacc[kb] = sat_mfma_32x32x16_bf16(ka, qf[NP - 1][s], sacc[kb]);
-                    sacc[kb] = sat_mfma_32x32x16_bf16(kl, qf[0][s], sacc[kb]);
-                }
+                bf16x8 ka[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + l31, 16 * s + 8 * hi);
+                sacc[kb] = sat_att_mma<NP>(ka, qf[s], sacc[kb]);
             }
         }
-        // ---- online softmax for this lane's query over its 32 (of 64) keys ----
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -154,8 +229,8 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
                 tmax = fmaxf(tmax, sacc[kb][r]);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);            // finite: every tile has >= 1 valid key
-        const float alpha = exp2f((m_run - m_new) * sl2);  // first tile: exp2(-inf) = 0
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f((m_run - m_new) * sl2);
         m_run = m_new;
         float psum = 0.0f;
 #pragma unroll
@@ -171,59 +246,23 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-
-        // ---- O^T += V^T P^T.  k-slot (hi, e) of MFMA u in sub-tile kb  <->  accumulator register 8u+e,
-        //      i.e. key kb*32 + 16u + 4hi + (e&3) + 8(e>>2) ----
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 bf16x8 pb[NP];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = sacc[kb][8 * u + e];
-                    if (SPLIT) {
-                        short a, c;
-                        sat_split_bf16(pv, &a, &c);
-                        pb[0][e] = a;
-                        pb[NP - 1][e] = c;
-                    } else {
-                        pb[0][e] = sat_f32_to_bf16(pv);
-                    }
-                }
+                sat_att_pack<NP>(sacc[kb], u, pb);
                 const int kofs = kb * 32 + 16 * u + 4 * hi;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const short* vr = &v_lds[0][t * 32 + l31][kofs];
-                    bf16x8 va;
-                    typedef short s4 __attribute__((ext_vector_type(4)));
-                    const s4 lo4 = *reinterpret_cast<const s4*>(vr);
-                    const s4 hi4 = *reinterpret_cast<const s4*>(vr + 8);
+                    bf16x8 va[NP];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        va[e] = lo4[e];
-                        va[4 + e] = hi4[e];
-                    }
-                    oacc[t] = sat_mfma_32x32x16_bf16(va, pb[0], oacc[t]);
-                    if (SPLIT) {
-                        const short* vl = &v_lds[NP - 1][t * 32 + l31][kofs];
-                        bf16x8 vb;
-                        const s4 lo4b = *reinterpret_cast<const s4*>(vl);
-                        const s4 hi4b = *reinterpret_cast<const s4*>(vl + 8);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            vb[e] = lo4b[e];
-                            vb[4 + e] = hi4b[e];
-                        }
-                        oacc[t] = sat_mfma_32x32x16_bf16(va, pb[NP - 1], oacc[t]);
-                        oacc[t] = sat_mfma_32x32x16_bf16(vb, pb[0], oacc[t]);
-                    }
+                    for (int pl = 0; pl < NP; ++pl) va[pl] = sat_att_frag_acc(v_lds[pl], t * 32 + l31, kofs);
+                    oacc[t] = sat_att_mma<NP>(va, pb, oacc[t]);
                 }
             }
-        }
     }
 
-    // ---- epilogue ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
     if (q_ok) {
@@ -233,23 +272,320 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                SatLoad<T>::put(p.o, obase + d, oacc[t][r] * inv_l);
+                SatOut<T>::put(p.o, obase + d, oacc[t][r] * inv_l);
             }
         if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = m_run * p.scale + logf(l_tot);
     }
 }
 
-extern "C" int sat_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long long sqb,
-                                 long long sqh, long long sqn, long long skb, long long skh, long long skn,
-                                 long long svb, long long svh, long long svn, int B, int H, int Hkv, int Nq, int Nk,
-                                 int head_dim, float scale, int dtype, void* stream) {
-    if (B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) { sat_set_error("sat_attention_fwd: empty shape"); return 1; }
-    if (head_dim != SAT_ATT_D) { sat_set_error("sat_attention_fwd: only head_dim == 64 (the Stable Audio DiT) is implemented"); return 1; }
-    if (H % Hkv != 0) { sat_set_error("sat_attention_fwd: H must be a multiple of Hkv"); return 1; }
-    if (dtype != 0 && dtype != 1) { sat_set_error("sat_attention_fwd: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
-    SatAttnParams p{q, k, v, o, lse, sqb, sqh, sqn, skb, skh, skn, svb, svh, svn, B, H, Hkv, Nq, Nk, scale};
+// ---------------------------------------------------------------------------------------------
+// backward, part 1: dQ.  Same roles as the forward (wave owns 32 queries, loop over key tiles).
+//   S^T = K Q^T ; P^T = exp(S^T*scale - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) scale ; dQ^T += K^T dS^T
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NP>
+__global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
+    __shared__ __attribute__((aligned(16))) short k_lds[NP][SAT_ATT_T][SAT_ATT_ROW];    // [key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds[NP][SAT_ATT_T][SAT_ATT_ROW];    // [key][d]
+    __shared__ __attribute__((aligned(16))) short kt_lds[NP][SAT_ATT_D][SAT_ATT_ROW];   // [d][key]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_in = qrow < p.Nqp, q_ok = qrow < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+
+    bf16x8 qf[4][NP], gf[4][NP];   // Q and dO fragments (d = 16 s + 8 hi + e)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (q_in) {
+                qf[s][pl] = *reinterpret_cast<const bf16x8*>(p.q_rm[pl] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+                gf[s][pl] = *reinterpret_cast<const bf16x8*>(p.do_rm[pl] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    qf[s][pl][e] = 0;
+                    gf[s][pl][e] = 0;
+                }
+            }
+        }
+    const float l2e = 1.4426950408889634f;
+    const float sl2 = p.scale * l2e;
+    const float lse2 = q_ok ? p.lse[((long long)b * p.H + h) * p.Nq + qrow] * l2e : 0.0f;
+    const float dsum = q_ok ? p.dsum[((long long)b * p.H + h) * p.Nq + qrow] : 0.0f;
+
+    f32x16 dq[2];   // dQ^T: rows d, cols q
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
+
+    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T) {
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            sat_att_stage<64, 64, SAT_ATT_ROW>(k_lds[pl], p.k_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
+            sat_att_stage<64, 64, SAT_ATT_ROW>(v_lds[pl], p.v_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
+            sat_att_stage<64, 64, SAT_ATT_ROW>(kt_lds[pl], p.k_tr[pl] + kplane + k0, (size_t)p.Nkp);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 ka[NP], va[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + l31, 16 * s + 8 * hi);
+                    va[pl] = sat_att_frag_rm(v_lds[pl], kb * 32 + l31, 16 * s + 8 * hi);
+                }
+                sacc = sat_att_mma<NP>(ka, qf[s], sacc);
+                pacc = sat_att_mma<NP>(va, gf[s], pacc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float pv = (key < p.Nk && q_ok) ? exp2f(sacc[r] * sl2 - lse2) : 0.0f;
+                sacc[r] = pv * (pacc[r] - dsum) * p.scale;   // dS^T
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 sb[NP];
+                sat_att_pack<NP>(sacc, u, sb);
+                const int kofs = kb * 32 + 16 * u + 4 * hi;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bf16x8 ka[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_acc(kt_lds[pl], t * 32 + l31, kofs);
+                    dq[t] = sat_att_mma<NP>(ka, sb, dq[t]);
+                }
+            }
+        }
+    }
+    if (q_ok) {
+        const long long obase = (((long long)b * p.H + h) * p.Nq + qrow) * SAT_ATT_D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) SatOut<T>::put(p.dq, obase + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, dq[t][r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV.  Wave owns 32 KEYS (columns); loops over the query heads of its kv group
+// and over 64-query tiles.
+//   S = Q K^T (rows q, cols key) ; P = exp(S*scale - lse[q]) ; dV^T += dO^T P ; dP = dO V^T ;
+//   dS = P (dP - D[q]) scale ; dK^T += Q^T dS
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NP, int TQ>   // TQ = queries per tile (64, or 32 for the two-plane variant: LDS budget)
+__global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) {
+    constexpr int TROW = TQ + 8;           // transposed-tile row (80 B or 144 B stride: conflict-free)
+    __shared__ __attribute__((aligned(16))) short q_lds[NP][TQ][SAT_ATT_ROW];    // [q][d]
+    __shared__ __attribute__((aligned(16))) short g_lds[NP][TQ][SAT_ATT_ROW];    // dO [q][d]
+    __shared__ __attribute__((aligned(16))) short qt_lds[NP][SAT_ATT_D][TROW];   // [d][q]
+    __shared__ __attribute__((aligned(16))) short gt_lds[NP][SAT_ATT_D][TROW];   // dO^T [d][q]
+    __shared__ float lse_lds[TQ], ds_lds[TQ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, hk = blockIdx.y;
+    const int group = p.H / p.Hkv;
+    const int krow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool k_in = krow < p.Nkp, k_ok = krow < p.Nk;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+
+    bf16x8 kf[4][NP], vf[4][NP];   // K and V fragments of this wave's keys (d = 16 s + 8 hi + e)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (k_in) {
+                kf[s][pl] = *reinterpret_cast<const bf16x8*>(p.k_rm[pl] + kplane + (size_t)krow * SAT_ATT_D + 16 * s + 8 * hi);
+                vf[s][pl] = *reinterpret_cast<const bf16x8*>(p.v_rm[pl] + kplane + (size_t)krow * SAT_ATT_D + 16 * s + 8 * hi);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    kf[s][pl][e] = 0;
+                    vf[s][pl][e] = 0;
+                }
+            }
+        }
+    const float l2e = 1.4426950408889634f;
+    const float sl2 = p.scale * l2e;
+    f32x16 dk[2], dv[2];   // dK^T, dV^T: rows d, cols key
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dk[t][r] = 0.0f;
+            dv[t][r] = 0.0f;
+        }
+
+    for (int hg = 0; hg < group; ++hg) {
+        const int h = hk * group + hg;
+        const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+        for (int q0 = 0; q0 < p.Nq; q0 += TQ) {
+            __syncthreads();
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                sat_att_stage<TQ, 64, SAT_ATT_ROW>(q_lds[pl], p.q_rm[pl] + qplane + (size_t)q0 * SAT_ATT_D, SAT_ATT_D);
+                sat_att_stage<TQ, 64, SAT_ATT_ROW>(g_lds[pl], p.do_rm[pl] + qplane + (size_t)q0 * SAT_ATT_D, SAT_ATT_D);
+                sat_att_stage<64, TQ, TROW>(qt_lds[pl], p.q_tr[pl] + qplane + q0, (size_t)p.Nqp);
+                sat_att_stage<64, TQ, TROW>(gt_lds[pl], p.do_tr[pl] + qplane + q0, (size_t)p.Nqp);
+            }
+            if (threadIdx.x < TQ) {
+                const int q = q0 + threadIdx.x;
+                const bool ok = q < p.Nq;
+                lse_lds[threadIdx.x] = ok ? p.lse[((long long)b * p.H + h) * p.Nq + q] * l2e : 0.0f;
+                ds_lds[threadIdx.x] = ok ? p.dsum[((long long)b * p.H + h) * p.Nq + q] : 0.0f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qb = 0; qb < TQ / 32; ++qb) {
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = 0.0f;
+                    pacc[r] = 0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 qa[NP], ga[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        qa[pl] = sat_att_frag_rm(q_lds[pl], qb * 32 + l31, 16 * s + 8 * hi);
+                        ga[pl] = sat_att_frag_rm(g_lds[pl], qb * 32 + l31, 16 * s + 8 * hi);
+                    }
+                    sacc = sat_att_mma<NP>(qa, kf[s], sacc);   // S[q][key]
+                    pacc = sat_att_mma<NP>(ga, vf[s], pacc);   // dP[q][key]
+                }
+                f32x16 pr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = (q0 + ql) < p.Nq && k_ok;
+                    const float pv = ok ? exp2f(sacc[r] * sl2 - lse_lds[ql]) : 0.0f;
+                    pr[r] = pv;
+                    sacc[r] = pv * (pacc[r] - ds_lds[ql]) * p.scale;   // dS[q][key]
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 pb[NP], sb[NP];
+                    sat_att_pack<NP>(pr, u, pb);
+                    sat_att_pack<NP>(sacc, u, sb);
+                    const int qofs = qb * 32 + 16 * u + 4 * hi;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        bf16x8 ga[NP], qa[NP];
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) {
+                            ga[pl] = sat_att_frag_acc(gt_lds[pl], t * 32 + l31, qofs);
+                            qa[pl] = sat_att_frag_acc(qt_lds[pl], t * 32 + l31, qofs);
+                        }
+                        dv[t] = sat_att_mma<NP>(ga, pb, dv[t]);
+                        dk[t] = sat_att_mma<NP>(qa, sb, dk[t]);
+                    }
+                }
+            }
+        }
+    }
+    if (k_ok) {
+        const long long obase = (((long long)b * p.Hkv + hk) * p.Nk + krow) * SAT_ATT_D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                SatOut<T>::put(p.dk, obase + d, dk[t][r]);
+                SatOut<T>::put(p.dv, obase + d, dv[t][r]);
+            }
+    }
+}
+
+// D[b][h][q] = sum_d dO[b][q][h*64+d] * O[b][q][h*64+d]    (both (B, Nq, H*64), model dtype)
+struct SatRowdotParams {
+    const void* a;
+    const void* b;
+    float* out;
+    int B, H, Nq;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_attn_rowdot_kernel(SatRowdotParams p) {
+    const long long total = (long long)p.B * p.H * p.Nq;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (b, h, q)
+    if (row >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int q = (int)(row % p.Nq);
+    const long long bh = row / p.Nq;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const long long i = ((long long)b * p.Nq + q) * ((long long)p.H * SAT_ATT_D) + (long long)h * SAT_ATT_D + lane;
+    const float s = sat_wave_sum(SatSrc<T>::at(p.a, i) * SatSrc<T>::at(p.b, i));
+    if (lane == 0) p.out[row] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+static int sat_attn_check(int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim, int dtype, const char* who) {
+    if (B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) { sat_set_error(who); return 1; }
+    if (head_dim != SAT_ATT_D) { sat_set_error("attention: only head_dim == 64 (the Stable Audio DiT) is implemented"); return 1; }
+    if (H % Hkv != 0) { sat_set_error("attention: H must be a multiple of Hkv"); return 1; }
+    if (Nqp < Nq || Nkp < Nk || Nqp % SAT_ATT_T || Nkp % SAT_ATT_T) { sat_set_error("attention: padded lengths must be multiples of 64 and cover N"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("attention: dtype must be 0 (f32, split planes) or 1 (bf16)"); return 1; }
+    return 0;
+}
+
+extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const short* k_hi, const short* k_lo,
+                                 const short* vt_hi, const short* vt_lo, void* o, float* lse, int B, int H, int Hkv,
+                                 int Nq, int Nk, int Nqp, int Nkp, int head_dim, float scale, int dtype, void* stream) {
+    if (sat_attn_check(B, H, Hkv, Nq, Nk, Nqp, Nkp, head_dim, dtype, "sat_attention_fwd: empty shape")) return 1;
+    SatAttnParams p{};
+    p.q_rm[0] = q_hi; p.q_rm[1] = q_lo; p.k_rm[0] = k_hi; p.k_rm[1] = k_lo; p.v_tr[0] = vt_hi; p.v_tr[1] = vt_lo;
+    p.o = o; p.lse = lse; p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
     dim3 grid(sat_cdiv(Nq, 128), H, B);
-    if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, true>), grid, dim3(256), stream, p);
-    else SAT_LAUNCH((sat_attn_fwd_kernel<short, false>), grid, dim3(256), stream, p);
+    if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_attention_fwd");
+}
+
+extern "C" int sat_attention_rowdot(const void* dout, const void* out, float* dsum, int B, int H, int Nq, int dtype,
+                                    void* stream) {
+    if (B <= 0 || H <= 0 || Nq <= 0) { sat_set_error("sat_attention_rowdot: empty shape"); return 1; }
+    SatRowdotParams p{dout, out, dsum, B, H, Nq};
+    dim3 grid((unsigned)sat_cdivll((long long)B * H * Nq, 4));
+    if (dtype == 0) SAT_LAUNCH(sat_attn_rowdot_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_attn_rowdot_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_attention_rowdot");
+}
+
+// planes[16]: {q_rm, k_rm, v_rm, k_tr, q_tr, do_rm, do_tr, (unused)} x {hi, lo}
+extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, const float* dsum, void* dq, void* dk,
+                                 void* dv, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim,
+                                 float scale, int dtype, void* stream) {
+    if (sat_attn_check(B, H, Hkv, Nq, Nk, Nqp, Nkp, head_dim, dtype, "sat_attention_bwd: empty shape")) return 1;
+    SatAttnParams p{};
+    for (int i = 0; i < 2; ++i) {
+        p.q_rm[i] = planes[0 + i]; p.k_rm[i] = planes[2 + i]; p.v_rm[i] = planes[4 + i]; p.k_tr[i] = planes[6 + i];
+        p.q_tr[i] = planes[8 + i]; p.do_rm[i] = planes[10 + i]; p.do_tr[i] = planes[12 + i];
+    }
+    p.lse = const_cast<float*>(lse); p.dsum = dsum; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
+    dim3 g1(sat_cdiv(Nq, 128), H, B), g2(sat_cdiv(Nk, 128), Hkv, B);
+    if (dtype == 0) {
+        SAT_LAUNCH((sat_attn_bwd_dq_kernel<float, 2>), g1, dim3(256), stream, p);
+        SAT_LAUNCH((sat_attn_bwd_dkv_kernel<float, 2, 32>), g2, dim3(256), stream, p);
+    } else {
+        SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
+        SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);
+    }
+    return sat_check_launch("sat_attention_bwd");
 }

@@ -307,6 +307,47 @@ __global__ void __launch_bounds__(256) sat_gate_residual_kernel(SatGateParams p)
         SatIO<T>::st(p.y, i, SatIO<T>::ld(p.x, i) * sat_sigmoid(1.0f - g) + SatIO<T>::ld(p.res, i));
     }
 }
+// backward of y = x * sigmoid(1 - gate[b]) + res:  dx = dy * s ; d_res = dy ; d_gate[b][c] = -sum_n dy * x * s * (1 - s)
+// thread per column, a workgroup walks SAT_LN_ROWS_PER_BLOCK rows of one batch item; part[b][chunk][D]
+struct SatGateBwdParams {
+    const void* dy;
+    const void* x;
+    const void* gate;
+    void* dx;
+    float* part;
+    long long gstride;
+    int B, N, D;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_gate_residual_bwd_kernel(SatGateBwdParams p) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * SAT_LN_ROWS_PER_BLOCK;
+    int r1 = r0 + SAT_LN_ROWS_PER_BLOCK;
+    if (r1 > p.N) r1 = p.N;
+    if (col >= p.D) return;
+    const float s = sat_sigmoid(1.0f - SatIO<T>::ld(p.gate, (long long)b * p.gstride + col));
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const long long i = ((long long)b * p.N + r) * p.D + col;
+        const float dy = SatIO<T>::ld(p.dy, i);
+        SatIO<T>::st(p.dx, i, dy * s);
+        acc += dy * SatIO<T>::ld(p.x, i);
+    }
+    p.part[((size_t)b * gridDim.y + blockIdx.y) * p.D + col] = -acc * s * (1.0f - s);
+}
+extern "C" int sat_gate_residual_bwd_nchunks(int N) { return sat_cdiv(N, SAT_LN_ROWS_PER_BLOCK); }
+extern "C" int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long long gstride, void* dx,
+                                     float* part, int B, int N, int D, int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || D <= 0) { sat_set_error("sat_gate_residual_bwd: empty shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_gate_residual_bwd: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    SatGateBwdParams p{dy, x, gate, dx, part, gstride, B, N, D};
+    dim3 grid(sat_cdiv(D, 256), sat_cdiv(N, SAT_LN_ROWS_PER_BLOCK), B);
+    if (dtype == 0) SAT_LAUNCH(sat_gate_residual_bwd_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_gate_residual_bwd_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_gate_residual_bwd");
+}
+
 extern "C" int sat_gate_residual(const void* x, const void* gate, long long gstride, const void* res, void* y, int B,
                                  int N, int D, int dtype, void* stream) {
     if (B <= 0 || N <= 0 || D <= 0) { sat_set_error("sat_gate_residual: empty shape"); return 1; }

@@ -234,22 +234,64 @@ class SatOps:
                 raise RuntimeError("stable_audio_tools_amd kernels need CUDA(HIP) tensors; there is no CPU path")
         return 0 if dt == torch.float32 else 1
 
-    def attention(self, q, k, v, scale, need_lse=False):
+    def attn_planes(self, t, row_major=True, transposed=False):
+        """(B, H, N, 64) strided fp32|bf16 (head dim contiguous) -> bf16 planes, zero padded to Np = ceil64(N):
+        dict with 'rm' = (hi, lo) of shape (B, H, Np, 64) and/or 'tr' = (hi, lo) of shape (B, H, 64, Np);
+        lo is None for bf16 sources."""
+        dt = self._dt(t)
+        if t.stride(3) != 1:
+            raise ValueError("head dim must be contiguous")
+        b, h, n, d = t.shape
+        npad = (n + 63) // 64 * 64
+        split = dt == 0
+
+        def alloc(shape, want):
+            return torch.empty(shape, dtype=torch.int16, device=t.device) if want else None
+        rm_hi, rm_lo = alloc((b, h, npad, d), row_major), alloc((b, h, npad, d), row_major and split)
+        tr_hi, tr_lo = alloc((b, h, d, npad), transposed), alloc((b, h, d, npad), transposed and split)
+        self._chk(self.lib.sat_attn_prepare(_ptr(t), t.stride(0), t.stride(1), t.stride(2), _ptr(rm_hi), _ptr(rm_lo),
+                                            _ptr(tr_hi), _ptr(tr_lo), b, h, n, npad, dt, self._stream(t)))
+        return {"rm": (rm_hi, rm_lo), "tr": (tr_hi, tr_lo), "n": n, "np": npad, "dt": dt}
+
+    def attention(self, q, k, v, scale, need_lse=False, return_planes=False):
         """q: (B, H, Nq, 64) k, v: (B, Hkv, Nk, 64) — any strides with the head dim contiguous.
-        Returns o: (B, Nq, H*64) [, lse (B, H, Nq) fp32]."""
+        Returns o: (B, Nq, H*64) [, lse (B, H, Nq) fp32] [, planes dict for the backward]."""
         dt = self._dt(q, k, v)
         b, h, nq, d = q.shape
         _, hk, nk, _ = k.shape
-        for t in (q, k, v):
-            if t.stride(3) != 1:
-                raise ValueError("head dim must be contiguous")
+        qp = self.attn_planes(q, row_major=True, transposed=return_planes)
+        kp = self.attn_planes(k, row_major=True, transposed=return_planes)
+        vp = self.attn_planes(v, row_major=return_planes, transposed=True)
         o = torch.empty(b, nq, h * d, dtype=q.dtype, device=q.device)
-        lse = torch.empty(b, h, nq, dtype=torch.float32, device=q.device) if need_lse else None
-        self._chk(self.lib.sat_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse),
-                                             q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                                             v.stride(0), v.stride(1), v.stride(2), b, h, hk, nq, nk, d, float(scale), dt,
-                                             self._stream(q)))
-        return (o, lse) if need_lse else o
+        lse = torch.empty(b, h, nq, dtype=torch.float32, device=q.device) if (need_lse or return_planes) else None
+        self._chk(self.lib.sat_attention_fwd(_ptr(qp["rm"][0]), _ptr(qp["rm"][1]), _ptr(kp["rm"][0]), _ptr(kp["rm"][1]),
+                                             _ptr(vp["tr"][0]), _ptr(vp["tr"][1]), _ptr(o), _ptr(lse), b, h, hk, nq, nk,
+                                             qp["np"], kp["np"], d, float(scale), dt, self._stream(q)))
+        out = (o,)
+        if need_lse or return_planes:
+            out += (lse,)
+        if return_planes:
+            out += ({"q": qp, "k": kp, "v": vp},)
+        return out[0] if len(out) == 1 else out
+
+    def attention_bwd(self, planes, o, do, lse, scale, hkv, nk):
+        """Gradients (dq (B,H,Nq,64), dk, dv (B,Hkv,Nk,64)) in the dtype of `o`; `planes` from attention(return_planes=True)."""
+        dt = self._dt(o, do)
+        b, nq, hd = o.shape
+        h = hd // 64
+        do = do.contiguous()
+        dsum = torch.empty(b, h, nq, dtype=torch.float32, device=o.device)
+        self._chk(self.lib.sat_attention_rowdot(_ptr(do), _ptr(o), _ptr(dsum), b, h, nq, dt, self._stream(o)))
+        gp = self.attn_planes(do.view(b, nq, h, 64).permute(0, 2, 1, 3), row_major=True, transposed=True)
+        qp, kp, vp = planes["q"], planes["k"], planes["v"]
+        ptrs = [qp["rm"], kp["rm"], vp["rm"], kp["tr"], qp["tr"], gp["rm"], gp["tr"], (None, None)]
+        arr = (ctypes.c_void_p * 16)(*[(x.data_ptr() if x is not None else None) for pair in ptrs for x in pair])
+        dq = torch.empty(b, h, nq, 64, dtype=o.dtype, device=o.device)
+        dk = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
+        dv = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
+        self._chk(self.lib.sat_attention_bwd(arr, _ptr(lse), _ptr(dsum), _ptr(dq), _ptr(dk), _ptr(dv), b, h, hkv, nq, nk,
+                                             qp["np"], kp["np"], 64, float(scale), dt, self._stream(o)))
+        return dq, dk, dv
 
     def layernorm(self, x, gamma, beta=None, scale=None, shift=None, eps=1e-5, save_stats=False):
         """x: (B, N, D) contiguous; gamma/beta fp32 (D,); scale/shift: (B, D) views (last dim contiguous) for adaLN."""
@@ -328,6 +370,18 @@ class SatOps:
         self._chk(self.lib.sat_gate_residual(_ptr(x), _ptr(gate), gate.stride(0), _ptr(res), _ptr(y), b, n, d, dt,
                                              self._stream(x)))
         return y
+
+    def gate_residual_bwd(self, dy, x, gate):
+        """Returns dx (B, N, D) and dgate (B, D) fp32 for y = x * sigmoid(1 - gate[b]) + res (d_res = dy)."""
+        dt = self._dt(dy, x, gate)
+        b, n, d = x.shape
+        dx = torch.empty_like(x)
+        nch = self.lib.sat_gate_residual_bwd_nchunks(n)
+        part = torch.empty(b, nch, d, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_gate_residual_bwd(_ptr(dy), _ptr(x), _ptr(gate), gate.stride(0), _ptr(dx), _ptr(part), b, n, d,
+                                                 dt, self._stream(x)))
+        dgate = torch.stack([self._reduce_rows(part[i], nch, d) for i in range(b)])
+        return dx, dgate
 
     # ------------------------------------------------------------------ optimizer
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):

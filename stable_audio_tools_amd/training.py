@@ -192,3 +192,65 @@ class AutoencoderTrainStep:
         self.opt.step(lr=self.current_lr(), grad_scale=self.comm.grad_scale)
         self.global_step += 1
         return {"loss": loss.detach(), "mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
+
+
+class DiTTrainStep:
+    """One optimisation step of the conditioned DiT on (pre-encoded) latents, data-parallel over the default
+    process group — restated from DiffusionCondTrainingWrapper.training_step
+    (training/diffusion.py:332-487): t ~ Sobol-uniform (:381-383, self.rng = SobolEngine(1, scramble=True) :253) or
+    logit-normal (:384-385); alphas/sigmas (:406-409); noised = x*alpha + noise*sigma (:415); v / rectified-flow
+    targets (:417-420); model(noised, t, cross_attn_cond, global_embed, cfg_dropout_prob) (:440 -> DiTWrapper.forward
+    models/diffusion.py:520-557); MSE (:449, losses.py:66-91); EMA (:489-491); AdamW.  The conditioner (T5 etc.) is out of
+    scope: its output tensors are inputs here.  mixed precision: `autocast_dtype=torch.bfloat16` runs the projections and
+    the HIP kernels in bf16 with fp32 master weights (Lightning '--precision bf16-mixed')."""
+
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-3, cfg_dropout_prob=0.1, timestep_sampler="uniform",
+                 use_ema=True, autocast_dtype=None, ops=None, ddp_mode="all_reduce", bucket_bytes=512 << 20, seed=0):
+        import math
+        self._math = math
+        self.model = model
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.flat = FlatParameters(list(model.parameters()), pad_to=max(world, 1))
+        self.opt = FusedAdamW(self.flat, lr, betas=betas, weight_decay=weight_decay, ops=ops, use_ema=use_ema)
+        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode)
+        self.cfg_dropout_prob = cfg_dropout_prob
+        self.timestep_sampler = timestep_sampler
+        self.rng = torch.quasirandom.SobolEngine(1, scramble=True, seed=seed)
+        self.autocast_dtype = autocast_dtype
+        self.objective = model.diffusion_objective
+        self.global_step = 0
+
+    def draw_timesteps(self, n, device):
+        if self.timestep_sampler == "uniform":
+            return self.rng.draw(n)[:, 0].to(device)
+        if self.timestep_sampler == "logit_normal":
+            return torch.sigmoid(torch.randn(n, device=device))
+        raise NotImplementedError(f"timestep_sampler {self.timestep_sampler!r} is not restated")
+
+    def __call__(self, latents, cross_attn_cond=None, global_embed=None, t=None, noise=None):
+        math = self._math
+        self.flat.zero_grad()
+        if t is None:
+            t = self.draw_timesteps(latents.shape[0], latents.device)
+        if self.objective == "v":
+            alphas, sigmas = torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
+        else:
+            alphas, sigmas = 1 - t, t
+        alphas, sigmas = alphas[:, None, None], sigmas[:, None, None]
+        if noise is None:
+            noise = torch.randn_like(latents)
+        noised = latents * alphas + noise * sigmas
+        targets = noise * alphas - latents * sigmas if self.objective == "v" else noise - latents
+        kw = dict(cross_attn_cond=cross_attn_cond, global_embed=global_embed, cfg_dropout_prob=self.cfg_dropout_prob)
+        if self.autocast_dtype is not None:
+            with torch.autocast("cuda" if latents.is_cuda else "cpu", dtype=self.autocast_dtype):
+                out = self.model(noised, t, **kw)
+        else:
+            out = self.model(noised, t, **kw)
+        loss = torch.nn.functional.mse_loss(out.float(), targets.float())
+        loss.backward()
+        self.flat.gather_grads()
+        self.comm()
+        self.opt.step(grad_scale=self.comm.grad_scale)
+        self.global_step += 1
+        return {"loss": loss.detach()}

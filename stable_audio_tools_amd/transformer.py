@@ -12,9 +12,11 @@ the Stable Audio DiT configs never enable (qk_norm, differential attention, conf
 memory tokens, sliding window, causal, flex-attention masks, abs/sinusoidal position embeddings)
 raise NotImplementedError.
 
-Round-1 status: forward path (sampling) complete and parity-tested; LayerNorm / rotary / SwiGLU have
-HIP backward kernels, the attention backward kernel is not written yet, so autograd through
-Attention raises NotImplementedError instead of falling back to a PyTorch implementation.
+Forward AND backward run on the HIP kernels: every fused operator is a torch.autograd.Function whose
+backward calls the matching kernel (LayerNorm+adaLN, rotary transpose, attention dQ / dK,dV with
+probabilities recomputed from the saved log-sum-exp, SwiGLU, gate/residual); the projections'
+gradients are nn.Linear's own (hipBLASLt).  Per-layer activation checkpointing of the reference
+(transformer.py:28-30, :840-845) is not needed at these sizes on 288 GB and is not applied.
 """
 import torch
 from torch import nn
@@ -120,14 +122,26 @@ class _RopeQKFn(torch.autograd.Function):
 
 
 class _AttentionCoreFn(torch.autograd.Function):
+    """o = softmax(q k^T * scale) v  on csrc/attention.hip; backward = sat_attention_bwd (dQ and dK/dV kernels
+    that recompute the probabilities from the saved log-sum-exp — nothing N x N is ever stored)."""
+
     @staticmethod
     def forward(ctx, q, k, v, scale):
-        return _ops().attention(q, k, v, scale)
+        ops = _ops()
+        if any(ctx.needs_input_grad[:3]):
+            o, lse, planes = ops.attention(q, k, v, scale, return_planes=True)
+            ctx.ops, ctx.scale, ctx.planes = ops, scale, planes
+            ctx.shapes = (q.shape, k.shape)
+            ctx.save_for_backward(o, lse)
+            return o
+        return ops.attention(q, k, v, scale)
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("stable_audio_tools_amd: the HIP attention backward kernel is not written yet "
-                                  "(round-1 scope is the DiT forward / sampling path); there is no PyTorch fallback")
+        o, lse = ctx.saved_tensors
+        (_, _, _, _), (_, hkv, nk, _) = ctx.shapes
+        dq, dk, dv = ctx.ops.attention_bwd(ctx.planes, o, g.contiguous(), lse, ctx.scale, hkv, nk)
+        return dq, dk, dv, None
 
 
 class _SwiGLUFn(torch.autograd.Function):
@@ -147,11 +161,18 @@ class _SwiGLUFn(torch.autograd.Function):
 class _GateResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gate, res):
-        return _ops().gate_residual(x.contiguous(), gate, res.contiguous())
+        ops = _ops()
+        x = x.contiguous()
+        ctx.ops = ops
+        ctx.save_for_backward(x, gate)
+        return ops.gate_residual(x, gate, res.contiguous())
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("stable_audio_tools_amd: gate/residual backward lands with the attention backward")
+        x, gate = ctx.saved_tensors
+        g = g.contiguous()
+        dx, dgate = ctx.ops.gate_residual_bwd(g, x, gate)
+        return dx, dgate.to(gate.dtype), g
 
 
 class GLU(nn.Module):
