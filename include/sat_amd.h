@@ -48,6 +48,19 @@ int sat_conv1d(const float* x, const float* w_packed, const float* bias, const f
                int dil, int pad, int tanh_out, void* stream);
 int sat_conv1d_partial_rows(int B, int Tout);
 
+/* The same stride-1 convolution (K <= 8, Cin % 8 == 0 — the k7 convs of every ResidualUnit, autoencoders.py:58-83,
+ * and their data-gradients) on the bf16 matrix cores at fp32 accuracy: operands split hi+lo, three MFMAs per product.
+ * Weights come from sat_pack_weights_bf16x3 (mode 0 forward, mode 1 = flipped/transposed for the data-gradient;
+ * sat_pack_weights_bf16x3_size gives the plane length in elements); snake_a / snake_ib are the pre-exponentiated
+ * SnakeBeta constants from sat_snake_consts (a = e^alpha, ib = 1/(e^beta + 1e-9)) or NULL.  Everything else as sat_conv1d. */
+int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
+                      const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
+                      const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
+                      int K, int dil, int pad, int tanh_out, void* stream);
+int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream);
+long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int mode);
+int sat_snake_consts(const float* alpha, const float* beta, float* a, float* ib, int C, void* stream);
+
 /* Transposed conv, K == 2*stride (the Oobleck resampler, autoencoders.py:266-268), polyphase form.
  * Also the data-gradient of the strided down-conv (:245-247).  w_packed: [r][j][Cin][Cout]
  * (sat_pack_weights mode 2).  Same prologue/epilogue options as sat_conv1d. stride in [2, 8]. */

@@ -21,6 +21,11 @@ SIGNATURES = {
     # conv1d.hip
     "sat_conv1d": (_I, [_P] * 12 + [_I] * 10 + [_P]),
     "sat_conv1d_partial_rows": (_I, [_I, _I]),
+    # conv1d_bf16x3.hip
+    "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
+    "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I]),
+    "sat_snake_consts": (_I, [_P, _P, _P, _P, _I, _P]),
     # convtr1d.hip
     "sat_convtr1d": (_I, [_P] * 12 + [_I] * 9 + [_P]),
     "sat_convtr1d_partial_rows": (_I, [_I, _I, _I, _I]),

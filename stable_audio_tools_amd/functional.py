@@ -57,10 +57,22 @@ class WeightNormFn(torch.autograd.Function):
 def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
     """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K)."""
     if stride == 1:
+        if ops.bf16x3_ok(w.shape[0], k, 1, dil):     # the dgrad conv's input channels are the forward conv's outputs
+            return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, dgrad=True), cin, k, dil, (k - 1) * dil - pad, tout=tin,
+                                     dsnake=dsnake, res=res)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
         return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res)
     wpb = ops.pack(w, PACK_POLYPHASE, stride)
     return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
+
+
+def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False):
+    """conv1d(snake(x), w) [+bias] [+res]: k = 5..8 stride-1 convs take the bf16x3 split-MFMA kernel
+    (fp32-accurate, csrc/conv1d_bf16x3.hip), everything else the fp32-MFMA kernel (csrc/conv1d.hip)."""
+    cout, cin, k = w.shape
+    if ops.bf16x3_ok(cin, k, stride, dil):
+        return ops.conv1d_bf16x3(x, ops.pack_bf16x3(w), cout, k, dil, pad, bias=bias, snake=snake, res=res, tanh_out=tanh_out)
+    return ops.conv1d(x, ops.pack(w, PACK_CONV_FWD), cout, k, stride, dil, pad, bias=bias, snake=snake, res=res, tanh_out=tanh_out)
 
 
 class SnakeConv1dFn(torch.autograd.Function):
@@ -73,9 +85,8 @@ class SnakeConv1dFn(torch.autograd.Function):
         w = w.contiguous()
         cout, cin, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
-        wp = ops.pack(w, PACK_CONV_FWD)
-        y = ops.conv1d(x, wp, cout, k, stride, dil, pad, bias=bias, snake=snake,
-                       res=res.contiguous() if res is not None else None, tanh_out=tanh_out)
+        y = _conv_fwd(ops, x, w, stride, dil, pad, bias=bias, snake=snake,
+                      res=res.contiguous() if res is not None else None, tanh_out=tanh_out)
         ctx.ops = ops
         ctx.cfg = (stride, dil, pad, tanh_out, bias is not None, res is not None, alpha is not None)
         ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None)
@@ -153,8 +164,8 @@ class ResidualUnitFn(torch.autograd.Function):
         c = x.shape[1]
         k1 = w1.shape[2]
         pad = dil * (k1 - 1) // 2
-        h = ops.conv1d(x, ops.pack(w1, PACK_CONV_FWD), c, k1, 1, dil, pad, bias=bias1, snake=(a1, b1))
-        y = ops.conv1d(h, ops.pack(w2, PACK_CONV_FWD), c, w2.shape[2], 1, 1, 0, bias=bias2, snake=(a2, b2), res=x)
+        h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1))
+        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x)
         ctx.ops = ops
         ctx.dil = dil
         ctx.save_for_backward(x, h, a1, b1, w1, a2, b2, w2)

@@ -17,7 +17,7 @@ def _header_decls():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"(?:const\s+char\s*\*|int)\s+(sat_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(?:const\s+char\s*\*|long\s+long|int)\s+(sat_\w+)\s*\(([^)]*)\)\s*;", src):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len(args.split(","))
         decls[m.group(1)] = n

@@ -47,6 +47,14 @@ for (C, T, S) in levels:
         ms = timeit(lambda: ops.conv1d(x, wp7, C, 7, 1, dil, 3 * dil, bias=bias, snake=(la, lb)))
         fl = 2 * C * C * 7 * T
         res[f"conv7_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=fl / ms / 1e9)
+    planes = ops.pack_bf16x3(w7)
+    for dil in (1, 9):
+        ms = timeit(lambda: ops.conv1d_bf16x3(x, planes, C, 7, dil, 3 * dil, bias=bias, snake=(la, lb)))
+        res[f"conv7x3_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
+    y_a = ops.conv1d(x, wp7, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
+    y_b = ops.conv1d_bf16x3(x, planes, C, 7, 9, 27, bias=bias, snake=(la, lb))
+    res[f"conv7x3_vs_f32_relerr_C{C}_T{T}"] = dict(err=float((y_a - y_b).abs().max() / y_a.abs().max()))
+    del y_a, y_b
     ms = timeit(lambda: ops.conv1d(x, wp1, C, 1, 1, 1, 0, bias=bias, snake=(la, lb), res=x))
     res[f"conv1_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9, gbps=3 * 4 * C * T / ms / 1e6)
     # down conv C -> 2C
@@ -70,6 +78,9 @@ for (C, T, S) in levels:
     wpb = ops.pack(w7, O.PACK_CONV_DGRAD)
     ms = timeit(lambda: ops.conv1d(dy, wpb, C, 7, 1, 9, 27, dsnake=(x, la, lb), res=dy))
     res[f"dgrad7_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
+    planes_b = ops.pack_bf16x3(w7, dgrad=True)
+    ms = timeit(lambda: ops.conv1d_bf16x3(dy, planes_b, C, 7, 9, 27, dsnake=(x, la, lb), res=dy))
+    res[f"dgrad7x3_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
     ms = timeit(lambda: ops.rowsum(dy))
     res[f"rowsum_C{C}_T{T}"] = dict(ms=ms, gbps=4 * C * T / ms / 1e6)
     del x, dy, xu
