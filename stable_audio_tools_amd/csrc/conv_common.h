@@ -38,7 +38,8 @@ struct SatSnakeGrad {
 };
 SAT_DEVICE SatSnakeGrad sat_snake_grad(float x, float a, float b) {
     const float ib = 1.0f / (b + 1e-9f);
-    const float s = sinf(a * x), c = cosf(a * x);
+    float s, c;
+    sat_sincos(a * x, &s, &c);
     const float s2 = 2.0f * s * c;  // sin(2 a x)
     SatSnakeGrad g;
     g.dx = 1.0f + a * ib * s2;
