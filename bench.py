@@ -157,35 +157,57 @@ def run_dit_sample(args):
 
 
 class ConvProfiler:
-    """Times every launch of the dominant kernel (sat_conv1d_kernel) with HIP events on the launch stream
-    and tallies its ALGORITHMIC flops (2 * Cin * Cout * K * Tout * B per launch — DESIGN.md §Kernels)."""
+    """Times every launch of the conv-family kernels with HIP events on the launch stream (torch's current stream ==
+    the stream handed to the C-ABI) and tallies their ALGORITHMIC flops (2 * Cin * Cout * K * Tout * B per launch;
+    wgrad: 2 * M * N * K * T * B — DESIGN.md §4).  Each C-ABI entry point issues exactly one launch of its kernel."""
+
+    # entry point -> (kernel name, peak TFLOP/s, flops(args))
+    #   fp32 kernels: peak = fp32 MFMA dense (157.3); bf16x3 kernels: peak = dense bf16 MFMA / 3 (three MFMAs per product)
+    SPECS = {
+        "sat_conv1d": ("sat_conv1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * a[17] * a[16]),
+        "sat_conv1d_bf16x3": ("sat_conv1d_bf16x3_kernel", 2500.0 / 3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
+        "sat_conv_wgrad": ("sat_conv_wgrad_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
+        "sat_conv_wgrad7_bf16x3": ("sat_wgrad7_bf16x3_kernel", 2500.0 / 3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
+    }
 
     def __init__(self, ops):
-        self.records = []
+        self.records = {k: [] for k in self.SPECS}
         self.enabled = False
-        orig = ops.lib.sat_conv1d   # the C-ABI entry point: exactly one sat_conv1d_kernel launch per call
+        for name, (_, _, flops) in self.SPECS.items():
+            self._wrap(ops.lib, name, flops)
+
+    def _wrap(self, lib, name, flops):
+        orig = getattr(lib, name)
 
         def timed(*a):
             if not self.enabled:
                 return orig(*a)
-            b, cin, cout, _tin, tout, k = a[12:18]
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
-            s.record()          # torch's current stream == the stream handed to the C-ABI (ops._stream)
+            s.record()
             rc = orig(*a)
             e.record()
-            self.records.append((s, e, 2.0 * b * cin * cout * k * tout))
+            self.records[name].append((s, e, flops(a)))
             return rc
 
-        ops.lib.sat_conv1d = timed
+        setattr(lib, name, timed)
 
     def summary(self):
+        """Per kernel: launches, total ms, total flops; returns (dominant kernel dict, all dicts)."""
         torch.cuda.synchronize()
-        ms = fl = 0.0
-        for s, e, f in self.records:
-            ms += s.elapsed_time(e)
-            fl += f
-        return len(self.records), ms, fl
+        out = []
+        for name, recs in self.records.items():
+            if not recs:
+                continue
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            kern, peak, _ = self.SPECS[name]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out.append({"kernel": kern, "launches": len(recs), "total_ms": ms, "avg_launch_ms": ms / len(recs),
+                        "achieved": ach, "peak": peak, "frac": ach / peak})
+        out.sort(key=lambda d: -d["total_ms"])
+        return (out[0] if out else None), out
 
 
 def cpu_baseline(cfg, nsamples):
@@ -351,8 +373,7 @@ def main():
     loss = float(out["loss"])
 
     if rank == 0:
-        nlaunch, ms, flops = prof.summary()
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        dom, allk = prof.summary()
         line = {
             "metric": "train-step samples/sec (47s@44.1kHz)",
             "value": args.batch * world * args.steps / elapsed,
@@ -367,13 +388,14 @@ def main():
                        "sample_size": args.sample_size, "channels": 2, "sample_rate": 44100,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": loss},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "sat_conv1d_kernel", "launches": nlaunch,
-                         "avg_launch_ms": (ms / nlaunch) if nlaunch else None,
-                         "note": "algorithmic flops 2*Cin*Cout*K*Tout*B per launch over HIP-event time of EVERY sat_conv1d_kernel "
-                                 "launch in the timed region (forward convs and data-gradients, incl. the dsnake epilogue "
-                                 "variant); peak = fp32 MFMA (v_mfma_f32_32x32x2_f32) dense"},
+            "roofline": {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
+                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "launches": dom["launches"],
+                         "avg_launch_ms": dom["avg_launch_ms"],
+                         "note": "dominant kernel by HIP-event time in the timed region; achieved = algorithmic flops "
+                                 "(2*Cin*Cout*K*Tout*B per conv launch, 2*M*N*K*T*B per wgrad launch) / event time over ALL its "
+                                 "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
+                                 "bf16x3 split kernels (three MFMAs per fp32-accurate product)",
+                         "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)

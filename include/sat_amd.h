@@ -80,6 +80,14 @@ int sat_conv_wgrad(const float* lo, const float* hi, const float* alpha, const f
                    int Thi, int K, int stride, int dil, int pad, void* stream);
 int sat_conv_wgrad_nsplit(int B, int M, int N, int Tlo, int K, int stride, int dil);
 
+/* The K = 7, stride-1, dilation 1|3|9 case of the above (every ResidualUnit's k7 conv) on the bf16 matrix cores at
+ * fp32 accuracy (hi/lo split).  dy: (B, M, T), x: (B, N, T) pre-activation, alpha/beta: SnakeBeta log-params of x or
+ * NULL.  Slab stride M*N*7; nsplit from sat_conv_wgrad7_bf16x3_nsplit. */
+int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, const float* beta, float* partial,
+                           long long so_m, long long so_n, long long so_k, int B, int M, int N, int T, int dil, int pad,
+                           void* stream);
+int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T);
+
 /* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */
 int sat_reduce_splits(const float* partial, float* out, long long count, int nsplit, float scale, int accumulate,
                       void* stream);

@@ -1,0 +1,242 @@
+// conv_wgrad_bf16x3.hip — weight gradient of the k = 7 stride-1 (dilated) convs — 7/8 of the conv stack's
+// weight-gradient FLOPs — on the bf16 matrix cores at fp32 accuracy (hi/lo split, 3 MFMAs per product,
+// fp32 accumulation; see conv1d_bf16x3.hip for the numerics).
+//
+//   dW[co][ci][tap] = sum_b sum_t  dy[b][co][t] * snake(x)[b][ci][t + tap*dil - pad]
+//
+// GEMM view: the MFMA reduction dim is TIME (16 consecutive steps per v_mfma_f32_32x32x16_bf16), rows = co,
+// cols = ci; a wave keeps 7 accumulator tiles (one per tap) of 32(co) x 32(ci), a workgroup covers
+// 128(co) x 32(ci); the (b, t) range is split over gridDim.z and the slabs summed by sat_reduce_splits.
+// The A fragment (8 consecutive t of one dy row) is an aligned 16-byte LDS read shared by all taps.  The B
+// fragment of tap k needs the x row shifted by k*dil samples — never 16-byte aligned — so a wave reads the
+// ALIGNED chunks covering [t, t + 8 + 6*dil) once per k-step and forms each tap's fragment with compile-time
+// register selection + v_alignbit (dil is a template parameter: 1, 3, 9).
+#include "conv_common.h"
+
+#define SAT_WB_TT 64                 // time steps per LDS stage (4 MFMA k-steps)
+#define SAT_WB_LOROW (SAT_WB_TT + 8) // 144 B rows: conflict-free b128
+#define SAT_WB_HIROW 136             // 64 + 54 + 8 (chunk overrun) = 126 -> 136 elements = 272 B rows: conflict-free b128
+
+struct SatWgBfParams {
+    const float* dy;     // (B, M, T)
+    const float* x;      // (B, N, T)   conv input (pre-activation)
+    const float* alpha;  // (N) snake log-params or null
+    const float* beta;
+    float* out;          // partial slabs [nsplit][M*N*7] addressed by so_*
+    long long so_split, so_m, so_n, so_k;
+    int B, M, N, T, pad;
+    int chunks_per_split, nchunks, nT;
+};
+
+#if defined(SAT_HIPEMU)
+static inline unsigned sat_alignbit(unsigned hi, unsigned lo, unsigned s) {
+    return (unsigned)((((unsigned long long)hi << 32) | lo) >> s);
+}
+#else
+SAT_DEVICE unsigned sat_alignbit(unsigned hi, unsigned lo, unsigned s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+#endif
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DIL>
+__global__ void __launch_bounds__(256) sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
+    constexpr int NCH = (6 * DIL + 7) / 8 + 1;                       // aligned 8-element chunks covering all 7 taps
+    __shared__ __attribute__((aligned(16))) short lo_lds[2][SAT_CO_T][SAT_WB_LOROW];   // dy  [plane][co][t]
+    __shared__ __attribute__((aligned(16))) short hi_lds[2][32][SAT_WB_HIROW];         // act [plane][ci][t]
+    __shared__ float sn_a[32], sn_ib[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * SAT_CO_T, n0 = blockIdx.y * 32;
+    const int m_w = wave * 32;
+    const bool wave_on = (m0 + m_w) < p.M;
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    if (tid < 32) {
+        const int c = n0 + tid;
+        float sa = 1.f, sib = 0.f;
+        if (p.alpha && c < p.N) {
+            sa = expf(p.alpha[c]);
+            sib = 1.0f / (expf(p.beta[c]) + 1e-9f);
+        }
+        sn_a[tid] = sa;
+        sn_ib[tid] = sib;
+    }
+    // hi-tile columns past the staged span are read by the chunk overrun of the last k-step: keep them zero
+    for (int i = tid; i < 2 * 32 * SAT_WB_HIROW; i += 256) (&hi_lds[0][0][0])[i] = 0;
+    __syncthreads();
+
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > p.nchunks) c_end = p.nchunks;
+    constexpr int HSPAN = SAT_WB_TT + 6 * DIL;                        // activation samples needed per stage
+
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int b = ch / p.nT;
+        const int tt0 = (ch - b * p.nT) * SAT_WB_TT;
+        // ---- stage dy: 128 rows x 64 t (8 float4 per thread, all loads first) ----
+        {
+            const float* src = p.dy + (size_t)b * p.M * p.T;
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                const int m = m0 + row, t = tt0 + c4;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M) {
+                    const float* s = src + (size_t)m * p.T + t;
+                    if (t + 3 < p.T && ((p.T & 3) == 0)) {
+                        q = *reinterpret_cast<const float4*>(s);
+                    } else {
+                        if (t + 0 < p.T) q.x = s[0];
+                        if (t + 1 < p.T) q.y = s[1];
+                        if (t + 2 < p.T) q.z = s[2];
+                        if (t + 3 < p.T) q.w = s[3];
+                    }
+                }
+                v[u] = q;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + u * 256;
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                typedef short s4 __attribute__((ext_vector_type(4)));
+                s4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const short hh = sat_f32_to_bf16(e[j]);
+                    h[j] = hh;
+                    l[j] = sat_f32_to_bf16(e[j] - sat_bf16_to_f32(hh));
+                }
+                *reinterpret_cast<s4*>(&lo_lds[0][row][c4]) = h;
+                *reinterpret_cast<s4*>(&lo_lds[1][row][c4]) = l;
+            }
+        }
+        // ---- stage snake(x): 32 rows x HSPAN samples starting at tt0 - pad (batches of 8 scalar loads) ----
+        {
+            const float* src = p.x + (size_t)b * p.N * p.T;
+            const int th0 = tt0 - p.pad;
+            constexpr int TOTAL = 32 * HSPAN;
+            for (int base = tid; base < TOTAL; base += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    const int row = idx / HSPAN, col = idx - row * HSPAN;
+                    const int n = n0 + row, t = th0 + col;
+                    v[u] = (idx < TOTAL && n < p.N && t >= 0 && t < p.T) ? src[(size_t)n * p.T + t] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < TOTAL) {
+                        const int row = idx / HSPAN, col = idx - row * HSPAN;
+                        const float o = p.alpha ? sat_snake(v[u], sn_a[row], sn_ib[row]) : v[u];
+                        const short hh = sat_f32_to_bf16(o);
+                        hi_lds[0][row][col] = hh;
+                        hi_lds[1][row][col] = sat_f32_to_bf16(o - sat_bf16_to_f32(hh));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (wave_on) {
+#pragma unroll
+            for (int ks = 0; ks < SAT_WB_TT / 16; ++ks) {
+                const int tb = 16 * ks + 8 * hi;
+                bf16x8 af[2];
+                u32x4 cw[2][NCH];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[pl] = *reinterpret_cast<const bf16x8*>(&lo_lds[pl][m_w + l31][tb]);
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) cw[pl][j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][l31][tb + 8 * j]);
+                }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int off = k * DIL;          // compile-time after unrolling
+                    const int wbase = (off >> 3) * 4 + ((off & 7) >> 1);   // first 32-bit word of the fragment
+                    const bool odd = (off & 1) != 0;
+                    bf16x8 bf[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        u32x4 r;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int w0 = wbase + i, w1 = wbase + i + 1;
+                            const unsigned a0 = cw[pl][w0 >> 2][w0 & 3];
+                            if (odd) {
+                                const unsigned a1 = cw[pl][w1 >> 2][w1 & 3];
+                                r[i] = sat_alignbit(a1, a0, 16);
+                            } else {
+                                r[i] = a0;
+                            }
+                        }
+                        bf[pl] = __builtin_bit_cast(bf16x8, r);
+                    }
+                    acc[k] = sat_mfma_32x32x16_bf16(af[0], bf[0], acc[k]);
+                    acc[k] = sat_mfma_32x32x16_bf16(af[0], bf[1], acc[k]);
+                    acc[k] = sat_mfma_32x32x16_bf16(af[1], bf[0], acc[k]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (wave_on) {
+        float* ob = p.out + (size_t)blockIdx.z * p.so_split;
+        const int n = n0 + l31;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + m_w + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < p.M && n < p.N) ob[(size_t)m * p.so_m + (size_t)n * p.so_n + (size_t)k * p.so_k] = acc[k][r];
+            }
+    }
+}
+
+struct SatWgBfPlan { int nsplit, cps, nchunks, nT; };
+static void sat_wgbf_plan(int B, int M, int N, int T, SatWgBfPlan* pl) {
+    pl->nT = sat_cdiv(T, SAT_WB_TT);
+    pl->nchunks = B * pl->nT;
+    const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N, 32);
+    int want = sat_cdiv(1024, tiles);
+    if (want > pl->nchunks) want = pl->nchunks;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    pl->cps = sat_cdiv(pl->nchunks, want);
+    pl->nsplit = sat_cdiv(pl->nchunks, pl->cps);
+}
+extern "C" int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T) {
+    SatWgBfPlan pl;
+    sat_wgbf_plan(B, M, N, T, &pl);
+    return pl.nsplit;
+}
+// dW[m][n][k] for a K = 7, stride-1 conv with dilation in {1, 3, 9}: dy (B, M, T), x (B, N, T) pre-activation,
+// alpha/beta = SnakeBeta log-params of the conv input (or NULL).  Writes nsplit slabs (element (m,n,k) at
+// m*so_m + n*so_n + k*so_k, slab stride M*N*7); sum them with sat_reduce_splits.
+extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, const float* beta, float* partial,
+                                      long long so_m, long long so_n, long long so_k, int B, int M, int N, int T, int dil,
+                                      int pad, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0 || T <= 0) { sat_set_error("sat_conv_wgrad7_bf16x3: empty shape"); return 1; }
+    if (dil != 1 && dil != 3 && dil != 9) { sat_set_error("sat_conv_wgrad7_bf16x3: dilation must be 1, 3 or 9 (the Oobleck ResidualUnits)"); return 1; }
+    if ((alpha == nullptr) != (beta == nullptr)) { sat_set_error("sat_conv_wgrad7_bf16x3: alpha/beta must both be given"); return 1; }
+    SatWgBfPlan pl;
+    sat_wgbf_plan(B, M, N, T, &pl);
+    SatWgBfParams p{dy, x, alpha, beta, partial, (long long)M * N * 7, so_m, so_n, so_k, B, M, N, T, pad, pl.cps, pl.nchunks, pl.nT};
+    dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, 32), pl.nsplit);
+    if (dil == 1) SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<1>, grid, dim3(256), stream, p);
+    else if (dil == 3) SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<3>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<9>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_conv_wgrad7_bf16x3");
+}

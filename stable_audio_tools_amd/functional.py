@@ -66,6 +66,13 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
     return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
 
 
+def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake):
+    """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 stride-1 convs take the bf16x3 split-MFMA kernel."""
+    if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
+        return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake)
+    return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
+
+
 def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False):
     """conv1d(snake(x), w) [+bias] [+res]: k = 5..8 stride-1 convs take the bf16x3 split-MFMA kernel
     (fp32-accurate, csrc/conv1d_bf16x3.hip), everything else the fp32-MFMA kernel (csrc/conv1d.hip)."""
@@ -106,7 +113,7 @@ class SnakeConv1dFn(torch.autograd.Function):
         dbias = ops.rowsum(dy) if has_bias else None
         dw = None
         if ctx.needs_input_grad[3]:
-            dw = ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
+            dw = _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake)
         dx = da = db = None
         if has_snake:
             dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
@@ -185,7 +192,7 @@ class ResidualUnitFn(torch.autograd.Function):
         dw2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2)
         dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2))
         dbias1 = ops.rowsum(dh)
-        dw1 = ops.conv_wgrad(dh, x, k1, 1, dil, pad1, snake=(a1, b1), snake_on=2)
+        dw1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1))
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
         return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None
 

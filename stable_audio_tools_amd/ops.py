@@ -207,6 +207,21 @@ class SatOps:
                                           self._stream(lo)))
         return self._reduce_rows(partial, nsplit, m * n * k).view(shape)
 
+    def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):
+        return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9) and n_in >= 32
+
+    def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None):
+        """dW (Cout, Cin, 7) of a k7 stride-1 conv: dy (B, Cout, T), x (B, Cin, T) pre-activation, snake = (log-alpha, log-beta)."""
+        b, m, t = dy.shape
+        n = x.shape[1]
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(dy, x, alpha, beta)
+        nsplit = self.lib.sat_conv_wgrad7_bf16x3_nsplit(b, m, n, t)
+        partial = torch.empty(nsplit, m * n * 7, dtype=torch.float32, device=dy.device)
+        self._chk(self.lib.sat_conv_wgrad7_bf16x3(_ptr(dy), _ptr(x), _ptr(alpha), _ptr(beta), _ptr(partial), n * 7, 7, 1,
+                                                  b, m, n, t, dil, pad, self._stream(dy)))
+        return self._reduce_rows(partial, nsplit, m * n * 7).view(m, n, 7)
+
     def rowsum(self, x):
         """(B, C, T) -> (C,) sum over batch and time."""
         self._f32(x)

@@ -73,6 +73,9 @@ for (C, T, S) in levels:
     dy = torch.randn(1, C, T, device=dev)
     ms = timeit(lambda: ops.conv_wgrad(dy, x, 7, 1, 9, 27, snake=(la, lb), snake_on=2))
     res[f"wgrad7_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
+    for dil in (1, 9):
+        ms = timeit(lambda: ops.conv_wgrad7_bf16x3(dy, x, dil, 3 * dil, snake=(la, lb)))
+        res[f"wgrad7x3_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
     ms = timeit(lambda: ops.conv_wgrad(dy, x, 1, 1, 1, 0, snake=(la, lb), snake_on=2))
     res[f"wgrad1_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9)
     wpb = ops.pack(w7, O.PACK_CONV_DGRAD)
