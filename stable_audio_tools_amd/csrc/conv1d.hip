@@ -33,7 +33,7 @@ struct SatConvLaunch {
 __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
     const SatConvParams& p = a.p;
     __shared__ float w_lds[SAT_W_ROWS][SAT_CO_T];  // [(c, tap)][co]
-    __shared__ float a_lds[SAT_A_FLOATS];          // [c][...] activation slab
+    __shared__ __attribute__((aligned(16))) float a_lds[SAT_A_FLOATS];   // [c][...] activation slab
     __shared__ float red_lds[2][2][SAT_CO_T];      // [quantity][t-wave][co] (backward epilogue)
     __shared__ float ep_lds[3][SAT_CO_T];          // per-row epilogue constants: bias, e^alpha2, e^beta2
 
@@ -70,55 +70,85 @@ __global__ void __launch_bounds__(256) sat_conv1d_kernel(SatConvLaunch a) {
     }
     // (visibility of ep_lds is ordered by the barriers of the K loop; Cin >= 1 guarantees one pass)
 
-    // Staging map: a WAVE walks one channel row at a time with its 64 lanes on 64 consecutive samples (256-byte
-    // coalesced runs); item `it` of a wave -> channel wave + 4*(it / nslot), sample lane + 64*(it % nslot).
-    // (The earlier thread-per-channel map gave 32-byte runs at 32 channels per chunk: k=1 convs ran at 1.5 TB/s.)
-    const int nslot = (nj + 63) >> 6;
-    const int nitems = ((CI_T + 3 - wave) >> 2) * nslot;      // items of this wave per chunk
-    __shared__ float sn_lds[2][2][32];                        // [chunk parity][a | ib][channel in chunk]
-    if (tid < CI_T) {
-        const int ci = tid;
-        const bool on = (p.alpha != nullptr) && ci < p.Cin;
-        sn_lds[0][0][tid] = on ? expf(p.alpha[ci]) : 1.0f;
-        sn_lds[0][1][tid] = on ? 1.0f / (expf(p.beta[ci]) + 1e-9f) : 0.0f;
-    }
-    __syncthreads();
+    // fixed staging channel per thread
+    const int tpc = 256 / CI_T;
+    const int sc = tid / tpc, sj0 = tid - sc * tpc;
 
-    int par = 0;
-    for (int ci0 = 0; ci0 < p.Cin; ci0 += CI_T, par ^= 1) {
-        // snake constants of the NEXT chunk (other parity buffer; ordered by this iteration's barriers)
-        if (tid < CI_T) {
-            const int ci = ci0 + CI_T + tid;
-            const bool on = (p.alpha != nullptr) && ci < p.Cin;
-            sn_lds[par ^ 1][0][tid] = on ? expf(p.alpha[ci]) : 1.0f;
-            sn_lds[par ^ 1][1][tid] = on ? 1.0f / (expf(p.beta[ci]) + 1e-9f) : 0.0f;
-        }
-        // ---- stage activations (snake applied once per element here); loads are issued in batches of 8 per
-        //      thread BEFORE any of them is consumed, so a chunk costs one HBM round trip, not one per element ----
-        const bool use_snake = (p.alpha != nullptr);
-        for (int it0 = 0; it0 < nitems; it0 += 8) {
-            float v[8];
+    for (int ci0 = 0; ci0 < p.Cin; ci0 += CI_T) {
+        // ---- stage activations (snake applied once per element here) ----
+        if (K == 1 && S == 1 && CI_T == 32 && p.pad == 0 && (p.Tin & 3) == 0) {
+            // 1x1 convs (HBM-bound: the k1 conv of every ResidualUnit and its data-gradient): 32 channels x 128
+            // samples per chunk as 4 float4 per thread, 32 lanes x 16 B = 512 contiguous bytes per channel row
+            float4 v[4];
+            float sa[4], sib[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = it0 + u;
-                const int cq = it / nslot;
-                const int c = wave + 4 * cq, j = lane + 64 * (it - cq * nslot);
-                const int ci = ci0 + c, tin = tin0 + j;
-                v[u] = (it < nitems && ci < p.Cin && j < nj && tin >= 0 && tin < p.Tin) ? xb[(size_t)ci * p.Tin + tin] : 0.0f;
+            for (int u = 0; u < 4; ++u) {
+                const int c = (tid >> 5) + 8 * u, t4 = (tid & 31) * 4;
+                const int ci = ci0 + c, tin = t0 + t4;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                sa[u] = 1.0f;
+                sib[u] = 0.0f;
+                if (ci < p.Cin) {
+                    const float* src = xb + (size_t)ci * p.Tin + tin;
+                    if (tin + 3 < p.Tin) {
+                        q = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (tin + 0 < p.Tin) q.x = src[0];
+                        if (tin + 1 < p.Tin) q.y = src[1];
+                        if (tin + 2 < p.Tin) q.z = src[2];
+                    }
+                    if (p.alpha) {
+                        sa[u] = expf(p.alpha[ci]);
+                        sib[u] = 1.0f / (expf(p.beta[ci]) + 1e-9f);
+                    }
+                }
+                v[u] = q;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = it0 + u;
-                const int cq = it / nslot;
-                const int c = wave + 4 * cq, j = lane + 64 * (it - cq * nslot);
-                if (it < nitems && j < nj) {
-                    const float o = use_snake ? sat_snake(v[u], sn_lds[par][0][c], sn_lds[par][1][c]) : v[u];   // snake(0) == 0
-                    int pos = j;
-                    if (S != 1) {
-                        const int q = j / S;
-                        pos = (j - q * S) * L + q;
+            for (int u = 0; u < 4; ++u) {
+                const int c = (tid >> 5) + 8 * u, t4 = (tid & 31) * 4;
+                float4 q = v[u];
+                if (p.alpha) {
+                    q.x = sat_snake(q.x, sa[u], sib[u]);
+                    q.y = sat_snake(q.y, sa[u], sib[u]);
+                    q.z = sat_snake(q.z, sa[u], sib[u]);
+                    q.w = sat_snake(q.w, sa[u], sib[u]);
+                }
+                *reinterpret_cast<float4*>(&a_lds[c * cs + t4]) = q;
+            }
+        } else if (sc < CI_T) {
+            const int ci = ci0 + sc;
+            const bool ch_ok = ci < p.Cin;
+            float sa = 1.0f, sib = 0.0f;
+            const bool use_snake = (p.alpha != nullptr) && ch_ok;
+            if (use_snake) {
+                sa = expf(p.alpha[ci]);
+                sib = 1.0f / (expf(p.beta[ci]) + 1e-9f);
+            }
+            const float* xr = xb + (size_t)ci * p.Tin;
+            float* arow = a_lds + sc * cs;
+            // loads are issued in batches of 8 per thread BEFORE any of them is consumed, so a chunk costs one
+            // HBM round trip instead of one per element
+            for (int jb = sj0; jb < nj; jb += 8 * tpc) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = jb + u * tpc;
+                    const int tin = tin0 + j;
+                    v[u] = (ch_ok && j < nj && tin >= 0 && tin < p.Tin) ? xr[tin] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = jb + u * tpc;
+                    if (j < nj) {
+                        const float o = use_snake ? sat_snake(v[u], sa, sib) : v[u];   // snake(0) == 0: padding stays 0
+                        int pos = j;
+                        if (S != 1) {
+                            const int q = j / S;
+                            pos = (j - q * S) * L + q;
+                        }
+                        arow[pos] = o;
                     }
-                    a_lds[c * cs + pos] = o;
                 }
             }
         }
