@@ -72,46 +72,55 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     }
 
     const int nchunks = p.Cin >> 3;
-    for (int c = 0; c < nchunks; ++c) {
+    // Register-staged software pipeline: the global loads of chunk c+1 are issued right after the barrier that
+    // publishes chunk c, so their HBM/L2 latency runs under chunk c's MFMA phase; they are converted and written
+    // to LDS after the phase's closing barrier.
+    const int srow = tid;                                 // activation time row owned by this thread (if < nrows)
+    const int stin = tin0 + srow;
+    const bool srow_ok = (srow < nrows) && stin >= 0 && stin < p.Tin;
+    float av[8];
+    bf16x8 wv[8];
+    auto issue_loads = [&](int c) {
         const int ci0 = c * 8;
-        // ---- activations: thread = one time row, 8 channels (loads issued together, then snake + split) ----
-        if (tid < nrows) {
-            const int tin = tin0 + tid;
-            const bool ok = tin >= 0 && tin < p.Tin;
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ok ? xb[(size_t)(ci0 + e) * p.Tin + tin] : 0.0f;
+        for (int e = 0; e < 8; ++e) av[e] = srow_ok ? xb[(size_t)(ci0 + e) * p.Tin + stin] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * 256;                 // plane = idx>>10, co = (idx>>3)&127, part = idx&7
+            const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
+            const short* src = (pl ? a.w_lo : a.w_hi) + (((size_t)c * a.cout_pad + co0 + co) * 64 + part * 8);
+            wv[u] = *reinterpret_cast<const bf16x8*>(src);
+        }
+    };
+    auto write_lds = [&](int c) {
+        const int ci0 = c * 8;
+        if (srow < nrows) {
             bf16x8 vh, vl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float o = v[e];
+                float o = av[e];
                 if (p.alpha) o = sat_snake(o, p.alpha[ci0 + e], p.beta[ci0 + e]);   // pre-exponentiated constants
                 short h, l;
                 sat_split2(o, &h, &l);
                 vh[e] = h;
                 vl[e] = l;
             }
-            *reinterpret_cast<bf16x8*>(&a_lds[0][tid][0]) = vh;
-            *reinterpret_cast<bf16x8*>(&a_lds[1][tid][0]) = vl;
+            *reinterpret_cast<bf16x8*>(&a_lds[0][srow][0]) = vh;
+            *reinterpret_cast<bf16x8*>(&a_lds[1][srow][0]) = vl;
         }
-        // ---- weights: [co 128][64 k] per plane, straight 16-byte copies (8 per thread) ----
-        {
-            bf16x8 wv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = tid + u * 256;             // 0..2047: plane = idx>>10, co = (idx>>3)&127, part = idx&7
-                const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
-                const short* src = (pl ? a.w_lo : a.w_hi) + (((size_t)c * a.cout_pad + co0 + co) * 64 + part * 8);
-                wv[u] = *reinterpret_cast<const bf16x8*>(src);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = tid + u * 256;
-                const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
-                *reinterpret_cast<bf16x8*>(&w_lds[pl][co][part * 8]) = wv[u];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * 256;
+            const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
+            *reinterpret_cast<bf16x8*>(&w_lds[pl][co][part * 8]) = wv[u];
         }
+    };
+
+    issue_loads(0);
+    for (int c = 0; c < nchunks; ++c) {
+        write_lds(c);
         __syncthreads();
+        if (c + 1 < nchunks) issue_loads(c + 1);
 
         if (wave_on) {
 #pragma unroll
