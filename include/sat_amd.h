@@ -48,17 +48,30 @@ int sat_conv1d(const float* x, const float* w_packed, const float* bias, const f
                int dil, int pad, int tanh_out, void* stream);
 int sat_conv1d_partial_rows(int B, int Tout);
 
-/* The same stride-1 convolution (K <= 8, Cin % 8 == 0 — the k7 convs of every ResidualUnit, autoencoders.py:58-83,
- * and their data-gradients) on the bf16 matrix cores at fp32 accuracy: operands split hi+lo, three MFMAs per product.
- * Weights come from sat_pack_weights_bf16x3 (mode 0 forward, mode 1 = flipped/transposed for the data-gradient;
- * sat_pack_weights_bf16x3_size gives the plane length in elements); snake_a / snake_ib are the pre-exponentiated
- * SnakeBeta constants from sat_snake_consts (a = e^alpha, ib = 1/(e^beta + 1e-9)) or NULL.  Everything else as sat_conv1d. */
+/* The convolutions of the stack on the bf16 matrix cores at fp32 accuracy (operands split hi+lo, three MFMAs per product).
+ * Every conv is run as a stride-1 implicit GEMM over virtual channels (csrc/conv1d_bf16x3.hip):
+ *   sat_conv1d_bf16x3:   stride 1 with K <= 8 (the k7 / k1 convs of every ResidualUnit, autoencoders.py:58-83, and their
+ *                        data-gradients), or stride S = power of two with K == 2S (the down-convs, :245-247, and the
+ *                        data-gradient of the up-convs) — space-to-depth on the input.
+ *   sat_convtr1d_bf16x3: conv_transpose1d, K == 2S, S a power of two (the up-convs, :266-268, and the data-gradient of
+ *                        the down-convs) — depth-to-space on the output.
+ * Weights come from sat_pack_weights_bf16x3(w[D0][D1][K], stride, mode): mode 0 = conv weight [out][in][K];
+ * mode 1 = data-gradient of a stride-1 conv (flipped/transposed); mode 2 = transposed-conv weight [in][out][K].
+ * sat_pack_weights_bf16x3_size gives the plane length in elements (-1: unsupported).  snake_a / snake_ib are the
+ * pre-exponentiated SnakeBeta constants from sat_snake_consts (a = e^alpha, ib = 1/(e^beta + 1e-9)) or NULL.
+ * Everything else (epilogue options, partial-sum layout) as sat_conv1d / sat_convtr1d; partial rows are
+ * sat_conv1d_partial_rows(B, Tout) resp. sat_convtr1d_bf16x3_partial_rows(B, Tout, stride, pad). */
 int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
                       const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                       const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
-                      int K, int dil, int pad, int tanh_out, void* stream);
-int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream);
-long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int mode);
+                      int K, int stride, int dil, int pad, int tanh_out, void* stream);
+int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
+                        const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
+                        const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
+                        int K, int stride, int pad, int tanh_out, void* stream);
+int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
+int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
+long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);
 int sat_snake_consts(const float* alpha, const float* beta, float* a, float* ib, int C, void* stream);
 
 /* Transposed conv, K == 2*stride (the Oobleck resampler, autoencoders.py:266-268), polyphase form.

@@ -22,9 +22,11 @@ SIGNATURES = {
     "sat_conv1d": (_I, [_P] * 12 + [_I] * 10 + [_P]),
     "sat_conv1d_partial_rows": (_I, [_I, _I]),
     # conv1d_bf16x3.hip
-    "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
-    "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I]),
+    "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 10 + [_P]),
+    "sat_convtr1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
+    "sat_convtr1d_bf16x3_partial_rows": (_I, [_I] * 4),
+    "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I, _I]),
     "sat_snake_consts": (_I, [_P, _P, _P, _P, _I, _P]),
     # conv_wgrad_bf16x3.hip
     "sat_conv_wgrad7_bf16x3": (_I, [_P] * 5 + [_L] * 3 + [_I] * 6 + [_P]),

@@ -18,14 +18,20 @@
 //     so a chunk's slab is a straight 16-byte-per-lane copy into padded LDS rows.
 #include "conv_common.h"
 
-#define SAT_BF_KROW 72    // bf16 per weight row in LDS: 8 groups x 8 + 8 pad (144 B stride, conflict-free b128)
-#define SAT_BF_AROWS 192  // max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
+#define SAT_BF_AROWS1 192  // CS == 1: max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
+#define SAT_BF_AROWSN 136  // CS  > 1: 128 + (taps-1) rows, taps <= 4, dil = 1
 
 struct SatConvBfLaunch {
-    SatConvParams p;       // p.w unused; p.alpha / p.beta hold PRE-EXPONENTIATED snake constants: a = e^alpha, ib = 1/(e^beta+1e-9)
-    const short* w_hi;     // [nchunks][CoutPad][8][8]
+    SatConvParams p;       // REAL tensor dims (Cin, Tin, Cout, Tout); p.K / p.dil / p.pad describe the VIRTUAL stride-1 conv;
+                           // p.w unused; p.alpha / p.beta hold PRE-EXPONENTIATED snake constants: a = e^alpha, ib = 1/(e^beta+1e-9)
+    const short* w_hi;     // [nchunks][cout_pad][NG][8]
     const short* w_lo;
-    int cout_pad;
+    int cout_pad;          // virtual output channels rounded up to the 128 tile
+    int cin_v, cout_v;     // virtual channel counts: Cin << sin_log2, Cout << sout_log2
+    int sin_log2;          // space-to-depth of the input:  x'[ci*S + r][q] = x[ci][q*S + r - in_shift]   (strided conv)
+    int sout_log2;         // depth-to-space of the output: y[co][q*S + r - out_shift] = y'[co*S + r][q]  (transposed conv)
+    int in_shift, out_shift;
+    int nq;                // virtual output positions
 };
 
 SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
@@ -34,10 +40,17 @@ SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
     *lo = sat_f32_to_bf16(x - sat_bf16_to_f32(h));
 }
 
+// NG = k-groups (8 values each) per K-chunk, CS = 8-channel sub-blocks per chunk; taps per sub-block KT = NG / CS.
+// group g of a chunk = (sub-block g / KT, tap g % KT).
+template <int NG, int CS>
 __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
+    constexpr int KT = NG / CS;
+    constexpr int KROW = NG * 8 + 8;                      // bf16 per weight row in LDS (+8 pad: conflict-free b128 reads)
+    constexpr int AROWS = (CS == 1) ? SAT_BF_AROWS1 : SAT_BF_AROWSN;
+    constexpr int NU = (CS * AROWS + 255) / 256;          // activation staging items (one time row x 8 channels) per thread
     const SatConvParams& p = a.p;
-    __shared__ __attribute__((aligned(16))) short w_lds[2][SAT_CO_T][SAT_BF_KROW];   // [plane][co][g*8+e]
-    __shared__ __attribute__((aligned(16))) short a_lds[2][SAT_BF_AROWS][8];         // [plane][time row][8 ci]
+    __shared__ __attribute__((aligned(16))) short w_lds[2][SAT_CO_T][KROW];        // [plane][co][g*8+e]
+    __shared__ __attribute__((aligned(16))) short a_lds[2][CS][AROWS][8];          // [plane][sub-block][time row][8 ci]
     __shared__ float red_lds[2][2][SAT_CO_T];
     __shared__ float ep_lds[3][SAT_CO_T];
 
@@ -50,10 +63,12 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     const int co_w = (wave >> 1) * 64, t_w = (wave & 1) * 64;
     const int K = p.K, dil = p.dil;
     const int nrows = SAT_T_T + (K - 1) * dil;
-    const int tin0 = t0 - p.pad;
+    const int q_in0 = t0 - p.pad;
+    const int si = a.sin_log2, so = a.sout_log2;
+    const int smask_i = (1 << si) - 1, smask_o = (1 << so) - 1;
     const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
-    const bool wave_on = (co0 + co_w) < p.Cout;
-    const bool mi1_on = (co0 + co_w + 32) < p.Cout;
+    const bool wave_on = (co0 + co_w) < a.cout_v;
+    const bool mi1_on = (co0 + co_w + 32) < a.cout_v;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -64,54 +79,72 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if (tid < SAT_CO_T) {
-        const int co = co0 + tid;
-        const bool ok = co < p.Cout;
+        const int m = co0 + tid;
+        const bool ok = m < a.cout_v;
+        const int co = m >> so;
         ep_lds[0][tid] = (ok && p.bias) ? p.bias[co] : 0.0f;
         ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[co]) : 1.0f;
         ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[co]) : 1.0f;
     }
 
-    const int nchunks = p.Cin >> 3;
+    const int nchunks = (a.cin_v + 8 * CS - 1) / (8 * CS);
     // Register-staged software pipeline: the global loads of chunk c+1 are issued right after the barrier that
     // publishes chunk c, so their HBM/L2 latency runs under chunk c's MFMA phase; they are converted and written
     // to LDS after the phase's closing barrier.
-    const int srow = tid;                                 // activation time row owned by this thread (if < nrows)
-    const int stin = tin0 + srow;
-    const bool srow_ok = (srow < nrows) && stin >= 0 && stin < p.Tin;
-    float av[8];
-    bf16x8 wv[8];
+    int s_cs[NU], s_row[NU], s_tin[NU];                    // per staging item: sub-block, time row, real input time of phase 0
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int it = tid + u * 256;
+        s_cs[u] = it / AROWS;
+        s_row[u] = it - s_cs[u] * AROWS;
+        if (s_cs[u] >= CS || s_row[u] >= nrows) s_row[u] = -1;
+        s_tin[u] = ((q_in0 + s_row[u]) << si) - a.in_shift;
+    }
+    float av[NU][8];
+    bf16x8 wv[NG];
     auto issue_loads = [&](int c) {
-        const int ci0 = c * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = srow_ok ? xb[(size_t)(ci0 + e) * p.Tin + stin] : 0.0f;
+        for (int u = 0; u < NU; ++u) {
+            const int v0 = (c * CS + s_cs[u]) * 8;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = tid + u * 256;                 // plane = idx>>10, co = (idx>>3)&127, part = idx&7
-            const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
-            const short* src = (pl ? a.w_lo : a.w_hi) + (((size_t)c * a.cout_pad + co0 + co) * 64 + part * 8);
+            for (int e = 0; e < 8; ++e) {
+                const int v = v0 + e;
+                const int tin = s_tin[u] + (v & smask_i);
+                const bool ok = s_row[u] >= 0 && v < a.cin_v && tin >= 0 && tin < p.Tin;
+                av[u][e] = ok ? xb[(size_t)(v >> si) * p.Tin + tin] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int idx = tid + u * 256;                 // part = idx % NG, co = (idx / NG) & 127, plane = idx / (NG * 128)
+            const int part = idx % NG, co = (idx / NG) & 127, pl = idx / (NG * 128);
+            const short* src = (pl ? a.w_lo : a.w_hi) + (((size_t)c * a.cout_pad + co0 + co) * NG + part) * 8;
             wv[u] = *reinterpret_cast<const bf16x8*>(src);
         }
     };
     auto write_lds = [&](int c) {
-        const int ci0 = c * 8;
-        if (srow < nrows) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (s_row[u] < 0) continue;
+            const int v0 = (c * CS + s_cs[u]) * 8;
             bf16x8 vh, vl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float o = av[e];
-                if (p.alpha) o = sat_snake(o, p.alpha[ci0 + e], p.beta[ci0 + e]);   // pre-exponentiated constants
+                float o = av[u][e];
+                const int v = v0 + e;
+                if (p.alpha && v < a.cin_v) o = sat_snake(o, p.alpha[v >> si], p.beta[v >> si]);   // pre-exponentiated constants
                 short h, l;
                 sat_split2(o, &h, &l);
                 vh[e] = h;
                 vl[e] = l;
             }
-            *reinterpret_cast<bf16x8*>(&a_lds[0][srow][0]) = vh;
-            *reinterpret_cast<bf16x8*>(&a_lds[1][srow][0]) = vl;
+            *reinterpret_cast<bf16x8*>(&a_lds[0][s_cs[u]][s_row[u]][0]) = vh;
+            *reinterpret_cast<bf16x8*>(&a_lds[1][s_cs[u]][s_row[u]][0]) = vl;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NG; ++u) {
             const int idx = tid + u * 256;
-            const int pl = idx >> 10, co = (idx >> 3) & 127, part = idx & 7;
+            const int part = idx % NG, co = (idx / NG) & 127, pl = idx / (NG * 128);
             *reinterpret_cast<bf16x8*>(&w_lds[pl][co][part * 8]) = wv[u];
         }
     };
@@ -124,16 +157,18 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
 
         if (wave_on) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < NG / 2; ++ks) {
                 const int g = 2 * ks + hi;                 // k-slots 0-7 <- group 2ks (lanes 0-31), 8-15 <- group 2ks+1
-                const int tap = (g < K) ? g : (K - 1);     // group >= K is a zero-weight pad; keep the row in range
+                const int cs = g / KT;
+                int tap = g - cs * KT;
+                if (tap >= K) tap = K - 1;                 // taps >= K are zero-weight pads; keep the row in range
                 bf16x8 wa[2][2], xa[2][2];                 // [mi|ni][plane]
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     wa[0][pl] = *reinterpret_cast<const bf16x8*>(&w_lds[pl][co_w + l31][g * 8]);
                     wa[1][pl] = *reinterpret_cast<const bf16x8*>(&w_lds[pl][co_w + 32 + l31][g * 8]);
-                    xa[0][pl] = *reinterpret_cast<const bf16x8*>(&a_lds[pl][t_w + l31 + tap * dil][0]);
-                    xa[1][pl] = *reinterpret_cast<const bf16x8*>(&a_lds[pl][t_w + 32 + l31 + tap * dil][0]);
+                    xa[0][pl] = *reinterpret_cast<const bf16x8*>(&a_lds[pl][cs][t_w + l31 + tap * dil][0]);
+                    xa[1][pl] = *reinterpret_cast<const bf16x8*>(&a_lds[pl][cs][t_w + 32 + l31 + tap * dil][0]);
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
@@ -150,7 +185,7 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
         __syncthreads();
     }
 
-    // ---------------------------------- epilogue (as conv1d.hip) ----------------------------------
+    // ------------- epilogue (as conv1d.hip; virtual channel m = co*S + r lands on y[co][q*S + r - out_shift]) -------------
     const bool bwd = (p.x2 != nullptr);
     if (bwd) {
         for (int i = tid; i < 2 * 2 * SAT_CO_T; i += 256) (&red_lds[0][0][0])[i] = 0.0f;
@@ -163,15 +198,17 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int co = co0 + col;
-                const bool co_ok = co < p.Cout;
+                const int m = co0 + col;
+                const bool m_ok = m < a.cout_v;
+                const int co = m >> so;
                 const float bias = ep_lds[0][col];
                 const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
                 float pda = 0.f, pdb = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    const int t = t0 + t_w + ni * 32 + l31;
-                    if (co_ok && t < p.Tout) {
+                    const int q = t0 + t_w + ni * 32 + l31;
+                    const int t = (q << so) + (m & smask_o) - a.out_shift;
+                    if (m_ok && t >= 0 && t < p.Tout) {
                         const size_t o = ((size_t)b * p.Cout + co) * p.Tout + t;
                         float v = acc[mi][ni][r] + bias;
                         if (bwd) {
@@ -198,57 +235,105 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     }
     if (bwd) {
         __syncthreads();
-        if (tid < SAT_CO_T && co0 + tid < p.Cout) {
+        const int m = co0 + tid;
+        if (tid < SAT_CO_T && (tid & smask_o) == 0 && m < a.cout_v) {      // one thread per REAL channel: sum its S phases
+            float sa = 0.f, sb = 0.f;
+            for (int r = 0; r <= smask_o; ++r) {
+                sa += red_lds[0][0][tid + r] + red_lds[0][1][tid + r];
+                sb += red_lds[1][0][tid + r] + red_lds[1][1][tid + r];
+            }
             const size_t row = (size_t)b * gridDim.x + blockIdx.x;
             const size_t nrows_p = (size_t)p.B * gridDim.x;
-            p.part_da[(size_t)(co0 + tid) * nrows_p + row] = red_lds[0][0][tid] + red_lds[0][1][tid];
-            p.part_db[(size_t)(co0 + tid) * nrows_p + row] = red_lds[1][0][tid] + red_lds[1][1][tid];
+            p.part_da[(size_t)(m >> so) * nrows_p + row] = sa;
+            p.part_db[(size_t)(m >> so) * nrows_p + row] = sb;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight preparation: torch conv weight w[Cout][Cin][K] (fp32) -> hi/lo bf16 planes
-//   [chunk = ci/8][co (padded to 128)][group g][e]  with value W_eff[co][8*chunk + e][tap g] (0 for g >= K, co >= Cout)
-//   mode 0 (forward):        W_eff[co][ci][tap] = w[co][ci][tap]
-//   mode 1 (data-gradient):  the flipped/transposed conv (in = Cout, out = Cin): W_eff[o][i][tap] = w[i][o][K-1-tap]
+// Plans.  Every conv of the stack is a stride-1 implicit GEMM over virtual channels:
+//   conv, stride 1:            K' = K,  plain channels
+//   conv, stride S, K = 2S:    K' = 2,  in-channels (ci, r):   x'[(ci,r)][q] = x[ci][q*S + r - pad],   W'[co][(ci,r)][j] = w[co][ci][j*S + r]
+//   conv_transpose, K = 2S:    K' = 2,  out-channels (co, r):  y[co][q*S + r - pad] = y'[(co,r)][q],
+//                              y'[(co,r)][q] = sum_ci W[ci][co][r+S] x[ci][q-1] + W[ci][co][r] x[ci][q]
+// ------------------------------------------------------------------------------------------------
+struct SatBfPlan { int ng, cs, kv; };     // groups per chunk, sub-blocks per chunk, virtual taps
+static bool sat_bf_plan(int K, int stride, int mode, SatBfPlan* pl) {
+    if (mode == 2 || stride > 1) {
+        if (K != 2 * stride || (stride & (stride - 1)) || stride > 64) return false;
+        *pl = SatBfPlan{8, 4, 2};
+        return true;
+    }
+    if (stride != 1 || K < 1 || K > 8) return false;
+    if (K == 1) *pl = SatBfPlan{4, 4, 1};
+    else if (K == 2) *pl = SatBfPlan{8, 4, K};
+    else if (K <= 4) *pl = SatBfPlan{8, 2, K};
+    else *pl = SatBfPlan{8, 1, K};
+    return true;
+}
+static int sat_log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation: torch weight w[D0][D1][K] (fp32) -> hi/lo bf16 planes [chunk][m (padded to 128)][group g][e]
+// holding W'[m][v][tap] with v = (chunk*CS + g/KT)*8 + e, tap = g % KT (0 where tap/m/v are out of range):
+//   mode 0 (conv, w = [out][in][K]):            stride 1: W' = w[m][v][tap];   stride S: W' = w[m][v/S][tap*S + v%S]
+//   mode 1 (data-gradient of a stride-1 conv):  W'[m][v][tap] = w[v][m][K-1-tap]
+//   mode 2 (conv_transpose, w = [in][out][K]):  W'[m][v][0] = w[v][m/S][m%S + S],  W'[m][v][1] = w[v][m/S][m%S]
 // ------------------------------------------------------------------------------------------------
 struct SatPackBfParams {
     const float* w;
     short* hi;
     short* lo;
-    int D0, D1, K, mode, n_out, n_in, out_pad;
+    int D0, D1, K, S, mode, ng, cs, kv, m_v, v_v, out_pad;
     long long total;
 };
 __global__ void __launch_bounds__(256) sat_pack_bf16x3_kernel(SatPackBfParams p) {
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= p.total) return;
-    const int e = (int)(o & 7), g = (int)((o >> 3) & 7);
-    const long long q = o >> 6;
-    const int co = (int)(q % p.out_pad), chunk = (int)(q / p.out_pad);
-    const int ci = chunk * 8 + e;
-    float v = 0.0f;
-    if (g < p.K && co < p.n_out && ci < p.n_in) {
-        if (p.mode == 0) v = p.w[((size_t)co * p.D1 + ci) * p.K + g];
-        else v = p.w[((size_t)ci * p.D1 + co) * p.K + (p.K - 1 - g)];
+    const int e = (int)(o & 7);
+    long long q = o >> 3;
+    const int g = (int)(q % p.ng);
+    q /= p.ng;
+    const int m = (int)(q % p.out_pad), chunk = (int)(q / p.out_pad);
+    const int kt = p.ng / p.cs;
+    const int v = (chunk * p.cs + g / kt) * 8 + e, tap = g % kt;
+    float val = 0.0f;
+    if (tap < p.kv && m < p.m_v && v < p.v_v) {
+        if (p.mode == 0) val = p.w[((size_t)m * p.D1 + v / p.S) * p.K + tap * p.S + v % p.S];
+        else if (p.mode == 1) val = p.w[((size_t)v * p.D1 + m) * p.K + (p.K - 1 - tap)];
+        else val = p.w[((size_t)v * p.D1 + m / p.S) * p.K + (m % p.S) + (tap == 0 ? p.S : 0)];
     }
     short h, l;
-    sat_split2(v, &h, &l);
+    sat_split2(val, &h, &l);
     p.hi[o] = h;
     p.lo[o] = l;
 }
 
-extern "C" long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int mode) {
-    const int n_out = mode == 0 ? D0 : D1, n_in = mode == 0 ? D1 : D0;
-    if (K < 1 || K > 8 || (n_in & 7)) return -1;
-    return (long long)(n_in / 8) * (sat_cdiv(n_out, SAT_CO_T) * SAT_CO_T) * 64;
+static bool sat_pack_bf_geometry(int D0, int D1, int K, int stride, int mode, SatPackBfParams* p) {
+    SatBfPlan pl;
+    if (mode < 0 || mode > 2 || D0 <= 0 || D1 <= 0 || !sat_bf_plan(K, stride, mode, &pl)) return false;
+    if (mode == 1 && stride != 1) return false;
+    p->D0 = D0; p->D1 = D1; p->K = K; p->S = stride; p->mode = mode;
+    p->ng = pl.ng; p->cs = pl.cs; p->kv = pl.kv;
+    if (mode == 0) { p->m_v = D0; p->v_v = D1 * stride; }
+    else if (mode == 1) { p->m_v = D1; p->v_v = D0; }
+    else { p->m_v = D1 * stride; p->v_v = D0; }
+    p->out_pad = sat_cdiv(p->m_v, SAT_CO_T) * SAT_CO_T;
+    p->total = (long long)sat_cdiv(p->v_v, 8 * pl.cs) * p->out_pad * pl.ng * 8;
+    return true;
 }
-extern "C" int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream) {
-    const long long total = sat_pack_weights_bf16x3_size(D0, D1, K, mode);
-    if (total <= 0 || (mode != 0 && mode != 1)) { sat_set_error("sat_pack_weights_bf16x3: needs K <= 8, in-channels % 8 == 0, mode 0|1"); return 1; }
-    SatPackBfParams p{w, hi, lo, D0, D1, K, mode, mode == 0 ? D0 : D1, mode == 0 ? D1 : D0, 0, total};
-    p.out_pad = sat_cdiv(p.n_out, SAT_CO_T) * SAT_CO_T;
-    SAT_LAUNCH(sat_pack_bf16x3_kernel, dim3((unsigned)sat_cdivll(total, 256)), dim3(256), stream, p);
+extern "C" long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode) {
+    SatPackBfParams p{};
+    return sat_pack_bf_geometry(D0, D1, K, stride, mode, &p) ? p.total : -1;
+}
+extern "C" int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream) {
+    SatPackBfParams p{};
+    if (!sat_pack_bf_geometry(D0, D1, K, stride, mode, &p)) {
+        sat_set_error("sat_pack_weights_bf16x3: needs stride 1 with K <= 8, or K == 2*stride with a power-of-two stride; mode 0|1|2");
+        return 1;
+    }
+    p.w = w; p.hi = hi; p.lo = lo;
+    SAT_LAUNCH(sat_pack_bf16x3_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
     return sat_check_launch("sat_pack_weights_bf16x3");
 }
 
@@ -267,25 +352,76 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
     return sat_check_launch("sat_snake_consts");
 }
 
-// Same contract as sat_conv1d (stride 1), with the weights given as sat_pack_weights_bf16x3 planes and the
-// SnakeBeta constants given pre-exponentiated (sat_snake_consts), or NULL for no activation.
+static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
+    dim3 grid(sat_cdiv(a.nq, SAT_T_T), a.cout_pad / SAT_CO_T, a.p.B);
+    if (pl.ng == 8 && pl.cs == 1) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 1>), grid, dim3(256), stream, a); }
+    else if (pl.ng == 8 && pl.cs == 2) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 2>), grid, dim3(256), stream, a); }
+    else if (pl.ng == 8 && pl.cs == 4) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4>), grid, dim3(256), stream, a); }
+    else { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<4, 4>), grid, dim3(256), stream, a); }
+    return sat_check_launch(what);
+}
+
+// Same contract as sat_conv1d (y[co][t] = sum W[co][ci][k] act(x)[ci][t*stride + k*dil - pad]), with the weights given
+// as sat_pack_weights_bf16x3 planes (mode 0, or mode 1 for a stride-1 data-gradient) and the SnakeBeta constants given
+// pre-exponentiated (sat_snake_consts), or NULL for no activation.  stride 1: K <= 8; stride S: K == 2S, S a power of two.
 extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias,
                                  const float* snake_a, const float* snake_ib, const float* res, float* y,
                                  const float* x2, const float* alpha2, const float* beta2, float* part_da,
-                                 float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad,
-                                 int tanh_out, void* stream) {
+                                 float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil,
+                                 int pad, int tanh_out, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3: empty shape"); return 1; }
-    if (K < 1 || K > 8 || dil < 1 || (Cin & 7)) { sat_set_error("sat_conv1d_bf16x3: needs K <= 8 and Cin % 8 == 0"); return 1; }
-    if (SAT_T_T + (K - 1) * dil > SAT_BF_AROWS) { sat_set_error("sat_conv1d_bf16x3: receptive field too large for the LDS slab"); return 1; }
+    SatBfPlan pl;
+    if (!sat_bf_plan(K, stride, 0, &pl) || dil < 1 || (stride > 1 && dil != 1)) {
+        sat_set_error("sat_conv1d_bf16x3: needs stride 1 with K <= 8, or K == 2*stride (power-of-two stride, dilation 1)");
+        return 1;
+    }
+    if (SAT_T_T + (pl.kv - 1) * dil > (pl.cs == 1 ? SAT_BF_AROWS1 : SAT_BF_AROWSN)) { sat_set_error("sat_conv1d_bf16x3: receptive field too large for the LDS slab"); return 1; }
     if ((snake_a == nullptr) != (snake_ib == nullptr)) { sat_set_error("sat_conv1d_bf16x3: snake constants must both be given"); return 1; }
     if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3: backward epilogue needs alpha2/beta2/partials"); return 1; }
     SatConvBfLaunch a;
     a.p = SatConvParams{x, nullptr, bias, snake_a, snake_ib, res, y, x2, alpha2, beta2, part_da, part_db,
-                        B, Cin, Cout, Tin, Tout, K, 1, dil, pad, tanh_out};
+                        B, Cin, Cout, Tin, Tout, pl.kv, 1, dil, stride == 1 ? pad : 0, tanh_out};
     a.w_hi = w_hi;
     a.w_lo = w_lo;
+    a.cout_v = Cout;
     a.cout_pad = sat_cdiv(Cout, SAT_CO_T) * SAT_CO_T;
-    dim3 grid(sat_cdiv(Tout, SAT_T_T), sat_cdiv(Cout, SAT_CO_T), B);
-    SAT_LAUNCH(sat_conv1d_bf16x3_kernel, grid, dim3(256), stream, a);
-    return sat_check_launch("sat_conv1d_bf16x3");
+    a.cin_v = Cin * stride;
+    a.sin_log2 = sat_log2i(stride);
+    a.sout_log2 = 0;
+    a.in_shift = stride == 1 ? 0 : pad;
+    a.out_shift = 0;
+    a.nq = Tout;
+    return sat_bf_launch("sat_conv1d_bf16x3", a, pl, stream);
+}
+
+// Same contract as sat_convtr1d (y[co][q*stride + k - pad] += W[ci][co][k] act(x)[ci][q], K == 2*stride, power-of-two
+// stride), weights as sat_pack_weights_bf16x3 planes (mode 2).
+extern "C" int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias,
+                                   const float* snake_a, const float* snake_ib, const float* res, float* y,
+                                   const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                                   float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride,
+                                   int pad, int tanh_out, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_convtr1d_bf16x3: empty shape"); return 1; }
+    SatBfPlan pl;
+    if (!sat_bf_plan(K, stride, 2, &pl) || pad < 0) { sat_set_error("sat_convtr1d_bf16x3: needs K == 2*stride with a power-of-two stride"); return 1; }
+    if ((snake_a == nullptr) != (snake_ib == nullptr)) { sat_set_error("sat_convtr1d_bf16x3: snake constants must both be given"); return 1; }
+    if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_convtr1d_bf16x3: backward epilogue needs alpha2/beta2/partials"); return 1; }
+    SatConvBfLaunch a;
+    a.p = SatConvParams{x, nullptr, bias, snake_a, snake_ib, res, y, x2, alpha2, beta2, part_da, part_db,
+                        B, Cin, Cout, Tin, Tout, 2, 1, 1, 1, tanh_out};
+    a.w_hi = w_hi;
+    a.w_lo = w_lo;
+    a.cout_v = Cout * stride;
+    a.cout_pad = sat_cdiv(a.cout_v, SAT_CO_T) * SAT_CO_T;
+    a.cin_v = Cin;
+    a.sin_log2 = 0;
+    a.sout_log2 = sat_log2i(stride);
+    a.in_shift = 0;
+    a.out_shift = pad;
+    a.nq = sat_cdiv(Tout + pad, stride);
+    return sat_bf_launch("sat_convtr1d_bf16x3", a, pl, stream);
+}
+extern "C" int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad) {
+    if (B <= 0 || Tout <= 0 || stride < 1 || pad < 0) return -1;
+    return B * sat_cdiv(sat_cdiv(Tout + pad, stride), SAT_T_T);
 }

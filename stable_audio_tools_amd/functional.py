@@ -57,11 +57,14 @@ class WeightNormFn(torch.autograd.Function):
 def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
     """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K)."""
     if stride == 1:
-        if ops.bf16x3_ok(w.shape[0], k, 1, dil):     # the dgrad conv's input channels are the forward conv's outputs
-            return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, dgrad=True), cin, k, dil, (k - 1) * dil - pad, tout=tin,
+        if ops.bf16x3_ok(k, 1, dil):
+            return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
                                      dsnake=dsnake, res=res)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
         return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res)
+    if ops.bf16x3_ok(k, stride, dil, transposed=True):   # (Cout, Cin, K) is the [in][out][K] weight of the transposed conv
+        return ops.convtr1d_bf16x3(dy, ops.pack_bf16x3(w, mode=2, stride=stride), cin, k, stride, pad, tout=tin,
+                                   dsnake=dsnake, res=res)
     wpb = ops.pack(w, PACK_POLYPHASE, stride)
     return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
 
@@ -73,13 +76,23 @@ def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake):
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
 
 
-def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False):
-    """conv1d(snake(x), w) [+bias] [+res]: k = 5..8 stride-1 convs take the bf16x3 split-MFMA kernel
-    (fp32-accurate, csrc/conv1d_bf16x3.hip), everything else the fp32-MFMA kernel (csrc/conv1d.hip)."""
+def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None):
+    """conv1d(snake(x), w) [+bias] [+res]: the bf16x3 split-MFMA kernel (fp32-accurate, csrc/conv1d_bf16x3.hip) where
+    its shape rules allow, else the fp32-MFMA kernel (csrc/conv1d.hip)."""
     cout, cin, k = w.shape
-    if ops.bf16x3_ok(cin, k, stride, dil):
-        return ops.conv1d_bf16x3(x, ops.pack_bf16x3(w), cout, k, dil, pad, bias=bias, snake=snake, res=res, tanh_out=tanh_out)
-    return ops.conv1d(x, ops.pack(w, PACK_CONV_FWD), cout, k, stride, dil, pad, bias=bias, snake=snake, res=res, tanh_out=tanh_out)
+    if ops.bf16x3_ok(k, stride, dil):
+        return ops.conv1d_bf16x3(x, ops.pack_bf16x3(w, stride=stride), cout, k, stride, dil, pad, tout=tout, bias=bias,
+                                 snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake)
+    return ops.conv1d(x, ops.pack(w, PACK_CONV_FWD), cout, k, stride, dil, pad, tout=tout, bias=bias, snake=snake, res=res,
+                      tanh_out=tanh_out, dsnake=dsnake)
+
+
+def _convtr_fwd(ops, x, w, stride, pad, bias=None, snake=None):
+    """conv_transpose1d(snake(x), w (Cin, Cout, K)) [+bias]."""
+    cin, cout, k = w.shape
+    if ops.bf16x3_ok(k, stride, 1, transposed=True):
+        return ops.convtr1d_bf16x3(x, ops.pack_bf16x3(w, mode=2, stride=stride), cout, k, stride, pad, bias=bias, snake=snake)
+    return ops.convtr1d(x, ops.pack(w, PACK_POLYPHASE, stride), cout, k, stride, pad, bias=bias, snake=snake)
 
 
 class SnakeConv1dFn(torch.autograd.Function):
@@ -132,8 +145,7 @@ class SnakeConvTr1dFn(torch.autograd.Function):
         w = w.contiguous()
         cin, cout, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
-        wp = ops.pack(w, PACK_POLYPHASE, stride)
-        y = ops.convtr1d(x, wp, cout, k, stride, pad, bias=bias, snake=snake)
+        y = _convtr_fwd(ops, x, w, stride, pad, bias=bias, snake=snake)
         ctx.ops = ops
         ctx.cfg = (stride, pad, bias is not None, alpha is not None)
         ctx.save_for_backward(x, alpha, beta, w)
@@ -149,13 +161,12 @@ class SnakeConvTr1dFn(torch.autograd.Function):
         snake = (alpha, beta) if has_snake else None
         dbias = ops.rowsum(dy) if has_bias else None
         dw = ops.conv_wgrad(x, dy, k, stride, 1, pad, snake=snake, snake_on=1)
-        # dgrad of a transposed conv is the strided conv with in=Cout, out=Cin: packed [co][k][ci]
-        wpb = ops.pack(w, PACK_CONV_FWD)
+        # dgrad of a transposed conv is the strided conv with in=Cout, out=Cin: w (Cin, Cout, K) is its [out][in][K] weight
         dx = da = db = None
         if has_snake:
-            dx, da, db = ops.conv1d(dy, wpb, cin, k, stride, 1, pad, tout=x.shape[2], dsnake=(x, alpha, beta))
+            dx, da, db = _conv_fwd(ops, dy, w, stride, 1, pad, dsnake=(x, alpha, beta), tout=x.shape[2])
         elif ctx.needs_input_grad[0]:
-            dx = ops.conv1d(dy, wpb, cin, k, stride, 1, pad, tout=x.shape[2])
+            dx = _conv_fwd(ops, dy, w, stride, 1, pad, tout=x.shape[2])
         return dx, da, db, dw, dbias, None, None, None
 
 

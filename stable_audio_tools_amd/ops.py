@@ -110,22 +110,28 @@ class SatOps:
             return y, self._sum_last(pda), self._sum_last(pdb)
         return y
 
-    # -- bf16x3 split-MFMA path for the k = 5..8 stride-1 convs (csrc/conv1d_bf16x3.hip) --
-    use_bf16x3 = True   # fp32-accurate (hi/lo split, 3 MFMAs per product); set False to force the fp32-MFMA kernel
+    # -- bf16x3 split-MFMA path (csrc/conv1d_bf16x3.hip): stride-1 convs with K <= 8, and the K == 2*stride
+    #    down / up (transposed) convs with a power-of-two stride --
+    use_bf16x3 = True   # fp32-accurate (hi/lo split, 3 MFMAs per product); set False to force the fp32-MFMA kernels
 
-    def bf16x3_ok(self, cin, k, stride, dil):
-        return self.use_bf16x3 and stride == 1 and 5 <= k <= 8 and cin % 8 == 0 and 128 + (k - 1) * dil <= 192
+    def bf16x3_ok(self, k, stride, dil, transposed=False):
+        if not self.use_bf16x3:
+            return False
+        if transposed or stride > 1:
+            return k == 2 * stride and stride & (stride - 1) == 0 and dil == 1
+        return k == 1 or (2 <= k <= 4 and dil == 1) or (5 <= k <= 8 and 128 + (k - 1) * dil <= 192)
 
-    def pack_bf16x3(self, w, dgrad=False):
-        """w: torch conv weight (Cout, Cin, K) fp32 -> (hi, lo) int16 planes for conv1d_bf16x3."""
+    def pack_bf16x3(self, w, mode=0, stride=1):
+        """w: (D0, D1, K) fp32 -> (hi, lo) int16 planes.  mode 0: conv weight [out][in][K]; mode 1: data-gradient of a
+        stride-1 conv; mode 2: transposed-conv weight [in][out][K]."""
         self._f32(w)
         d0, d1, k = w.shape
-        n = self.lib.sat_pack_weights_bf16x3_size(d0, d1, k, int(dgrad))
+        n = self.lib.sat_pack_weights_bf16x3_size(d0, d1, k, stride, mode)
         if n <= 0:
             raise RuntimeError("sat_pack_weights_bf16x3: unsupported shape")
         hi = torch.empty(n, dtype=torch.int16, device=w.device)
         lo = torch.empty(n, dtype=torch.int16, device=w.device)
-        self._chk(self.lib.sat_pack_weights_bf16x3(_ptr(w), _ptr(hi), _ptr(lo), d0, d1, k, int(dgrad), self._stream(w)))
+        self._chk(self.lib.sat_pack_weights_bf16x3(_ptr(w), _ptr(hi), _ptr(lo), d0, d1, k, stride, mode, self._stream(w)))
         return hi, lo
 
     def snake_consts(self, alpha, beta):
@@ -135,12 +141,8 @@ class SatOps:
         self._chk(self.lib.sat_snake_consts(_ptr(alpha), _ptr(beta), _ptr(a), _ptr(ib), alpha.numel(), self._stream(alpha)))
         return a, ib
 
-    def conv1d_bf16x3(self, x, w_planes, cout, k, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
-                      tanh_out=False, dsnake=None):
-        """Same contract as conv1d (stride 1); `snake` = (log-alpha, log-beta) as everywhere else."""
+    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake):
         b, cin, tin = x.shape
-        if tout is None:
-            tout = tin + 2 * pad - dil * (k - 1)
         self._f32(x, bias, res)
         sa = sib = None
         if snake is not None:
@@ -150,15 +152,34 @@ class SatOps:
         if dsnake is not None:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
-            rows = self.lib.sat_conv1d_partial_rows(b, tout)
             pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
             pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
-        self._chk(self.lib.sat_conv1d_bf16x3(_ptr(x), _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(sa), _ptr(sib),
-                                             _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
-                                             b, cin, cout, tin, tout, k, dil, pad, int(tanh_out), self._stream(x)))
+        self._chk(fn(_ptr(x), _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(sa), _ptr(sib),
+                     _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
+                     b, cin, cout, tin, tout, *dims, int(tanh_out), self._stream(x)))
         if dsnake is not None:
             return y, self._sum_last(pda), self._sum_last(pdb)
         return y
+
+    def conv1d_bf16x3(self, x, w_planes, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
+                      tanh_out=False, dsnake=None):
+        """Same contract as conv1d; `snake` = (log-alpha, log-beta) as everywhere else."""
+        b, cin, tin = x.shape
+        if tout is None:
+            tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        rows = self.lib.sat_conv1d_partial_rows(b, tout)
+        return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
+                                 bias, snake, res, tanh_out, dsnake)
+
+    def convtr1d_bf16x3(self, x, w_planes, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
+                        tanh_out=False, dsnake=None):
+        """Same contract as convtr1d."""
+        b, cin, tin = x.shape
+        if tout is None:
+            tout = (tin - 1) * stride - 2 * pad + k
+        rows = self.lib.sat_convtr1d_bf16x3_partial_rows(b, tout, stride, pad)
+        return self._bf16x3_call(self.lib.sat_convtr1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, pad),
+                                 bias, snake, res, tanh_out, dsnake)
 
     def convtr1d(self, x, w_packed, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
                  tanh_out=False, dsnake=None):

@@ -49,19 +49,25 @@ for (C, T, S) in levels:
         res[f"conv7_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=fl / ms / 1e9)
     planes = ops.pack_bf16x3(w7)
     for dil in (1, 9):
-        ms = timeit(lambda: ops.conv1d_bf16x3(x, planes, C, 7, dil, 3 * dil, bias=bias, snake=(la, lb)))
+        ms = timeit(lambda: ops.conv1d_bf16x3(x, planes, C, 7, 1, dil, 3 * dil, bias=bias, snake=(la, lb)))
         res[f"conv7x3_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
     y_a = ops.conv1d(x, wp7, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
-    y_b = ops.conv1d_bf16x3(x, planes, C, 7, 9, 27, bias=bias, snake=(la, lb))
+    y_b = ops.conv1d_bf16x3(x, planes, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
     res[f"conv7x3_vs_f32_relerr_C{C}_T{T}"] = dict(err=float((y_a - y_b).abs().max() / y_a.abs().max()))
     del y_a, y_b
     ms = timeit(lambda: ops.conv1d(x, wp1, C, 1, 1, 1, 0, bias=bias, snake=(la, lb), res=x))
     res[f"conv1_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9, gbps=3 * 4 * C * T / ms / 1e6)
+    p1 = ops.pack_bf16x3(w1)
+    ms = timeit(lambda: ops.conv1d_bf16x3(x, p1, C, 1, 1, 1, 0, bias=bias, snake=(la, lb), res=x))
+    res[f"conv1x3_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9, gbps=3 * 4 * C * T / ms / 1e6)
     # down conv C -> 2C
     wd = torch.randn(2 * C, C, 2 * S, device=dev) / (C * 2 * S) ** 0.5
     wpd = ops.pack(wd, O.PACK_CONV_FWD)
     ms = timeit(lambda: ops.conv1d(x, wpd, 2 * C, 2 * S, S, 1, (S + 1) // 2, snake=(la, lb)))
     res[f"down_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
+    pd = ops.pack_bf16x3(wd, stride=S)
+    ms = timeit(lambda: ops.conv1d_bf16x3(x, pd, 2 * C, 2 * S, S, 1, (S + 1) // 2, snake=(la, lb)))
+    res[f"downx3_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
     # up conv 2C -> C  (input at T/S)
     xu = torch.randn(1, 2 * C, T // S, device=dev) * 0.5
     la2 = torch.randn(2 * C, device=dev) * 0.1
@@ -69,6 +75,9 @@ for (C, T, S) in levels:
     wpu = ops.pack(wu, O.PACK_POLYPHASE, S)
     ms = timeit(lambda: ops.convtr1d(xu, wpu, C, 2 * S, S, (S + 1) // 2, snake=(la2, la2)))
     res[f"up_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
+    pu = ops.pack_bf16x3(wu, mode=2, stride=S)
+    ms = timeit(lambda: ops.convtr1d_bf16x3(xu, pu, C, 2 * S, S, (S + 1) // 2, snake=(la2, la2)))
+    res[f"upx3_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
     # backward pieces for the k7 conv
     dy = torch.randn(1, C, T, device=dev)
     ms = timeit(lambda: ops.conv_wgrad(dy, x, 7, 1, 9, 27, snake=(la, lb), snake_on=2))
@@ -81,8 +90,8 @@ for (C, T, S) in levels:
     wpb = ops.pack(w7, O.PACK_CONV_DGRAD)
     ms = timeit(lambda: ops.conv1d(dy, wpb, C, 7, 1, 9, 27, dsnake=(x, la, lb), res=dy))
     res[f"dgrad7_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
-    planes_b = ops.pack_bf16x3(w7, dgrad=True)
-    ms = timeit(lambda: ops.conv1d_bf16x3(dy, planes_b, C, 7, 9, 27, dsnake=(x, la, lb), res=dy))
+    planes_b = ops.pack_bf16x3(w7, mode=1)
+    ms = timeit(lambda: ops.conv1d_bf16x3(dy, planes_b, C, 7, 1, 9, 27, dsnake=(x, la, lb), res=dy))
     res[f"dgrad7x3_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
     ms = timeit(lambda: ops.rowsum(dy))
     res[f"rowsum_C{C}_T{T}"] = dict(ms=ms, gbps=4 * C * T / ms / 1e6)
@@ -104,6 +113,14 @@ wp = ops.pack(w, O.PACK_CONV_FWD)
 la = torch.zeros(128, device=dev)
 ms = timeit(lambda: ops.conv1d(xl, wp, 2, 7, 1, 1, 3, snake=(la, la)))
 res["last_conv_128_2"] = dict(ms=ms, gbps=4 * 130 * T0 / ms / 1e6)
+pl = ops.pack_bf16x3(w)
+ms = timeit(lambda: ops.conv1d_bf16x3(xl, pl, 2, 7, 1, 1, 3, snake=(la, la)))
+res["last_conv_128_2_x3"] = dict(ms=ms, gbps=4 * 130 * T0 / ms / 1e6)
+w = torch.randn(128, 2, 7, device=dev)
+pf = ops.pack_bf16x3(w)
+ms = timeit(lambda: ops.conv1d_bf16x3(x2, pf, 128, 7, 1, 1, 3))
+res["first_conv_2_128_x3"] = dict(ms=ms, gbps=4 * 130 * T0 / ms / 1e6)
+print("x3 first", res["first_conv_2_128_x3"], "last", res["last_conv_128_2_x3"], flush=True)
 print("first", res["first_conv_2_128"], "last", res["last_conv_128_2"], flush=True)
 del x2, xl
 torch.cuda.empty_cache()
