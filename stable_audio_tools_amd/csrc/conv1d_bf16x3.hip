@@ -41,13 +41,18 @@ SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
 }
 
 // NG = k-groups (8 values each) per K-chunk, CS = 8-channel sub-blocks per chunk; taps per sub-block KT = NG / CS.
-// group g of a chunk = (sub-block g / KT, tap g % KT).
-template <int NG, int CS>
+// group g of a chunk = (sub-block g / KT, tap g % KT).  GATHER: the input is read space-to-depth (sin_log2 > 0).
+//
+// Activation staging is the VALU-heavy part (SnakeBeta + hi/lo split per element), so it is laid out to keep every
+// channel index wave-uniform (scalar address arithmetic, s_load for the snake constants): a wave owns one sub-block
+// (CS > 1) and its lanes are time rows; the (K'-1) halo rows of a CS > 1 chunk are staged one ELEMENT per lane.
+template <int NG, int CS, bool GATHER>
 __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
     constexpr int KT = NG / CS;
     constexpr int KROW = NG * 8 + 8;                      // bf16 per weight row in LDS (+8 pad: conflict-free b128 reads)
     constexpr int AROWS = (CS == 1) ? SAT_BF_AROWS1 : SAT_BF_AROWSN;
-    constexpr int NU = (CS * AROWS + 255) / 256;          // activation staging items (one time row x 8 channels) per thread
+    constexpr int WPS = 4 / CS;                           // waves per sub-block
+    constexpr int NU = (CS == 1) ? 1 : 128 / (64 * WPS);  // main staging items (one time row x 8 channels) per thread
     const SatConvParams& p = a.p;
     __shared__ __attribute__((aligned(16))) short w_lds[2][SAT_CO_T][KROW];        // [plane][co][g*8+e]
     __shared__ __attribute__((aligned(16))) short a_lds[2][CS][AROWS][8];          // [plane][sub-block][time row][8 ci]
@@ -64,11 +69,12 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     const int K = p.K, dil = p.dil;
     const int nrows = SAT_T_T + (K - 1) * dil;
     const int q_in0 = t0 - p.pad;
-    const int si = a.sin_log2, so = a.sout_log2;
+    const int si = GATHER ? a.sin_log2 : 0, so = a.sout_log2;
     const int smask_i = (1 << si) - 1, smask_o = (1 << so) - 1;
     const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
     const bool wave_on = (co0 + co_w) < a.cout_v;
     const bool mi1_on = (co0 + co_w + 32) < a.cout_v;
+    const bool has_snake = p.alpha != nullptr;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -91,27 +97,41 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     // Register-staged software pipeline: the global loads of chunk c+1 are issued right after the barrier that
     // publishes chunk c, so their HBM/L2 latency runs under chunk c's MFMA phase; they are converted and written
     // to LDS after the phase's closing barrier.
-    int s_cs[NU], s_row[NU], s_tin[NU];                    // per staging item: sub-block, time row, real input time of phase 0
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int it = tid + u * 256;
-        s_cs[u] = it / AROWS;
-        s_row[u] = it - s_cs[u] * AROWS;
-        if (s_cs[u] >= CS || s_row[u] >= nrows) s_row[u] = -1;
-        s_tin[u] = ((q_in0 + s_row[u]) << si) - a.in_shift;
-    }
+    const int cs_w = SAT_UNIFORM(wave / WPS);             // this wave's sub-block
+    const int row0 = (wave % WPS) * 64 + lane;            // its first time row; item u is row0 + u * 64 * WPS
+    // halo rows (CS > 1 only): row 128 + lane/8, element lane%8, staged by the first wave of each sub-block
+    const int nhalo = (CS > 1) ? (nrows - SAT_T_T) * 8 : 0;
+    const bool halo_on = (CS > 1) && (wave % WPS) == 0 && lane < nhalo;
+    const int h_row = SAT_T_T + (lane >> 3), h_e = lane & 7;
     float av[NU][8];
+    float hv = 0.0f, h_a = 0.0f, h_ib = 0.0f;
     bf16x8 wv[NG];
+    // element (virtual channel v, time row) -> real input: channel v >> si at time ((q_in0 + row) << si) + (v & mask) - in_shift;
+    // channels past the end are clamped (their weights are zero), times outside [0, Tin) read as 0 (= snake(0)).
+    auto load_elem = [&](int v, int row) -> float {
+        int ch = v >> si;
+        ch = ch < p.Cin ? ch : p.Cin - 1;
+        const int tin = ((q_in0 + row) << si) + (v & smask_i) - (GATHER ? a.in_shift : 0);
+        const bool ok = (unsigned)tin < (unsigned)p.Tin;
+        const float val = xb[(size_t)ch * p.Tin + (ok ? tin : 0)];
+        return ok ? val : 0.0f;
+    };
     auto issue_loads = [&](int c) {
+        const int v0 = (c * CS + cs_w) * 8;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int v0 = (c * CS + s_cs[u]) * 8;
+            const int row = row0 + u * 64 * WPS;
+            if (CS == 1 && row >= nrows) continue;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int v = v0 + e;
-                const int tin = s_tin[u] + (v & smask_i);
-                const bool ok = s_row[u] >= 0 && v < a.cin_v && tin >= 0 && tin < p.Tin;
-                av[u][e] = ok ? xb[(size_t)(v >> si) * p.Tin + tin] : 0.0f;
+            for (int e = 0; e < 8; ++e) av[u][e] = load_elem(v0 + e, row);
+        }
+        if (CS > 1 && halo_on) {
+            hv = load_elem(v0 + h_e, h_row);
+            if (has_snake) {
+                int ch = (v0 + h_e) >> si;
+                ch = ch < p.Cin ? ch : p.Cin - 1;
+                h_a = p.alpha[ch];
+                h_ib = p.beta[ch];
             }
         }
 #pragma unroll
@@ -123,23 +143,41 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
         }
     };
     auto write_lds = [&](int c) {
+        const int v0 = (c * CS + cs_w) * 8;
+        float sa[8], sib[8];
+        if (has_snake) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                  // wave-uniform channel -> scalar loads; pre-exponentiated constants
+                int ch = (v0 + e) >> si;
+                ch = ch < p.Cin ? ch : p.Cin - 1;
+                sa[e] = p.alpha[ch];
+                sib[e] = p.beta[ch];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            if (s_row[u] < 0) continue;
-            const int v0 = (c * CS + s_cs[u]) * 8;
-            bf16x8 vh, vl;
+            const int row = row0 + u * 64 * WPS;
+            if (CS == 1 && row >= nrows) continue;
+            uint32_t ph[4], pl[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float o = av[u][e];
-                const int v = v0 + e;
-                if (p.alpha && v < a.cin_v) o = sat_snake(o, p.alpha[v >> si], p.beta[v >> si]);   // pre-exponentiated constants
-                short h, l;
-                sat_split2(o, &h, &l);
-                vh[e] = h;
-                vl[e] = l;
+            for (int e = 0; e < 8; e += 2) {
+                float o0 = av[u][e], o1 = av[u][e + 1];
+                if (has_snake) {
+                    o0 = sat_snake(o0, sa[e], sib[e]);
+                    o1 = sat_snake(o1, sa[e + 1], sib[e + 1]);
+                }
+                sat_split2_pk(o0, o1, &ph[e >> 1], &pl[e >> 1]);
             }
-            *reinterpret_cast<bf16x8*>(&a_lds[0][s_cs[u]][s_row[u]][0]) = vh;
-            *reinterpret_cast<bf16x8*>(&a_lds[1][s_cs[u]][s_row[u]][0]) = vl;
+            *reinterpret_cast<u32x4*>(&a_lds[0][cs_w][row][0]) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+            *reinterpret_cast<u32x4*>(&a_lds[1][cs_w][row][0]) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+        }
+        if (CS > 1 && halo_on) {
+            float o = hv;
+            if (has_snake) o = sat_snake(o, h_a, h_ib);
+            short h, l;
+            sat_split2(o, &h, &l);
+            a_lds[0][cs_w][h_row][h_e] = h;
+            a_lds[1][cs_w][h_row][h_e] = l;
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
@@ -354,10 +392,11 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
 
 static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
     dim3 grid(sat_cdiv(a.nq, SAT_T_T), a.cout_pad / SAT_CO_T, a.p.B);
-    if (pl.ng == 8 && pl.cs == 1) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 1>), grid, dim3(256), stream, a); }
-    else if (pl.ng == 8 && pl.cs == 2) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 2>), grid, dim3(256), stream, a); }
-    else if (pl.ng == 8 && pl.cs == 4) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4>), grid, dim3(256), stream, a); }
-    else { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<4, 4>), grid, dim3(256), stream, a); }
+    if (a.sin_log2 > 0) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4, true>), grid, dim3(256), stream, a); }     // strided: always plan (8, 4)
+    else if (pl.ng == 8 && pl.cs == 1) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 1, false>), grid, dim3(256), stream, a); }
+    else if (pl.ng == 8 && pl.cs == 2) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 2, false>), grid, dim3(256), stream, a); }
+    else if (pl.ng == 8 && pl.cs == 4) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4, false>), grid, dim3(256), stream, a); }
+    else { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<4, 4, false>), grid, dim3(256), stream, a); }
     return sat_check_launch(what);
 }
 

@@ -19,6 +19,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define SAT_WAVE 64
 
@@ -124,6 +125,34 @@ SAT_DEVICE float sat_bf16_to_f32(short s) {
     return f;
 }
 
+// hi/lo bf16 split of two fp32 values: x = hi + lo with |x - hi - lo| <= 2^-17 |x|.  Returns the two hi (resp. lo)
+// bf16 patterns packed as (b << 16) | a.  gfx950 has a packed RNE convert (v_cvt_pk_bf16_f32): 5 VALU ops per pair.
+SAT_DEVICE void sat_split2_pk(float a, float b, uint32_t* hi, uint32_t* lo) {
+#if defined(SAT_HIPEMU)
+    const short ha = sat_f32_to_bf16(a), hb = sat_f32_to_bf16(b);
+    const short la = sat_f32_to_bf16(a - sat_bf16_to_f32(ha)), lb = sat_f32_to_bf16(b - sat_bf16_to_f32(hb));
+    *hi = ((uint32_t)(uint16_t)hb << 16) | (uint16_t)ha;
+    *lo = ((uint32_t)(uint16_t)lb << 16) | (uint16_t)la;
+#else
+    typedef __bf16 sat_bf2 __attribute__((ext_vector_type(2)));
+    typedef float sat_f2 __attribute__((ext_vector_type(2)));
+    const sat_f2 v = {a, b};
+    const sat_bf2 h = __builtin_convertvector(v, sat_bf2);
+    const sat_f2 d = v - __builtin_convertvector(h, sat_f2);
+    const sat_bf2 l = __builtin_convertvector(d, sat_bf2);
+    *hi = __builtin_bit_cast(uint32_t, h);
+    *lo = __builtin_bit_cast(uint32_t, l);
+#endif
+}
+
+// a value known to be identical in every lane of the wave -> scalar register (lets the compiler use s_load for
+// addresses derived from it)
+#if defined(SAT_HIPEMU)
+#define SAT_UNIFORM(x) (x)
+#else
+#define SAT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 // wave64 all-lane sum
 SAT_DEVICE float sat_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -153,12 +182,25 @@ SAT_DEVICE void sat_sincos(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sin^2(y), abs error < 1e-7 for |y| < 1e4: reduce by pi/2 to r in [-pi/4, pi/4], sin^2(r) = r^2 * P(r^2) (Taylor through
+// r^12, truncation < 4e-9), odd quadrants give 1 - sin^2(r).  ~16 VALU ops — this is the SnakeBeta prologue of every conv.
+SAT_DEVICE float sat_sin2(float y) {
+    const float kf = rintf(y * 0.63661977236758134f);
+    float r = fmaf(-kf, 1.5707962512969971f, y);
+    r = fmaf(-kf, 7.5497894158615964e-08f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, -4.2755598311e-6f, 1.4109347443e-4f);      // -2/467775, 2/14175
+    p = fmaf(r2, p, -3.1746031746e-3f);                          // -1/315
+    p = fmaf(r2, p, 4.4444444444e-2f);                           // 2/45
+    p = fmaf(r2, p, -3.3333333333e-1f);                          // -1/3
+    const float s2 = fmaf(r2 * r2, p, r2);
+    return ((int)kf & 1) ? 1.0f - s2 : s2;
+}
+
 // SnakeBeta activation (reference: stable_audio_tools/models/blocks.py:291-292, :321-329).
 // a = exp(alpha_log), ib = 1/(exp(beta_log) + 1e-9) are prepared once per channel by the caller.
 SAT_DEVICE float sat_snake(float x, float a, float ib) {
-    float s, c;
-    sat_sincos(x * a, &s, &c);
-    return x + ib * s * s;
+    return fmaf(ib, sat_sin2(x * a), x);
 }
 
 // ---------------------------------------------------------------------------------------------
