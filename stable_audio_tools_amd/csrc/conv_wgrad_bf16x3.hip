@@ -36,10 +36,13 @@ static inline unsigned sat_alignbit(unsigned hi, unsigned lo, unsigned s) {
 SAT_DEVICE unsigned sat_alignbit(unsigned hi, unsigned lo, unsigned s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 #endif
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int DIL>
-__global__ void __launch_bounds__(256) sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
     constexpr int NCH = (6 * DIL + 7) / 8 + 1;                       // aligned 8-element chunks covering all 7 taps
     __shared__ __attribute__((aligned(16))) short lo_lds[2][SAT_CO_T][SAT_WB_LOROW];   // dy  [plane][co][t]
     __shared__ __attribute__((aligned(16))) short hi_lds[2][32][SAT_WB_HIROW];         // act [plane][ci][t]
@@ -82,10 +85,11 @@ __global__ void __launch_bounds__(256) sat_wgrad7_bf16x3_kernel(SatWgBfParams p)
         // ---- stage dy: 128 rows x 64 t (8 float4 per thread, all loads first) ----
         {
             const float* src = p.dy + (size_t)b * p.M * p.T;
-            float4 v[8];
+            for (int half = 0; half < 2; ++half) {
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = tid + u * 256;
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + (half * 4 + u) * 256;
                 const int row = idx >> 4, c4 = (idx & 15) * 4;
                 const int m = m0 + row, t = tt0 + c4;
                 float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,45 +107,51 @@ __global__ void __launch_bounds__(256) sat_wgrad7_bf16x3_kernel(SatWgBfParams p)
                 v[u] = q;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = tid + u * 256;
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + (half * 4 + u) * 256;
                 const int row = idx >> 4, c4 = (idx & 15) * 4;
-                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                typedef short s4 __attribute__((ext_vector_type(4)));
-                s4 h, l;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const short hh = sat_f32_to_bf16(e[j]);
-                    h[j] = hh;
-                    l[j] = sat_f32_to_bf16(e[j] - sat_bf16_to_f32(hh));
-                }
-                *reinterpret_cast<s4*>(&lo_lds[0][row][c4]) = h;
-                *reinterpret_cast<s4*>(&lo_lds[1][row][c4]) = l;
+                uint32_t h0, h1, l0, l1;
+                sat_split2_pk(v[u].x, v[u].y, &h0, &l0);
+                sat_split2_pk(v[u].z, v[u].w, &h1, &l1);
+                typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u2*>(&lo_lds[0][row][c4]) = u2{h0, h1};
+                *reinterpret_cast<u2*>(&lo_lds[1][row][c4]) = u2{l0, l1};
+            }
             }
         }
         // ---- stage snake(x): 32 rows x HSPAN samples starting at tt0 - pad (batches of 8 scalar loads) ----
         {
             const float* src = p.x + (size_t)b * p.N * p.T;
             const int th0 = tt0 - p.pad;
-            constexpr int TOTAL = 32 * HSPAN;
+            constexpr int HP = HSPAN / 2;                 // HSPAN is even: pairs never straddle rows
+            constexpr int TOTAL = 32 * HP;
             for (int base = tid; base < TOTAL; base += 8 * 256) {
-                float v[8];
+                float v[8][2];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int idx = base + u * 256;
-                    const int row = idx / HSPAN, col = idx - row * HSPAN;
+                    const int row = idx / HP, col = (idx - row * HP) * 2;
                     const int n = n0 + row, t = th0 + col;
-                    v[u] = (idx < TOTAL && n < p.N && t >= 0 && t < p.T) ? src[(size_t)n * p.T + t] : 0.0f;
+                    const bool ok = idx < TOTAL && n < p.N;
+                    const float* s = src + (size_t)(ok ? n : 0) * p.T;
+                    v[u][0] = (ok && t >= 0 && t < p.T) ? s[t] : 0.0f;
+                    v[u][1] = (ok && t + 1 >= 0 && t + 1 < p.T) ? s[t + 1] : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int idx = base + u * 256;
                     if (idx < TOTAL) {
-                        const int row = idx / HSPAN, col = idx - row * HSPAN;
-                        const float o = p.alpha ? sat_snake(v[u], sn_a[row], sn_ib[row]) : v[u];
-                        const short hh = sat_f32_to_bf16(o);
-                        hi_lds[0][row][col] = hh;
-                        hi_lds[1][row][col] = sat_f32_to_bf16(o - sat_bf16_to_f32(hh));
+                        const int row = idx / HP, col = (idx - row * HP) * 2;
+                        float o0 = v[u][0], o1 = v[u][1];
+                        if (p.alpha) {
+                            const float sa = sn_a[row], sib = sn_ib[row];
+                            o0 = sat_snake(o0, sa, sib);
+                            o1 = sat_snake(o1, sa, sib);
+                        }
+                        uint32_t h, l;
+                        sat_split2_pk(o0, o1, &h, &l);
+                        *reinterpret_cast<uint32_t*>(&hi_lds[0][row][col]) = h;
+                        *reinterpret_cast<uint32_t*>(&hi_lds[1][row][col]) = l;
                     }
                 }
             }
@@ -152,40 +162,39 @@ __global__ void __launch_bounds__(256) sat_wgrad7_bf16x3_kernel(SatWgBfParams p)
             for (int ks = 0; ks < SAT_WB_TT / 16; ++ks) {
                 const int tb = 16 * ks + 8 * hi;
                 bf16x8 af[2];
-                u32x4 cw[2][NCH];
+                af[0] = *reinterpret_cast<const bf16x8*>(&lo_lds[0][m_w + l31][tb]);
+                af[1] = *reinterpret_cast<const bf16x8*>(&lo_lds[1][m_w + l31][tb]);
+                // one activation plane at a time (halves the live chunk registers): hi plane pairs with dy hi + lo,
+                // lo plane with dy hi only
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    af[pl] = *reinterpret_cast<const bf16x8*>(&lo_lds[pl][m_w + l31][tb]);
+                    u32x4 cw[NCH];
+#if !defined(SAT_HIPEMU)
+                    asm volatile("" ::: "memory");       // keep the two planes' chunk loads from being hoisted together
+#endif
 #pragma unroll
-                    for (int j = 0; j < NCH; ++j) cw[pl][j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][l31][tb + 8 * j]);
-                }
+                    for (int j = 0; j < NCH; ++j) cw[j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][l31][tb + 8 * j]);
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int off = k * DIL;          // compile-time after unrolling
-                    const int wbase = (off >> 3) * 4 + ((off & 7) >> 1);   // first 32-bit word of the fragment
-                    const bool odd = (off & 1) != 0;
-                    bf16x8 bf[2];
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
+                    for (int k = 0; k < 7; ++k) {
+                        const int off = k * DIL;          // compile-time after unrolling
+                        const int wbase = (off >> 3) * 4 + ((off & 7) >> 1);   // first 32-bit word of the fragment
+                        const bool odd = (off & 1) != 0;
                         u32x4 r;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int w0 = wbase + i, w1 = wbase + i + 1;
-                            const unsigned a0 = cw[pl][w0 >> 2][w0 & 3];
+                            const unsigned a0 = cw[w0 >> 2][w0 & 3];
                             if (odd) {
-                                const unsigned a1 = cw[pl][w1 >> 2][w1 & 3];
+                                const unsigned a1 = cw[w1 >> 2][w1 & 3];
                                 r[i] = sat_alignbit(a1, a0, 16);
                             } else {
                                 r[i] = a0;
                             }
                         }
-                        bf[pl] = __builtin_bit_cast(bf16x8, r);
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, r);
+                        acc[k] = sat_mfma_32x32x16_bf16(af[0], bf, acc[k]);
+                        if (pl == 0) acc[k] = sat_mfma_32x32x16_bf16(af[1], bf, acc[k]);
                     }
-                    acc[k] = sat_mfma_32x32x16_bf16(af[0], bf[0], acc[k]);
-                    acc[k] = sat_mfma_32x32x16_bf16(af[0], bf[1], acc[k]);
-                    acc[k] = sat_mfma_32x32x16_bf16(af[1], bf[0], acc[k]);
                 }
             }
         }
