@@ -101,6 +101,14 @@ int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, 
                            void* stream);
 int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T);
 
+/* sat_conv_wgrad for K == 1 (stride 1; the k1 conv of every ResidualUnit) and K == 2*stride with a power-of-two stride
+ * (the down / up convs, autoencoders.py:245-247, :266-268) on the bf16 matrix cores at fp32 accuracy.  Same arguments as
+ * sat_conv_wgrad (dilation 1); slab stride M*N*K; nsplit from sat_conv_wgrad_bf16x3_nsplit (-1: unsupported shape). */
+int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const float* alpha, const float* beta, int snake_on,
+                          float* partial, long long so_m, long long so_n, long long so_k, int B, int M, int N, int Tlo,
+                          int Thi, int K, int stride, int pad, void* stream);
+int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K, int stride);
+
 /* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */
 int sat_reduce_splits(const float* partial, float* out, long long count, int nsplit, float scale, int accumulate,
                       void* stream);

@@ -31,6 +31,8 @@ SIGNATURES = {
     # conv_wgrad_bf16x3.hip
     "sat_conv_wgrad7_bf16x3": (_I, [_P] * 5 + [_L] * 3 + [_I] * 6 + [_P]),
     "sat_conv_wgrad7_bf16x3_nsplit": (_I, [_I] * 4),
+    "sat_conv_wgrad_bf16x3": (_I, [_P] * 4 + [_I, _P] + [_L] * 3 + [_I] * 8 + [_P]),
+    "sat_conv_wgrad_bf16x3_nsplit": (_I, [_I] * 6),
     # convtr1d.hip
     "sat_convtr1d": (_I, [_P] * 12 + [_I] * 9 + [_P]),
     "sat_convtr1d_partial_rows": (_I, [_I, _I, _I, _I]),

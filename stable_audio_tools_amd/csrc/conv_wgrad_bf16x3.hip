@@ -249,3 +249,278 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
     else SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<9>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_conv_wgrad7_bf16x3");
 }
+
+// =====================================================================================================================
+// The short-kernel weight gradients: k = 1 convs (one tap) and the K = 2*stride down / up convs (two virtual taps
+// over space-to-depth rows of the longer tensor) — same contract as sat_conv_wgrad (conv_wgrad.hip):
+//
+//   dW[m][n][k = j*S + r] = sum_b sum_t  actA(lo[b][m][t]) * actB(hi[b][n][(t + j)*S + r - pad])
+//
+// With one or two taps a 128 x 32 tile would restage operands far too often per MFMA, so the workgroup tile is
+// 128 (lo rows) x 128 (virtual hi rows v = n*S + r), a wave owns 64 x 64 (2 x 2 MFMA tiles per tap).  The hi tile is
+// staged by walking each real channel's contiguous samples and scattering them to row n*S + u%S, column u/S.
+// =====================================================================================================================
+#define SAT_WS_TT 64
+#define SAT_WS_LOROW (SAT_WS_TT + 8)   // 144 B rows
+#define SAT_WS_HIROW (SAT_WS_TT + 16)  // 160 B rows: 64 + the tap-1 chunk overrun
+
+struct SatWgSmallParams {
+    const float* lo;     // (B, M, Tlo)
+    const float* hi;     // (B, N, Thi)
+    const float* alpha;  // snake log-params of lo's channels (snake_on == 1) or hi's (snake_on == 2), or null
+    const float* beta;
+    float* out;
+    long long so_split, so_m, so_n, so_k;
+    int B, M, N, Tlo, Thi, pad, snake_on, s_log2;
+    int chunks_per_split, nchunks, nT;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
+    constexpr int NCH = NT;                                          // aligned chunks per fragment row read
+    __shared__ __attribute__((aligned(16))) short lo_lds[2][SAT_CO_T][SAT_WS_LOROW];
+    __shared__ __attribute__((aligned(16))) short hi_lds[2][SAT_CO_T][SAT_WS_HIROW];
+    __shared__ float sn_a[SAT_CO_T], sn_ib[SAT_CO_T];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sl = p.s_log2, S = 1 << sl;
+    const int m0 = blockIdx.x * SAT_CO_T, v0 = blockIdx.y * SAT_CO_T;
+    const int n_base = v0 >> sl, nc = SAT_CO_T >> sl;                // real hi channels of this tile
+    const int NV = p.N << sl;
+    const int m_w = (wave >> 1) * 64, v_w = (wave & 1) * 64;
+    const bool wave_on = (m0 + m_w) < p.M && (v0 + v_w) < NV;
+    const bool snake_lo = p.alpha && p.snake_on == 1, snake_hi = p.alpha && p.snake_on == 2;
+
+    f32x16 acc[2][2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.0f;
+
+    if (tid < SAT_CO_T) {
+        float sa = 1.f, sib = 0.f;
+        const int c = snake_lo ? m0 + tid : n_base + tid;
+        const bool ok = snake_lo ? c < p.M : (snake_hi && tid < nc && c < p.N);
+        if (ok) {
+            sa = expf(p.alpha[c]);
+            sib = 1.0f / (expf(p.beta[c]) + 1e-9f);
+        }
+        sn_a[tid] = sa;
+        sn_ib[tid] = sib;
+    }
+    __syncthreads();
+
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > p.nchunks) c_end = p.nchunks;
+    const int rs = (SAT_WS_TT + NT - 1) << sl;                       // real samples per hi channel and stage
+    const int up = rs >> 1;                                          // ... in pairs (rs is even)
+    const int total_units = nc * up;
+
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int b = ch / p.nT;
+        const int tt0 = (ch - b * p.nT) * SAT_WS_TT;
+        // ---- stage lo: 128 rows x 64 t ----
+        {
+            const float* src = p.lo + (size_t)b * p.M * p.Tlo;
+            for (int half = 0; half < 2; ++half) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = tid + (half * 4 + u) * 256;
+                    const int row = idx >> 4, c4 = (idx & 15) * 4;
+                    const int m = m0 + row, t = tt0 + c4;
+                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < p.M) {
+                        const float* s = src + (size_t)m * p.Tlo + t;
+                        if (t + 3 < p.Tlo && ((p.Tlo & 3) == 0)) {
+                            q = *reinterpret_cast<const float4*>(s);
+                        } else {
+                            if (t + 0 < p.Tlo) q.x = s[0];
+                            if (t + 1 < p.Tlo) q.y = s[1];
+                            if (t + 2 < p.Tlo) q.z = s[2];
+                            if (t + 3 < p.Tlo) q.w = s[3];
+                        }
+                    }
+                    v[u] = q;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = tid + (half * 4 + u) * 256;
+                    const int row = idx >> 4, c4 = (idx & 15) * 4;
+                    float4 q = v[u];
+                    if (snake_lo) {
+                        const float sa = sn_a[row], sib = sn_ib[row];
+                        q.x = sat_snake(q.x, sa, sib);
+                        q.y = sat_snake(q.y, sa, sib);
+                        q.z = sat_snake(q.z, sa, sib);
+                        q.w = sat_snake(q.w, sa, sib);
+                    }
+                    uint32_t h0, h1, l0, l1;
+                    sat_split2_pk(q.x, q.y, &h0, &l0);
+                    sat_split2_pk(q.z, q.w, &h1, &l1);
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u2*>(&lo_lds[0][row][c4]) = u2{h0, h1};
+                    *reinterpret_cast<u2*>(&lo_lds[1][row][c4]) = u2{l0, l1};
+                }
+            }
+        }
+        // ---- stage hi: nc real channels x rs contiguous samples from tt0*S - pad, scattered to (n*S + u%S, u/S) ----
+        {
+            const float* src = p.hi + (size_t)b * p.N * p.Thi;
+            const int th0 = (tt0 << sl) - p.pad;
+            for (int base = tid; base < total_units; base += 8 * 256) {
+                float v[8][2];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    const int cl = idx / up, uu = (idx - cl * up) * 2;
+                    const int n = n_base + cl, t = th0 + uu;
+                    const bool ok = idx < total_units && n < p.N;
+                    const float* s = src + (size_t)(ok ? n : 0) * p.Thi;
+                    v[u][0] = (ok && t >= 0 && t < p.Thi) ? s[t] : 0.0f;
+                    v[u][1] = (ok && t + 1 >= 0 && t + 1 < p.Thi) ? s[t + 1] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total_units) {
+                        const int cl = idx / up, uu = (idx - cl * up) * 2;
+                        float o0 = v[u][0], o1 = v[u][1];
+                        if (snake_hi) {
+                            const float sa = sn_a[cl], sib = sn_ib[cl];
+                            o0 = sat_snake(o0, sa, sib);
+                            o1 = sat_snake(o1, sa, sib);
+                        }
+                        uint32_t h, l;
+                        sat_split2_pk(o0, o1, &h, &l);
+                        if (sl == 0) {
+                            *reinterpret_cast<uint32_t*>(&hi_lds[0][cl][uu]) = h;
+                            *reinterpret_cast<uint32_t*>(&hi_lds[1][cl][uu]) = l;
+                        } else {
+                            const int row = (cl << sl) + (uu & (S - 1)), col = uu >> sl;   // uu, S even: uu+1 is the next row
+                            hi_lds[0][row][col] = (short)(h & 0xffffu);
+                            hi_lds[0][row + 1][col] = (short)(h >> 16);
+                            hi_lds[1][row][col] = (short)(l & 0xffffu);
+                            hi_lds[1][row + 1][col] = (short)(l >> 16);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (wave_on) {
+#pragma unroll
+            for (int ks = 0; ks < SAT_WS_TT / 16; ++ks) {
+                const int tb = 16 * ks + 8 * hi;
+                bf16x8 af[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        af[mi][pl] = *reinterpret_cast<const bf16x8*>(&lo_lds[pl][m_w + mi * 32 + l31][tb]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        u32x4 cw[NCH];
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) cw[j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][v_w + ni * 32 + l31][tb + 8 * j]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            u32x4 r = cw[0];
+                            if (j == 1) {
+                                r[0] = sat_alignbit(cw[0][1], cw[0][0], 16);
+                                r[1] = sat_alignbit(cw[0][2], cw[0][1], 16);
+                                r[2] = sat_alignbit(cw[0][3], cw[0][2], 16);
+                                r[3] = sat_alignbit(cw[NCH - 1][0], cw[0][3], 16);
+                            }
+                            const bf16x8 bf = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) {
+                                acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][0], bf, acc[mi][ni][j]);
+                                if (pl == 0) acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][1], bf, acc[mi][ni][j]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (wave_on) {
+        float* ob = p.out + (size_t)blockIdx.z * p.so_split;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int v = v0 + v_w + ni * 32 + l31;
+                const int n = v >> sl, ph = v & (S - 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + m_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (m < p.M && n < p.N)
+                            ob[(size_t)m * p.so_m + (size_t)n * p.so_n + (size_t)(j * S + ph) * p.so_k] = acc[mi][ni][j][r];
+                    }
+            }
+    }
+}
+
+static bool sat_wgs_plan(int B, int M, int N, int Tlo, int K, int stride, SatWgBfPlan* pl, int* s_log2, int* nt) {
+    if (B <= 0 || M <= 0 || N <= 0 || Tlo <= 0) return false;
+    if (K == 1 && stride == 1) { *s_log2 = 0; *nt = 1; }
+    else if (K == 2 * stride && stride >= 2 && stride <= 64 && (stride & (stride - 1)) == 0) {
+        int l = 0;
+        while ((1 << l) < stride) ++l;
+        *s_log2 = l;
+        *nt = 2;
+    } else return false;
+    pl->nT = sat_cdiv(Tlo, SAT_WS_TT);
+    pl->nchunks = B * pl->nT;
+    const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N << *s_log2, SAT_CO_T);
+    int want = sat_cdiv(1024, tiles);
+    if (want > pl->nchunks) want = pl->nchunks;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    pl->cps = sat_cdiv(pl->nchunks, want);
+    pl->nsplit = sat_cdiv(pl->nchunks, pl->cps);
+    return true;
+}
+extern "C" int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K, int stride) {
+    SatWgBfPlan pl;
+    int sl, nt;
+    return sat_wgs_plan(B, M, N, Tlo, K, stride, &pl, &sl, &nt) ? pl.nsplit : -1;
+}
+// Same contract as sat_conv_wgrad for K == 1 (stride 1) and K == 2*stride (power-of-two stride, dilation 1), on the
+// bf16 matrix cores at fp32 accuracy.  Slab stride M*N*K; nsplit from sat_conv_wgrad_bf16x3_nsplit (-1: unsupported).
+extern "C" int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const float* alpha, const float* beta, int snake_on,
+                                     float* partial, long long so_m, long long so_n, long long so_k, int B, int M, int N,
+                                     int Tlo, int Thi, int K, int stride, int pad, void* stream) {
+    SatWgBfPlan pl;
+    int sl, nt;
+    if (!sat_wgs_plan(B, M, N, Tlo, K, stride, &pl, &sl, &nt)) {
+        sat_set_error("sat_conv_wgrad_bf16x3: needs K == 1 (stride 1) or K == 2*stride with a power-of-two stride");
+        return 1;
+    }
+    if (Thi <= 0 || pad < 0) { sat_set_error("sat_conv_wgrad_bf16x3: bad shape"); return 1; }
+    if (alpha && (snake_on != 1 && snake_on != 2)) { sat_set_error("sat_conv_wgrad_bf16x3: snake_on must be 1 (lo) or 2 (hi)"); return 1; }
+    if ((alpha == nullptr) != (beta == nullptr)) { sat_set_error("sat_conv_wgrad_bf16x3: alpha/beta must both be given"); return 1; }
+    SatWgSmallParams p{lo, hi, alpha, beta, partial, (long long)M * N * K, so_m, so_n, so_k,
+                       B, M, N, Tlo, Thi, pad, alpha ? snake_on : 0, sl, pl.cps, pl.nchunks, pl.nT};
+    dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N << sl, SAT_CO_T), pl.nsplit);
+    if (nt == 1) SAT_LAUNCH(sat_wgrad_small_bf16x3_kernel<1>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_wgrad_small_bf16x3_kernel<2>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_conv_wgrad_bf16x3");
+}

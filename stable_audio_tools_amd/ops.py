@@ -213,7 +213,11 @@ class SatOps:
         _, n, thi = hi.shape
         alpha, beta = snake if snake is not None else (None, None)
         self._f32(lo, hi, alpha, beta)
-        nsplit = self.lib.sat_conv_wgrad_nsplit(bsz, m, n, tlo, k, stride, dil)
+        x3 = self.use_bf16x3 and dil == 1 and self.lib.sat_conv_wgrad_bf16x3_nsplit(bsz, m, n, tlo, k, stride) > 0
+        if x3:
+            nsplit = self.lib.sat_conv_wgrad_bf16x3_nsplit(bsz, m, n, tlo, k, stride)
+        else:
+            nsplit = self.lib.sat_conv_wgrad_nsplit(bsz, m, n, tlo, k, stride, dil)
         if nsplit < 0:
             raise RuntimeError("sat_conv_wgrad: receptive field too large")
         partial = torch.empty(nsplit, m * n * k, dtype=torch.float32, device=lo.device)
@@ -223,9 +227,14 @@ class SatOps:
         else:
             so_m, so_n, so_k = n * k, k, 1
             shape = (m, n, k)
-        self._chk(self.lib.sat_conv_wgrad(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta), snake_on if snake is not None else 0,
-                                          _ptr(partial), so_m, so_n, so_k, bsz, m, n, tlo, thi, k, stride, dil, pad,
-                                          self._stream(lo)))
+        if x3:
+            self._chk(self.lib.sat_conv_wgrad_bf16x3(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta),
+                                                     snake_on if snake is not None else 0, _ptr(partial), so_m, so_n, so_k,
+                                                     bsz, m, n, tlo, thi, k, stride, pad, self._stream(lo)))
+        else:
+            self._chk(self.lib.sat_conv_wgrad(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta), snake_on if snake is not None else 0,
+                                              _ptr(partial), so_m, so_n, so_k, bsz, m, n, tlo, thi, k, stride, dil, pad,
+                                              self._stream(lo)))
         return self._reduce_rows(partial, nsplit, m * n * k).view(shape)
 
     def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):

@@ -87,6 +87,13 @@ for (C, T, S) in levels:
         res[f"wgrad7x3_d{dil}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
     ms = timeit(lambda: ops.conv_wgrad(dy, x, 1, 1, 1, 0, snake=(la, lb), snake_on=2))
     res[f"wgrad1_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9)
+    dyd = torch.randn(1, 2 * C, T // S, device=dev)
+    ms = timeit(lambda: ops.conv_wgrad(dyd, x, 2 * S, S, 1, (S + 1) // 2, snake=(la, lb), snake_on=2))
+    res[f"wgrad_down_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
+    xu2 = torch.randn(1, 2 * C, T // S, device=dev) * 0.5
+    ms = timeit(lambda: ops.conv_wgrad(xu2, dy, 2 * S, S, 1, (S + 1) // 2, snake=(la2, la2), snake_on=1))
+    res[f"wgrad_up_s{S}_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * 2 * C * 2 * S * (T // S) / ms / 1e9)
+    del dyd, xu2
     wpb = ops.pack(w7, O.PACK_CONV_DGRAD)
     ms = timeit(lambda: ops.conv1d(dy, wpb, C, 7, 1, 9, 27, dsnake=(x, la, lb), res=dy))
     res[f"dgrad7_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
