@@ -1,0 +1,146 @@
+"""Kernel-level parity of the conv building blocks (forward + all gradients) against torch fp32 conv ops — the
+reference's own building blocks (autoencoders.py:58-83, :245-247, :266-268 use nn.Conv1d / nn.ConvTranspose1d).
+CPU leg: the kernel sources under the host simulator (tests/emu), shapes chosen to walk every K-chunk pipeline
+length (1..5 chunks: prologue, steady state, tail) of every bf16x3 plan, partial chunks and partial tiles.
+GPU leg: the same cases through the gfx950 library."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stable_audio_tools_amd import functional as Fn
+
+TOL = 2e-4   # relative to the reference tensor's max-abs; bf16x3 products are ~2^-16 accurate
+
+
+def snake(x, la, lb):
+    a = la.exp()[None, :, None]
+    b = lb.exp()[None, :, None]
+    return x + (1.0 / (b + 1e-9)) * torch.sin(x * a) ** 2
+
+
+def _leaf(gen, dev, *shape, s=1.0):
+    return (torch.randn(*shape, generator=gen) * s).to(dev).requires_grad_(True)
+
+
+def _compare(outs, refs, inputs, gen, tol=TOL):
+    gy = [torch.randn(r.shape, generator=gen).to(r.device) for r in refs]
+    g1 = torch.autograd.grad(outs, inputs, gy, allow_unused=True)
+    g2 = torch.autograd.grad(refs, inputs, gy, allow_unused=True)
+    for a, b in list(zip(outs, refs)) + [(a, b) for a, b in zip(g1, g2) if b is not None]:
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(b.abs().max().item(), 1e-3), (err, b.abs().max().item())
+
+
+# (B, Cin, Cout, T, K, dil): k7 chunks of 8 channels, k1 chunks of 32, k3 chunks of 8
+S1_CASES = [(1, 8, 8, 300, 7, 1), (1, 16, 70, 280, 7, 3), (2, 24, 8, 200, 7, 9), (1, 32, 130, 150, 7, 9), (1, 40, 6, 520, 7, 3),
+            (1, 6, 40, 150, 7, 9), (1, 32, 8, 140, 1, 1), (1, 64, 130, 200, 1, 1), (1, 96, 8, 130, 1, 1), (2, 160, 20, 100, 1, 1),
+            (1, 70, 20, 150, 1, 1), (1, 12, 4, 100, 3, 1), (1, 9, 5, 77, 2, 1), (1, 20, 5, 90, 5, 2)]
+DOWN_CASES = [(1, 8, 16, 256, 2), (2, 12, 20, 333, 4), (1, 6, 130, 1100, 8), (1, 40, 6, 300, 2), (1, 8, 8, 520, 4)]
+UP_CASES = [(1, 16, 8, 40, 2), (2, 12, 20, 33, 4), (1, 6, 130, 70, 8), (1, 70, 6, 150, 2), (1, 48, 8, 131, 4)]
+
+
+def _run_s1(ops, dev, case, use_x3):
+    B, Cin, Cout, T, K, dil = case
+    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    ops.use_bf16x3 = use_x3
+    try:
+        x = _leaf(gen, dev, B, Cin, T)
+        la, lb = _leaf(gen, dev, Cin, s=.3), _leaf(gen, dev, Cin, s=.3)
+        w, bias = _leaf(gen, dev, Cout, Cin, K, s=.2), _leaf(gen, dev, Cout)
+        pad = dil * (K - 1) // 2
+        tout = T + 2 * pad - dil * (K - 1)
+        res = _leaf(gen, dev, B, Cout, tout)
+        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, w, bias, res, 1, dil, pad, False, ops)
+        y2 = F.conv1d(snake(x, la, lb), w, bias, padding=pad, dilation=dil) + res
+        _compare([y1], [y2], [x, la, lb, w, bias, res], gen)
+    finally:
+        ops.use_bf16x3 = True
+
+
+def _run_down(ops, dev, case, use_x3):
+    B, Cin, Cout, T, S = case
+    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    ops.use_bf16x3 = use_x3
+    try:
+        K, pad = 2 * S, math.ceil(S / 2)
+        x = _leaf(gen, dev, B, Cin, T)
+        la, lb = _leaf(gen, dev, Cin, s=.3), _leaf(gen, dev, Cin, s=.3)
+        w, bias = _leaf(gen, dev, Cout, Cin, K, s=.2), _leaf(gen, dev, Cout)
+        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, w, bias, None, S, 1, pad, False, ops)
+        y2 = F.conv1d(snake(x, la, lb), w, bias, stride=S, padding=pad)
+        _compare([y1], [y2], [x, la, lb, w, bias], gen)
+    finally:
+        ops.use_bf16x3 = True
+
+
+def _run_up(ops, dev, case, use_x3):
+    B, Cin, Cout, T, S = case
+    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    ops.use_bf16x3 = use_x3
+    try:
+        K, pad = 2 * S, math.ceil(S / 2)
+        x = _leaf(gen, dev, B, Cin, T)
+        la, lb = _leaf(gen, dev, Cin, s=.3), _leaf(gen, dev, Cin, s=.3)
+        w, bias = _leaf(gen, dev, Cin, Cout, K, s=.2), _leaf(gen, dev, Cout)
+        y1 = Fn.SnakeConvTr1dFn.apply(x, la, lb, w, bias, S, pad, ops)
+        y2 = F.conv_transpose1d(snake(x, la, lb), w, bias, stride=S, padding=pad)
+        _compare([y1], [y2], [x, la, lb, w, bias], gen)
+    finally:
+        ops.use_bf16x3 = True
+
+
+def _run_nosnake_tanh(ops, dev):
+    gen = torch.Generator().manual_seed(7)
+    x = _leaf(gen, dev, 1, 16, 190)
+    w = _leaf(gen, dev, 2, 16, 7, s=.2)
+    y1 = Fn.SnakeConv1dFn.apply(x, None, None, w, None, None, 1, 1, 3, True, ops)
+    y2 = torch.tanh(F.conv1d(x, w, None, padding=3))
+    _compare([y1], [y2], [x, w], gen)
+
+
+@pytest.mark.parametrize("case", S1_CASES)
+def test_conv_stride1_sim(emu, case):
+    _run_s1(emu, "cpu", case, True)
+
+
+@pytest.mark.parametrize("case", DOWN_CASES)
+def test_conv_down_sim(emu, case):
+    _run_down(emu, "cpu", case, True)
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv_up_sim(emu, case):
+    _run_up(emu, "cpu", case, True)
+
+
+def test_conv_fp32_kernels_sim(emu):
+    _run_s1(emu, "cpu", S1_CASES[1], False)
+    _run_s1(emu, "cpu", S1_CASES[7], False)
+    _run_down(emu, "cpu", DOWN_CASES[1], False)
+    _run_up(emu, "cpu", UP_CASES[1], False)
+    _run_nosnake_tanh(emu, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_x3", [True, False])
+def test_conv_kernels_gpu(hip, use_x3):
+    for case in S1_CASES:
+        _run_s1(hip, "cuda", case, use_x3)
+    for case in DOWN_CASES:
+        _run_down(hip, "cuda", case, use_x3)
+    for case in UP_CASES:
+        _run_up(hip, "cuda", case, use_x3)
+    _run_nosnake_tanh(hip, "cuda")
+
+
+@pytest.mark.gpu
+def test_conv_kernels_gpu_large(hip):
+    """Full-width tiles and long K loops (the shapes the bench runs), against torch on the same device."""
+    for case in [(1, 128, 128, 8192, 7, 9), (1, 256, 256, 4096, 1, 1), (1, 1024, 1024, 512, 7, 3)]:
+        _run_s1(hip, "cuda", case, True)
+    _run_down(hip, "cuda", (1, 128, 256, 8192, 2), True)
+    _run_down(hip, "cuda", (1, 512, 1024, 4096, 8), True)
+    _run_up(hip, "cuda", (1, 256, 128, 2048, 4), True)
+    _run_up(hip, "cuda", (1, 1024, 512, 512, 8), True)
