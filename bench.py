@@ -161,23 +161,28 @@ class ConvProfiler:
     the stream handed to the C-ABI) and tallies their ALGORITHMIC flops (2 * Cin * Cout * K * Tout * B per launch;
     wgrad: 2 * M * N * K * T * B — DESIGN.md §4).  Each C-ABI entry point issues exactly one launch of its kernel."""
 
-    # entry point -> (kernel name, peak TFLOP/s, flops(args))
+    # entry point -> (kernel name (or args -> name), peak TFLOP/s, flops(args))
     #   fp32 kernels: peak = fp32 MFMA dense (157.3); bf16x3 kernels: peak = dense bf16 MFMA / 3 (three MFMAs per product)
+    X3 = 2500.0 / 3
     SPECS = {
         "sat_conv1d": ("sat_conv1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * a[17] * a[16]),
-        "sat_conv1d_bf16x3": ("sat_conv1d_bf16x3_kernel", 2500.0 / 3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_conv1d_bf16x3": (lambda a: "sat_conv1d_bf16x3_k7_kernel" if (a[18] >= 5 and a[19] == 1) else "sat_conv1d_bf16x3_kernel",
+                              X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),
         "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
         "sat_conv_wgrad": ("sat_conv_wgrad_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
-        "sat_conv_wgrad7_bf16x3": ("sat_wgrad7_bf16x3_kernel", 2500.0 / 3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
+        "sat_conv_wgrad7_bf16x3": ("sat_wgrad7_bf16x3_kernel", X3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
+        "sat_conv_wgrad_bf16x3": ("sat_wgrad_small_bf16x3_kernel", X3, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
     }
 
     def __init__(self, ops):
-        self.records = {k: [] for k in self.SPECS}
+        self.records = {}            # kernel name -> [(start, end, flops)]
+        self.peaks = {}
         self.enabled = False
-        for name, (_, _, flops) in self.SPECS.items():
-            self._wrap(ops.lib, name, flops)
+        for name, (kern, peak, flops) in self.SPECS.items():
+            self._wrap(ops.lib, name, kern, peak, flops)
 
-    def _wrap(self, lib, name, flops):
+    def _wrap(self, lib, name, kern, peak, flops):
         orig = getattr(lib, name)
 
         def timed(*a):
@@ -188,7 +193,9 @@ class ConvProfiler:
             s.record()
             rc = orig(*a)
             e.record()
-            self.records[name].append((s, e, flops(a)))
+            k = kern(a) if callable(kern) else kern
+            self.peaks[k] = peak
+            self.records.setdefault(k, []).append((s, e, flops(a)))
             return rc
 
         setattr(lib, name, timed)
@@ -197,12 +204,12 @@ class ConvProfiler:
         """Per kernel: launches, total ms, total flops; returns (dominant kernel dict, all dicts)."""
         torch.cuda.synchronize()
         out = []
-        for name, recs in self.records.items():
+        for kern, recs in self.records.items():
             if not recs:
                 continue
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
             fl = sum(f for _, _, f in recs)
-            kern, peak, _ = self.SPECS[name]
+            peak = self.peaks[kern]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out.append({"kernel": kern, "launches": len(recs), "total_ms": ms, "avg_launch_ms": ms / len(recs),
                         "achieved": ach, "peak": peak, "frac": ach / peak})

@@ -60,7 +60,7 @@ int sat_conv1d_partial_rows(int B, int Tout);
  * sat_pack_weights_bf16x3_size gives the plane length in elements (-1: unsupported).  snake_a / snake_ib are the
  * pre-exponentiated SnakeBeta constants from sat_snake_consts (a = e^alpha, ib = 1/(e^beta + 1e-9)) or NULL.
  * Everything else (epilogue options, partial-sum layout) as sat_conv1d / sat_convtr1d; partial rows are
- * sat_conv1d_partial_rows(B, Tout) resp. sat_convtr1d_bf16x3_partial_rows(B, Tout, stride, pad). */
+ * sat_conv1d_bf16x3_partial_rows(B, Tout, K, stride) resp. sat_convtr1d_bf16x3_partial_rows(B, Tout, stride, pad). */
 int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
                       const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                       const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
@@ -69,6 +69,7 @@ int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, co
                         const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                         const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
                         int K, int stride, int pad, int tanh_out, void* stream);
+int sat_conv1d_bf16x3_partial_rows(int B, int Tout, int K, int stride);
 int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
 int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
 long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);
@@ -112,7 +113,8 @@ int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K, int stride
 /* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */
 int sat_reduce_splits(const float* partial, float* out, long long count, int nsplit, float scale, int accumulate,
                       void* stream);
-/* bias gradient: partial[z][c] = sum over the z-th time slice and all b of x[b][c][t]; z < sat_rowsum_nsplit(T) */
+/* bias gradient / row sums: partial[c][z] = sum over the z-th time slice and all b of x[b][c][t]; z < nsplit = sat_rowsum_nsplit(T).
+ * nsplit > 1: sum the (1, C, nsplit) partials with a second call. */
 int sat_rowsum(const float* x, float* partial, int B, int C, int T, void* stream);
 int sat_rowsum_nsplit(int T);
 

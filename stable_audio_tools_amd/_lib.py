@@ -24,6 +24,7 @@ SIGNATURES = {
     # conv1d_bf16x3.hip
     "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 10 + [_P]),
     "sat_convtr1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
+    "sat_conv1d_bf16x3_partial_rows": (_I, [_I] * 4),
     "sat_convtr1d_bf16x3_partial_rows": (_I, [_I] * 4),
     "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I, _I]),

@@ -17,6 +17,7 @@
 //   * weights are pre-split and pre-arranged by sat_pack_weights_bf16x3 as [chunk][co][group][8],
 //     so a chunk's slab is a straight 16-byte-per-lane copy into padded LDS rows.
 #include "conv_common.h"
+#include <type_traits>
 
 #define SAT_BF_AROWS1 192  // CS == 1: max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
 #define SAT_BF_AROWSN 136  // CS  > 1: 128 + (taps-1) rows, taps <= 4, dil = 1
@@ -390,7 +391,13 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
     return sat_check_launch("sat_snake_consts");
 }
 
+#include "conv1d_bf16x3_k7.h"     // the pipelined kernel of the (8, 1) plan
+
 static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
+    if (pl.ng == 8 && pl.cs == 1 && a.sin_log2 == 0 && a.sout_log2 == 0) {
+        sat_bf_launch_k7(a, stream);
+        return sat_check_launch(what);
+    }
     dim3 grid(sat_cdiv(a.nq, SAT_T_T), a.cout_pad / SAT_CO_T, a.p.B);
     if (a.sin_log2 > 0) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4, true>), grid, dim3(256), stream, a); }     // strided: always plan (8, 4)
     else if (pl.ng == 8 && pl.cs == 1) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 1, false>), grid, dim3(256), stream, a); }
@@ -414,7 +421,7 @@ extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short*
         sat_set_error("sat_conv1d_bf16x3: needs stride 1 with K <= 8, or K == 2*stride (power-of-two stride, dilation 1)");
         return 1;
     }
-    if (SAT_T_T + (pl.kv - 1) * dil > (pl.cs == 1 ? SAT_BF_AROWS1 : SAT_BF_AROWSN)) { sat_set_error("sat_conv1d_bf16x3: receptive field too large for the LDS slab"); return 1; }
+    if ((pl.kv - 1) * dil > (pl.cs == 1 ? 62 : SAT_BF_AROWSN - SAT_T_T)) { sat_set_error("sat_conv1d_bf16x3: receptive field too large for the LDS slab"); return 1; }
     if ((snake_a == nullptr) != (snake_ib == nullptr)) { sat_set_error("sat_conv1d_bf16x3: snake constants must both be given"); return 1; }
     if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3: backward epilogue needs alpha2/beta2/partials"); return 1; }
     SatConvBfLaunch a;
@@ -459,6 +466,13 @@ extern "C" int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const shor
     a.out_shift = pad;
     a.nq = sat_cdiv(Tout + pad, stride);
     return sat_bf_launch("sat_convtr1d_bf16x3", a, pl, stream);
+}
+// rows of the snake-gradient partial-sum planes written by sat_conv1d_bf16x3 (one per batch item and time tile)
+extern "C" int sat_conv1d_bf16x3_partial_rows(int B, int Tout, int K, int stride) {
+    SatBfPlan pl;
+    if (B <= 0 || Tout <= 0 || !sat_bf_plan(K, stride, 0, &pl)) return -1;
+    const bool k7 = pl.ng == 8 && pl.cs == 1 && stride == 1;
+    return B * sat_cdiv(Tout, k7 ? SAT_K7_T : SAT_T_T);
 }
 extern "C" int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad) {
     if (B <= 0 || Tout <= 0 || stride < 1 || pad < 0) return -1;

@@ -38,12 +38,12 @@ struct SatSnakeGrad {
 };
 SAT_DEVICE SatSnakeGrad sat_snake_grad(float x, float a, float b) {
     const float ib = 1.0f / (b + 1e-9f);
-    float s, c;
-    sat_sincos(a * x, &s, &c);
-    const float s2 = 2.0f * s * c;  // sin(2 a x)
+    float s2, c2;
+    sat_sincos2(a * x, &s2, &c2);                 // sin(2 a x), cos(2 a x)
+    const float sq = fmaf(-0.5f, c2, 0.5f);       // sin^2(a x)
     SatSnakeGrad g;
     g.dx = 1.0f + a * ib * s2;
     g.dla = x * a * ib * s2;
-    g.dlb = -(s * s) * ib * ib * b;
+    g.dlb = -sq * ib * ib * b;
     return g;
 }

@@ -164,37 +164,30 @@ SAT_DEVICE float sat_half_sum(float v) {
     return v;
 }
 
-// sin and cos together, ~1 ulp for |x| < ~1e4 (activations are O(1..100)): 3-constant Cody-Waite reduction
-// by pi/2 + degree-7/8 minimax polynomials on [-pi/4, pi/4].  ~25 VALU ops; the library sinf()+cosf() pair
-// costs several hundred and was the bottleneck of the snake-gradient epilogue (profiles/r01c).
-SAT_DEVICE void sat_sincos(float x, float* sn, float* cs) {
-    const float kf = rintf(x * 0.63661977236758134f);           // x * 2/pi
-    float r = fmaf(-kf, 1.5707962512969971f, x);                // pi/2 = hi + mid + lo
-    r = fmaf(-kf, 7.5497894158615964e-08f, r);
-    r = fmaf(-kf, 5.3903029534742384e-15f, r);
-    const float r2 = r * r;
-    const float s = fmaf(r * r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.7183114e-6f, -1.9839334e-4f), 8.3333310e-3f), -1.6666667e-1f), r);
-    const float c = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.4433157e-5f, -1.3887316e-3f), 4.1666646e-2f), -0.5f), 1.0f);
-    const int q = (int)kf;
-    const float ss = (q & 1) ? c : s;
-    const float cc = (q & 1) ? s : c;
-    *sn = (q & 2) ? -ss : ss;
-    *cs = ((q + 1) & 2) ? -cc : cc;
+// sin(2y) and cos(2y) on the hardware transcendental unit: v_sin_f32 / v_cos_f32 take their argument in revolutions,
+// so the angle is y/pi reduced to its fraction.  The product y * (1/pi) is carried in two pieces (the fma recovers its
+// rounding error, plus the second word of 1/pi) so that the reduction stays exact to ~2^-24 of a revolution for
+// |y| < 1e4 — measured error of the pair on gfx950: < 4e-7 absolute.  7 VALU issues (2 of them transcendental) against
+// ~25 for the polynomial sat_sincos; this is the SnakeBeta prologue / gradient epilogue of every conv.
+SAT_DEVICE void sat_sincos2(float y, float* s2y, float* c2y) {
+    const float hi = y * 0.31830987334251404f;                       // fl(1/pi)
+    float lo = fmaf(y, 0.31830987334251404f, -hi);
+    lo = fmaf(y, 1.2841276486e-08f, lo);                             // 1/pi - fl(1/pi)
+#if defined(SAT_HIPEMU)
+    const float f = (hi - floorf(hi)) + lo;
+    *s2y = sinf(6.283185307179586f * f);
+    *c2y = cosf(6.283185307179586f * f);
+#else
+    const float f = __builtin_amdgcn_fractf(hi) + lo;
+    *s2y = __builtin_amdgcn_sinf(f);
+    *c2y = __builtin_amdgcn_cosf(f);
+#endif
 }
-
-// sin^2(y), abs error < 1e-7 for |y| < 1e4: reduce by pi/2 to r in [-pi/4, pi/4], sin^2(r) = r^2 * P(r^2) (Taylor through
-// r^12, truncation < 4e-9), odd quadrants give 1 - sin^2(r).  ~16 VALU ops — this is the SnakeBeta prologue of every conv.
+// sin^2(y) = (1 - cos 2y) / 2
 SAT_DEVICE float sat_sin2(float y) {
-    const float kf = rintf(y * 0.63661977236758134f);
-    float r = fmaf(-kf, 1.5707962512969971f, y);
-    r = fmaf(-kf, 7.5497894158615964e-08f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, -4.2755598311e-6f, 1.4109347443e-4f);      // -2/467775, 2/14175
-    p = fmaf(r2, p, -3.1746031746e-3f);                          // -1/315
-    p = fmaf(r2, p, 4.4444444444e-2f);                           // 2/45
-    p = fmaf(r2, p, -3.3333333333e-1f);                          // -1/3
-    const float s2 = fmaf(r2 * r2, p, r2);
-    return ((int)kf & 1) ? 1.0f - s2 : s2;
+    float s, c;
+    sat_sincos2(y, &s, &c);
+    return fmaf(-0.5f, c, 0.5f);
 }
 
 // SnakeBeta activation (reference: stable_audio_tools/models/blocks.py:291-292, :321-329).

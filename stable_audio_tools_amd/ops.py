@@ -80,6 +80,12 @@ class SatOps:
         self._chk(self.lib.sat_reduce_splits(_ptr(partial), _ptr(out), count, rows, scale, 0, self._stream(partial)))
         return out
 
+    def _sum_pair(self, pda, pdb):
+        """The two (C, R) snake-gradient partial planes (halves of one (2, C, R) buffer) -> (C,), (C,) in one reduction."""
+        c, r = pda.shape
+        both = self.rowsum(pda._base.view(1, 2 * c, r) if pda._base is not None else torch.stack([pda, pdb]).view(1, 2 * c, r))
+        return both[:c], both[c:]
+
     def _sum_last(self, partial):
         """(C, R) -> (C,): bandwidth-efficient reduction of per-tile partial sums (sat_rowsum)."""
         c, r = partial.shape
@@ -101,13 +107,12 @@ class SatOps:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
             rows = self.lib.sat_conv1d_partial_rows(b, tout)
-            pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
-            pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
+            pda, pdb = torch.empty(2, cout, rows, dtype=torch.float32, device=x.device).unbind(0)
         self._chk(self.lib.sat_conv1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
                                       _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                                       b, cin, cout, tin, tout, k, stride, dil, pad, int(tanh_out), self._stream(x)))
         if dsnake is not None:
-            return y, self._sum_last(pda), self._sum_last(pdb)
+            return (y, *self._sum_pair(pda, pdb))
         return y
 
     # -- bf16x3 split-MFMA path (csrc/conv1d_bf16x3.hip): stride-1 convs with K <= 8, and the K == 2*stride
@@ -119,7 +124,7 @@ class SatOps:
             return False
         if transposed or stride > 1:
             return k == 2 * stride and stride & (stride - 1) == 0 and dil == 1
-        return k == 1 or (2 <= k <= 4 and dil == 1) or (5 <= k <= 8 and 128 + (k - 1) * dil <= 192)
+        return k == 1 or (2 <= k <= 4 and dil == 1) or (5 <= k <= 8 and (k - 1) * dil <= 62)
 
     def pack_bf16x3(self, w, mode=0, stride=1):
         """w: (D0, D1, K) fp32 -> (hi, lo) int16 planes.  mode 0: conv weight [out][in][K]; mode 1: data-gradient of a
@@ -152,13 +157,12 @@ class SatOps:
         if dsnake is not None:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
-            pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
-            pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
+            pda, pdb = torch.empty(2, cout, rows, dtype=torch.float32, device=x.device).unbind(0)
         self._chk(fn(_ptr(x), _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(sa), _ptr(sib),
                      _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                      b, cin, cout, tin, tout, *dims, int(tanh_out), self._stream(x)))
         if dsnake is not None:
-            return y, self._sum_last(pda), self._sum_last(pdb)
+            return (y, *self._sum_pair(pda, pdb))
         return y
 
     def conv1d_bf16x3(self, x, w_planes, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
@@ -167,7 +171,7 @@ class SatOps:
         b, cin, tin = x.shape
         if tout is None:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        rows = self.lib.sat_conv1d_partial_rows(b, tout)
+        rows = self.lib.sat_conv1d_bf16x3_partial_rows(b, tout, k, stride)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
                                  bias, snake, res, tanh_out, dsnake)
 
@@ -197,13 +201,12 @@ class SatOps:
             rows = self.lib.sat_convtr1d_partial_rows(b, tout, stride, pad)
             if rows < 0:
                 raise RuntimeError("sat_convtr1d: unsupported stride")
-            pda = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
-            pdb = torch.empty(cout, rows, dtype=torch.float32, device=x.device)
+            pda, pdb = torch.empty(2, cout, rows, dtype=torch.float32, device=x.device).unbind(0)
         self._chk(self.lib.sat_convtr1d(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(res), _ptr(y),
                                         _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                                         b, cin, cout, tin, tout, k, stride, pad, int(tanh_out), self._stream(x)))
         if dsnake is not None:
-            return y, self._sum_last(pda), self._sum_last(pdb)
+            return (y, *self._sum_pair(pda, pdb))
         return y
 
     def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False):
@@ -253,13 +256,17 @@ class SatOps:
         return self._reduce_rows(partial, nsplit, m * n * 7).view(m, n, 7)
 
     def rowsum(self, x):
-        """(B, C, T) -> (C,) sum over batch and time."""
+        """(B, C, T) -> (C,) sum over batch and time: per-(channel, time split) partial sums laid out [C][nsplit], summed
+        by a second pass of the same kernel (deterministic, no atomics)."""
         self._f32(x)
         b, c, t = x.shape
-        ns = self.lib.sat_rowsum_nsplit(t)
-        partial = torch.empty(ns, c, dtype=torch.float32, device=x.device)
-        self._chk(self.lib.sat_rowsum(_ptr(x), _ptr(partial), b, c, t, self._stream(x)))
-        return self._reduce_rows(partial, ns, c)
+        while True:
+            ns = self.lib.sat_rowsum_nsplit(t)
+            partial = torch.empty(c, ns, dtype=torch.float32, device=x.device)
+            self._chk(self.lib.sat_rowsum(_ptr(x), _ptr(partial), b, c, t, self._stream(x)))
+            if ns == 1:
+                return partial.view(c)
+            x, b, t = partial, 1, ns
 
     # ------------------------------------------------------------------ VAE bottleneck
     def vae_sample_fwd(self, pre, noise):
