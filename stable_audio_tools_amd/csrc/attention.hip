@@ -46,30 +46,71 @@ template <typename T> struct SatSrc;
 template <> struct SatSrc<float> { static SAT_DEVICE float at(const void* p, long long i) { return ((const float*)p)[i]; } };
 template <> struct SatSrc<short> { static SAT_DEVICE float at(const void* p, long long i) { return sat_bf16_to_f32(((const short*)p)[i]); } };
 
+// One 64 (n) x 64 (d) tile per workgroup; a thread converts 8 consecutive d of one row (16-byte plane stores), the
+// transposed planes go through an LDS tile and are written 8 consecutive n at a time.
 template <typename T>
 __global__ void __launch_bounds__(256) sat_attn_prepare_kernel(SatPrepParams p) {
-    __shared__ short t_hi[SAT_ATT_D][SAT_ATT_T + 2];
-    __shared__ short t_lo[SAT_ATT_D][SAT_ATT_T + 2];
+    __shared__ __attribute__((aligned(16))) short t_hi[SAT_ATT_T][SAT_ATT_D + 8];   // [n][d]
+    __shared__ __attribute__((aligned(16))) short t_lo[SAT_ATT_T][SAT_ATT_D + 8];
     const int n0 = blockIdx.x * SAT_ATT_T, h = blockIdx.y, b = blockIdx.z;
     const long long base = (long long)b * p.sb + (long long)h * p.sh;
     const size_t plane = ((size_t)b * p.H + h) * (size_t)p.Np * SAT_ATT_D;
-    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D; i += 256) {
-        const int r = i >> 6, d = i & 63;
+    const bool want_tr = p.tr_hi != nullptr || p.tr_lo != nullptr;
+    const bool vec_src = ((p.sn & 7) == 0) && ((p.sb & 7) == 0) && ((p.sh & 7) == 0) &&
+                         (((uintptr_t)p.src & 15) == 0);                              // 16-byte loads allowed
+    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D / 8; i += 256) {
+        const int r = i >> 3, d0 = (i & 7) * 8;
         const int n = n0 + r;
-        const float x = (n < p.N) ? SatSrc<T>::at(p.src, base + (long long)n * p.sn + d) : 0.0f;
-        const short hi = sat_f32_to_bf16(x);
-        const short lo = sat_f32_to_bf16(x - sat_bf16_to_f32(hi));
-        if (p.rm_hi) p.rm_hi[plane + (size_t)n * SAT_ATT_D + d] = hi;
-        if (p.rm_lo) p.rm_lo[plane + (size_t)n * SAT_ATT_D + d] = lo;
-        t_hi[d][r] = hi;
-        t_lo[d][r] = lo;
+        float x[8];
+        if (n < p.N) {
+            const long long off = base + (long long)n * p.sn + d0;
+            if (vec_src) {
+                if (sizeof(T) == 2) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>((const short*)p.src + off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[2 * j] = __builtin_bit_cast(float, v[j] << 16);
+                        x[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u);
+                    }
+                } else {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>((const float*)p.src + off);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>((const float*)p.src + off + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = SatSrc<T>::at(p.src, off + j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = 0.0f;
+        }
+        uint32_t wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sat_split2_pk(x[2 * j], x[2 * j + 1], &wh[j], &wl[j]);
+        const u32x4 vh{wh[0], wh[1], wh[2], wh[3]}, vl{wl[0], wl[1], wl[2], wl[3]};
+        const size_t o = plane + (size_t)n * SAT_ATT_D + d0;
+        if (p.rm_hi) *reinterpret_cast<u32x4*>(p.rm_hi + o) = vh;
+        if (p.rm_lo) *reinterpret_cast<u32x4*>(p.rm_lo + o) = vl;
+        if (want_tr) {
+            *reinterpret_cast<u32x4*>(&t_hi[r][d0]) = vh;
+            *reinterpret_cast<u32x4*>(&t_lo[r][d0]) = vl;
+        }
     }
-    if (p.tr_hi == nullptr && p.tr_lo == nullptr) return;   // block-uniform
+    if (!want_tr) return;   // block-uniform
     __syncthreads();
-    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D; i += 256) {
-        const int d = i >> 6, r = i & 63;
-        if (p.tr_hi) p.tr_hi[plane + (size_t)d * p.Np + n0 + r] = t_hi[d][r];
-        if (p.tr_lo) p.tr_lo[plane + (size_t)d * p.Np + n0 + r] = t_lo[d][r];
+    for (int i = threadIdx.x; i < SAT_ATT_T * SAT_ATT_D / 8; i += 256) {
+        const int d = i >> 3, r0 = (i & 7) * 8;
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            vh[j] = t_hi[r0 + j][d];
+            vl[j] = t_lo[r0 + j][d];
+        }
+        const size_t o = plane + (size_t)d * p.Np + n0 + r0;
+        if (p.tr_hi) *reinterpret_cast<bf16x8*>(p.tr_hi + o) = vh;
+        if (p.tr_lo) *reinterpret_cast<bf16x8*>(p.tr_lo + o) = vl;
     }
 }
 

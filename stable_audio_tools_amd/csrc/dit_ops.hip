@@ -98,6 +98,159 @@ __global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_kernel(SatLnParams p
     }
 }
 
+// ---- vector paths: a wave keeps its whole row in registers (16-byte loads / stores), used when D is a multiple of
+// 64 lanes x 16 bytes and every pointer is 16-byte aligned (the DiT shapes: d = 1536).  One pass over HBM.
+template <typename T> struct SatVec;
+template <> struct SatVec<float> {
+    static constexpr int N = 4, MAXC = 16;            // floats per 16 bytes; row chunks of 256 elements, D <= 4096
+    static SAT_DEVICE void ld(const void* p, long long i, float* o) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)p + i);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static SAT_DEVICE void st(void* p, long long i, const float* o) {
+        *reinterpret_cast<f32x4*>((float*)p + i) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+};
+template <> struct SatVec<short> {
+    static constexpr int N = 8, MAXC = 8;             // bf16 per 16 bytes; row chunks of 512 elements, D <= 4096
+    static SAT_DEVICE void ld(const void* p, long long i, float* o) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>((const short*)p + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = __builtin_bit_cast(float, v[j] << 16);
+            o[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u);
+        }
+    }
+    static SAT_DEVICE void st(void* p, long long i, const float* o) {
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = (uint32_t)(uint16_t)sat_f32_to_bf16(o[2 * j]) | ((uint32_t)(uint16_t)sat_f32_to_bf16(o[2 * j + 1]) << 16);
+        *reinterpret_cast<u32x4*>((short*)p + i) = v;
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_fwd_vec_kernel(SatLnParams p) {
+    constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;   // whole wave exits together; no block barrier below
+    const long long base = (long long)row * p.D;
+    const int nc = p.D / (64 * N);
+    float xs[MAXC][N];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            SatVec<T>::ld(p.x, base + (c * 64 + lane) * N, xs[c]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s += xs[c][j];
+        }
+    }
+    const float mean = sat_wave_sum(s) / (float)p.D;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float d = xs[c][j] - mean;
+                v += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(sat_wave_sum(v) / (float)p.D + p.eps);
+    const long long mb = p.scale ? (long long)(row / p.rows_per_batch) * p.mod_stride : 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            const int i0 = (c * 64 + lane) * N;
+            float g[N], o[N];
+#pragma unroll
+            for (int j = 0; j < N; j += 4) SatVec<float>::ld(p.gamma, i0 + j, g + j);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = (xs[c][j] - mean) * rstd * g[j];
+            if (p.beta) {
+#pragma unroll
+                for (int j = 0; j < N; j += 4) SatVec<float>::ld(p.beta, i0 + j, g + j);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += g[j];
+            }
+            if (p.scale) {
+                float sc[N], sh[N];
+                SatVec<T>::ld(p.scale, mb + i0, sc);
+                SatVec<T>::ld(p.shift, mb + i0, sh);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] = o[j] * (1.0f + sc[j]) + sh[j];
+            }
+            SatVec<T>::st(p.y, base + i0, o);
+        }
+    }
+    if (lane == 0 && p.mean) {
+        p.mean[row] = mean;
+        p.rstd[row] = rstd;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_vec_kernel(SatLnParams p) {
+    constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const long long base = (long long)row * p.D;
+    const int nc = p.D / (64 * N);
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    const long long mb = p.scale ? (long long)(row / p.rows_per_batch) * p.mod_stride : 0;
+    float gs[MAXC][N], xh[MAXC][N];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            const int i0 = (c * 64 + lane) * N;
+            float gam[N];
+            SatVec<T>::ld(p.dy, base + i0, gs[c]);
+            SatVec<T>::ld(p.x, base + i0, xh[c]);
+#pragma unroll
+            for (int j = 0; j < N; j += 4) SatVec<float>::ld(p.gamma, i0 + j, gam + j);
+            if (p.scale) {
+                float sc[N];
+                SatVec<T>::ld(p.scale, mb + i0, sc);
+#pragma unroll
+                for (int j = 0; j < N; ++j) gs[c][j] *= 1.0f + sc[j];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                gs[c][j] *= gam[j];
+                xh[c][j] = (xh[c][j] - mean) * rstd;
+                s1 += gs[c][j];
+                s2 += gs[c][j] * xh[c][j];
+            }
+        }
+    }
+    s1 = sat_wave_sum(s1) / (float)p.D;
+    s2 = sat_wave_sum(s2) / (float)p.D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = rstd * (gs[c][j] - s1 - xh[c][j] * s2);
+            SatVec<T>::st(p.dx, base + (c * 64 + lane) * N, o);
+        }
+    }
+}
+
+static bool sat_ln_vec_ok(const SatLnParams& p, int elem_bytes) {
+    const int n = 16 / elem_bytes, maxc = elem_bytes == 4 ? 16 : 8;
+    if (p.D % (64 * n) != 0 || p.D / (64 * n) > maxc) return false;
+    const void* ptrs[] = {p.x, p.gamma, p.beta, p.scale, p.shift, p.y, p.dy, p.dx};
+    for (const void* q : ptrs)
+        if (q && ((uintptr_t)q & 15)) return false;
+    return !p.scale || (p.mod_stride % n) == 0;
+}
+
 // parameter / modulation gradients: thread per column, a workgroup walks a slab of rows of ONE batch item.
 //   part[0] : d_gamma  = sum dy*(1+scale) * xhat
 //   part[1] : d_scale  = sum dy * ln   (ln = xhat*gamma + beta)        (adaLN only)
@@ -144,7 +297,10 @@ extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float*
     p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.y = y; p.mean = mean; p.rstd = rstd;
     p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch; p.eps = eps;
     dim3 grid(sat_cdiv(rows, 4));
-    if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);
+    if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {
+        if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<float>, grid, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<short>, grid, dim3(256), stream, p);
+    } else if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);
     else SAT_LAUNCH(sat_layernorm_fwd_kernel<short>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_layernorm_fwd");
 }
@@ -163,11 +319,14 @@ extern "C" int sat_layernorm_bwd(const void* dy, const void* x, const float* gam
     p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch;
     dim3 g1(sat_cdiv(rows, 4));
     dim3 g2(sat_cdiv(D, 256), sat_cdiv(rows_per_batch, SAT_LN_ROWS_PER_BLOCK), rows / rows_per_batch);
+    const bool vec = sat_ln_vec_ok(p, dtype == 0 ? 4 : 2);
     if (dtype == 0) {
-        SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<float>, g1, dim3(256), stream, p);
+        if (vec) SAT_LAUNCH(sat_layernorm_bwd_dx_vec_kernel<float>, g1, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<float>, g1, dim3(256), stream, p);
         SAT_LAUNCH(sat_layernorm_bwd_param_kernel<float>, g2, dim3(256), stream, p);
     } else {
-        SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<short>, g1, dim3(256), stream, p);
+        if (vec) SAT_LAUNCH(sat_layernorm_bwd_dx_vec_kernel<short>, g1, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<short>, g1, dim3(256), stream, p);
         SAT_LAUNCH(sat_layernorm_bwd_param_kernel<short>, g2, dim3(256), stream, p);
     }
     return sat_check_launch("sat_layernorm_bwd");

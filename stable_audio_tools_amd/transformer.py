@@ -30,11 +30,14 @@ def _ops():
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, scale, shift, eps):
+    def forward(ctx, x, gamma, beta, scale, shift, eps, g32=None, b32=None):
+        """g32 / b32: optional fp32 copies of gamma / beta prepared by the caller (the kernels read fp32 parameters)."""
         ops = _ops()
         x = x.contiguous()
-        g32 = gamma.float().contiguous()
-        b32 = beta.float().contiguous() if beta is not None else None
+        if g32 is None:
+            g32 = gamma.float().contiguous()
+        if b32 is None and beta is not None:
+            b32 = beta.float().contiguous()
         if any(ctx.needs_input_grad):   # (torch.is_grad_enabled() is always False inside Function.forward)
             y, mean, rstd = ops.layernorm(x, g32, b32, scale, shift, eps, save_stats=True)
             ctx.save_for_backward(x, g32, b32, scale, mean, rstd)
@@ -50,7 +53,7 @@ class LayerNormFn(torch.autograd.Function):
         dx, dgamma, dscale, dshift = ctx.ops.layernorm_bwd(dy.contiguous(), x, g32, b32, scale, mean, rstd)
         if dscale is not None:
             dscale, dshift = dscale.to(scale.dtype), dshift.to(scale.dtype)
-        return dx, dgamma.to(ctx.gdtype), None, dscale, dshift, None
+        return dx, dgamma.to(ctx.gdtype), None, dscale, dshift, None, None, None
 
 
 class LayerNorm(nn.Module):
@@ -66,10 +69,24 @@ class LayerNorm(nn.Module):
             self.register_buffer("beta", torch.zeros(dim))
         self.eps = eps
         self.force_fp32 = force_fp32   # statistics are always fp32 in the HIP kernel
+        self._f32_cache = {}
+
+    def _as_f32(self, name):
+        """fp32 view of a parameter for the kernels; for a bf16/fp16 module the converted copy is cached until the
+        parameter changes (in-place version counter / storage)."""
+        t = getattr(self, name)
+        if t.dtype == torch.float32:
+            return t.detach()
+        key = (t.data_ptr(), t._version, t.device)
+        hit = self._f32_cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, t.detach().float().contiguous())
+            self._f32_cache[name] = hit
+        return hit[1]
 
     def forward(self, x, scale=None, shift=None):
         """scale/shift: optional (B, D) adaLN modulation fused into the same pass: LN(x)*(1+scale)+shift."""
-        return LayerNormFn.apply(x, self.gamma, self.beta, scale, shift, self.eps)
+        return LayerNormFn.apply(x, self.gamma, self.beta, scale, shift, self.eps, self._as_f32("gamma"), self._as_f32("beta"))
 
 
 class RotaryEmbedding(nn.Module):
