@@ -226,6 +226,77 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
         for (int i = tid; i < 2 * TW * CO_T; i += NT) (&red_lds[0][0][0])[i] = 0.0f;
         __syncthreads();
     }
+    const bool vec4 = (p.Tout & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.x2 | (uintptr_t)p.res) & 15) == 0;
+    if (vec4) {
+        // 16-byte epilogue: each wave transposes its accumulators through LDS (the weight buffers are free now) so that
+        // a lane owns 4 consecutive time steps of a row; the x2 / res loads of a 32-row half are all issued before use.
+        if (!bwd) __syncthreads();                          // (bwd already synchronised above)
+        float (*tile)[68] = reinterpret_cast<float (*)[68]>(wave < 4 ? &w_lds0[0][0][0] : &w_lds1[0][0][0]) + (wave & 3) * 32;
+        const int lr = lane >> 4, t4 = (lane & 15) * 4;    // this lane's row within a group of 4, its 4 time steps
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const bool half_on = wave_on && (mi == 0 || mi1_on);
+            if (mi == 1) __syncthreads();                   // every wave is done reading its first half
+            if (half_on) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile[(r & 3) + 8 * (r >> 2) + 4 * hi][ni * 32 + l31] = acc[mi][ni][r];
+            }
+            __syncthreads();                                // (a wave only reads its own tile: this orders its own lanes)
+            if (half_on) {
+                const int tg = t0 + t_w + t4;
+                f32x4 xv[8], rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = co_w + mi * 32 + j * 4 + lr;
+                    const int co = co0 + col;
+                    const bool ok = co < a.cout_v && tg < p.Tout;
+                    const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? tg : 0);
+                    xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(p.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    rv[j] = (p.res && ok) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = j * 4 + lr;
+                    const int col = co_w + mi * 32 + row;
+                    const int co = co0 + col;
+                    const bool ok = co < a.cout_v && tg < p.Tout;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
+                    const float bias = ep_lds[0][col];
+                    const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
+                    float pda = 0.f, pdb = 0.f;
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = av[e] + bias;
+                        if (bwd) {
+                            const SatSnakeGrad g = sat_snake_grad(xv[j][e], a2, b2);
+                            pda += v * g.dla;
+                            pdb += v * g.dlb;
+                            v *= g.dx;
+                        }
+                        v += rv[j][e];
+                        if (p.tanh_out) v = tanhf(v);
+                        ov[e] = v;
+                    }
+                    if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (bwd) {
+                        if (!ok) { pda = 0.f; pdb = 0.f; }
+#pragma unroll
+                        for (int m = 8; m >= 1; m >>= 1) {     // sum over the 16 lanes that share this row
+                            pda += __shfl_xor(pda, m);
+                            pdb += __shfl_xor(pdb, m);
+                        }
+                        if ((lane & 15) == 0) {
+                            red_lds[0][wave % TW][col] = pda;
+                            red_lds[1][wave % TW][col] = pdb;
+                        }
+                    }
+                }
+            }
+        }
+    } else
     if (wave_on) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {

@@ -219,7 +219,7 @@ static void sat_wgbf_plan(int B, int M, int N, int T, SatWgBfPlan* pl) {
     pl->nT = sat_cdiv(T, SAT_WB_TT);
     pl->nchunks = B * pl->nT;
     const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N, 32);
-    int want = sat_cdiv(1024, tiles);
+    int want = sat_cdiv(512, tiles);   // 2 workgroups per CU in flight: one full wave of the grid
     if (want > pl->nchunks) want = pl->nchunks;
     if (want < 1) want = 1;
     if (want > 512) want = 512;
@@ -490,7 +490,7 @@ static bool sat_wgs_plan(int B, int M, int N, int Tlo, int K, int stride, SatWgB
     pl->nT = sat_cdiv(Tlo, SAT_WS_TT);
     pl->nchunks = B * pl->nT;
     const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N << *s_log2, SAT_CO_T);
-    int want = sat_cdiv(1024, tiles);
+    int want = sat_cdiv(512, tiles);   // 2 workgroups per CU in flight: one full wave of the grid
     if (want > pl->nchunks) want = pl->nchunks;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
