@@ -55,8 +55,13 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     constexpr int WPS = 4 / CS;                           // waves per sub-block
     constexpr int NU = (CS == 1) ? 1 : 128 / (64 * WPS);  // main staging items (one time row x 8 channels) per thread
     const SatConvParams& p = a.p;
-    __shared__ __attribute__((aligned(16))) short w_lds[2][SAT_CO_T][KROW];        // [plane][co][g*8+e]
-    __shared__ __attribute__((aligned(16))) short a_lds[2][CS][AROWS][8];          // [plane][sub-block][time row][8 ci]
+    // one LDS pool: the weight slab and the activation slab of the K loop, reused by the epilogue as the per-wave
+    // transposition tiles (4 waves x 32 rows x 68 floats)
+    constexpr int W_BYTES = 2 * SAT_CO_T * KROW * 2, A_BYTES = 2 * CS * AROWS * 8 * 2, T_BYTES = 4 * 32 * 68 * 4;
+    constexpr int POOL = (W_BYTES + A_BYTES) > T_BYTES ? (W_BYTES + A_BYTES) : T_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds_pool[POOL];
+    short (*w_lds)[SAT_CO_T][KROW] = reinterpret_cast<short (*)[SAT_CO_T][KROW]>(lds_pool);                 // [plane][co][g*8+e]
+    short (*a_lds)[CS][AROWS][8] = reinterpret_cast<short (*)[CS][AROWS][8]>(lds_pool + W_BYTES);           // [plane][sub-block][time row][8 ci]
     __shared__ float red_lds[2][2][SAT_CO_T];
     __shared__ float ep_lds[3][SAT_CO_T];
 
@@ -230,6 +235,77 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
         for (int i = tid; i < 2 * 2 * SAT_CO_T; i += 256) (&red_lds[0][0][0])[i] = 0.0f;
         __syncthreads();
     }
+    const bool vec4 = so == 0 && a.out_shift == 0 && (p.Tout & 3) == 0 &&
+                      (((uintptr_t)p.y | (uintptr_t)p.x2 | (uintptr_t)p.res) & 15) == 0;
+    if (vec4) {
+        // 16-byte epilogue (plain output addressing): each wave transposes its accumulators through LDS so that a lane
+        // owns 4 consecutive time steps of a row; the x2 / res loads of a 32-row half are all issued before use.
+        if (!bwd) __syncthreads();                          // the K loop's slabs are free (bwd synchronised above)
+        float (*tile)[68] = reinterpret_cast<float (*)[68]>(lds_pool) + wave * 32;
+        const int lr = lane >> 4, t4 = (lane & 15) * 4;    // this lane's row within a group of 4, its 4 time steps
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const bool half_on = wave_on && (mi == 0 || mi1_on);
+            if (mi == 1) __syncthreads();                   // every wave is done reading its first half
+            if (half_on) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile[(r & 3) + 8 * (r >> 2) + 4 * hi][ni * 32 + l31] = acc[mi][ni][r];
+            }
+            __syncthreads();                                // (a wave only reads its own tile: this orders its own lanes)
+            if (half_on) {
+                const int tg = t0 + t_w + t4;
+                f32x4 xv[8], rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int co = co0 + co_w + mi * 32 + j * 4 + lr;
+                    const bool ok = co < p.Cout && tg < p.Tout;
+                    const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? tg : 0);
+                    xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(p.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    rv[j] = (p.res && ok) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = j * 4 + lr;
+                    const int col = co_w + mi * 32 + row;
+                    const int co = co0 + col;
+                    const bool ok = co < p.Cout && tg < p.Tout;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
+                    const float bias = ep_lds[0][col];
+                    const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
+                    float pda = 0.f, pdb = 0.f;
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = av[e] + bias;
+                        if (bwd) {
+                            const SatSnakeGrad g = sat_snake_grad(xv[j][e], a2, b2);
+                            pda += v * g.dla;
+                            pdb += v * g.dlb;
+                            v *= g.dx;
+                        }
+                        v += rv[j][e];
+                        if (p.tanh_out) v = tanhf(v);
+                        ov[e] = v;
+                    }
+                    if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (bwd) {
+                        if (!ok) { pda = 0.f; pdb = 0.f; }
+#pragma unroll
+                        for (int m = 8; m >= 1; m >>= 1) {     // sum over the 16 lanes that share this row
+                            pda += __shfl_xor(pda, m);
+                            pdb += __shfl_xor(pdb, m);
+                        }
+                        if ((lane & 15) == 0) {
+                            red_lds[0][wave & 1][col] = pda;
+                            red_lds[1][wave & 1][col] = pdb;
+                        }
+                    }
+                }
+            }
+        }
+    } else
     if (wave_on) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {

@@ -100,6 +100,9 @@ for (C, T, S) in levels:
     planes_b = ops.pack_bf16x3(w7, mode=1)
     ms = timeit(lambda: ops.conv1d_bf16x3(dy, planes_b, C, 7, 1, 9, 27, dsnake=(x, la, lb), res=dy))
     res[f"dgrad7x3_d9_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * 7 * T / ms / 1e9)
+    p1b = ops.pack_bf16x3(w1, mode=1)
+    ms = timeit(lambda: ops.conv1d_bf16x3(dy, p1b, C, 1, 1, 1, 0, dsnake=(x, la, lb)))
+    res[f"dgrad1x3_C{C}_T{T}"] = dict(ms=ms, tflops=2 * C * C * T / ms / 1e9, gbps=3 * 4 * C * T / ms / 1e6)
     ms = timeit(lambda: ops.rowsum(dy))
     res[f"rowsum_C{C}_T{T}"] = dict(ms=ms, gbps=4 * C * T / ms / 1e6)
     del x, dy, xu
