@@ -68,9 +68,12 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int t0 = blockIdx.x * SAT_T_T;
-    const int co0 = blockIdx.y * SAT_CO_T;
-    const int b = blockIdx.z;
+    // grid = (time tiles, channel tiles, B): the channel tiles of one activation window share an XCD (sat_xcd_tile)
+    int co_tile, win;
+    sat_xcd_tile(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.y, gridDim.x * gridDim.z, &co_tile, &win);
+    const int b = win / (int)gridDim.x, t_tile = win - b * (int)gridDim.x;
+    const int t0 = t_tile * SAT_T_T;
+    const int co0 = co_tile * SAT_CO_T;
     const int co_w = (wave >> 1) * 64, t_w = (wave & 1) * 64;
     const int K = p.K, dil = p.dil;
     const int nrows = SAT_T_T + (K - 1) * dil;
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch 
                 sa += red_lds[0][0][tid + r] + red_lds[0][1][tid + r];
                 sb += red_lds[1][0][tid + r] + red_lds[1][1][tid + r];
             }
-            const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+            const size_t row = (size_t)b * gridDim.x + t_tile;
             const size_t nrows_p = (size_t)p.B * gridDim.x;
             p.part_da[(size_t)(m >> so) * nrows_p + row] = sa;
             p.part_db[(size_t)(m >> so) * nrows_p + row] = sb;

@@ -43,9 +43,12 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int co0 = blockIdx.x * CO_T;                    // channel tiles vary fastest: they share one activation window (L2)
-    const int t0 = blockIdx.y * T_T;
-    const int b = blockIdx.z;
+    // grid = (channel tiles, time tiles, B): the channel tiles of one activation window share an XCD (sat_xcd_tile)
+    int co_tile, win;
+    sat_xcd_tile(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y * gridDim.z, &co_tile, &win);
+    const int b = win / (int)gridDim.y, t_tile = win - b * (int)gridDim.y;
+    const int co0 = co_tile * CO_T;
+    const int t0 = t_tile * T_T;
     const int co_w = (wave / TW) * 64, t_w = (wave % TW) * 64;
     const int K = p.K, dil = p.dil;
     const int nrows = T_T + (K - 1) * dil;
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
                 sa += red_lds[0][w][tid];
                 sb += red_lds[1][w][tid];
             }
-            const size_t row = (size_t)b * gridDim.y + blockIdx.y;
+            const size_t row = (size_t)b * gridDim.y + t_tile;
             const size_t nrows_p = (size_t)p.B * gridDim.y;
             p.part_da[(size_t)m * nrows_p + row] = sa;
             p.part_db[(size_t)m * nrows_p + row] = sb;

@@ -50,7 +50,10 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int m0 = blockIdx.x * SAT_CO_T, n0 = blockIdx.y * 32;
+    // grid = (co tiles, ci tiles, splits): the tiles of one split read the same dy / x time range -> same XCD
+    int mn_tile, split;
+    sat_xcd_tile(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y, gridDim.z, &mn_tile, &split);
+    const int m0 = (mn_tile % (int)gridDim.x) * SAT_CO_T, n0 = (mn_tile / (int)gridDim.x) * 32;
     const int m_w = wave * 32;
     const bool wave_on = (m0 + m_w) < p.M;
 
@@ -74,7 +77,7 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
     for (int i = tid; i < 2 * 32 * SAT_WB_HIROW; i += 256) (&hi_lds[0][0][0])[i] = 0;
     __syncthreads();
 
-    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_begin = split * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > p.nchunks) c_end = p.nchunks;
     constexpr int HSPAN = SAT_WB_TT + 6 * DIL;                        // activation samples needed per stage
@@ -202,7 +205,7 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
     }
 
     if (wave_on) {
-        float* ob = p.out + (size_t)blockIdx.z * p.so_split;
+        float* ob = p.out + (size_t)split * p.so_split;
         const int n = n0 + l31;
 #pragma unroll
         for (int k = 0; k < 7; ++k)
@@ -289,7 +292,9 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int sl = p.s_log2, S = 1 << sl;
-    const int m0 = blockIdx.x * SAT_CO_T, v0 = blockIdx.y * SAT_CO_T;
+    int mn_tile, split;
+    sat_xcd_tile(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y, gridDim.z, &mn_tile, &split);
+    const int m0 = (mn_tile % (int)gridDim.x) * SAT_CO_T, v0 = (mn_tile / (int)gridDim.x) * SAT_CO_T;
     const int n_base = v0 >> sl, nc = SAT_CO_T >> sl;                // real hi channels of this tile
     const int NV = p.N << sl;
     const int m_w = (wave >> 1) * 64, v_w = (wave & 1) * 64;
@@ -319,7 +324,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
     }
     __syncthreads();
 
-    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_begin = split * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > p.nchunks) c_end = p.nchunks;
     const int rs = (SAT_WS_TT + NT - 1) << sl;                       // real samples per hi channel and stage
@@ -459,7 +464,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
     }
 
     if (wave_on) {
-        float* ob = p.out + (size_t)blockIdx.z * p.so_split;
+        float* ob = p.out + (size_t)split * p.so_split;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

@@ -153,6 +153,25 @@ SAT_DEVICE void sat_split2_pk(float a, float b, uint32_t* hi, uint32_t* lo) {
 #define SAT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// XCD-aware tile order.  Workgroups are dealt round-robin (in linear id order) to the 8 XCDs, each with its own L2, so the
+// `nshare` tiles that read the same operand slab (the channel tiles of one activation window, the (co, ci) tiles of one
+// split-K time range) get linear ids that differ by multiples of 8: same XCD, dispatched together, one HBM fetch.
+// L = linear workgroup id, nouter = number of slabs; returns the tile index within the slab's group and the slab index.
+// (Placement is a speed heuristic only — nothing depends on it for correctness.)
+SAT_DEVICE void sat_xcd_tile(int L, int nshare, int nouter, int* share_idx, int* outer_idx) {
+    const int ngroups = nouter >> 3;                  // full groups of 8 slabs
+    const int per_group = 8 * nshare;
+    if (L < ngroups * per_group) {
+        const int grp = L / per_group, rem = L - grp * per_group;
+        *share_idx = rem >> 3;
+        *outer_idx = grp * 8 + (rem & 7);
+    } else {                                          // the last < 8 slabs: natural order
+        const int R = L - ngroups * per_group;
+        *share_idx = R % nshare;
+        *outer_idx = ngroups * 8 + R / nshare;
+    }
+}
+
 // wave64 all-lane sum
 SAT_DEVICE float sat_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -241,7 +241,7 @@ class SatOps:
         return self._reduce_rows(partial, nsplit, m * n * k).view(shape)
 
     def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):
-        return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9) and n_in >= 32
+        return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9)
 
     def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None):
         """dW (Cout, Cin, 7) of a k7 stride-1 conv: dy (B, Cout, T), x (B, Cin, T) pre-activation, snake = (log-alpha, log-beta)."""

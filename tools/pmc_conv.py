@@ -1,5 +1,5 @@
 """Run ONE conv configuration a few times (for rocprofv3 --pmc runs).  usage: pmc_conv.py <kind> [C] [T]
-kind: conv7 | dgrad7 | conv1 | down | up | wgrad7 | wgrad1"""
+kind: conv7 | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | calib"""
 import os
 import sys
 
@@ -37,6 +37,10 @@ elif kind == "wgrad7":
     fn = lambda: ops.conv_wgrad7_bf16x3(dy, x, 9, 27, snake=(la, lb))
 elif kind == "wgrad1":
     fn = lambda: ops.conv_wgrad(dy, x, 1, 1, 1, 0, snake=(la, lb), snake_on=2)
+elif kind == "calib":
+    # known-traffic calibration launches: sat_rowsum reads C*T*4 bytes with 16-byte loads; the torch copy reads and
+    # writes C*T*4 bytes
+    fn = lambda: (ops.rowsum(x), x.clone())
 else:
     raise SystemExit("unknown kind")
 for _ in range(4):
