@@ -47,10 +47,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 class AttnProfiler:
-    """HIP-event timing + algorithmic flops (4*Nq*Nk*64*H*B) of every sat_attn_fwd_kernel launch."""
+    """HIP-event timing + algorithmic flops (4*Nq*Nk*64*H*B) of every sat_attn_fwd_kernel launch, self-attention
+    (Nk == Nq) and cross-attention (Nk = context length) kept apart."""
 
     def __init__(self, ops):
-        self.records = []
+        self.records = {"self": [], "cross": []}
         self.enabled = False
         orig = ops.lib.sat_attention_fwd
 
@@ -64,15 +65,28 @@ class AttnProfiler:
             s.record()
             rc = orig(*a)
             e.record()
-            self.records.append((s, e, 4.0 * b * h * nq * nk * d))
+            self.records["self" if nq == nk else "cross"].append((s, e, 4.0 * b * h * nq * nk * d))
             return rc
 
         ops.lib.sat_attention_fwd = timed
 
-    def summary(self):
+    def summary(self, which="self"):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        return len(self.records), ms, sum(f for _, _, f in self.records)
+        recs = self.records[which]
+        ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+        return len(recs), ms, sum(f for _, _, f in recs)
+
+    def roofline(self, peak):
+        """roofline object of the self-attention launches (the dominant ones); cross-attention listed beside it."""
+        nl, ms, fl = self.summary("self")
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        nc, msc, flc = self.summary("cross")
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "kernel": "sat_attn_fwd_kernel", "launches": nl, "avg_launch_ms": ms / nl if nl else None,
+                "cross_attention": {"launches": nc, "avg_launch_ms": msc / nc if nc else None,
+                                    "achieved": flc / (msc * 1e-3) / 1e12 if msc > 0 else 0.0},
+                "note": "self-attention launches: algorithmic flops 4*N*N*64*H*B over HIP-event time on the launch stream; "
+                        "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split); cross-attention (GQA, M=130 keys) apart"}
 
 
 def dit_cpu_baseline(dcfg, latent_len, ctx_len):
@@ -97,6 +111,31 @@ def dit_cpu_baseline(dcfg, latent_len, ctx_len):
         dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"1 sampler step (oracle DiT forward, fp32, CFG batch 2, N={latent_len + 1}) in {dt:.2f} s"}
+
+
+def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
+    """Oracle DiT training evaluation (fp32 forward + autograd backward of the v-objective MSE, one sample) on <=16 host
+    threads."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dit_oracle
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    model = DiffusionTransformer(**dcfg)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
+    cross = torch.randn(1, ctx_len, dcfg["cond_token_dim"], generator=g)
+    glob = torch.randn(1, dcfg["global_cond_dim"], generator=g)
+    t = torch.tensor([0.5])
+    t0 = time.perf_counter()
+    out = dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=1.0)
+    loss = (out - torch.randn(out.shape, generator=g)).square().mean()
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 sample: oracle DiT forward + autograd backward (fp32, N={latent_len + 1}, no optimizer step) in {dt:.2f} s"}
 
 
 def run_dit_sample(args):
@@ -134,8 +173,6 @@ def run_dit_sample(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof.enabled = False
-    nl, ms, fl = prof.summary()
-    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     peak = PEAK_BF16_MFMA_TFLOPS if args.dit_dtype == "bf16" else PEAK_BF16_MFMA_TFLOPS / 3.0
     n = tlat + 1
     line = {
@@ -145,11 +182,7 @@ def run_dit_sample(args):
         "config": {"workload": "stable_audio_open_1_0 DiT (d=1536, 24 layers, 24x64 heads, GQA cross-attn to 130x768 context), "
                                "v-DDIM sampler with CFG scale 6 + rescale (model batch 2B), random init",
                    "latent_frames": tlat, "tokens": n, "context": m, "per_gpu_batch": b, "finite": bool(torch.isfinite(out.float()).all())},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel": "sat_attn_fwd_kernel", "launches": nl,
-                     "avg_launch_ms": ms / nl if nl else None,
-                     "note": "algorithmic flops 4*Nq*Nk*64*H*B per launch (self N=1025 and GQA cross M=130) over HIP-event time; "
-                             "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split)"},
+        "roofline": prof.roofline(peak),
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = dit_cpu_baseline(dcfg, tlat, m)
@@ -217,6 +250,18 @@ class ConvProfiler:
         return (out[0] if out else None), out
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of the DEFAULT workload (rocprofv3 cannot collect
+    counters from inside this process: tools/collect_profiles.sh runs the separate --pmc passes on this same command)."""
+    if args.sample_size != 2097152 or args.batch != 1:
+        return None
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))
+        return doc["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, nsamples):
     """The oracle (CPU restatement of the reference path, oracle/*.py) timed on this box's host cores on a
     bounded sample: ONE generator step (fwd + autograd bwd + torch AdamW) on a `nsamples`-long stereo crop;
@@ -275,6 +320,8 @@ def run_dit_train(args):
     model = model.to(dev).train(True)
     mixed = args.dit_dtype == "bf16"
     stepper = DiTTrainStep(model, lr=5e-5, cfg_dropout_prob=0.1, autocast_dtype=torch.bfloat16 if mixed else None)
+    from stable_audio_tools_amd import ops as O
+    prof = AttnProfiler(O.get_ops())
     b, tlat, m = args.batch, cfg["latent_length"], cfg["context_length"]
     g = torch.Generator().manual_seed(rank)
     lat = torch.randn(b, dcfg["io_channels"], tlat, generator=g).to(dev)
@@ -288,11 +335,13 @@ def run_dit_train(args):
     for _ in range(args.warmup):
         stepper(lat, cross_attn_cond=cross, global_embed=glob)
     sync()
+    prof.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = stepper(lat, cross_attn_cond=cross, global_embed=glob)
     sync()
     elapsed = time.perf_counter() - t0
+    prof.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -310,7 +359,10 @@ def run_dit_train(args):
                                        "fused_adamw_ema), pre-encoded latents, synthetic conditioning tensors, random init, no activation checkpointing",
                            "latent_frames": tlat, "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                            "final_loss": float(out["loss"]), "model_tflop_per_sample_fwd_bwd": 3 * fwd / 1e12,
-                           "achieved_model_tflops": 3 * fwd * b * world * args.steps / elapsed / 1e12}}
+                           "achieved_model_tflops": 3 * fwd * b * world * args.steps / elapsed / 1e12},
+                "roofline": prof.roofline(PEAK_BF16_MFMA_TFLOPS if mixed else PEAK_BF16_MFMA_TFLOPS / 3.0)}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = dit_train_cpu_baseline(dcfg, tlat, m)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -396,12 +448,15 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
-                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "launches": dom["launches"],
+                         "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], args), "kernel": dom["kernel"],
+                         "launches": dom["launches"],
                          "avg_launch_ms": dom["avg_launch_ms"],
                          "note": "dominant kernel by HIP-event time in the timed region; achieved = algorithmic flops "
                                  "(2*Cin*Cout*K*Tout*B per conv launch, 2*M*N*K*T*B per wgrad launch) / event time over ALL its "
                                  "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
-                                 "bf16x3 split kernels (three MFMAs per fp32-accurate product)",
+                                 "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
+                                 "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
+                                 "same command (profiles/r01g_pmc_traffic.json; null for a non-default workload size)",
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
         if world == 1 and not args.no_cpu_baseline:
