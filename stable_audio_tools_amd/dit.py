@@ -167,8 +167,11 @@ class DiffusionTransformer(nn.Module):
         else:
             sigma = t
 
+        # the reference reads sigma[0] on the host (dit.py:324); with the default full interval the test is always true for
+        # sigma in [0, 1], so the device->host sync is skipped (it would also forbid HIP-graph capture of the step)
+        full_interval = cfg_interval[0] <= 0.0 and cfg_interval[1] >= 1.0
         use_cfg = cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None) \
-            and bool(cfg_interval[0] <= sigma[0] <= cfg_interval[1])   # reads sigma[0] only (dit.py:324)
+            and (full_interval or bool(cfg_interval[0] <= sigma[0] <= cfg_interval[1]))
         if not use_cfg:
             return self._forward(x, t, cross_attn_cond=cross_attn_cond, global_embed=global_embed, prepend_cond=prepend_cond,
                                  prepend_cond_mask=prepend_cond_mask, **common)
