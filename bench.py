@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="items per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="items per GPU per step (default: 1 for vae_train and dit_sample, 4 for dit_train)")
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
@@ -40,7 +41,10 @@ def parse():
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
                          "dit_sample: configs[2] DiT sampling steps/s (the metric's second half)")
     ap.add_argument("--dit-dtype", choices=["bf16", "f32"], default="bf16")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.workload == "dit_train" else 1
+    return args
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
