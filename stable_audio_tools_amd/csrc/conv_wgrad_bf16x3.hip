@@ -12,6 +12,7 @@
 // ALIGNED chunks covering [t, t + 8 + 6*dil) once per k-step and forms each tap's fragment with compile-time
 // register selection + v_alignbit (dil is a template parameter: 1, 3, 9).
 #include "conv_common.h"
+#include <type_traits>
 
 #define SAT_WB_TT 64                 // time steps per LDS stage (4 MFMA k-steps)
 #define SAT_WB_LOROW (SAT_WB_TT + 8) // 144 B rows: conflict-free b128
@@ -217,12 +218,15 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
     }
 }
 
-struct SatWgBfPlan { int nsplit, cps, nchunks, nT; };
+#include "conv_wgrad7_bf16x3_pipe.h"     // the 8-wave pipelined kernel (128 x 64 tiles) for N >= 64
+
+struct SatWgBfPlan { int nsplit, cps, nchunks, nT; bool pipe; };
 static void sat_wgbf_plan(int B, int M, int N, int T, SatWgBfPlan* pl) {
     pl->nT = sat_cdiv(T, SAT_WB_TT);
     pl->nchunks = B * pl->nT;
-    const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N, 32);
-    int want = sat_cdiv(512, tiles);   // 2 workgroups per CU in flight: one full wave of the grid
+    pl->pipe = N >= SAT_WP_NI && (T & 3) == 0;     // at least one full 64-channel column block; 16-byte dy loads
+    const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N, pl->pipe ? SAT_WP_NI : 32);
+    int want = sat_cdiv(512, tiles);               // pipelined kernel: 1 workgroup per CU, two rounds; 4-wave kernel: 2 per CU, one round
     if (want > pl->nchunks) want = pl->nchunks;
     if (want < 1) want = 1;
     if (want > 512) want = 512;
@@ -246,6 +250,13 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
     SatWgBfParams p{dy, x, alpha, beta, partial, (long long)M * N * 7, so_m, so_n, so_k, B, M, N, T, pad, pl.cps, pl.nchunks, pl.nT};
+    if (pl.pipe) {
+        dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, SAT_WP_NI), pl.nsplit);
+        if (dil == 1) SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<1>, grid, dim3(SAT_WP_NT), stream, p);
+        else if (dil == 3) SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<3>, grid, dim3(SAT_WP_NT), stream, p);
+        else SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<9>, grid, dim3(SAT_WP_NT), stream, p);
+        return sat_check_launch("sat_conv_wgrad7_bf16x3");
+    }
     dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, 32), pl.nsplit);
     if (dil == 1) SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<1>, grid, dim3(256), stream, p);
     else if (dil == 3) SAT_LAUNCH(sat_wgrad7_bf16x3_kernel<3>, grid, dim3(256), stream, p);
