@@ -158,13 +158,19 @@ SAT_DEVICE bf16x8 sat_att_frag_acc(short (*t)[LROW], int row, int kofs) {
 }
 template <int NP>
 SAT_DEVICE void sat_att_pack(const f32x16& acc, int u, bf16x8 (&out)[NP]) {
+    uint32_t wh[4], wl[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = acc[8 * u + e];
-        const short hi = sat_f32_to_bf16(x);
-        out[0][e] = hi;
-        if (NP == 2) out[NP - 1][e] = sat_f32_to_bf16(x - sat_bf16_to_f32(hi));
-    }
+    for (int j = 0; j < 4; ++j) sat_split2_pk(acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1], &wh[j], &wl[j]);   // packed RNE converts
+    out[0] = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+    if (NP == 2) out[NP - 1] = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+}
+// 2^x on the transcendental unit (v_exp_f32); the arguments here are <= 0 and underflow to 0 as they should
+SAT_DEVICE float sat_exp2(float x) {
+#if defined(SAT_HIPEMU)
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
 }
 // acc += A * B with the 1- or 3-MFMA product
 template <int NP>
@@ -206,8 +212,9 @@ template <> struct SatOut<short> { static SAT_DEVICE void put(void* p, long long
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NP>
 __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
-    __shared__ __attribute__((aligned(16))) short k_lds[NP][SAT_ATT_T][SAT_ATT_ROW];   // [key][d]
-    __shared__ __attribute__((aligned(16))) short v_lds[NP][SAT_ATT_D][SAT_ATT_ROW];   // [d][key]
+    // K / V^T tiles double-buffered in LDS; tile k+1 travels through registers while tile k is consumed: one barrier per tile
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];   // [buffer][plane][key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][plane][d][key]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -238,14 +245,40 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
     float m_run = -INFINITY, l_run = 0.0f;
     const float sl2 = p.scale * 1.4426950408889634f;
 
-    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T) {
-        __syncthreads();
+    // a 64 x 64 bf16 tile = 512 16-byte pieces = 2 per thread and plane
+    bf16x8 kreg[NP][2], vreg[NP][2];
+    auto tile_load = [&](int k0) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            sat_att_stage<64, 64, SAT_ATT_ROW>(k_lds[pl], p.k_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
-            sat_att_stage<64, 64, SAT_ATT_ROW>(v_lds[pl], p.v_tr[pl] + kplane + k0, (size_t)p.Nkp);
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                kreg[pl][j] = *reinterpret_cast<const bf16x8*>(p.k_rm[pl] + kplane + (size_t)(k0 + r) * SAT_ATT_D + part * 8);
+                vreg[pl][j] = *reinterpret_cast<const bf16x8*>(p.v_tr[pl] + kplane + (size_t)r * p.Nkp + k0 + part * 8);
+            }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                *reinterpret_cast<bf16x8*>(&k_lds2[buf][pl][r][part * 8]) = kreg[pl][j];
+                *reinterpret_cast<bf16x8*>(&v_lds2[buf][pl][r][part * 8]) = vreg[pl][j];
+            }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
+        short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW] = k_lds2[buf];
+        short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW] = v_lds2[buf];
+        if (k0 + SAT_ATT_T < p.Nk) {
+            tile_store(buf ^ 1);                                         // tile k+1: registers -> the other buffer
+            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);   // tile k+2 -> registers (lands during this tile's math)
         }
-        __syncthreads();
 
         f32x16 sacc[2];
 #pragma unroll
@@ -261,24 +294,30 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
             }
         }
         float tmax = -INFINITY;
+        if (k0 + SAT_ATT_T > p.Nk) {                      // only the last tile holds padded keys (block-uniform)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.Nk) sacc[kb][r] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (key >= p.Nk) sacc[kb][r] = -INFINITY;
-                tmax = fmaxf(tmax, sacc[kb][r]);
-            }
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f((m_run - m_new) * sl2);
+        const float alpha = sat_exp2((m_run - m_new) * sl2);
         m_run = m_new;
+        const float mb = m_new * sl2;
         float psum = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f((sacc[kb][r] - m_new) * sl2);
+                const float pv = sat_exp2(fmaf(sacc[kb][r], sl2, -mb));
                 sacc[kb][r] = pv;
                 psum += pv;
             }
@@ -302,6 +341,7 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
                     oacc[t] = sat_att_mma<NP>(va, pb, oacc[t]);
                 }
             }
+        __syncthreads();
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -395,7 +435,7 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float pv = (key < p.Nk && q_ok) ? exp2f(sacc[r] * sl2 - lse2) : 0.0f;
+                const float pv = (key < p.Nk && q_ok) ? sat_exp2(fmaf(sacc[r], sl2, -lse2)) : 0.0f;
                 sacc[r] = pv * (pacc[r] - dsum) * p.scale;   // dS^T
             }
 #pragma unroll
@@ -514,7 +554,7 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) 
                 for (int r = 0; r < 16; ++r) {
                     const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const bool ok = (q0 + ql) < p.Nq && k_ok;
-                    const float pv = ok ? exp2f(sacc[r] * sl2 - lse_lds[ql]) : 0.0f;
+                    const float pv = ok ? sat_exp2(fmaf(sacc[r], sl2, -lse_lds[ql])) : 0.0f;
                     pr[r] = pv;
                     sacc[r] = pv * (pacc[r] - ds_lds[ql]) * p.scale;   // dS[q][key]
                 }
