@@ -54,14 +54,16 @@ class AttnProfiler:
     """HIP-event timing + algorithmic flops (4*Nq*Nk*64*H*B) of every sat_attn_fwd_kernel launch, self-attention
     (Nk == Nq) and cross-attention (Nk = context length) kept apart."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, max_launches=192):
         self.records = {"self": [], "cross": []}
         self.enabled = False
-        orig = ops.lib.sat_attention_fwd
+        self.budget = max_launches     # only the first launches of the timed region carry events: a sampler step is
+        orig = ops.lib.sat_attention_fwd   # host-bound, and two event objects per launch would slow the measured loop
 
         def timed(*a):
-            if not self.enabled:
+            if not self.enabled or self.budget <= 0:
                 return orig(*a)
+            self.budget -= 1
             b, h, _hkv, nq, nk = a[8:13]
             d = a[15]
             s = torch.cuda.Event(enable_timing=True)
@@ -89,7 +91,7 @@ class AttnProfiler:
                 "kernel": "sat_attn_fwd_kernel", "launches": nl, "avg_launch_ms": ms / nl if nl else None,
                 "cross_attention": {"launches": nc, "avg_launch_ms": msc / nc if nc else None,
                                     "achieved": flc / (msc * 1e-3) / 1e12 if msc > 0 else 0.0},
-                "note": "self-attention launches: algorithmic flops 4*N*N*64*H*B over HIP-event time on the launch stream; "
+                "note": "self-attention launches (the first ~4 model evaluations of the timed region): algorithmic flops 4*N*N*64*H*B over HIP-event time on the launch stream; "
                         "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split); cross-attention (GQA, M=130 keys) apart"}
 
 
