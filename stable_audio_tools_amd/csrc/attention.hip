@@ -160,7 +160,10 @@ template <int NP>
 SAT_DEVICE void sat_att_pack(const f32x16& acc, int u, bf16x8 (&out)[NP]) {
     uint32_t wh[4], wl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sat_split2_pk(acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1], &wh[j], &wl[j]);   // packed RNE converts
+    for (int j = 0; j < 4; ++j) {                        // packed RNE converts
+        if (NP == 2) sat_split2_pk(acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1], &wh[j], &wl[j]);
+        else wh[j] = sat_cvt2_pk(acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1]);
+    }
     out[0] = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
     if (NP == 2) out[NP - 1] = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
 }

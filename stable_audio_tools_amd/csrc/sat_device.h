@@ -145,6 +145,18 @@ SAT_DEVICE void sat_split2_pk(float a, float b, uint32_t* hi, uint32_t* lo) {
 #endif
 }
 
+// two fp32 -> packed bf16 (RNE), (b << 16) | a: one v_cvt_pk_bf16_f32
+SAT_DEVICE uint32_t sat_cvt2_pk(float a, float b) {
+#if defined(SAT_HIPEMU)
+    return ((uint32_t)(uint16_t)sat_f32_to_bf16(b) << 16) | (uint16_t)sat_f32_to_bf16(a);
+#else
+    typedef __bf16 sat_bf2 __attribute__((ext_vector_type(2)));
+    typedef float sat_f2 __attribute__((ext_vector_type(2)));
+    const sat_f2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sat_bf2));
+#endif
+}
+
 // a value known to be identical in every lane of the wave -> scalar register (lets the compiler use s_load for
 // addresses derived from it)
 #if defined(SAT_HIPEMU)
