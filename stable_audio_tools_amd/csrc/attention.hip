@@ -474,11 +474,13 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 template <typename T, int NP, int TQ>   // TQ = queries per tile (64, or 32 for the two-plane variant: LDS budget)
 __global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) {
     constexpr int TROW = TQ + 8;           // transposed-tile row (80 B or 144 B stride: conflict-free)
-    __shared__ __attribute__((aligned(16))) short q_lds[NP][TQ][SAT_ATT_ROW];    // [q][d]
-    __shared__ __attribute__((aligned(16))) short g_lds[NP][TQ][SAT_ATT_ROW];    // dO [q][d]
-    __shared__ __attribute__((aligned(16))) short qt_lds[NP][SAT_ATT_D][TROW];   // [d][q]
-    __shared__ __attribute__((aligned(16))) short gt_lds[NP][SAT_ATT_D][TROW];   // dO^T [d][q]
-    __shared__ float lse_lds[TQ], ds_lds[TQ];
+    // the four query-side tiles (Q, dO row-major; Q^T, dO^T) are double-buffered: tile i+1 travels through registers while
+    // tile i is consumed — one barrier per tile
+    __shared__ __attribute__((aligned(16))) short q_lds2[2][NP][TQ][SAT_ATT_ROW];    // [buffer][plane][q][d]
+    __shared__ __attribute__((aligned(16))) short g_lds2[2][NP][TQ][SAT_ATT_ROW];    // dO [q][d]
+    __shared__ __attribute__((aligned(16))) short qt_lds2[2][NP][SAT_ATT_D][TROW];   // [d][q]
+    __shared__ __attribute__((aligned(16))) short gt_lds2[2][NP][SAT_ATT_D][TROW];   // dO^T [d][q]
+    __shared__ float lse_lds2[2][TQ], ds_lds2[2][TQ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, hk = blockIdx.y;
@@ -514,25 +516,77 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) 
             dv[t][r] = 0.0f;
         }
 
-    for (int hg = 0; hg < group; ++hg) {
+    constexpr int PQ = TQ * 8 / 256;            // 16-byte pieces per thread of a [TQ][64] tile
+    constexpr int PT = 64 * (TQ / 8) / 256;     // ... of a [64][TQ] tile
+    bf16x8 rq[NP][PQ], rg[NP][PQ], rqt[NP][PT], rgt[NP][PT];
+    float r_lse = 0.0f, r_ds = 0.0f;
+    const int nqt = (p.Nq + TQ - 1) / TQ, ntiles = group * nqt;
+    auto tile_load = [&](int it) {
+        const int hg = it / nqt, q0 = (it - hg * nqt) * TQ;
         const int h = hk * group + hg;
         const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
-        for (int q0 = 0; q0 < p.Nq; q0 += TQ) {
-            __syncthreads();
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                sat_att_stage<TQ, 64, SAT_ATT_ROW>(q_lds[pl], p.q_rm[pl] + qplane + (size_t)q0 * SAT_ATT_D, SAT_ATT_D);
-                sat_att_stage<TQ, 64, SAT_ATT_ROW>(g_lds[pl], p.do_rm[pl] + qplane + (size_t)q0 * SAT_ATT_D, SAT_ATT_D);
-                sat_att_stage<64, TQ, TROW>(qt_lds[pl], p.q_tr[pl] + qplane + q0, (size_t)p.Nqp);
-                sat_att_stage<64, TQ, TROW>(gt_lds[pl], p.do_tr[pl] + qplane + q0, (size_t)p.Nqp);
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int j = 0; j < PQ; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                rq[pl][j] = *reinterpret_cast<const bf16x8*>(p.q_rm[pl] + qplane + (size_t)(q0 + r) * SAT_ATT_D + part * 8);
+                rg[pl][j] = *reinterpret_cast<const bf16x8*>(p.do_rm[pl] + qplane + (size_t)(q0 + r) * SAT_ATT_D + part * 8);
             }
-            if (threadIdx.x < TQ) {
-                const int q = q0 + threadIdx.x;
-                const bool ok = q < p.Nq;
-                lse_lds[threadIdx.x] = ok ? p.lse[((long long)b * p.H + h) * p.Nq + q] * l2e : 0.0f;
-                ds_lds[threadIdx.x] = ok ? p.dsum[((long long)b * p.H + h) * p.Nq + q] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int c = threadIdx.x + j * 256, r = c / (TQ / 8), part = c - r * (TQ / 8);
+                rqt[pl][j] = *reinterpret_cast<const bf16x8*>(p.q_tr[pl] + qplane + (size_t)r * p.Nqp + q0 + part * 8);
+                rgt[pl][j] = *reinterpret_cast<const bf16x8*>(p.do_tr[pl] + qplane + (size_t)r * p.Nqp + q0 + part * 8);
             }
-            __syncthreads();
+        }
+        if (threadIdx.x < TQ) {
+            const int q = q0 + threadIdx.x;
+            const bool ok = q < p.Nq;
+            r_lse = ok ? p.lse[((long long)b * p.H + h) * p.Nq + q] * l2e : 0.0f;
+            r_ds = ok ? p.dsum[((long long)b * p.H + h) * p.Nq + q] : 0.0f;
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int j = 0; j < PQ; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                *reinterpret_cast<bf16x8*>(&q_lds2[buf][pl][r][part * 8]) = rq[pl][j];
+                *reinterpret_cast<bf16x8*>(&g_lds2[buf][pl][r][part * 8]) = rg[pl][j];
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int c = threadIdx.x + j * 256, r = c / (TQ / 8), part = c - r * (TQ / 8);
+                *reinterpret_cast<bf16x8*>(&qt_lds2[buf][pl][r][part * 8]) = rqt[pl][j];
+                *reinterpret_cast<bf16x8*>(&gt_lds2[buf][pl][r][part * 8]) = rgt[pl][j];
+            }
+        }
+        if (threadIdx.x < TQ) {
+            lse_lds2[buf][threadIdx.x] = r_lse;
+            ds_lds2[buf][threadIdx.x] = r_ds;
+        }
+    };
+
+    tile_load(0);
+    tile_store(0);
+    if (ntiles > 1) tile_load(1);
+    __syncthreads();
+    for (int it = 0, buf = 0; it < ntiles; ++it, buf ^= 1) {
+        short (*q_lds)[TQ][SAT_ATT_ROW] = q_lds2[buf];
+        short (*g_lds)[TQ][SAT_ATT_ROW] = g_lds2[buf];
+        short (*qt_lds)[SAT_ATT_D][TROW] = qt_lds2[buf];
+        short (*gt_lds)[SAT_ATT_D][TROW] = gt_lds2[buf];
+        const float* lse_lds = lse_lds2[buf];
+        const float* ds_lds = ds_lds2[buf];
+        const int q0 = (it % nqt) * TQ;
+        if (it + 1 < ntiles) {
+            tile_store(buf ^ 1);                          // tile it+1: registers -> the other buffer
+            if (it + 2 < ntiles) tile_load(it + 2);       // tile it+2 -> registers
+        }
+        {
+            {
 #pragma unroll
             for (int qb = 0; qb < TQ / 32; ++qb) {
                 f32x16 sacc, pacc;
@@ -580,7 +634,9 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) 
                     }
                 }
             }
+            }
         }
+        __syncthreads();
     }
     if (k_ok) {
         const long long obase = (((long long)b * p.Hkv + hk) * p.Nk + krow) * SAT_ATT_D;
