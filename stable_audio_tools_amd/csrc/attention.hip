@@ -368,9 +368,10 @@ __global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NP>
 __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
-    __shared__ __attribute__((aligned(16))) short k_lds[NP][SAT_ATT_T][SAT_ATT_ROW];    // [key][d]
-    __shared__ __attribute__((aligned(16))) short v_lds[NP][SAT_ATT_T][SAT_ATT_ROW];    // [key][d]
-    __shared__ __attribute__((aligned(16))) short kt_lds[NP][SAT_ATT_D][SAT_ATT_ROW];   // [d][key]
+    // K, V (row-major) and K^T tiles double-buffered; tile k+1 travels through registers while tile k is consumed
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];    // [buffer][plane][key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];    // [key][d]
+    __shared__ __attribute__((aligned(16))) short kt_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [d][key]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -407,15 +408,42 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
 
-    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T) {
-        __syncthreads();
+    bf16x8 rk[NP][2], rv[NP][2], rkt[NP][2];
+    auto tile_load = [&](int k0) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            sat_att_stage<64, 64, SAT_ATT_ROW>(k_lds[pl], p.k_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
-            sat_att_stage<64, 64, SAT_ATT_ROW>(v_lds[pl], p.v_rm[pl] + kplane + (size_t)k0 * SAT_ATT_D, SAT_ATT_D);
-            sat_att_stage<64, 64, SAT_ATT_ROW>(kt_lds[pl], p.k_tr[pl] + kplane + k0, (size_t)p.Nkp);
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                rk[pl][j] = *reinterpret_cast<const bf16x8*>(p.k_rm[pl] + kplane + (size_t)(k0 + r) * SAT_ATT_D + part * 8);
+                rv[pl][j] = *reinterpret_cast<const bf16x8*>(p.v_rm[pl] + kplane + (size_t)(k0 + r) * SAT_ATT_D + part * 8);
+                rkt[pl][j] = *reinterpret_cast<const bf16x8*>(p.k_tr[pl] + kplane + (size_t)r * p.Nkp + k0 + part * 8);
+            }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+                *reinterpret_cast<bf16x8*>(&k_lds2[buf][pl][r][part * 8]) = rk[pl][j];
+                *reinterpret_cast<bf16x8*>(&v_lds2[buf][pl][r][part * 8]) = rv[pl][j];
+                *reinterpret_cast<bf16x8*>(&kt_lds2[buf][pl][r][part * 8]) = rkt[pl][j];
+            }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
+        short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW] = k_lds2[buf];
+        short (*v_lds)[SAT_ATT_T][SAT_ATT_ROW] = v_lds2[buf];
+        short (*kt_lds)[SAT_ATT_D][SAT_ATT_ROW] = kt_lds2[buf];
+        if (k0 + SAT_ATT_T < p.Nk) {
+            tile_store(buf ^ 1);
+            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
         }
-        __syncthreads();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 sacc, pacc;
@@ -455,6 +483,7 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
                 }
             }
         }
+        __syncthreads();
     }
     if (q_ok) {
         const long long obase = (((long long)b * p.H + h) * p.Nq + qrow) * SAT_ATT_D;
@@ -472,7 +501,11 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 //   dS = P (dP - D[q]) scale ; dK^T += Q^T dS
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NP, int TQ>   // TQ = queries per tile (64, or 32 for the two-plane variant: LDS budget)
-__global__ void __launch_bounds__(256) sat_attn_bwd_dkv_kernel(SatAttnParams p) {
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))   // two workgroups per CU (2 x 75 KB of LDS): one stages while the other computes
+#endif
+sat_attn_bwd_dkv_kernel(SatAttnParams p) {
     constexpr int TROW = TQ + 8;           // transposed-tile row (80 B or 144 B stride: conflict-free)
     // the four query-side tiles (Q, dO row-major; Q^T, dO^T) are double-buffered: tile i+1 travels through registers while
     // tile i is consumed — one barrier per tile
