@@ -214,7 +214,11 @@ template <> struct SatOut<short> { static SAT_DEVICE void put(void* p, long long
 // forward
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NP>
-__global__ void __launch_bounds__(256) sat_attn_fwd_kernel(SatAttnParams p) {
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(3)))       // >= 3 workgroups per CU so that softmax VALU of one overlaps MFMAs of another
+#endif
+sat_attn_fwd_kernel(SatAttnParams p) {
     // K / V^T tiles double-buffered in LDS; tile k+1 travels through registers while tile k is consumed: one barrier per tile
     __shared__ __attribute__((aligned(16))) short k_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];   // [buffer][plane][key][d]
     __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][plane][d][key]
