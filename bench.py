@@ -30,8 +30,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 3 vae_train, 50 dit_sample, 5 dit_train)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 1 / 5 / 2)")
     ap.add_argument("--batch", type=int, default=None,
                     help="items per GPU per step (default: 1 for vae_train and dit_sample, 4 for dit_train)")
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
@@ -44,6 +44,11 @@ def parse():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.workload == "dit_train" else 1
+    dsteps, dwarm = {"vae_train": (3, 1), "dit_sample": (50, 5), "dit_train": (5, 2)}[args.workload]
+    if args.steps is None:
+        args.steps = dsteps
+    if args.warmup is None:
+        args.warmup = dwarm
     return args
 
 
