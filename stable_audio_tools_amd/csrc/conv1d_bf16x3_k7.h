@@ -19,12 +19,6 @@
 #define SAT_K7_AROWS 320          // 256 main rows + up to 62 halo rows + scratch rows; the last one is the dummy row
 #define SAT_K7_KROW 72            // 8 groups x 8 + 8 pad bf16 per weight row (144 B: conflict-free b128 reads)
 
-template <int B, class T>
-SAT_DEVICE T& sat_sel(T& a, T& b) {
-    if constexpr (B == 0) return a;
-    else return b;
-}
-
 template <bool SNAKE, bool EXACT>
 __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConvBfLaunch a) {
     constexpr int CO_T = SAT_K7_CO, T_T = SAT_K7_T, NT = SAT_K7_NT, AROWS = SAT_K7_AROWS, KROW = SAT_K7_KROW;
@@ -109,9 +103,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
     };
     auto write_lds = [&](auto buf_c, auto set_c) {
         constexpr int st = decltype(set_c)::value;
-        auto& w_lds = sat_sel<decltype(buf_c)::value>(w_lds0, w_lds1);
-        auto& a_lds = sat_sel<decltype(buf_c)::value>(a_lds0, a_lds1);
-        auto& c_lds = sat_sel<decltype(buf_c)::value>(c_lds0, c_lds1);     // chunk c's constants live in slot c & 1 = buffer index
+        auto& w_lds = sat_pick<decltype(buf_c)::value>(w_lds0, w_lds1);
+        auto& a_lds = sat_pick<decltype(buf_c)::value>(a_lds0, a_lds1);
+        auto& c_lds = sat_pick<decltype(buf_c)::value>(c_lds0, c_lds1);     // chunk c's constants live in slot c & 1 = buffer index
 #pragma unroll
         for (int it = 0; it < NEL; ++it) {
             const int id = tid + it * NT;
@@ -133,12 +127,12 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
         }
     };
     auto store_consts = [&](auto slot_c, float v) {
-        auto& c_lds = sat_sel<decltype(slot_c)::value>(c_lds0, c_lds1);
+        auto& c_lds = sat_pick<decltype(slot_c)::value>(c_lds0, c_lds1);
         (&c_lds[0][0])[c_idx] = v;
     };
     auto mfma_phase = [&](auto buf_c) {
-        auto& w_lds = sat_sel<decltype(buf_c)::value>(w_lds0, w_lds1);
-        auto& a_lds = sat_sel<decltype(buf_c)::value>(a_lds0, a_lds1);
+        auto& w_lds = sat_pick<decltype(buf_c)::value>(w_lds0, w_lds1);
+        auto& a_lds = sat_pick<decltype(buf_c)::value>(a_lds0, a_lds1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int g = 2 * ks + hi;                     // k-slots 0-7 <- tap group 2ks (lanes 0-31), 8-15 <- group 2ks+1

@@ -16,12 +16,6 @@
 #define SAT_WP_NT 512
 #define SAT_WP_NI 64                 // input channels per workgroup
 
-template <int B, class T>
-SAT_DEVICE T& sat_wsel(T& a, T& b) {
-    if constexpr (B == 0) return a;
-    else return b;
-}
-
 template <int DIL>
 __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWgBfParams p) {
     constexpr int NCH = (6 * DIL + 7) / 8 + 1;                       // aligned 8-element chunks covering all 7 taps
@@ -111,8 +105,8 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     };
     auto write_lds = [&](auto buf_c) {
         constexpr int st = 0;
-        auto& lo_lds = sat_wsel<decltype(buf_c)::value>(lo_lds0, lo_lds1);
-        auto& hi_lds = sat_wsel<decltype(buf_c)::value>(hi_lds0, hi_lds1);
+        auto& lo_lds = sat_pick<decltype(buf_c)::value>(lo_lds0, lo_lds1);
+        auto& hi_lds = sat_pick<decltype(buf_c)::value>(hi_lds0, hi_lds1);
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
             const int row = (tid >> 4) + u * 32, c4 = (tid & 15) * 4;
@@ -146,8 +140,8 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
         }
     };
     auto mfma_phase = [&](auto buf_c) {
-        auto& lo_lds = sat_wsel<decltype(buf_c)::value>(lo_lds0, lo_lds1);
-        auto& hi_lds = sat_wsel<decltype(buf_c)::value>(hi_lds0, hi_lds1);
+        auto& lo_lds = sat_pick<decltype(buf_c)::value>(lo_lds0, lo_lds1);
+        auto& hi_lds = sat_pick<decltype(buf_c)::value>(hi_lds0, hi_lds1);
 #pragma unroll
         for (int ks = 0; ks < SAT_WB_TT / 16; ++ks) {
             const int tb = 16 * ks + 8 * hi;

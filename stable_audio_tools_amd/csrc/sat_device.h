@@ -184,6 +184,14 @@ SAT_DEVICE void sat_xcd_tile(int L, int nshare, int nouter, int* share_idx, int*
     }
 }
 
+// compile-time pick of one of two objects (the two halves of a double buffer are separate __shared__ arrays so that the
+// compiler knows reads of one and writes of the other never alias)
+template <int B, class T>
+SAT_DEVICE T& sat_pick(T& a, T& b) {
+    if constexpr (B == 0) return a;
+    else return b;
+}
+
 // wave64 all-lane sum
 SAT_DEVICE float sat_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

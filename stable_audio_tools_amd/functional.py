@@ -70,7 +70,8 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
 
 
 def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake):
-    """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 stride-1 convs take the bf16x3 split-MFMA kernel."""
+    """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 (dilation 1/3/9) -> the 7-tap bf16x3 kernels; k1 and K = 2*stride ->
+    the short-kernel bf16x3 wgrad (chosen inside ops.conv_wgrad); anything else -> the fp32-MFMA kernel."""
     if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
         return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake)
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
