@@ -96,18 +96,23 @@ int sat_conv_wgrad_nsplit(int B, int M, int N, int Tlo, int K, int stride, int d
 
 /* The K = 7, stride-1, dilation 1|3|9 case of the above (every ResidualUnit's k7 conv) on the bf16 matrix cores at
  * fp32 accuracy (hi/lo split).  dy: (B, M, T), x: (B, N, T) pre-activation, alpha/beta: SnakeBeta log-params of x or
- * NULL.  Slab stride M*N*7; nsplit from sat_conv_wgrad7_bf16x3_nsplit. */
+ * NULL.  Slab stride M*N*7; nsplit from sat_conv_wgrad7_bf16x3_nsplit.  dy_rowsum (or NULL): [M][nsplit] per-split sums over
+ * (b, t) of the dy rows — the conv's bias gradient, produced by the workgroups that stream dy anyway (sum the nsplit
+ * columns with sat_rowsum); only the 4-wave kernel (N < 64 or T % 4 != 0, see sat_conv_wgrad7_bf16x3_fuses_rowsum) has the
+ * registers for it — the pipelined kernel measured 60 % slower with it. */
 int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, const float* beta, float* partial,
                            long long so_m, long long so_n, long long so_k, int B, int M, int N, int T, int dil, int pad,
-                           void* stream);
+                           float* dy_rowsum, void* stream);
 int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T);
+int sat_conv_wgrad7_bf16x3_fuses_rowsum(int B, int M, int N, int T);
 
 /* sat_conv_wgrad for K == 1 (stride 1; the k1 conv of every ResidualUnit) and K == 2*stride with a power-of-two stride
  * (the down / up convs, autoencoders.py:245-247, :266-268) on the bf16 matrix cores at fp32 accuracy.  Same arguments as
- * sat_conv_wgrad (dilation 1); slab stride M*N*K; nsplit from sat_conv_wgrad_bf16x3_nsplit (-1: unsupported shape). */
+ * sat_conv_wgrad (dilation 1); slab stride M*N*K; nsplit from sat_conv_wgrad_bf16x3_nsplit (-1: unsupported shape).
+ * lo_rowsum (or NULL): [M][nsplit] per-split row sums of the raw lo tensor (the bias gradient when lo = dy). */
 int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const float* alpha, const float* beta, int snake_on,
                           float* partial, long long so_m, long long so_n, long long so_k, int B, int M, int N, int Tlo,
-                          int Thi, int K, int stride, int pad, void* stream);
+                          int Thi, int K, int stride, int pad, float* lo_rowsum, void* stream);
 int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K, int stride);
 
 /* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */

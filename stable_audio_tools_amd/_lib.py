@@ -30,9 +30,10 @@ SIGNATURES = {
     "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I, _I]),
     "sat_snake_consts": (_I, [_P, _P, _P, _P, _I, _P]),
     # conv_wgrad_bf16x3.hip
-    "sat_conv_wgrad7_bf16x3": (_I, [_P] * 5 + [_L] * 3 + [_I] * 6 + [_P]),
+    "sat_conv_wgrad7_bf16x3": (_I, [_P] * 5 + [_L] * 3 + [_I] * 6 + [_P, _P]),
     "sat_conv_wgrad7_bf16x3_nsplit": (_I, [_I] * 4),
-    "sat_conv_wgrad_bf16x3": (_I, [_P] * 4 + [_I, _P] + [_L] * 3 + [_I] * 8 + [_P]),
+    "sat_conv_wgrad7_bf16x3_fuses_rowsum": (_I, [_I] * 4),
+    "sat_conv_wgrad_bf16x3": (_I, [_P] * 4 + [_I, _P] + [_L] * 3 + [_I] * 8 + [_P, _P]),
     "sat_conv_wgrad_bf16x3_nsplit": (_I, [_I] * 6),
     # convtr1d.hip
     "sat_convtr1d": (_I, [_P] * 12 + [_I] * 9 + [_P]),

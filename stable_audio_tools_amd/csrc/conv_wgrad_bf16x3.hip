@@ -27,7 +27,17 @@ struct SatWgBfParams {
     long long so_split, so_m, so_n, so_k;
     int B, M, N, T, pad;
     int chunks_per_split, nchunks, nT;
+    float* rowsum;       // or null: [M][nsplit] per-split sums over (b, t) of dy rows (the conv's bias gradient), written by
+    int nsplit;          //          the workgroups of the first column tile — dy streams through them anyway
 };
+
+// sum of a float4 over the 16 consecutive lanes that hold one staged row (64 time steps); valid in lanes with (lane & 15) == 0
+SAT_DEVICE float sat_row16_sum(float4 q) {
+    float s = (q.x + q.y) + (q.z + q.w);
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) s += __shfl_xor(s, m);
+    return s;
+}
 
 #if defined(SAT_HIPEMU)
 static inline unsigned sat_alignbit(unsigned hi, unsigned lo, unsigned s) {
@@ -63,6 +73,9 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
     for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    const bool want_rs = p.rowsum != nullptr && n0 == 0;     // block-uniform
+    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row (tid >> 4) + 16 i, valid in lanes with (tid & 15) == 0
 
     if (tid < 32) {
         const int c = n0 + tid;
@@ -114,6 +127,7 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
             for (int u = 0; u < 4; ++u) {
                 const int idx = tid + (half * 4 + u) * 256;
                 const int row = idx >> 4, c4 = (idx & 15) * 4;
+                if (want_rs) rs[half * 4 + u] += sat_row16_sum(v[u]);
                 uint32_t h0, h1, l0, l1;
                 sat_split2_pk(v[u].x, v[u].y, &h0, &l0);
                 sat_split2_pk(v[u].z, v[u].w, &h1, &l1);
@@ -205,6 +219,13 @@ sat_wgrad7_bf16x3_kernel(SatWgBfParams p) {
         __syncthreads();
     }
 
+    if (want_rs && (tid & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + (tid >> 4) + 16 * i;
+            if (m < p.M) p.rowsum[(size_t)m * p.nsplit + split] = rs[i];
+        }
+    }
     if (wave_on) {
         float* ob = p.out + (size_t)split * p.so_split;
         const int n = n0 + l31;
@@ -238,18 +259,25 @@ extern "C" int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T) {
     sat_wgbf_plan(B, M, N, T, &pl);
     return pl.nsplit;
 }
+extern "C" int sat_conv_wgrad7_bf16x3_fuses_rowsum(int B, int M, int N, int T) {
+    SatWgBfPlan pl;
+    sat_wgbf_plan(B, M, N, T, &pl);
+    return pl.pipe ? 0 : 1;
+}
 // dW[m][n][k] for a K = 7, stride-1 conv with dilation in {1, 3, 9}: dy (B, M, T), x (B, N, T) pre-activation,
 // alpha/beta = SnakeBeta log-params of the conv input (or NULL).  Writes nsplit slabs (element (m,n,k) at
 // m*so_m + n*so_n + k*so_k, slab stride M*N*7); sum them with sat_reduce_splits.
 extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, const float* beta, float* partial,
                                       long long so_m, long long so_n, long long so_k, int B, int M, int N, int T, int dil,
-                                      int pad, void* stream) {
+                                      int pad, float* dy_rowsum, void* stream) {
     if (B <= 0 || M <= 0 || N <= 0 || T <= 0) { sat_set_error("sat_conv_wgrad7_bf16x3: empty shape"); return 1; }
     if (dil != 1 && dil != 3 && dil != 9) { sat_set_error("sat_conv_wgrad7_bf16x3: dilation must be 1, 3 or 9 (the Oobleck ResidualUnits)"); return 1; }
     if ((alpha == nullptr) != (beta == nullptr)) { sat_set_error("sat_conv_wgrad7_bf16x3: alpha/beta must both be given"); return 1; }
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
-    SatWgBfParams p{dy, x, alpha, beta, partial, (long long)M * N * 7, so_m, so_n, so_k, B, M, N, T, pad, pl.cps, pl.nchunks, pl.nT};
+    if (dy_rowsum && pl.pipe) { sat_set_error("sat_conv_wgrad7_bf16x3: dy_rowsum is only produced by the 4-wave kernel (N < 64 or T % 4 != 0); use sat_rowsum"); return 1; }
+    SatWgBfParams p{dy, x, alpha, beta, partial, (long long)M * N * 7, so_m, so_n, so_k, B, M, N, T, pad, pl.cps, pl.nchunks, pl.nT,
+                    dy_rowsum, pl.nsplit};
     if (pl.pipe) {
         dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, SAT_WP_NI), pl.nsplit);
         if (dil == 1) SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<1>, grid, dim3(SAT_WP_NT), stream, p);
@@ -287,6 +315,8 @@ struct SatWgSmallParams {
     long long so_split, so_m, so_n, so_k;
     int B, M, N, Tlo, Thi, pad, snake_on, s_log2;
     int chunks_per_split, nchunks, nT;
+    float* rowsum;       // or null: [M][nsplit] per-split sums over (b, t) of the raw lo rows (bias gradient when lo = dy)
+    int nsplit;
 };
 
 template <int NT>
@@ -321,6 +351,9 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
             for (int k = 0; k < NT; ++k)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.0f;
+
+    const bool want_rs = p.rowsum != nullptr && v0 == 0;     // block-uniform
+    float rsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row (tid >> 4) + 16 i, valid in lanes with (tid & 15) == 0
 
     if (tid < SAT_CO_T) {
         float sa = 1.f, sib = 0.f;
@@ -374,6 +407,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
                     const int idx = tid + (half * 4 + u) * 256;
                     const int row = idx >> 4, c4 = (idx & 15) * 4;
                     float4 q = v[u];
+                    if (want_rs) rsum[half * 4 + u] += sat_row16_sum(q);
                     if (snake_lo) {
                         const float sa = sn_a[row], sib = sn_ib[row];
                         q.x = sat_snake(q.x, sa, sib);
@@ -474,6 +508,13 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
         __syncthreads();
     }
 
+    if (want_rs && (tid & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + (tid >> 4) + 16 * i;
+            if (m < p.M) p.rowsum[(size_t)m * p.nsplit + split] = rsum[i];
+        }
+    }
     if (wave_on) {
         float* ob = p.out + (size_t)split * p.so_split;
 #pragma unroll
@@ -523,7 +564,7 @@ extern "C" int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K,
 // bf16 matrix cores at fp32 accuracy.  Slab stride M*N*K; nsplit from sat_conv_wgrad_bf16x3_nsplit (-1: unsupported).
 extern "C" int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const float* alpha, const float* beta, int snake_on,
                                      float* partial, long long so_m, long long so_n, long long so_k, int B, int M, int N,
-                                     int Tlo, int Thi, int K, int stride, int pad, void* stream) {
+                                     int Tlo, int Thi, int K, int stride, int pad, float* lo_rowsum, void* stream) {
     SatWgBfPlan pl;
     int sl, nt;
     if (!sat_wgs_plan(B, M, N, Tlo, K, stride, &pl, &sl, &nt)) {
@@ -534,7 +575,7 @@ extern "C" int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const flo
     if (alpha && (snake_on != 1 && snake_on != 2)) { sat_set_error("sat_conv_wgrad_bf16x3: snake_on must be 1 (lo) or 2 (hi)"); return 1; }
     if ((alpha == nullptr) != (beta == nullptr)) { sat_set_error("sat_conv_wgrad_bf16x3: alpha/beta must both be given"); return 1; }
     SatWgSmallParams p{lo, hi, alpha, beta, partial, (long long)M * N * K, so_m, so_n, so_k,
-                       B, M, N, Tlo, Thi, pad, alpha ? snake_on : 0, sl, pl.cps, pl.nchunks, pl.nT};
+                       B, M, N, Tlo, Thi, pad, alpha ? snake_on : 0, sl, pl.cps, pl.nchunks, pl.nT, lo_rowsum, pl.nsplit};
     dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N << sl, SAT_CO_T), pl.nsplit);
     if (nt == 1) SAT_LAUNCH(sat_wgrad_small_bf16x3_kernel<1>, grid, dim3(256), stream, p);
     else SAT_LAUNCH(sat_wgrad_small_bf16x3_kernel<2>, grid, dim3(256), stream, p);

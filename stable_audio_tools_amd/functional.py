@@ -69,12 +69,13 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
     return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
 
 
-def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake):
+def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False):
     """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 (dilation 1/3/9) -> the 7-tap bf16x3 kernels; k1 and K = 2*stride ->
-    the short-kernel bf16x3 wgrad (chosen inside ops.conv_wgrad); anything else -> the fp32-MFMA kernel."""
+    the short-kernel bf16x3 wgrad (chosen inside ops.conv_wgrad); anything else -> the fp32-MFMA kernel.
+    bias_grad=True returns (dW, dbias): the bf16x3 kernels sum the dy rows they stream anyway."""
     if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
-        return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake)
-    return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2)
+        return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake, dy_rowsum=bias_grad)
+    return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad)
 
 
 def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None):
@@ -124,10 +125,13 @@ class SnakeConv1dFn(torch.autograd.Function):
             dy = dy * (1.0 - y * y)
         snake = (alpha, beta) if has_snake else None
         dres = dy if has_res else None
-        dbias = ops.rowsum(dy) if has_bias else None
-        dw = None
+        dw = dbias = None
         if ctx.needs_input_grad[3]:
-            dw = _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake)
+            dw = _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=has_bias)
+            if has_bias:
+                dw, dbias = dw
+        elif has_bias:
+            dbias = ops.rowsum(dy)
         dx = da = db = None
         if has_snake:
             dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
@@ -200,11 +204,9 @@ class ResidualUnitFn(torch.autograd.Function):
         pad1 = dil * (k1 - 1) // 2
         t = x.shape[2]
         dy = dy.contiguous()
-        dbias2 = ops.rowsum(dy)
-        dw2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2)
+        dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
         dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2))
-        dbias1 = ops.rowsum(dh)
-        dw1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1))
+        dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
         return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None
 

@@ -209,9 +209,10 @@ class SatOps:
             return (y, *self._sum_pair(pda, pdb))
         return y
 
-    def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False):
+    def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False, lo_rowsum=False):
         """dW[m][n][k] = sum_{b,t} actA(lo[b,m,t]) * actB(hi[b,n,t*s + k*d - pad]).
-        Returns (M, N, K); with transposed_out=True returns it laid out as (N, M, K)."""
+        Returns (M, N, K); with transposed_out=True returns it laid out as (N, M, K).
+        lo_rowsum=True also returns sum_{b,t} lo[b,m,t] (the bias gradient when lo = dy): (dW, (M,))."""
         bsz, m, tlo = lo.shape
         _, n, thi = hi.shape
         alpha, beta = snake if snake is not None else (None, None)
@@ -230,21 +231,28 @@ class SatOps:
         else:
             so_m, so_n, so_k = n * k, k, 1
             shape = (m, n, k)
+        rs = None
         if x3:
+            fused = lo_rowsum and not (snake is not None and snake_on == 1)     # the kernel sums the rows it stages anyway
+            rs = torch.empty(m, nsplit, dtype=torch.float32, device=lo.device) if fused else None
             self._chk(self.lib.sat_conv_wgrad_bf16x3(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta),
                                                      snake_on if snake is not None else 0, _ptr(partial), so_m, so_n, so_k,
-                                                     bsz, m, n, tlo, thi, k, stride, pad, self._stream(lo)))
+                                                     bsz, m, n, tlo, thi, k, stride, pad, _ptr(rs), self._stream(lo)))
         else:
             self._chk(self.lib.sat_conv_wgrad(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta), snake_on if snake is not None else 0,
                                               _ptr(partial), so_m, so_n, so_k, bsz, m, n, tlo, thi, k, stride, dil, pad,
                                               self._stream(lo)))
-        return self._reduce_rows(partial, nsplit, m * n * k).view(shape)
+        dw = self._reduce_rows(partial, nsplit, m * n * k).view(shape)
+        if not lo_rowsum:
+            return dw
+        return dw, (self._sum_last(rs) if rs is not None else self.rowsum(lo))
 
     def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):
         return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9)
 
-    def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None):
-        """dW (Cout, Cin, 7) of a k7 stride-1 conv: dy (B, Cout, T), x (B, Cin, T) pre-activation, snake = (log-alpha, log-beta)."""
+    def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None, dy_rowsum=False):
+        """dW (Cout, Cin, 7) of a k7 stride-1 conv: dy (B, Cout, T), x (B, Cin, T) pre-activation, snake = (log-alpha, log-beta).
+        dy_rowsum=True also returns the bias gradient sum_{b,t} dy (fused into the kernel): (dW, (Cout,))."""
         b, m, t = dy.shape
         n = x.shape[1]
         alpha, beta = snake if snake is not None else (None, None)
@@ -253,9 +261,14 @@ class SatOps:
         partial = torch.empty(nsplit, m * n * 7, dtype=torch.float32, device=dy.device)
         # slabs are written tap-major ([7][M][N]: the 32 lanes of an accumulator row store 128 contiguous bytes; the
         # reference (M, N, 7) order would scatter 4-byte stores 28 bytes apart — 6.7x the write traffic, measured)
+        fused = dy_rowsum and self.lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(b, m, n, t) == 1
+        rs = torch.empty(m, nsplit, dtype=torch.float32, device=dy.device) if fused else None
         self._chk(self.lib.sat_conv_wgrad7_bf16x3(_ptr(dy), _ptr(x), _ptr(alpha), _ptr(beta), _ptr(partial), n, 1, m * n,
-                                                  b, m, n, t, dil, pad, self._stream(dy)))
-        return self._reduce_rows(partial, nsplit, m * n * 7).view(7, m, n).permute(1, 2, 0).contiguous()
+                                                  b, m, n, t, dil, pad, _ptr(rs), self._stream(dy)))
+        dw = self._reduce_rows(partial, nsplit, m * n * 7).view(7, m, n).permute(1, 2, 0).contiguous()
+        if not dy_rowsum:
+            return dw
+        return dw, (self._sum_last(rs) if fused else self.rowsum(dy))
 
     def rowsum(self, x):
         """(B, C, T) -> (C,) sum over batch and time: per-(channel, time split) partial sums laid out [C][nsplit], summed
