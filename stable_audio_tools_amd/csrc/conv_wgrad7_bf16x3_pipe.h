@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     auto mfma_phase = [&](auto buf_c) {
         auto& lo_lds = sat_pick<decltype(buf_c)::value>(lo_lds0, lo_lds1);
         auto& hi_lds = sat_pick<decltype(buf_c)::value>(hi_lds0, hi_lds1);
-#pragma unroll
+#pragma unroll 2
         for (int ks = 0; ks < SAT_WB_TT / 16; ++ks) {
             const int tb = 16 * ks + 8 * hi;
             bf16x8 af[2];
