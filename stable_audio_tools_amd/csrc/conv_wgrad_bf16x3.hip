@@ -375,6 +375,106 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
     const int up = rs >> 1;                                          // ... in pairs (rs is even)
     const int total_units = nc * up;
 
+    auto mfma_stage = [&]() {
+        if (wave_on) {
+#pragma unroll
+            for (int ks = 0; ks < SAT_WS_TT / 16; ++ks) {
+                const int tb = 16 * ks + 8 * hi;
+                bf16x8 af[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        af[mi][pl] = *reinterpret_cast<const bf16x8*>(&lo_lds[pl][m_w + mi * 32 + l31][tb]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        u32x4 cw[NCH];
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) cw[j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][v_w + ni * 32 + l31][tb + 8 * j]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            u32x4 r = cw[0];
+                            if (j == 1) {
+                                r[0] = sat_alignbit(cw[0][1], cw[0][0], 16);
+                                r[1] = sat_alignbit(cw[0][2], cw[0][1], 16);
+                                r[2] = sat_alignbit(cw[0][3], cw[0][2], 16);
+                                r[3] = sat_alignbit(cw[NCH - 1][0], cw[0][3], 16);
+                            }
+                            const bf16x8 bf = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) {
+                                acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][0], bf, acc[mi][ni][j]);
+                                if (pl == 0) acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][1], bf, acc[mi][ni][j]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // k = 1 convs (NT == 1, no padding, 16-byte aligned rows): both operands are 128 x 64 tiles read as float4, and the
+    // stage is software-pipelined — the loads of stage c+1 are issued before the MFMAs of stage c
+    const bool fast1 = (NT == 1) && sl == 0 && p.pad == 0 && (p.Tlo & 3) == 0 && p.Thi == p.Tlo;
+    if (fast1) {
+        float4 vlo[8], vhi[8];
+        const int row0 = tid >> 4, c4 = (tid & 15) * 4;
+        auto issue = [&](int ch) {
+            const int b = ch / p.nT;
+            const int tt0 = (ch - b * p.nT) * SAT_WS_TT;
+            const float* slo = p.lo + (size_t)b * p.M * p.Tlo;
+            const float* shi = p.hi + (size_t)b * p.N * p.Thi;
+            const bool t_ok = tt0 + c4 < p.Tlo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + row0 + 16 * u, n = v0 + row0 + 16 * u;
+                const bool okm = t_ok && m < p.M, okn = t_ok && n < p.N;
+                const float4 a = *reinterpret_cast<const float4*>(slo + (size_t)(okm ? m : 0) * p.Tlo + (okm ? tt0 + c4 : 0));
+                const float4 c = *reinterpret_cast<const float4*>(shi + (size_t)(okn ? n : 0) * p.Thi + (okn ? tt0 + c4 : 0));
+                vlo[u] = okm ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+                vhi[u] = okn ? c : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto convert = [&]() {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = row0 + 16 * u;
+                float4 q = vlo[u];
+                if (want_rs) rsum[u] += sat_row16_sum(q);
+                if (snake_lo) {
+                    const float sa = sn_a[row], sib = sn_ib[row];
+                    q.x = sat_snake(q.x, sa, sib); q.y = sat_snake(q.y, sa, sib);
+                    q.z = sat_snake(q.z, sa, sib); q.w = sat_snake(q.w, sa, sib);
+                }
+                uint32_t h0, h1, l0, l1;
+                sat_split2_pk(q.x, q.y, &h0, &l0);
+                sat_split2_pk(q.z, q.w, &h1, &l1);
+                *reinterpret_cast<u2*>(&lo_lds[0][row][c4]) = u2{h0, h1};
+                *reinterpret_cast<u2*>(&lo_lds[1][row][c4]) = u2{l0, l1};
+                q = vhi[u];
+                if (snake_hi) {
+                    const float sa = sn_a[row], sib = sn_ib[row];
+                    q.x = sat_snake(q.x, sa, sib); q.y = sat_snake(q.y, sa, sib);
+                    q.z = sat_snake(q.z, sa, sib); q.w = sat_snake(q.w, sa, sib);
+                }
+                sat_split2_pk(q.x, q.y, &h0, &l0);
+                sat_split2_pk(q.z, q.w, &h1, &l1);
+                *reinterpret_cast<u2*>(&hi_lds[0][row][c4]) = u2{h0, h1};
+                *reinterpret_cast<u2*>(&hi_lds[1][row][c4]) = u2{l0, l1};
+            }
+        };
+        issue(c_begin);
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            convert();
+            __syncthreads();
+            if (ch + 1 < c_end) issue(ch + 1);
+            mfma_stage();
+            __syncthreads();
+        }
+    } else
     for (int ch = c_begin; ch < c_end; ++ch) {
         const int b = ch / p.nT;
         const int tt0 = (ch - b * p.nT) * SAT_WS_TT;
@@ -468,43 +568,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
             }
         }
         __syncthreads();
-        if (wave_on) {
-#pragma unroll
-            for (int ks = 0; ks < SAT_WS_TT / 16; ++ks) {
-                const int tb = 16 * ks + 8 * hi;
-                bf16x8 af[2][2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        af[mi][pl] = *reinterpret_cast<const bf16x8*>(&lo_lds[pl][m_w + mi * 32 + l31][tb]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        u32x4 cw[NCH];
-#pragma unroll
-                        for (int j = 0; j < NCH; ++j) cw[j] = *reinterpret_cast<const u32x4*>(&hi_lds[pl][v_w + ni * 32 + l31][tb + 8 * j]);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            u32x4 r = cw[0];
-                            if (j == 1) {
-                                r[0] = sat_alignbit(cw[0][1], cw[0][0], 16);
-                                r[1] = sat_alignbit(cw[0][2], cw[0][1], 16);
-                                r[2] = sat_alignbit(cw[0][3], cw[0][2], 16);
-                                r[3] = sat_alignbit(cw[NCH - 1][0], cw[0][3], 16);
-                            }
-                            const bf16x8 bf = __builtin_bit_cast(bf16x8, r);
-#pragma unroll
-                            for (int mi = 0; mi < 2; ++mi) {
-                                acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][0], bf, acc[mi][ni][j]);
-                                if (pl == 0) acc[mi][ni][j] = sat_mfma_32x32x16_bf16(af[mi][1], bf, acc[mi][ni][j]);
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        mfma_stage();
         __syncthreads();
     }
 
