@@ -77,6 +77,26 @@ def test_argument_validation_never_launches():
     assert lib.sat_stft_tiles(2048, 512, 2097152) == 513
     assert lib.sat_stft_tiles(2048, 512, 1000) == -1        # reflect pad needs T > n_fft/2
     assert lib.sat_convtr1d_partial_rows(1, 64, 16, 8) == -1
+    # bf16x3 family: geometry rules, plan sizes and partial-plane sizes (host code only)
+    assert lib.sat_conv1d_bf16x3(*([null] * 13), 1, 8, 8, 64, 64, 9, 1, 1, 4, 0, null) != 0
+    assert b"K <= 8" in lib.sat_last_error()
+    assert lib.sat_conv1d_bf16x3(*([null] * 13), 1, 8, 8, 64, 21, 6, 3, 1, 2, 0, null) != 0      # K = 2*stride but stride not 2^n
+    assert lib.sat_conv1d_bf16x3(*([null] * 13), 1, 8, 8, 64, 64, 7, 1, 12, 36, 0, null) != 0
+    assert b"receptive field" in lib.sat_last_error()
+    assert lib.sat_convtr1d_bf16x3(*([null] * 13), 1, 8, 8, 16, 64, 6, 4, 2, 0, null) != 0
+    assert b"2*stride" in lib.sat_last_error()
+    assert lib.sat_pack_weights_bf16x3_size(128, 128, 7, 1, 0) == 16 * 128 * 64       # 16 chunks of 8 channels x 8 tap groups
+    assert lib.sat_pack_weights_bf16x3_size(128, 128, 1, 1, 0) == 4 * 128 * 32        # 4 chunks of 32 channels
+    assert lib.sat_pack_weights_bf16x3_size(256, 128, 4, 2, 0) == 8 * 256 * 64        # 128*2 virtual channels, 2 taps
+    assert lib.sat_pack_weights_bf16x3_size(128, 128, 6, 3, 0) == -1                  # stride 3: fp32-MFMA fallback kernels
+    assert lib.sat_conv1d_bf16x3_partial_rows(1, 2097152, 7, 1) == 8192               # k7: 256-wide time tiles
+    assert lib.sat_conv1d_bf16x3_partial_rows(1, 2097152, 1, 1) == 16384              # others: 128-wide
+    assert lib.sat_conv_wgrad_bf16x3_nsplit(1, 128, 128, 2097152, 1, 1) == 512
+    assert lib.sat_conv_wgrad_bf16x3_nsplit(1, 128, 128, 65536, 3, 1) == -1
+    assert lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(1, 128, 2, 2097152) == 1             # narrow input: 4-wave kernel
+    assert lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(1, 128, 128, 2097152) == 0           # pipelined kernel: separate sat_rowsum
+    assert lib.sat_conv_wgrad7_bf16x3(*([null] * 5), 7, 1, 0, 1, 8, 8, 64, 2, 6, null, null) != 0
+    assert b"dilation" in lib.sat_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
