@@ -67,3 +67,69 @@ def test_dit_train_step_bf16_autocast_gpu(hip):
     losses = [float(stepper(inp["x"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], t=inp["t"], noise=noise)["loss"])
               for _ in range(10)]
     assert all(math.isfinite(v) for v in losses) and min(losses[-3:]) < losses[0], losses
+
+
+# ---- N > 1: world_size-2 gloo processes on CPU (kernels on the simulator) — BASELINE.json configs[3] (DiT training, DDP) ----
+def _dit_ddp_worker(rank, world, port, q):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for pth in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from emu_util import emu_ops
+    from stable_audio_tools_amd import functional
+    from stable_audio_tools_amd.training import DiTTrainStep
+    functional._TEST_OPS = emu_ops()
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, _ = _build("tiny_adaln", 710, "cpu")
+        model.train(True)
+        stepper = DiTTrainStep(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-3, cfg_dropout_prob=0.0, use_ema=True)
+        inp = dit_inputs("tiny_adaln")
+        x0 = torch.from_numpy(seeded.seeded_array(tuple(inp["x"].shape), 1000))
+        noise = torch.from_numpy(seeded.seeded_array(tuple(inp["x"].shape), 2000))
+        t = torch.tensor([0.3, 0.8])
+        sl = slice(rank, rank + 1)                               # global batch of 2, one item per rank
+        stepper(x0[sl], cross_attn_cond=inp["cross_attn_cond"][sl], global_embed=inp["global_embed"][sl], t=t[sl], noise=noise[sl])
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        q.put((rank, [g.numpy() for g in gathered] if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dit_data_parallel_step_gloo_world2(emu_modules):
+    """Every rank ends the step with identical parameters, equal to a single-process step on the concatenated batch
+    (the v-objective MSE is a per-item mean, so the mean of per-rank gradients is the batch gradient)."""
+    import os
+
+    import torch.multiprocessing as mp
+    from stable_audio_tools_amd.training import DiTTrainStep
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_dit_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = (torch.from_numpy(a) for a in results[0])
+    assert torch.equal(r0, r1), "ranks diverged after the all-reduced step"
+    model, sd = _build("tiny_adaln", 710, "cpu")
+    model.train(True)
+    init = torch.cat([p.detach().reshape(-1).clone() for p in model.parameters()])
+    stepper = DiTTrainStep(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-3, cfg_dropout_prob=0.0, use_ema=True)
+    inp = dit_inputs("tiny_adaln")
+    x0 = torch.from_numpy(seeded.seeded_array(tuple(inp["x"].shape), 1000))
+    noise = torch.from_numpy(seeded.seeded_array(tuple(inp["x"].shape), 2000))
+    stepper(x0, cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], t=torch.tensor([0.3, 0.8]), noise=noise)
+    single = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    upd_ddp, upd_single = r0 - init, single - init
+    assert float((upd_ddp - upd_single).norm() / upd_single.norm()) < 5e-2
