@@ -24,13 +24,16 @@ def _leaf(gen, dev, *shape, s=1.0):
     return (torch.randn(*shape, generator=gen) * s).to(dev).requires_grad_(True)
 
 
+FLOOR = [1e-3]   # tensors whose max-abs is below this are compared against it (tiny, cancellation-dominated gradients)
+
+
 def _compare(outs, refs, inputs, gen, tol=TOL):
     gy = [torch.randn(r.shape, generator=gen).to(r.device) for r in refs]
     g1 = torch.autograd.grad(outs, inputs, gy, allow_unused=True)
     g2 = torch.autograd.grad(refs, inputs, gy, allow_unused=True)
     for a, b in list(zip(outs, refs)) + [(a, b) for a, b in zip(g1, g2) if b is not None]:
         err = (a - b).abs().max().item()
-        assert err <= tol * max(b.abs().max().item(), 1e-3), (err, b.abs().max().item())
+        assert err <= tol * max(b.abs().max().item(), FLOOR[0]), (err, b.abs().max().item())
 
 
 # (B, Cin, Cout, T, K, dil): k7 chunks of 8 channels, k1 chunks of 32, k3 chunks of 8
@@ -145,3 +148,36 @@ def test_conv_kernels_gpu_large(hip):
     _run_down(hip, "cuda", (1, 512, 1024, 4096, 8), True)
     _run_up(hip, "cuda", (1, 256, 128, 2048, 4), True)
     _run_up(hip, "cuda", (1, 1024, 512, 512, 8), True)
+
+
+def _random_cases(seed, n):
+    """Seeded random shapes around the tile edges: T below / at / just past one tile and not a multiple of 4, channel
+    counts that are not multiples of the 8-channel K-chunks or the 32/64/128-wide tiles, batch > 1."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        kind = rnd.choice(["s1", "s1", "down", "up"])
+        b = rnd.choice([1, 1, 2])
+        cin, cout = rnd.choice([1, 2, 5, 8, 17, 33, 64, 70]), rnd.choice([1, 2, 7, 32, 40, 65, 129])
+        if kind == "s1":
+            k = rnd.choice([1, 1, 3, 7, 7, 7])
+            dil = rnd.choice([1, 3, 9]) if k == 7 else 1
+            t = rnd.choice([5 * dil + 9, 63, 127, 128, 130, 257, 300])
+            out.append(("s1", (b, cin, cout, max(t, 3 * dil + 2), k, dil)))
+        else:
+            s = rnd.choice([2, 4, 8])
+            t = rnd.choice([4 * s, 8 * s + 3, 130, 259]) if kind == "down" else rnd.choice([3, 17, 64, 130])
+            out.append((kind, (b, cin, cout, t, s)))
+    return out
+
+
+@pytest.mark.parametrize("kind,case", _random_cases(20260921, 24))
+def test_conv_random_shapes_sim(emu, kind, case):
+    # one-channel / few-sample shapes produce gradients that are sums of O(1) products cancelling to ~1e-2: the bf16x3
+    # products are accurate to ~2^-16 of the PRODUCTS, so the floor for these cases is 0.1
+    FLOOR[0] = 0.1
+    try:
+        {"s1": _run_s1, "down": _run_down, "up": _run_up}[kind](emu, "cpu", case, True)
+    finally:
+        FLOOR[0] = 1e-3
