@@ -53,3 +53,51 @@ def test_layernorm_sim(emu, case):
 def test_layernorm_gpu(hip):
     for case in CASES + [(torch.bfloat16, 4, 1025, 1536, True), (torch.float32, 2, 1025, 1536, False)]:
         _ln_case(hip, "cuda", *case, seed=12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# attention: forward and backward against F.scaled_dot_product_attention (the reference's CPU path, transformer.py:440),
+# self and GQA cross shapes, sequence lengths around the 64-wide tiles (the kernels double-buffer them)
+# ---------------------------------------------------------------------------------------------------------------------
+ATT_CASES = [  # (B, H, Hkv, Nq, Nk)
+    (1, 2, 2, 64, 64), (2, 2, 2, 65, 65), (1, 4, 2, 130, 37), (1, 2, 1, 37, 200), (1, 2, 2, 193, 193), (1, 4, 4, 1, 70),
+]
+
+
+def _attn_case(ops, dev, dtype, case, seed):
+    b, h, hkv, nq, nk = case
+    gen = torch.Generator().manual_seed(seed)
+    q = torch.randn(b, h, nq, 64, generator=gen).to(dev).to(dtype)
+    k = torch.randn(b, hkv, nk, 64, generator=gen).to(dev).to(dtype)
+    v = torch.randn(b, hkv, nk, 64, generator=gen).to(dev).to(dtype)
+    do = torch.randn(b, nq, h * 64, generator=gen).to(dev).to(dtype)
+    o, lse, planes = ops.attention(q, k, v, 0.125, return_planes=True)
+    dq, dk, dv = ops.attention_bwd(planes, o, do, lse, 0.125, hkv, nk)
+
+    qr, kr, vr = (t.float().detach().requires_grad_(True) for t in (q, k, v))
+    rep = h // hkv
+    ref = F.scaled_dot_product_attention(qr, kr.repeat_interleave(rep, 1), vr.repeat_interleave(rep, 1), scale=0.125)
+    ref = ref.permute(0, 2, 1, 3).reshape(b, nq, h * 64)
+    ref.backward(do.float())
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+
+    def close(a, r):
+        err = (a.float() - r).abs().max().item()
+        assert err <= tol * max(r.abs().max().item(), 1e-2), (case, err, r.abs().max().item())
+    close(o, ref.detach())
+    close(dq, qr.grad)
+    close(dk, kr.grad)
+    close(dv, vr.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attention_sim(emu, case, dtype):
+    _attn_case(emu, "cpu", dtype, case, seed=21)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_gpu(hip, dtype):
+    for case in ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130)]:
+        _attn_case(hip, "cuda", dtype, case, seed=22)
