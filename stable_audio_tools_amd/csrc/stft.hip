@@ -229,100 +229,111 @@ __global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
     }
 }
 
+// One workgroup handles its SAT_STFT_NG frame groups for ALL views (sum / difference / left / right): the per-view
+// time-domain gradients are overlap-added straight into two per-CHANNEL LDS buffers (weights va, vb of the view), so the
+// global scatter is one atomic per sample and channel instead of one per sample, channel and view.
 __global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
     __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
-    __shared__ float obuf[SAT_STFT_OBUF];
+    __shared__ float obuf_a[SAT_STFT_OBUF], obuf_b[SAT_STFT_OBUF];
     const SatFftLds L{re, im, twr, twi};
     const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
-    const int item = blockIdx.y, view = blockIdx.z;
-    const float c1 = p.coef[(item * p.NV + view) * 3 + 0];
-    const float c2 = p.coef[(item * p.NV + view) * 3 + 1];
-    const float c3 = p.coef[(item * p.NV + view) * 3 + 2];
+    const int item = blockIdx.y;
     sat_fft_init_twiddles(L, n);
     const int fpb = SAT_STFT_NG * p.fb;
     const int olen = (fpb - 1) * p.hop + n;
-    for (int i = threadIdx.x; i < olen; i += 256) obuf[i] = 0.f;
+    for (int i = threadIdx.x; i < olen; i += 256) {
+        obuf_a[i] = 0.f;
+        obuf_b[i] = 0.f;
+    }
     __syncthreads();
     const int fbase = blockIdx.x * fpb;
-    for (int g = 0; g < SAT_STFT_NG; ++g) {
-        const int f0 = fbase + g * p.fb;
-        if (f0 >= p.nframes) break;
-        sat_stft_load_frames(p, L, item, view, f0);
-        __syncthreads();
-        sat_fft_run(L, n, log2n, p.fb);
-        // dL/dY per bin, kept in registers while the LDS frame buffer is recycled
-        float gr[5], gi[5];
+    for (int view = 0; view < p.NV; ++view) {
+        const float c1 = p.coef[(item * p.NV + view) * 3 + 0];
+        const float c2 = p.coef[(item * p.NV + view) * 3 + 1];
+        const float c3 = p.coef[(item * p.NV + view) * 3 + 2];
+        const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
+        for (int g = 0; g < SAT_STFT_NG; ++g) {
+            const int f0 = fbase + g * p.fb;
+            if (f0 >= p.nframes) break;
+            sat_stft_load_frames(p, L, item, view, f0);
+            __syncthreads();
+            sat_fft_run(L, n, log2n, p.fb);
+            // dL/dY per bin, kept in registers while the LDS frame buffer is recycled
+            float gr[5], gi[5];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            gr[u] = 0.f;
-            gi[u] = 0.f;
-            const int i = threadIdx.x + u * 256;
-            if (i < p.fb * nb) {
-                const int fi = i / nb, k = i - fi * nb;
-                if (f0 + fi < p.nframes) {
-                    float xr, xi, yr, yi;
-                    sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
-                    const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
-                    const float xm = sqrtf(fmaxf(px, 1e-8f)), ym = sqrtf(fmaxf(py, 1e-8f));
-                    const float dl = logf(ym) - logf(xm);
-                    const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
-                    // clamp(min=eps) passes no gradient below eps (auraloss.py:385-387)
-                    if (!p.wrt_x) {
-                        if (py > 1e-8f) {
-                            const float gm = c1 * ((ym - xm) - c2 * ym) + c3 * sg / ym;
-                            gr[u] = gm * yr / ym;
-                            gi[u] = gm * yi / ym;
+            for (int u = 0; u < 5; ++u) {
+                gr[u] = 0.f;
+                gi[u] = 0.f;
+                const int i = threadIdx.x + u * 256;
+                if (i < p.fb * nb) {
+                    const int fi = i / nb, k = i - fi * nb;
+                    if (f0 + fi < p.nframes) {
+                        float xr, xi, yr, yi;
+                        sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
+                        const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
+                        const float xm = sqrtf(fmaxf(px, 1e-8f)), ym = sqrtf(fmaxf(py, 1e-8f));
+                        const float dl = logf(ym) - logf(xm);
+                        const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+                        // clamp(min=eps) passes no gradient below eps (auraloss.py:385-387)
+                        if (!p.wrt_x) {
+                            if (py > 1e-8f) {
+                                const float gm = c1 * ((ym - xm) - c2 * ym) + c3 * sg / ym;
+                                gr[u] = gm * yr / ym;
+                                gi[u] = gm * yi / ym;
+                            }
+                        } else if (px > 1e-8f) {
+                            const float gm = -c1 * (ym - xm) - c3 * sg / xm;
+                            gr[u] = gm * xr / xm;
+                            gi[u] = gm * xi / xm;
                         }
-                    } else if (px > 1e-8f) {
-                        const float gm = -c1 * (ym - xm) - c3 * sg / xm;
-                        gr[u] = gm * xr / xm;
-                        gi[u] = gm * xi / xm;
                     }
                 }
             }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < p.fb * n; i += 256) {
-            re[i] = 0.f;
-            im[i] = 0.f;
-        }
-        __syncthreads();
-        // adjoint DFT: Re(sum_k G[k] e^{+2 pi i jk/n}) = Re(DFT(conj G))[j]
+            __syncthreads();
+            for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+                re[i] = 0.f;
+                im[i] = 0.f;
+            }
+            __syncthreads();
+            // adjoint DFT: Re(sum_k G[k] e^{+2 pi i jk/n}) = Re(DFT(conj G))[j]
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int i = threadIdx.x + u * 256;
-            if (i < p.fb * nb) {
-                const int fi = i / nb, k = i - fi * nb;
-                const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
-                if (k < n) {  // k == n/2 < n always; guard keeps the index in range for n == 1 corner
-                    re[fi * n + kr] = gr[u];
-                    im[fi * n + kr] = -gi[u];
+            for (int u = 0; u < 5; ++u) {
+                const int i = threadIdx.x + u * 256;
+                if (i < p.fb * nb) {
+                    const int fi = i / nb, k = i - fi * nb;
+                    const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
+                    if (k < n) {  // k == n/2 < n always; guard keeps the index in range for n == 1 corner
+                        re[fi * n + kr] = gr[u];
+                        im[fi * n + kr] = -gi[u];
+                    }
                 }
             }
-        }
-        __syncthreads();
-        sat_fft_run(L, n, log2n, p.fb);
-        for (int i = threadIdx.x; i < p.fb * n; i += 256) {
-            const int fi = i >> log2n, j = i & (n - 1);
-            if (f0 + fi < p.nframes) {
-                const float v = re[i] * sat_hann(L, j, n);
-                atomicAdd(&obuf[(g * p.fb + fi) * p.hop + j], v);
+            __syncthreads();
+            sat_fft_run(L, n, log2n, p.fb);
+            for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+                const int fi = i >> log2n, j = i & (n - 1);
+                if (f0 + fi < p.nframes) {
+                    const float v = re[i] * sat_hann(L, j, n);
+                    const int o = (g * p.fb + fi) * p.hop + j;
+                    atomicAdd(&obuf_a[o], va * v);
+                    if (p.C > 1) atomicAdd(&obuf_b[o], vb * v);
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // scatter: obuf[i] belongs to padded-signal index fbase*hop + i  ->  sample (.. - n/2), reflected
-    const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
     float* d0 = p.dy + (size_t)item * p.C * p.T;
     const int last = (p.nframes - 1) * p.hop + n;  // one past the last padded index any frame touches
     for (int i = threadIdx.x; i < olen; i += 256) {
         const int pidx = fbase * p.hop + i;
         if (pidx < last) {
-            const float v = obuf[i];
-            if (v != 0.f) {
-                const int t = sat_reflect(pidx - (n >> 1), p.T);
-                atomicAdd(&d0[t], va * v);
-                if (p.C > 1) atomicAdd(&d0[p.T + t], vb * v);
+            const int t = sat_reflect(pidx - (n >> 1), p.T);
+            const float a = obuf_a[i];
+            if (a != 0.f) atomicAdd(&d0[t], a);
+            if (p.C > 1) {
+                const float bch = obuf_b[i];
+                if (bch != 0.f) atomicAdd(&d0[p.T + t], bch);
             }
         }
     }
@@ -370,7 +381,7 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     if (sat_stft_plan(n_fft, hop, T, &p)) { sat_set_error("sat_stft_bwd: unsupported n_fft/hop/T"); return 1; }
     p.x = x; p.y = y; p.views = views; p.partial = nullptr; p.coef = coef; p.dy = dy;
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = wrt_x;
-    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, 1);       // the views are looped inside the workgroup
     SAT_LAUNCH(sat_stft_bwd_kernel, grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }
