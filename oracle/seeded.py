@@ -97,3 +97,39 @@ def seeded_state_dict(shapes, seed):
             a = rs.standard_normal(size=shape)
         out[key] = a.astype(np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Full-width cases (BASELINE.json configs[1] / configs[2] at their real widths, short crops) — oracle/gen_golden_full.py
+# ---------------------------------------------------------------------------------------------------------------
+import json as _json
+import os as _os
+
+_CFG_DIR = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "stable_audio_tools_amd", "configs")
+
+# stable_audio_2_0_vae architecture on a 32768-sample stereo crop (16 latent frames), batch 1
+FULL_VAE = {"seed": 2100, "batch": 1, "length": 32768, "kl_weight": 1e-4}
+# Stable Audio Open DiT block stack: d=1536, 24 x 64 heads, GQA 24:12 cross-attention, N = 1 + 1024 tokens, M = 130
+FULL_DIT = {"seed": 2300, "latent_length": 1024, "context_length": 130,
+            "config": dict(io_channels=64, embed_dim=1536, depth=24, num_heads=24, cond_token_dim=768, global_cond_dim=1536,
+                           project_cond_tokens=False, transformer_type="continuous_transformer")}
+FULL_KEEP_NUMEL = 4096       # gradients up to this size are stored whole, larger ones as norm + a seeded probe
+FULL_PROBE = 1024
+
+
+def full_vae_config():
+    """The shipped stable_audio_2_0_vae.json (reference configs/model_configs/autoencoders/stable_audio_2_0_vae.json)."""
+    with open(_os.path.join(_CFG_DIR, "stable_audio_2_0_vae.json")) as f:
+        return _json.load(f)
+
+
+def full_vae_inputs():
+    """(audio, vae noise, projection) of the full-width VAE case."""
+    b, n, s = FULL_VAE["batch"], FULL_VAE["length"], FULL_VAE["seed"]
+    return (seeded_array((b, 2, n), s + 1, scale=0.1), seeded_array((b, 64, n // 2048), s + 2), seeded_array((b, 2, n), s + 3))
+
+
+def probe_index(name, numel, count=FULL_PROBE):
+    """Seeded sample of flat indices of a large gradient tensor (depends only on the parameter name and size)."""
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+    return np.sort(rs.choice(numel, size=min(count, numel), replace=False))
