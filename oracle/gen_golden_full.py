@@ -57,7 +57,7 @@ def _ref_generator_loss(al, reals, decoded, kl, dtype):
     return 1.0 * l_sd + 0.5 * l_l + 0.5 * l_r + seeded.FULL_VAE["kl_weight"] * kl, (l_sd, l_l, l_r)
 
 
-def _vae_run(al, dtype):
+def _vae_run(al, dtype, perturb=0.0):
     from stable_audio_tools.models.autoencoders import create_autoencoder_from_config
     spec = seeded.FULL_VAE
     cfg = seeded.full_vae_config()
@@ -72,13 +72,20 @@ def _vae_run(al, dtype):
     z = noise * stdev + mean
     kl = (mean * mean + stdev * stdev - torch.log(stdev * stdev) - 1).sum(1).mean()
     dec = model.decode(z)
-    loss_gen, parts = _ref_generator_loss(al, audio, dec, kl, dtype)
+    dec_for_loss = dec
+    if perturb:
+        # conditioning probe: the generator loss evaluated on the decoded audio displaced by a seeded perturbation of
+        # relative size `perturb` (the forward accuracy of a float32-class implementation that is not bit-identical)
+        delta = torch.from_numpy(seeded.seeded_array(tuple(dec.shape), spec["seed"] + 9)).to(dtype)
+        dec_for_loss = dec + perturb * dec.detach().abs().max() * delta
+    loss_gen, parts = _ref_generator_loss(al, audio, dec_for_loss, kl, dtype)
     loss_lin = (dec * proj).sum() / proj.numel() ** 0.5 + 0.1 * kl
     names = [n for n, _ in model.named_parameters()]
     params = list(model.parameters())
+    g_dec = torch.autograd.grad(loss_gen, dec, retain_graph=True)[0]      # dL/d(decoded): the MR-STFT backward alone
     g_gen = torch.autograd.grad(loss_gen, params, retain_graph=True)
     g_lin = torch.autograd.grad(loss_lin, params)
-    return dict(names=names, pre=pre.detach(), z=z.detach(), kl=kl.detach(), dec=dec.detach(), loss_gen=loss_gen.detach(),
+    return dict(g_dec=g_dec, names=names, pre=pre.detach(), z=z.detach(), kl=kl.detach(), dec=dec.detach(), loss_gen=loss_gen.detach(),
                 loss_lin=loss_lin.detach(), parts=[p.detach() for p in parts], g_gen=g_gen, g_lin=g_lin)
 
 
@@ -87,11 +94,14 @@ def gen_vae():
     t0 = time.time()
     r32 = _vae_run(al, torch.float32)
     r64 = _vae_run(al, torch.float64)
+    rpt = _vae_run(al, torch.float64, perturb=seeded.FULL_VAE["fwd_eps"])
     out = {"pre": r32["pre"].numpy(), "z": r32["z"].numpy(), "kl": r32["kl"].numpy(), "decoded": r32["dec"].numpy(),
            "loss_gen": r32["loss_gen"].numpy(), "loss_lin": r32["loss_lin"].numpy(),
            "loss_sd": r32["parts"][0].numpy(), "loss_left": r32["parts"][1].numpy(), "loss_right": r32["parts"][2].numpy(),
            "loss_gen_f64": r64["loss_gen"].numpy(), "decoded_f32_vs_f64": np.float64(_rel(r32["dec"], r64["dec"]))}
-    worst = {"gen": 0.0, "lin": 0.0}
+    out["gdec_f64"] = r64["g_dec"].float().numpy()                      # dL/d(decoded) of the generator loss, float64 run
+    out["gdec_refdist"] = np.float64(_rel(r32["g_dec"], r64["g_dec"]))
+    worst = {"gen": 0.0, "lin": 0.0, "sens": 0.0}
     for i, n in enumerate(r32["names"]):
         for tag in ("gen", "lin"):
             g64, g32 = r64["g_" + tag][i], r32["g_" + tag][i]
@@ -99,13 +109,18 @@ def gen_vae():
             worst[tag] = max(worst[tag], d)
             out[f"gnorm_{tag}/{n}"] = np.float64(g64.norm().item())
             out[f"refdist_{tag}/{n}"] = np.float64(d)
+            if tag == "gen":
+                sens = _rel(rpt["g_gen"][i], g64)
+                worst["sens"] = max(worst["sens"], sens)
+                out[f"sens_gen/{n}"] = np.float64(sens)
             if g64.numel() <= seeded.FULL_KEEP_NUMEL:
                 out[f"grad_{tag}/{n}"] = g64.float().numpy()
             else:
                 out[f"probe_{tag}/{n}"] = g64.reshape(-1)[seeded.probe_index(n, g64.numel())].float().numpy()
     np.savez_compressed(os.path.join(OUT, "full_vae.npz"), **out)
     print(f"full_vae: decoded {tuple(r32['dec'].shape)} loss_gen {float(r32['loss_gen']):.6f} (f64 {float(r64['loss_gen']):.6f}) "
-          f"ref f32-vs-f64 grad distance: gen {worst['gen']:.2e} lin {worst['lin']:.2e}  [{time.time() - t0:.0f} s]")
+          f"ref f32-vs-f64 grad distance: gen {worst['gen']:.2e} lin {worst['lin']:.2e}; dL/ddec {float(out['gdec_refdist']):.2e}; "
+          f"gen-grad sensitivity to a {seeded.FULL_VAE['fwd_eps']:.0e} forward perturbation {worst['sens']:.2e}  [{time.time() - t0:.0f} s]")
 
 
 def dit_full_inputs(batch):

@@ -260,10 +260,27 @@ class AudioAutoencoder(nn.Module):
         if not chunked:
             return self.encode(audio, **kwargs)
         r = int(self.downsampling_ratio)
-        out = torch.zeros((audio.shape[0], self.latent_dim, audio.shape[2] // r), device=audio.device, dtype=audio.dtype)
-        for win in _chunk_windows(audio.shape[2] // r, chunk_size, overlap):
-            y = self.encode(audio[:, :, win.src0 * r:win.src1 * r])
-            out[:, :, win.dst0:win.dst1] = y[:, :, win.keep0:win.keep1]
+        total = audio.shape[2]                      # samples; the grid is laid out in samples as the reference does (:622-635)
+        csz, hop = chunk_size * r, (chunk_size - overlap) * r
+        starts = list(range(0, total - csz + 1, hop))
+        if not starts:
+            raise ValueError("chunked encode needs at least chunk_size latent frames of audio")
+        if starts[-1] + csz != total:
+            starts.append(total - csz)              # final chunk = audio[..., -chunk_size:]  (:633)
+        y_size = total // r
+        out = torch.zeros((audio.shape[0], self.latent_dim, y_size), device=audio.device, dtype=audio.dtype)
+        half = overlap // 2
+        for i, s0 in enumerate(starts):
+            y = self.encode(audio[:, :, s0:s0 + csz], **kwargs)
+            last = i == len(starts) - 1
+            t1 = y_size if last else i * hop // r + chunk_size
+            t0 = t1 - y.shape[2] if last else i * hop // r
+            k0, k1 = 0, y.shape[2]
+            if i > 0:
+                t0, k0 = t0 + half, k0 + half
+            if not last:
+                t1, k1 = t1 - half, k1 - half
+            out[:, :, t0:t1] = y[:, :, k0:k1]
         return out
 
     def decode_audio(self, latents, chunked=False, overlap=32, chunk_size=128, **kwargs):

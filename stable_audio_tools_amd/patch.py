@@ -1,0 +1,87 @@
+"""Registry that swaps the MI355X-native hot-path modules into the reference package, so that the
+reference's own factories, samplers and training wrappers run unchanged on top of them.
+
+    import stable_audio_tools                     # the reference (Stability-AI/stable-audio-tools)
+    import stable_audio_tools_amd
+    stable_audio_tools_amd.patch_reference()
+    model = stable_audio_tools.models.factory.create_model_from_config(model_config)   # native DiT / Oobleck inside
+    model.load_state_dict(reference_checkpoint)                                        # same keys and shapes
+    audio = stable_audio_tools.inference.generation.generate_diffusion_cond(model, ...)
+
+The reference has no plugin interface: its factories resolve class names in their own
+module namespace at call time —
+  models/diffusion.py:507-519   DiTWrapper.__init__            -> DiffusionTransformer
+  models/autoencoders.py:783-865 create_encoder/decoder_from_config -> OobleckEncoder / OobleckDecoder
+  models/factory.py:32-54        create_pretransform_from_config    -> pretransforms.AutoencoderPretransform
+  models/factory.py:89-99        create_bottleneck_from_config      -> bottleneck.VAEBottleneck
+  training/losses/auraloss.py    STFTLoss / MultiResolutionSTFTLoss / SumAndDifferenceSTFTLoss (training/autoencoders.py:142-146)
+— so rebinding those names is the whole integration.  Everything else (ConditionedDiffusionModelWrapper,
+conditioners, AudioAutoencoder's chunking glue, samplers, Lightning wrappers) stays the reference's code and
+only ever calls the module API the native classes mirror.
+"""
+import importlib
+import sys
+
+
+def _registry():
+    from . import auraloss, autoencoders, bottleneck, dit, pretransforms, transformer
+    return [
+        # (reference module, attribute, native object)
+        ("models.dit", "DiffusionTransformer", dit.DiffusionTransformer),
+        ("models.diffusion", "DiffusionTransformer", dit.DiffusionTransformer),
+        ("models.transformer", "ContinuousTransformer", transformer.ContinuousTransformer),
+        ("models.dit", "ContinuousTransformer", transformer.ContinuousTransformer),
+        ("models.autoencoders", "OobleckEncoder", autoencoders.OobleckEncoder),
+        ("models.autoencoders", "OobleckDecoder", autoencoders.OobleckDecoder),
+        ("models.bottleneck", "VAEBottleneck", bottleneck.VAEBottleneck),
+        ("models.pretransforms", "AutoencoderPretransform", pretransforms.AutoencoderPretransform),
+        ("models.autoencoders", "AutoencoderPretransform", pretransforms.AutoencoderPretransform),
+        ("training.losses.auraloss", "STFTLoss", auraloss.STFTLoss),
+        ("training.losses.auraloss", "MultiResolutionSTFTLoss", auraloss.MultiResolutionSTFTLoss),
+        ("training.losses.auraloss", "SumAndDifferenceSTFTLoss", auraloss.SumAndDifferenceSTFTLoss),
+        ("training.losses", "MultiResolutionSTFTLoss", auraloss.MultiResolutionSTFTLoss),
+        ("training.losses", "SumAndDifferenceSTFTLoss", auraloss.SumAndDifferenceSTFTLoss),
+        ("training.autoencoders", "MultiResolutionSTFTLoss", auraloss.MultiResolutionSTFTLoss),
+        ("training.autoencoders", "SumAndDifferenceSTFTLoss", auraloss.SumAndDifferenceSTFTLoss),
+    ]
+
+
+class PatchHandle:
+    """What patch_reference() returns: `.applied` lists (module, attribute) pairs that were rebound, `.skipped` the
+    ones whose reference module is not importable in this environment (e.g. the training package without
+    pytorch_lightning); `.undo()` restores the reference's own classes."""
+
+    def __init__(self):
+        self.applied, self.skipped, self._saved = [], [], []
+
+    def undo(self):
+        for mod, attr, old in reversed(self._saved):
+            setattr(mod, attr, old)
+        self._saved.clear()
+        self.applied.clear()
+
+
+def patch_reference(package="stable_audio_tools", import_missing=("models",)):
+    """Rebind the hot-path class names inside the reference package `package` to the native classes.
+
+    Modules of the reference that are already imported are always patched; those under the sub-packages named
+    in `import_missing` are imported first (the models package is safe to import; `training` drags in
+    pytorch_lightning and is only patched when the host program has imported it)."""
+    handle = PatchHandle()
+    for sub, attr, native in _registry():
+        name = f"{package}.{sub}"
+        mod = sys.modules.get(name)
+        if mod is None and sub.split(".")[0] in import_missing:
+            try:
+                mod = importlib.import_module(name)
+            except Exception:   # noqa: BLE001 — optional third-party imports of the reference
+                mod = None
+        if mod is None or not hasattr(mod, attr):
+            handle.skipped.append((name, attr))
+            continue
+        handle._saved.append((mod, attr, getattr(mod, attr)))
+        setattr(mod, attr, native)
+        handle.applied.append((name, attr))
+    if not handle.applied:
+        raise RuntimeError(f"patch_reference: nothing to patch — is the reference package {package!r} importable?")
+    return handle

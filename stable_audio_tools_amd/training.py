@@ -163,7 +163,12 @@ class AutoencoderTrainStep:
         if self.sched is not None and self.sched["type"] != "InverseLR":
             raise NotImplementedError("only the InverseLR scheduler is restated")
         lc = tr["loss_configs"]
-        self.w_kl = lc.get("bottleneck", {}).get("weights", {}).get("kl", 0.0)
+        self.w_kl = lc.get("bottleneck", {}).get("weights", {}).get("kl", 1e-6)      # wrapper default: training/autoencoders.py:644-647
+        tw = lc.get("time", {}).get("weights", {})
+        if any(float(tw.get(k, 0.0)) > 0 for k in ("l1", "l2")):
+            raise NotImplementedError("time-domain l1/l2 loss terms are not restated on the HIP path")
+        if float(tr.get("clip_grad_norm", 0.0)) > 0:
+            raise NotImplementedError("clip_grad_norm is not restated on the HIP path")
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
@@ -215,7 +220,8 @@ class DiTTrainStep:
         self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode)
         self.cfg_dropout_prob = cfg_dropout_prob
         self.timestep_sampler = timestep_sampler
-        self.rng = torch.quasirandom.SobolEngine(1, scramble=True, seed=seed)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.rng = torch.quasirandom.SobolEngine(1, scramble=True, seed=seed + rank)   # per-rank stream, as train.py:30-33 offsets the seed
         self.autocast_dtype = autocast_dtype
         self.objective = model.diffusion_objective
         self.global_step = 0

@@ -64,7 +64,8 @@ class LayerNorm(nn.Module):
         else:
             self.gamma = nn.Parameter(torch.ones(dim))
         if bias:
-            self.beta = nn.Parameter(torch.zeros(dim))
+            # the backward kernel does not produce d(beta); no Stable Audio config sets norm_kwargs.bias
+            raise NotImplementedError("LayerNorm(bias=True) is not on the HIP path (the reference default is a zero buffer)")
         else:
             self.register_buffer("beta", torch.zeros(dim))
         self.eps = eps
@@ -305,7 +306,8 @@ class TransformerBlock(nn.Module):
         d = self.dim
         if self.global_cond_dim is not None and self.global_cond_dim > 0 and global_cond is not None:
             # adaLN: (to_scale_shift_gate + global_cond).chunk(6)   (transformer.py:677)
-            mod = (self.to_scale_shift_gate + global_cond).contiguous()          # (B, 6D)
+            # cast to the activation dtype: under bf16 autocast the fp32 parameter promotes the sum to fp32 while x is bf16
+            mod = (self.to_scale_shift_gate + global_cond).to(x.dtype).contiguous()   # (B, 6D)
             scale_self, shift_self, gate_self = mod[:, 0:d], mod[:, d:2 * d], mod[:, 2 * d:3 * d]
             scale_ff, shift_ff, gate_ff = mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], mod[:, 5 * d:6 * d]
             h = self.self_attn(self.pre_norm(x, scale_self, shift_self), rotary_pos_emb=rotary_pos_emb)

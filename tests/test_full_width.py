@@ -5,10 +5,16 @@ reference itself (oracle/gen_golden_full.py -> tests/golden/full_*.npz):
     32768-sample stereo crop: pre-latents, z, KL, decoded audio, the generator loss (MR-STFT sum/diff + L + R, 7
     resolutions, A-weighted, + 1e-4 KL) and gradients of EVERY parameter (norm for all; full tensor or a seeded
     1024-element probe per parameter) for (i) a linear functional of the output — well conditioned, held to 1e-3 — and
-    (ii) the generator loss, whose float32 gradient is ill-conditioned in the reference itself (A-weighted magnitudes at
-    the 1e-4 clamp): the fixture holds the reference's float64 gradient and the distance of the reference's own float32
-    gradient to it (up to 1.5e-3, concentrated in the 16-frame layers next to the bottleneck); the HIP path must be
-    within max(1e-3, 3 x that distance) of the float64 gradient, parameter by parameter.
+    (ii) the generator loss.  Its gradient is ill-conditioned in the reference itself: the A-weighted log-magnitude
+    term weights a bin by 1/|Y| and the clamp at 1e-4 (auraloss.py:385-387) switches bins on and off, so (a) the
+    reference's own float32 gradient is up to 1.5e-3 from its float64 gradient (3.4e-3 for dL/d(decoded)) and (b)
+    displacing the decoded audio by 1e-5 of its peak (the accuracy class of ANY non-bit-identical float32-class forward;
+    ours: bf16x3 products, 8e-6 measured) moves the float64 reference's parameter gradients by up to 4.1e-2.  Both
+    numbers are measured by the generator on the reference and stored per parameter in the fixture.  The test therefore
+    checks the two factors of the chain rule separately at the float32 bar — the MR-STFT backward ALONE on the golden
+    decoded audio (<= max(1e-3, 3 x the reference's float32 distance)), the conv-stack backward through the linear
+    functional (1e-3) — and the composite at max(1e-3, 3 x reference float32 distance, reference sensitivity to the
+    1e-5 forward displacement), parameter by parameter.
   * 2 layers of the Stable Audio Open DiT block (d=1536, 24 x 64 heads, GQA 24:12, N=1025, M=130, batch 2): fp32 at
     1e-3 (output, hidden states, loss, every gradient) and bf16 with the bound stated at the assert.
   * depth-24 forward (plain and CFG), fp32 at 1e-3 and bf16 vs the fp32 reference with the bound stated at the assert.
@@ -41,6 +47,7 @@ def l2_err(a, b):
 def _check_grads(g, tag, names, grads, bar):
     """Every parameter: gradient norm, and the stored full tensor / probe, each within bar(name)."""
     worst = ("", 0.0, 0.0)
+    bad = []
     for n, gr in zip(names, grads):
         tol = bar(n)
         gn = float(g[f"gnorm_{tag}/{n}"]) if f"gnorm_{tag}/{n}" in g else float(g[f"gnorm/{n}"])
@@ -57,7 +64,9 @@ def _check_grads(g, tag, names, grads, bar):
         e = max(e, e_norm)
         if e / tol > worst[1]:
             worst = (n, e / tol, e)
-        assert e < tol, (tag, n, e, tol)
+        if not e < tol:
+            bad.append((n, float(f"{e:.3g}"), float(f"{tol:.3g}")))
+    assert not bad, (tag, len(bad), sorted(bad, key=lambda r: -r[1] / r[2])[:12])
     return worst
 
 
@@ -74,7 +83,7 @@ def _vae_state(shapes):
 def _vae_bar(g, tag):
     if tag == "lin":
         return lambda n: TOL
-    return lambda n: max(TOL, 3.0 * float(g[f"refdist_gen/{n}"]))
+    return lambda n: max(TOL, 3.0 * float(g[f"refdist_gen/{n}"]), float(g[f"sens_gen/{n}"]))
 
 
 def _vae_asserts(g, pre, z, kl, dec, loss_gen, loss_lin):
@@ -97,6 +106,11 @@ def test_vae_full_width_matches_reference_gpu(hip):
     model = model.cuda()
     audio, noise, proj = _vae_inputs("cuda")
     spectral = AutoencoderSpectralLoss(44100, weight=1.0, **seeded.STFT_CFG).cuda()
+    # the MR-STFT backward alone, at the reference's decoded audio
+    dref = torch.from_numpy(g["decoded"]).cuda().requires_grad_(True)
+    (gdec,) = torch.autograd.grad(spectral(audio, dref), dref)
+    e_dec = rel_err(gdec, g["gdec_f64"])
+    assert e_dec < max(TOL, 3.0 * float(g["gdec_refdist"])), (e_dec, float(g["gdec_refdist"]))
     z, info = model.encode(audio, return_info=True, noise=noise)
     dec = model.decode(z)
     loss_gen = spectral(audio, dec) + seeded.FULL_VAE["kl_weight"] * info["kl"]
@@ -109,6 +123,7 @@ def test_vae_full_width_matches_reference_gpu(hip):
     w_lin = _check_grads(g, "lin", names, g_lin, _vae_bar(g, "lin"))
     g_gen = torch.autograd.grad(loss_gen, params)
     w_gen = _check_grads(g, "gen", names, g_gen, _vae_bar(g, "gen"))
+    print(f"full-width VAE: decoded {rel_err(dec.detach(), g['decoded']):.2e}; dL/d(decoded) of the MR-STFT loss {e_dec:.2e} (reference f32: {float(g['gdec_refdist']):.2e})")
     print(f"full-width VAE: worst lin grad {w_lin[0]} {w_lin[2]:.2e}; worst gen grad {w_gen[0]} {w_gen[2]:.2e} ({w_gen[1]:.2f} of its bar)")
 
 
@@ -122,6 +137,9 @@ def test_vae_full_width_oracle_matches_reference():
     audio, noise, proj = _vae_inputs("cpu")
     z, kl, pre = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
     dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+    dref = torch.from_numpy(g["decoded"]).requires_grad_(True)
+    (gdec,) = torch.autograd.grad(stft_oracle.autoencoder_spectral_loss(audio, dref, seeded.STFT_CFG, 44100), dref)
+    assert rel_err(gdec, g["gdec_f64"]) < max(TOL, 3.0 * float(g["gdec_refdist"]))
     loss_gen = stft_oracle.autoencoder_spectral_loss(audio, dec, seeded.STFT_CFG, 44100) + seeded.FULL_VAE["kl_weight"] * kl
     loss_lin = (dec * proj).sum() / proj.numel() ** 0.5 + 0.1 * kl
     _vae_asserts(g, pre.detach(), z.detach(), kl.detach(), dec.detach(), loss_gen.detach(), loss_lin.detach())
@@ -222,11 +240,11 @@ def test_dit_block_full_width_oracle_matches_reference():
     _check_grads(g, "", names, grads[1:], lambda n: TOL)
 
 
-# depth 24: the float32 model is held to 1e-3; the bf16 model to a relative L2 distance of 6e-2 from the float32 reference
+# depth 24: the float32 model is held to 1e-3; the bf16 model to a relative L2 distance of 4e-2 from the float32 reference
 # (24 layers x ~12 bf16 roundings of the residual stream each, unit round-off 2e-3, accumulating like a random walk:
-# 2e-3 * sqrt(288) = 3.4e-2; bound = 2x that expectation).  CFG at scale 6 amplifies the difference of two such outputs,
+# 2e-3 * sqrt(288) = 3.4e-2 is the expectation if every rounding hit the full stream; measured 1.4e-2).  CFG at scale 6 amplifies the difference of two such outputs,
 # so the guided output is compared in float32 only.
-BF16_DEPTH24 = 6e-2
+BF16_DEPTH24 = 4e-2
 
 
 @pytest.mark.gpu
