@@ -231,6 +231,43 @@ int sat_gate_residual_bwd_nchunks(int N);
 int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long long gstride, void* dx, float* part,
                           int B, int N, int D, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense projections of the DiT — models/transformer.py: to_qkv :362/:481, to_out :364/:534, to_q / to_kv :356-357,
+ * GLU proj + x*silu(gate) :263-275, FeedForward linear_out :308, residual / gate updates :684-712; models/dit.py :49-77.
+ * Replaces nn.Linear (forward, data gradient, weight gradient) and the elementwise kernels that followed it.
+ * One "NT" kernel on the bf16 matrix cores (csrc/gemm.hip): C[M,N] = epilogue(A[M,K] · B[N,K]^T), fp32 accumulation.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* A (M, K), B (N, K): bf16, K contiguous, row strides lda / ldb in elements (multiples of 8; K and N multiples of 8).
+ * epilogue 0: C = acc [+ bias];  1: + res;  2: * sigmoid(1 - gate[m / rows_per_gate]) + res  (adaLN gate, :684/:699);
+ * 3: SwiGLU — B = [value rows | gate rows] (N = 2F): C (M, F) = (v + bv) * silu(g + bg); `pre` (M, 2F, row stride ldp),
+ * if not NULL, receives the pre-activation for the backward.  bias: fp32 (N) or NULL.  out_f32: C / res / gate / pre are
+ * fp32 instead of bf16.  splits > 1 (epilogue 0, fp32, no bias): split-K partial slabs, slab z at C + z*M*ldc — sum them
+ * with sat_reduce_splits.  zeros: >= 16 bytes of device zeros (source of K-tail chunks).  tile: 0 = 128x128 workgroup
+ * tile (4 waves), 1 = 256x128 (8 waves).  fp32 models run this kernel on sat_split_bf16x3 operands (K' = 3K). */
+int sat_gemm_bf16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
+                  const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
+                  long long ldp, const void* zeros, int M, int N, int K, int epilogue, int out_f32, int splits, int tile,
+                  void* stream);
+
+/* Attention input projections with head split, partial rotary (first 32 dims of each 64-dim head, rotate_half pairs
+ * (d, d+16), :155-174, table from sat_rope_tables; NULL = none) and the attention kernel's operand layout fused into the
+ * epilogue (:469-507).  B = nsec blocks of heads*64 rows, block i = section sec0+i of (q, k, v): to_qkv (0,3), to_q (0,1),
+ * to_kv (1,2).  q_rm / k_rm: (nb, heads, npad, 64) bf16; v_tr: (nb, heads, 64, npad) bf16.  Entries past ntok are not
+ * written (zero-fill the planes once). */
+int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
+                      void* q_rm, void* k_rm, void* v_tr, const void* zeros, int nb, int ntok, int npad, int heads,
+                      int K, int sec0, int nsec, int tile, void* stream);
+
+/* src (R, C) fp32 (src_f32 = 1) or bf16, row stride lds -> dst bf16: (R, C) row stride ldd; or, transpose = 1, (C, Rpad)
+ * with columns R..Rpad-1 zero (reduction-dim padding of the weight-gradient GEMM). */
+int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int R, int C, int Rpad, int src_f32,
+                  int transpose, void* stream);
+
+/* fp32 (R, C) -> bf16 (R, 3C): side 0 (activations) [hi | hi | lo], side 1 (weights) [hi | lo | hi], so that
+ * A' · B'^T = hi·hi + hi·lo + lo·hi  (|x - hi - lo| <= 2^-17 |x|). */
+int sat_split_bf16x3(const float* src, long long lds, void* dst, long long ldd, int R, int C, int side, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

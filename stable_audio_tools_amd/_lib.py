@@ -62,6 +62,11 @@ SIGNATURES = {
     "sat_attention_fwd": (_I, [_P] * 8 + [_I] * 8 + [_F, _I, _P]),
     "sat_attention_rowdot": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_attention_bwd": (_I, [_P] * 6 + [_I] * 8 + [_F, _I, _P]),
+    # gemm.hip
+    "sat_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P] + [_I] * 7 + [_P]),
+    "sat_gemm_qkv_bf16": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "sat_cast_bf16": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "sat_split_bf16x3": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
     # dit_ops.hip
     "sat_layernorm_fwd": (_I, [_P] * 5 + [_L] + [_P] * 3 + [_I] * 3 + [_F, _I, _P]),
     "sat_layernorm_bwd_nblocks": (_I, [_I, _I]),

@@ -1,0 +1,586 @@
+// gemm.hip — the dense projections of the DiT on the bf16 matrix cores, with the elementwise work that follows them
+// fused into the epilogue (reference: stable_audio_tools/models/transformer.py — to_qkv :362/:481, to_out :364/:534,
+// to_q / to_kv :356-357, GLU proj + x*silu(gate) :263-275, FF linear_out :308, the gate / residual updates :684-712).
+//
+//   C[M, N] = epilogue( A[M, K] · B[N, K]^T )        A, B bf16, both K-contiguous ("NT"), fp32 accumulation
+//
+// which is nn.Linear's forward as it stands (A = activations, B = weight (out, in)); the data gradient uses the transposed
+// weight copy and the weight gradient the transposed activations (sat_transpose_bf16), so one kernel serves all three.
+// float32 models run the same kernel on bf16x3-split operands laid out along K ([hi|hi|lo] x [hi|lo|hi], sat_split_bf16x3):
+// three MFMAs per product, ~2^-17 relative per product, fp32 accumulate — the arithmetic of the conv stack.
+//
+// Structure (one workgroup = BM x BN tile, waves as a WGM x WGN grid of 64 x 64 or 128 x 64 sub-tiles of 32x32x16 MFMAs):
+//   * K-steps of 64.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4: 1 KiB = 8 rows x 128 B per wave
+//     instruction, no VGPR round trip).  The LDS image is row-major with 128-byte rows; the 16-byte slot s of row r holds
+//     k-chunk s ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 lanes, 16 different rows, same chunk) then touches 16
+//     different 16-byte slots of the 256-byte bank row — conflict free.  LDS-DMA writes are lane-linear, so the swizzle is
+//     applied to the per-lane SOURCE address (same 128-byte global segment, permuted among 8 lanes).
+//   * two stage buffers; tile k+1 is in flight while tile k feeds the MFMAs; one barrier per K-step.
+//   * epilogue: each wave transposes its accumulators through a private 8 KiB LDS window (32 rows x 64 fp32) so that a
+//     lane owns 4 consecutive columns: bias / residual / gate loads and the stores are 8- or 16-byte accesses that cover
+//     whole 128-byte row segments.
+#include "sat_device.h"
+#include <type_traits>
+
+#if defined(SAT_HIPEMU)
+static inline void sat_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::lane_id(), g, 16); }
+#define SAT_WAIT_VMCNT(n)
+#define SAT_RAW_BARRIER() hipemu::block_barrier()
+#define SAT_WAIT_LGKM0()
+#define SAT_SCHED_FENCE()
+static inline void sat_wave_sync() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
+#define SAT_SETPRIO(x)
+#else
+// LDS destination = wave-uniform base + lane * 16 (cdna_hip_programming.md §5)
+SAT_DEVICE void sat_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// counted wait on this wave's LDS-DMA queue + a bare s_barrier: tiles further down the ring stay in flight across the barrier
+// (__syncthreads() would drain them: an LDS-DMA is a pending LDS write on the VM counter)
+#define SAT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define SAT_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+#define SAT_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+SAT_DEVICE void sat_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#define SAT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+
+enum { SAT_EPI_STORE = 0, SAT_EPI_RES = 1, SAT_EPI_GATE_RES = 2, SAT_EPI_SWIGLU = 3, SAT_EPI_QKV = 4 };
+
+struct SatGemmParams {
+    const short* A;       // (M, K) bf16
+    const short* B;       // (N, K) bf16
+    void* C;              // (M, ldc) bf16 or fp32; split-K: slab z at C + z * M * ldc (fp32)
+    const float* bias;    // (N) fp32 or null
+    const void* res;      // (M, ldr) dtype of C: added after the gate
+    const void* gate;     // (M / rows_per_gate, ldg) dtype of C: v * sigmoid(1 - gate)   (transformer.py:684, :699)
+    void* pre;            // SWIGLU: optional (M, ldp) copy of the pre-activation [x | gate] for the backward
+    const short* zeros;   // >= 16 bytes of zeros: source of the k-chunks past K
+    long long lda, ldb, ldc, ldr, ldg, ldp;
+    int M, N, K;
+    int rows_per_gate;
+    int klen;             // K range of one blockIdx.y slice (multiple of 64; == padded K without split-K)
+    int ntm, ntn;
+    // QKV epilogue: rotary + attention planes (attention.hip layouts)
+    const float* rope_cs; // (ntok, 16, 2) cos/sin
+    short* q_rm;          // (nb, H, Np, 64)
+    short* k_rm;
+    short* v_tr;          // (nb, H, 64, Np)
+    int ntok, npad, heads, rope_off, sec0;   // sec0: section of the first column block (0 q, 1 k, 2 v)
+};
+
+// ---- staging -------------------------------------------------------------------------------------------------------
+// One 1-KiB piece (8 tile rows x 128 B) of an operand tile: lane -> (row, 16-byte slot); the slot holds k-chunk slot ^ ((row>>1)&7).
+template <bool GLU>
+SAT_DEVICE void sat_gemm_stage_piece(const short* base, long long ld, int row0, int nrows, int k0, int kend, char* lds, const short* zeros,
+                                     int p, int lane, int glu_f, int glu_tile0) {
+    const int r = p * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr;
+    if constexpr (GLU) {   // tile row -> weight row: 64-row groups of [32 value rows | 32 gate rows]  (transformer.py:274)
+        gr = ((r >> 5) & 1) * glu_f + glu_tile0 + (r >> 6) * 32 + (r & 31);
+    } else {
+        gr = row0 + r;
+    }
+    gr = gr < nrows ? gr : nrows - 1;
+    const int k = k0 + c * 8;
+    const short* src = (k < kend) ? base + (long long)gr * ld + k : zeros;
+    sat_glds16(src, lds + p * 1024);
+}
+
+SAT_DEVICE bf16x8 sat_gemm_frag(const char* tile, int row, int kc) {
+    return *(const bf16x8*)(tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+}
+
+// ---- epilogue helpers ----------------------------------------------------------------------------------------------
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <bool F32>
+SAT_DEVICE f32x4 sat_load4(const void* base, long long idx) {
+    if constexpr (F32) {
+        return *(const f32x4*)((const float*)base + idx);
+    } else {
+        const u32x2 u = *(const u32x2*)((const short*)base + idx);
+        f32x4 v;
+        v[0] = __builtin_bit_cast(float, u[0] << 16);
+        v[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, u[1] << 16);
+        v[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+        return v;
+    }
+}
+template <bool F32>
+SAT_DEVICE void sat_store4(void* base, long long idx, f32x4 v) {
+    if constexpr (F32) {
+        *(f32x4*)((float*)base + idx) = v;
+    } else {
+        u32x2 u;
+        u[0] = sat_cvt2_pk(v[0], v[1]);
+        u[1] = sat_cvt2_pk(v[2], v[3]);
+        *(u32x2*)((short*)base + idx) = u;
+    }
+}
+SAT_DEVICE float sat_gemm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE, int EPI, bool F32OUT>
+__global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+    static_assert(TN == 2, "epilogue window is 64 columns wide");
+    constexpr int WIN = NSTAGE * STAGE / NW;     // per-wave epilogue window
+    constexpr int G = (BM + BN) / 8 / NW;        // LDS-DMA instructions per wave per tile
+    static_assert(WIN >= 64 * 33 * 4, "epilogue window (32 x 64 fp32, or 64 x 33 transposed) must fit");
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
+    const int wm = wave / WGN, wn = wave % WGN;
+    int tm, tn;
+    sat_xcd_tile((int)blockIdx.x, p.ntm, p.ntn, &tm, &tn);      // the m-tiles of one weight panel share an XCD's L2
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.klen;
+    const int kend = (kbeg + p.klen < p.K) ? kbeg + p.klen : p.K;
+    const int nk = (kend - kbeg + 63) >> 6;
+    constexpr bool GLU = (EPI == SAT_EPI_SWIGLU);
+    const int glu_f = p.N >> 1, glu_tile0 = tn * (BN / 2);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS-DMA instructions IB .. IE-1 (of G per wave) of tile kt into slot buf: instruction i of wave w moves piece i*NW + w of the
+    // stage image [A tile | B tile]; BM/8 is a multiple of NW, so "A or B" is a compile-time property of i
+    auto stage_range = [&](int kt, int buf, auto ib, auto ie) {
+        constexpr int IB = decltype(ib)::value, IE = decltype(ie)::value;
+        static_assert((BM / 8) % NW == 0, "A pieces must split evenly over the waves");
+        char* s = smem + buf * STAGE;
+        const int k0 = kbeg + kt * 64;
+#pragma unroll
+        for (int i = IB; i < IE; ++i) {
+            if (i * NW < BM / 8) sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, i * NW + wave, lane, 0, 0);
+            else sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, i * NW + wave - BM / 8, lane, glu_f, glu_tile0);
+        }
+    };
+    auto stage = [&](int kt, int buf) { stage_range(kt, buf, std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}); };
+    auto stage_part = [&](int kt, int buf, auto part) {      // one of the 4 portions of a tile's LDS-DMA instructions
+        constexpr int Q = decltype(part)::value;
+        stage_range(kt, buf, std::integral_constant<int, (G * Q) / 4>{}, std::integral_constant<int, (G * (Q + 1)) / 4>{});
+    };
+    auto frags = [&](const char* As, int ks, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+        const int kc = ks * 2 + (lane >> 5);
+        const char* Bs = As + ABYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = sat_gemm_frag(As, wm * (TM * 32) + i * 32 + (lane & 31), kc);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = sat_gemm_frag(Bs, wn * (TN * 32) + j * 32 + (lane & 31), kc);
+    };
+    auto mfmas = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+    };
+    if constexpr (PIPE == 2) {
+        // As PIPE == 1, with the refill of a drained slot spread over the K-step: a quarter of the tile's LDS-DMA instructions
+        // goes out behind each k-substep's MFMAs instead of all of them in one burst right after the barrier (32 back-to-back
+        // 1-KiB requests per workgroup stall the issuing waves on the memory pipeline's queue).  Slot of tile kt is drained at
+        // the hand-over of K-step kt; tile kt+NSTAGE is issued in quarters: one right there, three during K-step kt+1.
+        static_assert(NSTAGE >= 3, "spread refill needs a third slot");
+#pragma unroll
+        for (int s = 0; s < NSTAGE; ++s)
+            if (s < nk) stage(s, s);
+        if (nk >= NSTAGE) { SAT_WAIT_VMCNT((NSTAGE - 1) * G); } else { SAT_WAIT_VMCNT(0); }
+        SAT_RAW_BARRIER();
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+        frags(smem, 0, a0, b0);
+        int rd = 0, prev = NSTAGE - 1;
+        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+        using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* As = smem + rd * STAGE;
+            const int nx = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+            const bool refill_prev = kt >= 1 && kt - 1 + NSTAGE < nk;      // tile kt-1+NSTAGE goes to slot `prev`
+            frags(As, 1, a1, b1);
+            mfmas(a0, b0);
+            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q1{});
+            SAT_SCHED_FENCE();
+            frags(As, 2, a0, b0);
+            mfmas(a1, b1);
+            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q2{});
+            SAT_SCHED_FENCE();
+            frags(As, 3, a1, b1);
+            mfmas(a0, b0);
+            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q3{});
+            SAT_SCHED_FENCE();
+            if (kt + 1 < nk) {
+                SAT_WAIT_LGKM0();
+                // outstanding, oldest first: [tile kt+1 .. kt+NSTAGE-2 complete][tile kt+NSTAGE-1: all G pieces]  -> keep the tiles
+                // after kt+1 in flight
+                if (kt + NSTAGE - 1 < nk) { SAT_WAIT_VMCNT((NSTAGE - 2) * G); } else { SAT_WAIT_VMCNT(0); }
+                SAT_RAW_BARRIER();
+                SAT_SCHED_FENCE();
+                if (kt + NSTAGE < nk) stage_part(kt + NSTAGE, rd, Q0{});
+                frags(smem + nx * STAGE, 0, a0, b0);
+            }
+            SAT_SCHED_FENCE();
+            mfmas(a1, b1);
+            prev = rd;
+            rd = nx;
+        }
+        SAT_WAIT_LGKM0();
+    } else if constexpr (PIPE == 1) {
+        // Software pipeline: fragments of k-substep s+1 are read from LDS while the MFMAs of substep s run, and the hand-over to
+        // the next tile (counted wait on the LDS-DMA queue, barrier, refill of the slot just drained, first fragments of the new
+        // tile) sits between substeps 2 and 3, under the MFMAs of substep 2 and in front of those of substep 3.
+        // All NSTAGE slots are in use: tile kt+NSTAGE is issued at K-step kt into the slot tile kt occupied.
+#pragma unroll
+        for (int s = 0; s < NSTAGE; ++s)
+            if (s < nk) stage(s, s);
+        if (nk >= NSTAGE) { SAT_WAIT_VMCNT((NSTAGE - 1) * G); } else { SAT_WAIT_VMCNT(0); }
+        SAT_RAW_BARRIER();
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+        frags(smem, 0, a0, b0);
+        int rd = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* As = smem + rd * STAGE;
+            const int nx = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+            frags(As, 1, a1, b1);
+            mfmas(a0, b0);
+            SAT_SCHED_FENCE();
+            frags(As, 2, a0, b0);
+            mfmas(a1, b1);
+            SAT_SCHED_FENCE();
+            frags(As, 3, a1, b1);
+            mfmas(a0, b0);
+            SAT_SCHED_FENCE();
+            if (kt + 1 < nk) {
+                SAT_WAIT_LGKM0();          // every read of this tile's slot has completed (and a1 / b1 are in registers)
+                if (kt + NSTAGE - 1 < nk) { SAT_WAIT_VMCNT((NSTAGE - 2) * G); } else { SAT_WAIT_VMCNT(0); }
+                SAT_RAW_BARRIER();         // tile kt+1 has landed for everybody; the slot of tile kt is drained by everybody
+                SAT_SCHED_FENCE();
+                if (kt + NSTAGE < nk) stage(kt + NSTAGE, rd);
+                frags(smem + nx * STAGE, 0, a0, b0);
+            }
+            SAT_SCHED_FENCE();
+            mfmas(a1, b1);
+            rd = nx;
+        }
+        SAT_WAIT_LGKM0();
+    } else {
+    // (PIPE < 0: ablation builds of this plain loop for profiling — -1 without the LDS-DMA staging, -2 without fragment reads / MFMAs)
+    // ring of NSTAGE tiles: tiles kt .. kt+NSTAGE-2 are in flight when K-step kt starts
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk && PIPE != -1) stage(s, s);
+    int rd = 0, wr = NSTAGE - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of tile kt have landed (the NSTAGE-2 younger tiles may still be in flight; the tail drains) ...
+        if (kt + NSTAGE - 2 < nk) { SAT_WAIT_VMCNT((NSTAGE - 2) * G); } else { SAT_WAIT_VMCNT(0); }
+        SAT_RAW_BARRIER();     // ... everybody's have, and every wave is done reading the slot tile kt+NSTAGE-1 goes to
+        if (kt + NSTAGE - 1 < nk && PIPE != -1) stage(kt + NSTAGE - 1, wr);
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+        const char* As = smem + rd * STAGE;
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (PIPE != -2) {
+                bf16x8 a[TM], b[TN];
+                frags(As, ks, a, b);
+                mfmas(a, b);
+            }
+        }
+    }
+    }
+    SAT_RAW_BARRIER();         // stage buffers are free (no LDS-DMA is pending): each wave takes a private window for its epilogue
+
+    float* ep = (float*)(smem + wave * WIN);
+    const int hi = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        sat_wave_sync();
+        const int mrow0 = m0 + wm * (TM * 32) + i * 32;
+        if constexpr (EPI == SAT_EPI_QKV) {
+            // a 64-column window is one head of q, k or v (wave-uniform).  v goes out TRANSPOSED (nb, H, 64, Np): stage the
+            // window as [64 d][33] so that a lane reads 4 consecutive tokens of one head dim (odd stride: conflict free)
+            const int nwin = n0 + wn * 64;
+            if (nwin < p.N && nwin / (p.heads * 64) + p.sec0 == 2) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
+                sat_wave_sync();
+                const int h = (nwin % (p.heads * 64)) >> 6;
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int d = pass * 8 + (lane >> 3), tq = (lane & 7) * 4;
+                    const int m = mrow0 + tq;                 // 4 consecutive rows m .. m+3 (may straddle a batch item)
+                    short o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sat_f32_to_bf16(ep[d * 33 + tq + e]);
+                    const int b = m / p.ntok, t = m - b * p.ntok;
+                    short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
+                    if (m + 3 < p.M && t + 3 < p.ntok && ((t & 3) == 0)) {
+                        u32x2 u;
+                        u[0] = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+                        u[1] = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+                        *(u32x2*)dst = u;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int me = m + e;
+                            if (me < p.M) {
+                                const int be = me / p.ntok, te = me - be * p.ntok;
+                                p.v_tr[(((long long)be * p.heads + h) * 64 + d) * p.npad + te] = o[e];
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
+        sat_wave_sync();
+        if constexpr (EPI == SAT_EPI_SWIGLU) {
+            // window columns 0..31 = value, 32..63 = gate of output columns glu_tile0 + wn*32 + (0..31)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int rr = pass * 8 + (lane >> 3), cc = (lane & 7) * 4;
+                const int m = mrow0 + rr;
+                const int n = glu_tile0 + wn * 32 + cc;
+                f32x4 xv = *(const f32x4*)(ep + rr * 64 + cc);
+                f32x4 gv = *(const f32x4*)(ep + rr * 64 + 32 + cc);
+                if (m < p.M && n < glu_f) {
+                    if (p.bias) {
+                        xv += *(const f32x4*)(p.bias + n);
+                        gv += *(const f32x4*)(p.bias + glu_f + n);
+                    }
+                    if (p.pre) {
+                        sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + n, xv);
+                        sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + glu_f + n, gv);
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = xv[e] * gv[e] * sat_gemm_sigmoid(gv[e]);
+                    sat_store4<F32OUT>(p.C, (long long)m * p.ldc + n, o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int rr = pass * 4 + (lane >> 4), cc = (lane & 15) * 4;
+                const int m = mrow0 + rr;
+                const int n = n0 + wn * 64 + cc;
+                f32x4 v = *(const f32x4*)(ep + rr * 64 + cc);
+                if (m < p.M && n < p.N) {
+                    if (p.bias) v += *(const f32x4*)(p.bias + n);
+                    if constexpr (EPI == SAT_EPI_GATE_RES) {
+                        const f32x4 g = sat_load4<F32OUT>(p.gate, (long long)(m / p.rows_per_gate) * p.ldg + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= sat_gemm_sigmoid(1.0f - g[e]);
+                    }
+                    if constexpr (EPI == SAT_EPI_RES || EPI == SAT_EPI_GATE_RES) v += sat_load4<F32OUT>(p.res, (long long)m * p.ldr + n);
+                    if constexpr (EPI == SAT_EPI_QKV) {
+                        // fused to_qkv epilogue (transformer.py:481-507): split heads, partial rotary on q and k (first 32 dims
+                        // of each 64-dim head, rotate_half pairs (d, d+16)), and emit the attention kernel's operand planes:
+                        // q, k row-major (nb, H, Np, 64), v transposed (nb, H, 64, Np).  A 64-column window is exactly one head.
+                        const int hd = p.heads * 64;
+                        const int which = n / hd + p.sec0, h = (n % hd) >> 6, d = n & 63;     // 0 q, 1 k, 2 v
+                        const int b = m / p.ntok, t = m % p.ntok;
+                        if (p.rope_cs && d < 32) {
+                            // partner column d ^ 16 lives 4 lanes away in this row's 16-lane group
+                            f32x4 o;
+                            const f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
+                            const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float c = cs[2 * e], s = cs[2 * e + 1];
+                                o[e] = (d < 16) ? v[e] * c - pv[e] * s : v[e] * c + pv[e] * s;
+                            }
+                            v = o;
+                        }
+                        short* dst = (which == 0) ? p.q_rm : p.k_rm;
+                        sat_store4<false>(dst, (((long long)b * p.heads + h) * p.npad + t) * 64 + d, v);
+                    } else {
+                        sat_store4<F32OUT>(p.C, (long long)blockIdx.y * p.M * p.ldc + (long long)m * p.ldc + n, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static short* g_sat_zero_page = nullptr;   // set by the caller through sat_gemm_bf16's `zeros` argument (caller-owned)
+
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE>
+static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
+    p.ntm = sat_cdiv(p.M, BM);
+    p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
+    dim3 grid(p.ntm * p.ntn, splits), block(WGM * WGN * 64);
+#define SAT_GEMM_CASE(E, F)                                                                          \
+    if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
+        SAT_LAUNCH((sat_gemm_kernel<BM, BN, WGM, WGN, NSTAGE, PIPE, E, F>), grid, block, stream, p);               \
+        return sat_check_launch("sat_gemm_bf16");                                                    \
+    }
+    SAT_GEMM_CASE(SAT_EPI_STORE, false)
+    SAT_GEMM_CASE(SAT_EPI_STORE, true)
+    SAT_GEMM_CASE(SAT_EPI_RES, false)
+    SAT_GEMM_CASE(SAT_EPI_RES, true)
+    SAT_GEMM_CASE(SAT_EPI_GATE_RES, false)
+    SAT_GEMM_CASE(SAT_EPI_GATE_RES, true)
+    SAT_GEMM_CASE(SAT_EPI_SWIGLU, false)
+    SAT_GEMM_CASE(SAT_EPI_SWIGLU, true)
+    SAT_GEMM_CASE(SAT_EPI_QKV, false)
+#undef SAT_GEMM_CASE
+    sat_set_error("sat_gemm_bf16: unsupported epilogue / output type");
+    return 1;
+}
+
+// tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
+// 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure)
+static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
+    if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
+    if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
+    if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
+    if (tile == 4) return sat_gemm_launch<128, 128, 2, 2, 2, -1>(p, epi, f32out, splits, stream);
+    if (tile == 5) return sat_gemm_launch<128, 128, 2, 2, 2, -2>(p, epi, f32out, splits, stream);
+    return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
+}
+
+// C = epilogue(A · B^T).  A (M, K), B (N, K) bf16 with row strides lda / ldb (elements, multiples of 8; K % 8 == 0).
+// epilogue: 0 store [+bias]; 1 + res; 2 * sigmoid(1 - gate[m / rows_per_gate]) + res; 3 SwiGLU over B = [value rows | gate rows]
+// (N = 2F, C is (M, F), optional pre-activation copy `pre` (M, 2F)).  out_f32: C / res / gate / pre are fp32 instead of bf16.
+// splits > 1 (epilogue 0, fp32 out, no bias): K is cut into `splits` ranges, slab z is written at C + z * M * ldc — reduce with
+// sat_reduce_splits.  zeros: >= 16 bytes of device zeros.  tile: 0 = 128 x 128 (4 waves), 1 = 256 x 128 (8 waves).
+extern "C" int sat_gemm_bf16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
+                             const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
+                             long long ldp, const void* zeros, int M, int N, int K, int epilogue, int out_f32, int splits, int tile,
+                             void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) { sat_set_error("sat_gemm_bf16: empty shape"); return 1; }
+    if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 7) || (ldc & 3)) { sat_set_error("sat_gemm_bf16: K, N, lda, ldb must be multiples of 8"); return 1; }
+    if (!zeros) { sat_set_error("sat_gemm_bf16: zeros page required"); return 1; }
+    if (epilogue < 0 || epilogue > 3) { sat_set_error("sat_gemm_bf16: bad epilogue"); return 1; }
+    if ((epilogue == SAT_EPI_RES || epilogue == SAT_EPI_GATE_RES) && !res) { sat_set_error("sat_gemm_bf16: residual missing"); return 1; }
+    if (epilogue == SAT_EPI_GATE_RES && (!gate || rows_per_gate <= 0)) { sat_set_error("sat_gemm_bf16: gate missing"); return 1; }
+    if (epilogue == SAT_EPI_SWIGLU && (N & 15)) { sat_set_error("sat_gemm_bf16: SwiGLU needs N = 2F with F % 8 == 0"); return 1; }
+    if (splits < 1) splits = 1;
+    if (splits > 1 && (epilogue != SAT_EPI_STORE || !out_f32 || bias)) { sat_set_error("sat_gemm_bf16: split-K is plain fp32 output only"); return 1; }
+    SatGemmParams p{};
+    p.A = (const short*)A; p.B = (const short*)B; p.C = C; p.bias = bias; p.res = res; p.gate = gate; p.pre = pre;
+    p.zeros = (const short*)zeros;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldg = ldg; p.ldp = ldp;
+    p.M = M; p.N = N; p.K = K; p.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
+    const int ksteps = sat_cdiv(K, 64);
+    p.klen = sat_cdiv(ksteps, splits) * 64;
+    return sat_gemm_dispatch(p, epilogue, out_f32, splits, tile, stream);
+}
+
+// Attention input projections with the head split, the partial rotary and the attention kernel's operand layout fused into
+// the epilogue (transformer.py:469-507).  B holds `nsec` consecutive blocks of heads*64 rows; block i is section sec0 + i
+// (0 = q, 1 = k, 2 = v): to_qkv -> (sec0 0, nsec 3), to_q -> (0, 1), to_kv -> (1, 2).  q and k go to row-major planes
+// (nb, heads, Np, 64), v to the transposed plane (nb, heads, 64, Np), all bf16.  rope_cs (>= ntok + rope_off, 16, 2) fp32
+// cos/sin (sat_rope_tables) rotates the first 32 dims of every q / k head; NULL = no rotary (cross-attention, :689).
+// Plane rows / columns >= ntok are NOT written: the caller zero-fills the planes once.
+extern "C" int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
+                                 void* q_rm, void* k_rm, void* v_tr, const void* zeros, int nb, int ntok, int npad, int heads,
+                                 int K, int sec0, int nsec, int tile, void* stream) {
+    if (nb <= 0 || ntok <= 0 || heads <= 0 || K <= 0 || npad < ntok) { sat_set_error("sat_gemm_qkv_bf16: bad shape"); return 1; }
+    if ((K & 7) || (lda & 7) || (ldb & 7)) { sat_set_error("sat_gemm_qkv_bf16: K, lda, ldb must be multiples of 8"); return 1; }
+    if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3) { sat_set_error("sat_gemm_qkv_bf16: bad section range"); return 1; }
+    if ((sec0 == 0 && !q_rm) || (sec0 <= 1 && sec0 + nsec > 1 && !k_rm) || (sec0 + nsec > 2 && !v_tr)) { sat_set_error("sat_gemm_qkv_bf16: missing plane"); return 1; }
+    SatGemmParams p{};
+    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros;
+    p.lda = lda; p.ldb = ldb;
+    p.M = nb * ntok; p.N = nsec * heads * 64; p.K = K; p.rows_per_gate = 1;
+    p.klen = sat_cdiv(K, 64) * 64;
+    p.rope_cs = rope_cs; p.rope_off = rope_off; p.q_rm = (short*)q_rm; p.k_rm = (short*)k_rm; p.v_tr = (short*)v_tr;
+    p.ntok = ntok; p.npad = npad; p.heads = heads; p.sec0 = sec0;
+    return sat_gemm_dispatch(p, SAT_EPI_QKV, 0, 1, tile, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Operand preparation: cast / transpose / bf16x3 split, 16-byte accesses on both sides.
+//   dst[c][r] (C, ldd) <- src[r][c] (R, lds)   (mode bit 0: transpose), source fp32 or bf16, destination bf16;
+//   rows r in [R, Rpad) of a transposed destination are zero-filled (reduction-dim padding of the weight-gradient GEMM).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SatCastParams {
+    const void* src;
+    short* dst;
+    long long lds_, ldd;
+    int R, Cc, Rpad, src_f32, transpose;
+};
+__global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
+    __shared__ short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if (!p.transpose) {
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int r = r0 + (i >> 3), c = c0 + (i & 7) * 8;
+            if (r < p.R && c < p.Cc) {
+                short v[8];
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = c + e;
+                    float f = 0.f;
+                    if (cc < p.Cc) f = p.src_f32 ? ((const float*)p.src)[(long long)r * p.lds_ + cc] : sat_bf16_to_f32(((const short*)p.src)[(long long)r * p.lds_ + cc]);
+                    v[e] = sat_f32_to_bf16(f);
+                }
+                for (int e = 0; e < 8; ++e) if (c + e < p.Cc) p.dst[(long long)r * p.ldd + c + e] = v[e];
+            }
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = r0 + (i >> 6), c = c0 + (i & 63);
+        float f = 0.f;
+        if (r < p.R && c < p.Cc) f = p.src_f32 ? ((const float*)p.src)[(long long)r * p.lds_ + c] : sat_bf16_to_f32(((const short*)p.src)[(long long)r * p.lds_ + c]);
+        tile[i >> 6][i & 63] = sat_f32_to_bf16(f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = c0 + (i >> 6), r = r0 + (i & 63);
+        if (c < p.Cc && r < p.Rpad) p.dst[(long long)c * p.ldd + r] = tile[i & 63][i >> 6];
+    }
+}
+// src (R, C) fp32|bf16 row stride lds -> dst bf16: (R, ldd) copy/cast, or transposed (C, ldd) with rows R..Rpad-1 zero.
+extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int R, int C, int Rpad, int src_f32,
+                             int transpose, void* stream) {
+    if (R <= 0 || C <= 0) { sat_set_error("sat_cast_bf16: empty shape"); return 1; }
+    if (Rpad < R) Rpad = R;
+    SatCastParams p{src, (short*)dst, lds, ldd, R, C, Rpad, src_f32, transpose};
+    SAT_LAUNCH(sat_cast_kernel, dim3(sat_cdiv(C, 64), sat_cdiv(transpose ? Rpad : R, 64)), dim3(256), stream, p);
+    return sat_check_launch("sat_cast_bf16");
+}
+
+// fp32 (R, C) -> bf16 (R, 3C) split planes along K for the fp32-accurate GEMM: side 0 (activations / A) = [hi | hi | lo],
+// side 1 (weights / B) = [hi | lo | hi], so that A' · B'^T = hi·hi + hi·lo + lo·hi.
+struct SatSplitParams {
+    const float* src;
+    short* dst;
+    long long lds_, ldd;
+    int R, Cc, side;
+};
+__global__ void __launch_bounds__(256) sat_split_kernel(SatSplitParams p) {
+    const long long total = (long long)p.R * (p.Cc >> 1);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / (p.Cc >> 1)), c = (int)(i % (p.Cc >> 1)) * 2;
+        const float a = p.src[(long long)r * p.lds_ + c], b = p.src[(long long)r * p.lds_ + c + 1];
+        uint32_t hi, lo;
+        sat_split2_pk(a, b, &hi, &lo);
+        uint32_t* d = (uint32_t*)(p.dst + (long long)r * p.ldd + c);
+        d[0] = hi;
+        d[p.Cc >> 1] = p.side ? lo : hi;
+        d[p.Cc] = p.side ? hi : lo;
+    }
+}
+extern "C" int sat_split_bf16x3(const float* src, long long lds, void* dst, long long ldd, int R, int C, int side, void* stream) {
+    if (R <= 0 || C <= 0 || (C & 1)) { sat_set_error("sat_split_bf16x3: C must be even"); return 1; }
+    SatSplitParams p{src, (short*)dst, lds, ldd, R, C, side};
+    const long long total = (long long)R * (C >> 1);
+    SAT_LAUNCH(sat_split_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 4096 ? sat_cdivll(total, 256) : 4096)), dim3(256), stream, p);
+    return sat_check_launch("sat_split_bf16x3");
+}

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .linear import Linear
 from .transformer import ContinuousTransformer
 
 
@@ -48,22 +49,22 @@ class DiffusionTransformer(nn.Module):
         elif timestep_cond_type == "input_concat":
             assert timestep_embed_dim is not None, "timestep_embed_dim must be specified if timestep_cond_type is input_concat"
             input_concat_dim += timestep_embed_dim
-        self.to_timestep_embed = nn.Sequential(nn.Linear(timestep_features_dim, timestep_embed_dim, bias=True), nn.SiLU(),
-                                               nn.Linear(timestep_embed_dim, timestep_embed_dim, bias=True))
+        self.to_timestep_embed = nn.Sequential(Linear(timestep_features_dim, timestep_embed_dim, bias=True), nn.SiLU(),
+                                               Linear(timestep_embed_dim, timestep_embed_dim, bias=True))
         self.diffusion_objective = diffusion_objective
         if cond_token_dim > 0:
             cond_embed_dim = cond_token_dim if not project_cond_tokens else embed_dim
-            self.to_cond_embed = nn.Sequential(nn.Linear(cond_token_dim, cond_embed_dim, bias=False), nn.SiLU(),
-                                               nn.Linear(cond_embed_dim, cond_embed_dim, bias=False))
+            self.to_cond_embed = nn.Sequential(Linear(cond_token_dim, cond_embed_dim, bias=False), nn.SiLU(),
+                                               Linear(cond_embed_dim, cond_embed_dim, bias=False))
         else:
             cond_embed_dim = 0
         if global_cond_dim > 0:
             global_embed_dim = global_cond_dim if not project_global_cond else embed_dim
-            self.to_global_embed = nn.Sequential(nn.Linear(global_cond_dim, global_embed_dim, bias=False), nn.SiLU(),
-                                                 nn.Linear(global_embed_dim, global_embed_dim, bias=False))
+            self.to_global_embed = nn.Sequential(Linear(global_cond_dim, global_embed_dim, bias=False), nn.SiLU(),
+                                                 Linear(global_embed_dim, global_embed_dim, bias=False))
         if prepend_cond_dim > 0:
-            self.to_prepend_embed = nn.Sequential(nn.Linear(prepend_cond_dim, embed_dim, bias=False), nn.SiLU(),
-                                                  nn.Linear(embed_dim, embed_dim, bias=False))
+            self.to_prepend_embed = nn.Sequential(Linear(prepend_cond_dim, embed_dim, bias=False), nn.SiLU(),
+                                                  Linear(embed_dim, embed_dim, bias=False))
         self.input_concat_dim = input_concat_dim
         dim_in = io_channels + self.input_concat_dim
         self.patch_size = patch_size

@@ -1,0 +1,233 @@
+"""nn.Linear of the DiT on the native MFMA GEMM (csrc/gemm.hip) — forward, data gradient and weight gradient — with the
+elementwise work that follows a projection fused into its epilogue.
+
+Reference call sites (stable_audio_tools/models/transformer.py): to_qkv :362/:481, to_out :364/:534, to_q / to_kv :356-357,
+GLU.proj + x*silu(gate) :263-275, FeedForward linear_out :308, the residual / gate updates of TransformerBlock :684-712;
+models/dit.py: to_timestep_embed / to_cond_embed / to_global_embed :49-77.
+
+`Linear` keeps nn.Linear's parameter names (`weight` (out, in), `bias`) so state_dict keys are the reference's.
+
+Precision modes
+  * bf16 tensors, or fp32 master weights under torch.autocast(bf16): one bf16 MFMA per product, fp32 accumulation; weights
+    are cast once per optimizer step (cache keyed on the parameter version and the optimizer epoch, `bump_weight_epoch`).
+  * fp32 tensors: the same kernel on bf16x3-split operands ([hi|hi|lo] x [hi|lo|hi] along K): three MFMAs per product,
+    ~2^-17 relative per product — float32-class results for the 1e-3 parity bar.
+One kernel computes all three GEMMs of a layer: it is "NT" (both operands K-contiguous), which is nn.Linear's forward as
+stored; the data gradient runs on the transposed weight copy and the weight gradient on transposed activations
+(sat_cast_bf16 with transpose, zero padded along the reduction dim).
+"""
+import torch
+from torch import nn
+
+from . import functional as _fn
+
+_WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    """Called by the fused optimizer after it rewrote the flat parameter buffer in place (the HIP kernel does not touch
+    torch's version counters): drops every cached low-precision copy of a weight."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def _ops():
+    return _fn._ops(None)
+
+
+def _pad8(t):
+    """Pad the last dim of a 2-D tensor to a multiple of 8 with zeros (K of the GEMM must be a multiple of 8)."""
+    k = t.shape[1]
+    if k % 8 == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, 8 - k % 8))
+
+
+def _pad_rows8(t):
+    n = t.shape[0]
+    if n % 8 == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, 0, 0, 8 - n % 8))
+
+
+class _WeightCache:
+    """Low-precision / transposed / split copies of a module's parameters; each entry is valid for one
+    (storage, version, dtype, optimizer epoch) of the tensor it was made from."""
+
+    def __init__(self):
+        self.items = {}
+
+    def get(self, w, name, make):
+        key = (w.data_ptr(), w._version, w.dtype, w.device, _WEIGHT_EPOCH)
+        hit = self.items.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make())
+            self.items[name] = hit
+        return hit[1]
+
+
+def _operands(ops, x2, w, cache, lowp):
+    """GEMM operands (A, B) for y = x2 · w^T in the chosen precision mode."""
+    if lowp:
+        a = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2)
+        a = _pad8(a)
+        b = cache.get(w, "bf16", lambda: _pad_rows8(_pad8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
+        return a, b
+    a = ops.split_bf16x3(_pad8(x2.float()).contiguous(), 0)
+    b = cache.get(w, "x3", lambda: ops.split_bf16x3(_pad_rows8(_pad8(w.detach().float())).contiguous(), 1))
+    return a, b
+
+
+def _wgrad_splits(n, k, red):
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    return max(1, min(8, 256 // max(tiles, 1), (red + 511) // 512))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = epilogue(x · W^T + b).   mode: 'plain' | 'res' (y += res) | 'swiglu' (y = v * silu(g), W rows = [v | g])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, mode, lowp, cache):
+        ops = _ops()
+        shp = x.shape
+        k = shp[-1]
+        n = weight.shape[0]
+        x2 = x.reshape(-1, k)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        out_dtype = torch.bfloat16 if lowp else torch.float32
+        a, b = _operands(ops, x2, weight, cache, lowp)
+        bias32 = None
+        if bias is not None:
+            bias32 = cache.get(bias, "bias32", lambda: torch.nn.functional.pad(bias.detach().float(), (0, (-n) % 8)).contiguous())
+        need_grad = any(ctx.needs_input_grad[:4])
+        r2 = None
+        if mode == "res":
+            r2 = res.reshape(-1, n).to(out_dtype)
+            if r2.stride(1) != 1:
+                r2 = r2.contiguous()
+            if n % 8:
+                r2 = _pad8(r2)
+        pre = None
+        nout = n // 2 if mode == "swiglu" else n
+        npad = b.shape[0] // 2 if mode == "swiglu" else b.shape[0]
+        # the result is allocated in its final shape (an output that is a *view* of a tensor made inside a custom Function
+        # cannot be modified in place later, e.g. by the in-place rotary)
+        yfull = torch.empty(*shp[:-1], nout, dtype=out_dtype, device=x.device)
+        out2 = yfull.view(-1, nout) if npad == nout else None
+        if mode == "swiglu":
+            if n % 16:
+                raise ValueError("SwiGLU projection needs 2F output rows with F % 8 == 0")
+            y = ops.gemm_bf16(a, b, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
+            if need_grad:
+                y, pre = y
+        else:
+            y = ops.gemm_bf16(a, b, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
+                              out=out2)
+        if out2 is None:
+            yfull.view(-1, nout).copy_(y[:, :nout])
+        if need_grad:
+            ctx.save_for_backward(x2, weight, pre)
+            ctx.meta = (ops, shp, mode, lowp, cache, bias is not None, res is not None, x.dtype, weight.dtype,
+                        bias.dtype if bias is not None else None, res.dtype if res is not None else None, res.shape if res is not None else None)
+        return yfull
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, pre = ctx.saved_tensors
+        ops, shp, mode, lowp, cache, has_bias, has_res, xdt, wdt, bdt, rdt, rshape = ctx.meta
+        n, k = weight.shape
+        m = x2.shape[0]
+        dy2 = dy.reshape(m, -1)
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        dres = dy.to(rdt).reshape(rshape) if has_res and ctx.needs_input_grad[3] else None
+        if mode == "swiglu":
+            dz = ops.swiglu_bwd(pre, dy2.to(pre.dtype).contiguous())          # (M, 2F): d/d[v | g]
+        else:
+            dz = dy2
+        dx = dw = db = None
+        if lowp:
+            dzb = dz if dz.dtype == torch.bfloat16 else ops.cast_bf16(dz.contiguous())
+            if ctx.needs_input_grad[0]:
+                # dx (M, K) = dz (M, N) · W (N, K): NT form with B = W^T (K, N)
+                wt = cache.get(weight, "bf16_t", lambda: _pad8(ops.cast_bf16(weight.detach(), transpose=True, row_pad=8)))
+                dx = ops.gemm_bf16(_pad8(dzb), _pad_rows8(wt), out_dtype=torch.bfloat16)[:, :k]
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                # dW (N, K) = dz^T (N, Mp) · x^T (K, Mp)^T, reduction over the zero-padded token dim.  The bias gradient rides in
+                # the same GEMM: one extra "activation" row of ones makes column K of the result the column sum of dz.
+                dzt = _pad_rows8(ops.cast_bf16(dzb, transpose=True, row_pad=8))          # (N8, Mp)
+                k8 = (k + 7) // 8 * 8
+                xt = torch.empty(k8 + (8 if has_bias else 0), dzt.shape[1], dtype=torch.bfloat16, device=dzt.device)
+                ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
+                xt[k:].zero_()
+                if has_bias:
+                    xt[k8, :m] = 1.0
+                dwb = ops.gemm_bf16(dzt, xt, out_dtype=torch.float32, splits=_wgrad_splits(n, k, m))
+                if ctx.needs_input_grad[1]:
+                    dw = dwb[:n, :k]
+                if has_bias and ctx.needs_input_grad[2]:
+                    db = dwb[:n, k8]
+        else:
+            dz32 = dz.float()
+            if ctx.needs_input_grad[0]:
+                wt = cache.get(weight, "x3_t", lambda: ops.split_bf16x3(_pad_rows8(_pad8(weight.detach().float().t().contiguous())).contiguous(), 1))
+                dx = ops.gemm_bf16(ops.split_bf16x3(_pad8(dz32).contiguous(), 0), wt, out_dtype=torch.float32)[:, :k]
+            if ctx.needs_input_grad[1]:
+                dzt = _pad_rows8(_pad8(dz32.t().contiguous())).contiguous()              # (N, Mp)
+                xt = _pad_rows8(_pad8(x2.float().t().contiguous())).contiguous()         # (K, Mp)
+                dw = ops.gemm_bf16(ops.split_bf16x3(dzt, 0), ops.split_bf16x3(xt, 1), out_dtype=torch.float32,
+                                   splits=_wgrad_splits(n, k, 3 * m))[:n, :k]
+            if has_bias and ctx.needs_input_grad[2]:
+                db = ops.rowsum(dz32.t().contiguous().unsqueeze(0))
+        if dx is not None:
+            dx = dx.to(xdt).reshape(shp)
+        if dw is not None:
+            dw = dw.to(wdt)
+        if db is not None:
+            db = db.to(bdt)
+        return dx, dw, db, dres, None, None, None
+
+
+def _lowp(x, weight):
+    """bf16 MFMA path? (bf16 tensors, or bf16 autocast over fp32 master weights)"""
+    if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
+        return True
+    dev = "cuda" if x.is_cuda else "cpu"
+    if torch.is_autocast_enabled(dev):
+        if torch.get_autocast_dtype(dev) != torch.bfloat16:
+            raise NotImplementedError("only bf16 autocast is on the HIP path")
+        return True
+    if x.dtype != weight.dtype:
+        raise TypeError(f"Linear: input {x.dtype} vs weight {weight.dtype} outside autocast")
+    if x.dtype != torch.float32:
+        raise TypeError(f"Linear: unsupported dtype {x.dtype}")
+    return False
+
+
+class Linear(nn.Module):
+    """Drop-in for nn.Linear (same parameters, same init) running on csrc/gemm.hip."""
+
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=None):
+        super().__init__()
+        ref = nn.Linear(in_features, out_features, bias=bias, device=device, dtype=dtype)   # the reference's init
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = ref.weight
+        self.bias = ref.bias
+        self._cache = _WeightCache()
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
+
+    def lowp_weight(self):
+        """bf16 copy of the weight (cached), or None when the fused projection epilogues do not apply (K % 8 != 0)."""
+        if self.in_features % 8:
+            return None
+        w = self.weight
+        return self._cache.get(w, "bf16", lambda: _pad_rows8(w.detach() if w.dtype == torch.bfloat16 else _ops().cast_bf16(w.detach())))
+
+    def forward(self, x, res=None, mode=None):
+        """mode None: x W^T + b [+ res];  'swiglu': value * silu(gate) over W rows = [value | gate]."""
+        if mode is None:
+            mode = "res" if res is not None else "plain"
+        return LinearFn.apply(x, self.weight, self.bias, res, mode, _lowp(x, self.weight), self._cache)

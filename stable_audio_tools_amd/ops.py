@@ -500,6 +500,130 @@ class SatOps:
         dgate = torch.stack([self._reduce_rows(part[i], nch, d) for i in range(b)])
         return dx, dgate
 
+    # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
+    EPI_STORE, EPI_RES, EPI_GATE_RES, EPI_SWIGLU = 0, 1, 2, 3
+    gemm_tile = None     # None: pick per shape; 0 = 128x128 (4 waves), 1 = 256x128 (8 waves)
+
+    def _zeros_page(self, device):
+        z = getattr(self, "_zpage", None)
+        if z is None or z.device != device:
+            z = torch.zeros(64, dtype=torch.int16, device=device)
+            self._zpage = z
+        return z
+
+    def _pick_tile(self, m, n):
+        if self.gemm_tile is not None:
+            return self.gemm_tile
+        return 0
+
+    def gemm_bf16(self, a, b, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
+                  splits=1, out=None):
+        """C = epilogue(A · B^T): a (M, K), b (N, K) bf16 (row strides free, K contiguous), fp32 accumulation.
+        epilogue 0: [+bias]; 1: + res; 2: * sigmoid(1 - gate[m // rows_per_gate]) + res; 3: SwiGLU over b = [value rows | gate rows]
+        (returns (M, N/2), and the (M, N) pre-activation too with want_pre).  bias fp32 (N,); res / gate in out_dtype.
+        splits > 1: split-K slabs (splits, M, N) fp32, summed here with sat_reduce_splits."""
+        if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+            raise TypeError("gemm_bf16 takes bf16 operands (fp32 models go through split_bf16x3)")
+        if a.stride(1) != 1 or b.stride(1) != 1 or a.shape[1] != b.shape[1]:
+            raise ValueError("gemm_bf16: operands must be (rows, K) with K contiguous and equal")
+        if not self.simulator and not a.is_cuda:
+            raise RuntimeError("stable_audio_tools_amd kernels need CUDA(HIP) tensors; there is no CPU path")
+        m, k = a.shape
+        n = b.shape[0]
+        f32 = out_dtype == torch.float32
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("gemm_bf16: output is bf16 or fp32")
+        if bias is not None:
+            self._f32(bias)
+        for t in (res, gate):
+            if t is not None and (t.dtype != out_dtype or t.stride(-1) != 1):
+                raise TypeError("gemm_bf16: res / gate must have the output dtype and a contiguous last dim")
+        nout = n // 2 if epilogue == self.EPI_SWIGLU else n
+        if out is not None and splits == 1:
+            if tuple(out.shape) != (m, nout) or out.dtype != out_dtype or not out.is_contiguous():
+                raise ValueError("gemm_bf16: bad `out`")
+            c = out
+        else:
+            c = torch.empty((splits, m, nout) if splits > 1 else (m, nout), dtype=out_dtype, device=a.device)
+        pre = torch.empty(m, n, dtype=out_dtype, device=a.device) if (want_pre and epilogue == self.EPI_SWIGLU) else None
+        self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), nout, _ptr(bias),
+                                         _ptr(res), res.stride(0) if res is not None else 0,
+                                         _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_gate,
+                                         _ptr(pre), n, _ptr(self._zeros_page(a.device)), m, n, k, epilogue, int(f32), splits,
+                                         self._pick_tile(m, n), self._stream(a)))
+        if splits > 1:
+            c = self._reduce_rows(c.view(splits, m * nout), splits, m * nout).view(m, nout)
+        return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
+
+    def _plane_cache(self, key, shape, device):
+        """Persistent zero-initialised bf16 planes for the no-grad path: rows / columns past the sequence length are never
+        written by the projection epilogue, so one memset at first use keeps them zero for every later call."""
+        cache = self.__dict__.setdefault("_planes", {})
+        t = cache.get(key)
+        if t is None or t.shape != shape or t.device != device:
+            t = torch.zeros(shape, dtype=torch.int16, device=device)
+            cache[key] = t
+        return t
+
+    def gemm_heads_bf16(self, x, w, cs, heads, nb, ntok, sec0, nsec, reuse=None):
+        """Attention input projection with head split / rotary / plane layout fused (sat_gemm_qkv_bf16): x (nb*ntok, K) bf16,
+        w (nsec*heads*64, K) bf16, cs (>= ntok, 16, 2) fp32 rotary table or None.  Sections sec0 .. sec0+nsec-1 of (q, k, v).
+        Returns dict(q=, k= (nb,H,Np,64), v_tr= (nb,H,64,Np)) with the produced planes (bf16 bits as int16, zero padded).
+        reuse: a hashable tag -> the planes live in a per-ops cache (only safe when nothing keeps them for a backward)."""
+        if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+            raise TypeError("gemm_heads_bf16 takes bf16 operands")
+        if x.stride(1) != 1 or w.stride(1) != 1 or w.shape[0] != nsec * heads * 64 or x.shape[0] != nb * ntok:
+            raise ValueError("gemm_heads_bf16: bad operand layout")
+        npad = (ntok + 63) // 64 * 64
+        out = {"n": ntok, "np": npad}
+        for i, (name, shape) in enumerate((("q", (nb, heads, npad, 64)), ("k", (nb, heads, npad, 64)), ("v_tr", (nb, heads, 64, npad)))):
+            if sec0 <= i < sec0 + nsec:
+                out[name] = (self._plane_cache((reuse, name, shape), shape, x.device) if reuse is not None
+                             else torch.zeros(shape, dtype=torch.int16, device=x.device))
+        if cs is not None:
+            self._f32(cs)
+        self._chk(self.lib.sat_gemm_qkv_bf16(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
+                                             _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
+                                             nb, ntok, npad, heads, x.shape[1], sec0, nsec, self._pick_tile(nb * ntok, nsec * heads * 64),
+                                             self._stream(x)))
+        return out
+
+    def attention_planes(self, q_rm, k_rm, v_tr, nq, nk, scale, out_dtype=torch.bfloat16):
+        """Attention forward straight from bf16 operand planes (gemm_heads_bf16): q_rm (B,H,Npq,64), k_rm (B,Hkv,Npk,64),
+        v_tr (B,Hkv,64,Npk) -> o (B, Nq, H*64)."""
+        b, h, npq, d = q_rm.shape
+        hk, npk = k_rm.shape[1], k_rm.shape[2]
+        o = torch.empty(b, nq, h * d, dtype=out_dtype, device=q_rm.device)
+        if out_dtype != torch.bfloat16:
+            raise TypeError("attention_planes produces bf16")
+        self._chk(self.lib.sat_attention_fwd(_ptr(q_rm), None, _ptr(k_rm), None, _ptr(v_tr), None, _ptr(o), None, b, h, hk, nq, nk,
+                                             npq, npk, d, float(scale), 1, self._stream(q_rm)))
+        return o
+
+    def cast_bf16(self, src, transpose=False, row_pad=1, out=None):
+        """src (R, C) fp32|bf16 (last dim contiguous) -> bf16 (R, C), or transposed (C, Rp) with Rp = R rounded up to row_pad
+        (extra columns zero).  out: optional destination of that shape (row stride free)."""
+        dt = self._dt(src)
+        if src.dim() != 2 or src.stride(1) != 1:
+            raise ValueError("cast_bf16 takes a 2-D tensor with a contiguous last dim")
+        r, c = src.shape
+        rp = (r + row_pad - 1) // row_pad * row_pad
+        shape = (c, rp) if transpose else (r, c)
+        dst = out if out is not None else torch.empty(shape, dtype=torch.bfloat16, device=src.device)
+        if tuple(dst.shape) != shape or dst.dtype != torch.bfloat16 or dst.stride(1) != 1:
+            raise ValueError("cast_bf16: bad destination")
+        self._chk(self.lib.sat_cast_bf16(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), r, c, rp, int(dt == 0), int(transpose),
+                                         self._stream(src)))
+        return dst
+
+    def split_bf16x3(self, src, side):
+        """fp32 (R, C) -> bf16 (R, 3C): side 0 (activations) [hi|hi|lo], side 1 (weights) [hi|lo|hi]."""
+        self._f32(src)
+        r, c = src.shape
+        dst = torch.empty(r, 3 * c, dtype=torch.bfloat16, device=src.device)
+        self._chk(self.lib.sat_split_bf16x3(_ptr(src), src.stride(0), _ptr(dst), 3 * c, r, c, side, self._stream(src)))
+        return dst
+
     # ------------------------------------------------------------------ optimizer
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)

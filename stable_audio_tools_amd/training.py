@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as _fn
+from . import linear as _linear
 
 
 class FlatParameters:
@@ -137,6 +138,7 @@ class FusedAdamW:
         ops.adamw_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, grad_scale,
                        ema=self.ema, ema_decay=ema_decay(self.t) if self.ema is not None else 0.0)
+        _linear.bump_weight_epoch()      # the kernel rewrote the parameters in place: cached bf16 weight copies are stale
 
 
 class AutoencoderTrainStep:

@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import functional as _fn
+from .linear import Linear, _lowp
 
 
 def _ops():
@@ -198,10 +199,10 @@ class GLU(nn.Module):
         super().__init__()
         if use_conv:
             raise NotImplementedError("GLU(use_conv=True) is not used by the DiT and not implemented")
-        self.proj = nn.Linear(dim_in, dim_out * 2)
+        self.proj = Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        return _SwiGLUFn.apply(self.proj(x))     # x * silu(gate), transformer.py:274-275
+        return self.proj(x, mode="swiglu")       # x * silu(gate) in the GEMM epilogue (transformer.py:274-275)
 
 
 class FeedForward(nn.Module):
@@ -213,15 +214,16 @@ class FeedForward(nn.Module):
         inner_dim = int(dim * mult)
         dim_out = dim if dim_out is None else dim_out
         linear_in = GLU(dim, inner_dim)
-        linear_out = nn.Linear(inner_dim, dim_out, bias=not no_bias)
+        linear_out = Linear(inner_dim, dim_out, bias=not no_bias)
         if zero_init_output:
             nn.init.zeros_(linear_out.weight)
             if not no_bias:
                 nn.init.zeros_(linear_out.bias)
         self.ff = nn.Sequential(linear_in, nn.Identity(), linear_out, nn.Identity())
 
-    def forward(self, x):
-        return self.ff(x)
+    def forward(self, x, res=None):
+        """res: the residual stream — added in the output projection's epilogue (x = x + ff(...), transformer.py:711)."""
+        return self.ff[2](self.ff[0](x), res=res)
 
 
 class Attention(nn.Module):
@@ -237,31 +239,52 @@ class Attention(nn.Module):
         self.num_heads = dim // dim_heads
         self.kv_heads = dim_kv // dim_heads
         if dim_context is not None:
-            self.to_q = nn.Linear(dim, dim, bias=False)
-            self.to_kv = nn.Linear(dim_kv, dim_kv * 2, bias=False)
+            self.to_q = Linear(dim, dim, bias=False)
+            self.to_kv = Linear(dim_kv, dim_kv * 2, bias=False)
         else:
-            self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
-        self.to_out = nn.Linear(dim, dim, bias=False)
+            self.to_qkv = Linear(dim, dim * 3, bias=False)
+        self.to_out = Linear(dim, dim, bias=False)
         if zero_init_output:
             nn.init.zeros_(self.to_out.weight)
         self.causal = False
         self.scale = dim_heads ** -0.5
 
-    def forward(self, x, context=None, rotary_pos_emb=None, causal=None, **unsupported):
+    def forward(self, x, context=None, rotary_pos_emb=None, causal=None, res=None, **unsupported):
+        """res: the residual stream, added in the output projection's epilogue (x = x + attn(...), transformer.py:703-707)."""
         for k, v in unsupported.items():
             if v is not None:
                 raise NotImplementedError(f"Attention.forward({k}=...) is not on the HIP path")
         h, kv_h, dh = self.num_heads, self.kv_heads, self.dim_heads
         b, n, _ = x.shape
-        if hasattr(self, "to_q"):
-            kv_input = context if context is not None else x
+        cross = hasattr(self, "to_q")
+        if cross and rotary_pos_emb is not None:
+            raise NotImplementedError("rotary on a separate-projection attention is never used by the DiT")
+        kv_input = context if (cross and context is not None) else x
+        first = self.to_q if cross else self.to_qkv
+        if not torch.is_grad_enabled() and _lowp(x, first.weight) and first.lowp_weight() is not None \
+                and (not cross or self.to_kv.lowp_weight() is not None):
+            # inference, bf16: head split, rotary and the attention kernel's operand planes come straight out of the
+            # projection GEMM's epilogue (no qkv tensor, no rotary pass, no plane-preparation pass)
+            ops = _ops()
+            x2 = x.reshape(b * n, -1)
+            x2 = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2.contiguous())
+            if cross:
+                m = kv_input.shape[1]
+                c2 = kv_input.reshape(b * m, -1)
+                c2 = c2 if c2.dtype == torch.bfloat16 else ops.cast_bf16(c2.contiguous())
+                pq = ops.gemm_heads_bf16(x2, self.to_q.lowp_weight(), None, h, b, n, 0, 1, reuse="cross")
+                pkv = ops.gemm_heads_bf16(c2, self.to_kv.lowp_weight(), None, kv_h, b, m, 1, 2, reuse="cross")
+                out = ops.attention_planes(pq["q"], pkv["k"], pkv["v_tr"], n, m, self.scale)
+            else:
+                cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
+                pl = ops.gemm_heads_bf16(x2, self.to_qkv.lowp_weight(), cs, h, b, n, 0, 3, reuse="self")
+                out = ops.attention_planes(pl["q"], pl["k"], pl["v_tr"], n, n, self.scale)
+            return self.to_out(out, res=res)
+        if cross:
             q = self.to_q(x).view(b, n, h, dh).permute(0, 2, 1, 3)
             kv = self.to_kv(kv_input)
-            m = kv.shape[1]
             k = kv[..., :kv_h * dh].unflatten(-1, (kv_h, dh)).permute(0, 2, 1, 3)
             v = kv[..., kv_h * dh:].unflatten(-1, (kv_h, dh)).permute(0, 2, 1, 3)
-            if rotary_pos_emb is not None:
-                raise NotImplementedError("rotary on a separate-projection attention is never used by the DiT")
         else:
             qkv = self.to_qkv(x)
             if rotary_pos_emb is not None:
@@ -272,7 +295,7 @@ class Attention(nn.Module):
             k = qkv[..., hd:2 * hd].unflatten(-1, (h, dh)).permute(0, 2, 1, 3)
             v = qkv[..., 2 * hd:].unflatten(-1, (h, dh)).permute(0, 2, 1, 3)
         out = _AttentionCoreFn.apply(q, k, v, self.scale)       # (B, N, H*dh): heads already merged
-        return self.to_out(out)
+        return self.to_out(out, res=res)
 
 
 class TransformerBlock(nn.Module):
@@ -313,14 +336,14 @@ class TransformerBlock(nn.Module):
             h = self.self_attn(self.pre_norm(x, scale_self, shift_self), rotary_pos_emb=rotary_pos_emb)
             x = _GateResidualFn.apply(h, gate_self, x)                           # h*sigmoid(1-gate)+x  (:684-686)
             if context is not None and self.cross_attend:
-                x = x + self.cross_attn(self.cross_attend_norm(x), context=context)   # never modulated (:688-689)
+                x = self.cross_attn(self.cross_attend_norm(x), context=context, res=x)   # never modulated (:688-689)
             h = self.ff(self.ff_norm(x, scale_ff, shift_ff))
             x = _GateResidualFn.apply(h, gate_ff, x)
         else:
-            x = x + self.self_attn(self.pre_norm(x), rotary_pos_emb=rotary_pos_emb)
-            if context is not None and self.cross_attend:
-                x = x + self.cross_attn(self.cross_attend_norm(x), context=context)
-            x = x + self.ff(self.ff_norm(x))
+            x = self.self_attn(self.pre_norm(x), rotary_pos_emb=rotary_pos_emb, res=x)       # residual adds live in the
+            if context is not None and self.cross_attend:                                       # output projections' epilogues
+                x = self.cross_attn(self.cross_attend_norm(x), context=context, res=x)
+            x = self.ff(self.ff_norm(x), res=x)
         return x
 
 
@@ -334,13 +357,13 @@ class ContinuousTransformer(nn.Module):
             raise NotImplementedError("causal / conformer / abs-pos-emb / memory tokens / sliding window are not on the HIP path")
         self.dim, self.depth, self.causal = dim, depth, False
         self.layers = nn.ModuleList([])
-        self.project_in = nn.Linear(dim_in, dim, bias=False) if dim_in is not None else nn.Identity()
-        self.project_out = nn.Linear(dim, dim_out, bias=False) if dim_out is not None else nn.Identity()
+        self.project_in = Linear(dim_in, dim, bias=False) if dim_in is not None else nn.Identity()
+        self.project_out = Linear(dim, dim_out, bias=False) if dim_out is not None else nn.Identity()
         self.rotary_pos_emb = RotaryEmbedding(max(dim_heads // 2, 32)) if rotary_pos_emb else None
         self.num_memory_tokens = 0
         self.global_cond_embedder = None
         if global_cond_dim is not None:
-            self.global_cond_embedder = nn.Sequential(nn.Linear(global_cond_dim, dim), nn.SiLU(), nn.Linear(dim, dim * 6))
+            self.global_cond_embedder = nn.Sequential(Linear(global_cond_dim, dim), nn.SiLU(), Linear(dim, dim * 6))
         self.final_cross_attn_ix = final_cross_attn_ix
         self.sliding_window = None
         for i in range(depth):

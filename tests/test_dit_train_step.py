@@ -55,18 +55,30 @@ def test_dit_train_step_matches_oracle_gpu(hip):
     _steps("cuda")
 
 
-@pytest.mark.gpu
-def test_dit_train_step_bf16_autocast_gpu(hip):
-    """bf16-mixed (fp32 master weights, bf16 activations/kernels): finite loss that decreases on a fixed batch."""
+def _autocast_steps(device, name, idx, nsteps):
+    """bf16-mixed (fp32 master weights, bf16 activations / kernels, Lightning '--precision bf16-mixed'): finite loss that
+    decreases on a fixed batch.  Runs both global-conditioning modes: under autocast the adaLN modulation
+    (fp32 parameter + bf16 embedding) must be cast to the activation dtype (transformer.py:677)."""
     from stable_audio_tools_amd.training import DiTTrainStep
-    model, _ = _build("tiny_prepend", 700, "cuda")
+    model, _ = _build(name, 700 + 10 * idx, device)
     model.train(True)
     stepper = DiTTrainStep(model, lr=1e-4, cfg_dropout_prob=0.0, autocast_dtype=torch.bfloat16)
-    inp = {k: v.cuda() for k, v in dit_inputs("tiny_prepend").items()}
-    noise = torch.randn_like(inp["x"])
+    inp = {k: v.to(device) for k, v in dit_inputs(name).items()}
+    noise = torch.from_numpy(seeded.seeded_array(tuple(inp["x"].shape), 4321)).to(device)
     losses = [float(stepper(inp["x"], cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], t=inp["t"], noise=noise)["loss"])
-              for _ in range(10)]
+              for _ in range(nsteps)]
     assert all(math.isfinite(v) for v in losses) and min(losses[-3:]) < losses[0], losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx,name", [(0, "tiny_prepend"), (1, "tiny_adaln")])
+def test_dit_train_step_bf16_autocast_gpu(hip, idx, name):
+    _autocast_steps("cuda", name, idx, 10)
+
+
+@pytest.mark.parametrize("idx,name", [(0, "tiny_prepend"), (1, "tiny_adaln")])
+def test_dit_train_step_bf16_autocast_simulator(emu_modules, idx, name):
+    _autocast_steps("cpu", name, idx, 4)
 
 
 # ---- N > 1: world_size-2 gloo processes on CPU (kernels on the simulator) — BASELINE.json configs[3] (DiT training, DDP) ----

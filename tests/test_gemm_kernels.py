@@ -1,0 +1,124 @@
+"""Kernel-level tests of csrc/gemm.hip (the DiT projections: transformer.py:263,308,356-364,481-507) against plain torch
+fp32 matmuls of the same bf16-rounded operands: every epilogue, both tile shapes, ragged M / N / K (partial tiles, K tails
+that are not a multiple of the 64-wide K-step), split-K, the fused head-split / rotary / plane-layout epilogue, and the
+operand preparation kernels (cast, transpose, bf16x3 split).  CPU: the simulator; `-m gpu`: the gfx950 library, plus the
+BASELINE shapes (M = 2050 tokens, d = 1536, FF 12288) at full size."""
+import pytest
+import torch
+
+import dit_oracle
+from golden_util import rel_err
+
+SHAPES = [(130, 136, 72), (257, 128, 64), (70, 264, 200), (33, 64, 8)]
+
+
+def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3)):
+    torch.manual_seed(0)
+    for (m, n, k) in shapes:
+        a = torch.randn(m, k).bfloat16().to(dev)
+        b = torch.randn(n, k).bfloat16().to(dev)
+        bias = torch.randn(n).to(dev)
+        res = torch.randn(m, n).bfloat16().to(dev)
+        ref = (a.float() @ b.float().t()).cpu()
+        for tile in tiles:
+            ops.gemm_tile = tile
+            try:
+                assert rel_err(ops.gemm_bf16(a, b, out_dtype=torch.float32), ref) < 1e-5
+                assert rel_err(ops.gemm_bf16(a, b, bias=bias).float(), ref + bias.cpu()) < 6e-3            # bf16 output rounding
+                assert rel_err(ops.gemm_bf16(a, b, bias=bias, res=res, epilogue=ops.EPI_RES).float(), ref + bias.cpu() + res.float().cpu()) < 6e-3
+                nb = 2 if m % 2 == 0 else 1
+                gate = torch.randn(nb, n).to(dev)
+                c = ops.gemm_bf16(a, b, res=res.float(), gate=gate, rows_per_gate=m // nb, epilogue=ops.EPI_GATE_RES, out_dtype=torch.float32)
+                g = torch.sigmoid(1 - gate.cpu()).repeat_interleave(m // nb, 0)
+                assert rel_err(c, ref * g + res.float().cpu()) < 1e-5
+                if n % 16 == 0:
+                    c, pre = ops.gemm_bf16(a, b, bias=bias, epilogue=ops.EPI_SWIGLU, out_dtype=torch.float32, want_pre=True)
+                    full = ref + bias.cpu()
+                    assert rel_err(pre, full) < 1e-5
+                    assert rel_err(c, full[:, :n // 2] * torch.nn.functional.silu(full[:, n // 2:])) < 1e-5
+                assert rel_err(ops.gemm_bf16(a, b, out_dtype=torch.float32, splits=2), ref) < 1e-5
+            finally:
+                ops.gemm_tile = None
+
+
+def _heads_case(ops, dev, nb, ntok, heads, k):
+    torch.manual_seed(1)
+    x = torch.randn(nb * ntok, k).bfloat16().to(dev)
+    w = (torch.randn(3 * heads * 64, k) / k ** 0.5).bfloat16().to(dev)
+    inv = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    cs = ops.rope_tables(inv.to(dev), ntok + 3)          # longer table: freqs[-seq_len:] offset (transformer.py:162)
+    qkv = (x.float().cpu() @ w.float().cpu().t()).view(nb, ntok, 3, heads, 64)
+    q, kk, v = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    freqs = dit_oracle.rotary_freqs(inv, ntok + 3)[-ntok:]
+    qr, kr = dit_oracle.apply_rotary(q, freqs), dit_oracle.apply_rotary(kk, freqs)
+    for tile in (0, 1, 2, 3):
+        ops.gemm_tile = tile
+        try:
+            pl = ops.gemm_heads_bf16(x, w, cs, heads, nb, ntok, 0, 3)
+            qp, kp, vp = [pl[n].view(torch.bfloat16).float().cpu() for n in ("q", "k", "v_tr")]
+            assert rel_err(qp[:, :, :ntok], qr) < 6e-3 and rel_err(kp[:, :, :ntok], kr) < 6e-3
+            assert rel_err(vp[:, :, :, :ntok], v.transpose(2, 3)) < 6e-3
+            assert float(qp[:, :, ntok:].abs().max()) == 0.0 and float(vp[:, :, :, ntok:].abs().max()) == 0.0
+            # cross-attention projections: q only (no rotary), k/v from a context of another length
+            pq = ops.gemm_heads_bf16(x, w[:heads * 64], None, heads, nb, ntok, 0, 1)
+            assert rel_err(pq["q"].view(torch.bfloat16).float().cpu()[:, :, :ntok], q) < 6e-3
+            pkv = ops.gemm_heads_bf16(x, w[heads * 64:], None, heads, nb, ntok, 1, 2)
+            assert rel_err(pkv["k"].view(torch.bfloat16).float().cpu()[:, :, :ntok], kk) < 6e-3
+            assert rel_err(pkv["v_tr"].view(torch.bfloat16).float().cpu()[:, :, :, :ntok], v.transpose(2, 3)) < 6e-3
+            # the planes feed the attention kernel directly
+            o = ops.attention_planes(pl["q"], pl["k"], pl["v_tr"], ntok, ntok, 0.125)
+            ref = torch.nn.functional.scaled_dot_product_attention(qr, kr, v).permute(0, 2, 1, 3).reshape(nb, ntok, heads * 64)
+            assert rel_err(o.float(), ref) < 2e-2
+        finally:
+            ops.gemm_tile = None
+
+
+def _prep_case(ops, dev):
+    torch.manual_seed(2)
+    a = torch.randn(70, 136).to(dev)
+    assert rel_err(ops.cast_bf16(a).float(), a.bfloat16().float()) == 0.0
+    t = ops.cast_bf16(a, transpose=True, row_pad=64)
+    assert t.shape == (136, 128) and rel_err(t[:, :70].float(), a.t().bfloat16().float()) == 0.0 and float(t[:, 70:].abs().max()) == 0.0
+    ab = a.bfloat16()
+    assert rel_err(ops.cast_bf16(ab, transpose=True).float(), ab.t().float()) == 0.0
+    sa, sb = ops.split_bf16x3(a, 0).float(), ops.split_bf16x3(a, 1).float()
+    c = a.shape[1]
+    assert rel_err(sa[:, :c] + sa[:, 2 * c:], a) < 1e-5 and torch.equal(sa[:, :c], sa[:, c:2 * c])
+    assert rel_err(sb[:, :c] + sb[:, c:2 * c], a) < 1e-5 and torch.equal(sb[:, :c], sb[:, 2 * c:])
+    b = torch.randn(56, 136).to(dev)
+    cc = ops.gemm_bf16(ops.split_bf16x3(a, 0), ops.split_bf16x3(b, 1), out_dtype=torch.float32)
+    assert rel_err(cc, a.double().cpu() @ b.double().cpu().t()) < 2e-5        # fp32-class GEMM through the bf16x3 split
+
+
+def test_gemm_epilogues_simulator(emu):
+    _gemm_cases(emu, "cpu", SHAPES)
+
+
+def test_gemm_heads_epilogue_simulator(emu):
+    _heads_case(emu, "cpu", 2, 71, 3, 72)
+
+
+def test_gemm_operand_preparation_simulator(emu):
+    _prep_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_gemm_epilogues_gpu(hip):
+    _gemm_cases(hip, "cuda", SHAPES + [(2050, 1536, 1536), (2050, 4608, 1536), (260, 1536, 768)])
+
+
+@pytest.mark.gpu
+def test_gemm_ff_shapes_gpu(hip):
+    """The feed-forward pair at full size: SwiGLU projection 1536 -> 2 x 6144 and the 6144 -> 1536 output projection."""
+    _gemm_cases(hip, "cuda", [(2050, 12288, 1536), (2050, 1536, 6144)], tiles=(0, 1, 2, 3))
+
+
+@pytest.mark.gpu
+def test_gemm_heads_epilogue_gpu(hip):
+    _heads_case(hip, "cuda", 2, 71, 3, 72)
+    _heads_case(hip, "cuda", 2, 1025, 24, 1536)
+
+
+@pytest.mark.gpu
+def test_gemm_operand_preparation_gpu(hip):
+    _prep_case(hip, "cuda")

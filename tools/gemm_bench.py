@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Times csrc/gemm.hip on the DiT projection shapes (M = model batch x 1025 tokens) against torch.matmul (hipBLASLt) on
+the same operands.  Builder-side probe: prints one JSON line per shape / tile / epilogue."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stable_audio_tools_amd import ops as O  # noqa: E402
+
+
+def timeit(fn, reps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3   # us
+
+
+TILES = tuple(int(t) for t in os.environ.get('SAT_TILES', '0,1,2,3').split(','))
+
+
+def main():
+    ops = O.get_ops()
+    dev = "cuda"
+    torch.manual_seed(0)
+    ms = [int(a) for a in sys.argv[1:]] or [2050, 4100]
+    shapes = [("qkv", 4608, 1536), ("out", 1536, 1536), ("ff1", 12288, 1536), ("ff2", 1536, 6144), ("kv", 1536, 768)]
+    for m in ms:
+        for name, n, k in shapes:
+            mm = 260 * (m // 2050) if name == "kv" else m
+            a = torch.randn(mm, k, device=dev).bfloat16()
+            b = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+            res = torch.randn(mm, n, device=dev).bfloat16()
+            fl = 2.0 * mm * n * k
+            t_ref = timeit(lambda: torch.matmul(a, b.t()))
+            row = {"shape": name, "M": mm, "N": n, "K": k, "hipblaslt_us": round(t_ref, 1), "hipblaslt_tf": round(fl / t_ref / 1e6, 1)}
+            for tile in TILES:
+                ops.gemm_tile = tile
+                t = timeit(lambda: ops.gemm_bf16(a, b))
+                row[f"native_t{tile}_us"] = round(t, 1)
+                row[f"native_t{tile}_tf"] = round(fl / t / 1e6, 1)
+                if name in ("out", "ff2"):
+                    row[f"native_t{tile}_res_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, res=res, epilogue=ops.EPI_RES)), 1)
+                if name == "ff1":
+                    row[f"native_t{tile}_swiglu_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, epilogue=ops.EPI_SWIGLU)), 1)
+            ops.gemm_tile = None
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
