@@ -515,35 +515,70 @@ struct SatCastParams {
     long long lds_, ldd;
     int R, Cc, Rpad, src_f32, transpose;
 };
+// 8 consecutive source elements -> 8 bf16 (16 bytes); `vec` = the 16-byte path is legal for this launch
+SAT_DEVICE u32x4 sat_cast_load8(const SatCastParams& p, int r, int c, bool vec) {
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (r >= p.R || c >= p.Cc) return o;
+    if (vec && c + 8 <= p.Cc) {
+        if (p.src_f32) {
+            const f32x4* s = (const f32x4*)((const float*)p.src + (long long)r * p.lds_ + c);
+            const f32x4 a = s[0], b = s[1];
+            o[0] = sat_cvt2_pk(a[0], a[1]); o[1] = sat_cvt2_pk(a[2], a[3]);
+            o[2] = sat_cvt2_pk(b[0], b[1]); o[3] = sat_cvt2_pk(b[2], b[3]);
+        } else {
+            o = *(const u32x4*)((const short*)p.src + (long long)r * p.lds_ + c);
+        }
+        return o;
+    }
+    for (int e = 0; e < 8; ++e) {
+        uint32_t h = 0;
+        if (c + e < p.Cc)
+            h = (uint16_t)(p.src_f32 ? sat_f32_to_bf16(((const float*)p.src)[(long long)r * p.lds_ + c + e]) : ((const short*)p.src)[(long long)r * p.lds_ + c + e]);
+        o[e >> 1] |= h << (16 * (e & 1));
+    }
+    return o;
+}
 __global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
-    __shared__ short tile[64][66];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    if (!p.transpose) {
-        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
-            const int r = r0 + (i >> 3), c = c0 + (i & 7) * 8;
-            if (r < p.R && c < p.Cc) {
-                short v[8];
-                for (int e = 0; e < 8; ++e) {
-                    const int cc = c + e;
-                    float f = 0.f;
-                    if (cc < p.Cc) f = p.src_f32 ? ((const float*)p.src)[(long long)r * p.lds_ + cc] : sat_bf16_to_f32(((const short*)p.src)[(long long)r * p.lds_ + cc]);
-                    v[e] = sat_f32_to_bf16(f);
-                }
-                for (int e = 0; e < 8; ++e) if (c + e < p.Cc) p.dst[(long long)r * p.ldd + c + e] = v[e];
+    // 16-byte accesses need 16-byte aligned rows on both sides (checked on the host: vec flag rides in `transpose` bit 1)
+    const bool vec = (p.transpose & 2) != 0;
+    if (!(p.transpose & 1)) {
+        const int cchunks = (p.Cc + 7) >> 3;
+        const long long total = (long long)p.R * cchunks;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int r = (int)(i / cchunks), c = (int)(i % cchunks) * 8;
+            const u32x4 v = sat_cast_load8(p, r, c, vec);
+            short* d = p.dst + (long long)r * p.ldd + c;
+            if (vec && c + 8 <= p.Cc) {
+                *(u32x4*)d = v;
+            } else {
+                for (int e = 0; e < 8 && c + e < p.Cc; ++e) d[e] = (short)(v[e >> 1] >> (16 * (e & 1)));
             }
         }
         return;
     }
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = r0 + (i >> 6), c = c0 + (i & 63);
-        float f = 0.f;
-        if (r < p.R && c < p.Cc) f = p.src_f32 ? ((const float*)p.src)[(long long)r * p.lds_ + c] : sat_bf16_to_f32(((const short*)p.src)[(long long)r * p.lds_ + c]);
-        tile[i >> 6][i & 63] = sat_f32_to_bf16(f);
+    // transpose: 64 x 64 tile through LDS; rows of the tile are 66 shorts apart (a column read walks 33 banks per row)
+    __shared__ short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int rr = i >> 3, cc = (i & 7) * 8;
+        const u32x4 v = sat_cast_load8(p, r0 + rr, c0 + cc, vec);
+        uint32_t* t = (uint32_t*)&tile[rr][cc];
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int c = c0 + (i >> 6), r = r0 + (i & 63);
-        if (c < p.Cc && r < p.Rpad) p.dst[(long long)c * p.ldd + r] = tile[i & 63][i >> 6];
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int cc = i >> 3, rr = (i & 7) * 8;
+        const int c = c0 + cc, r = r0 + rr;
+        if (c >= p.Cc || r >= p.Rpad) continue;
+        u32x4 o;
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)(uint16_t)tile[rr + 2 * e][cc] | ((uint32_t)(uint16_t)tile[rr + 2 * e + 1][cc] << 16);
+        short* d = p.dst + (long long)c * p.ldd + r;
+        if (vec && r + 8 <= p.Rpad) {
+            *(u32x4*)d = o;
+        } else {
+            for (int e = 0; e < 8 && r + e < p.Rpad; ++e) d[e] = (short)(o[e >> 1] >> (16 * (e & 1)));
+        }
     }
 }
 // src (R, C) fp32|bf16 row stride lds -> dst bf16: (R, ldd) copy/cast, or transposed (C, ldd) with rows R..Rpad-1 zero.
@@ -551,8 +586,16 @@ extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long lon
                              int transpose, void* stream) {
     if (R <= 0 || C <= 0) { sat_set_error("sat_cast_bf16: empty shape"); return 1; }
     if (Rpad < R) Rpad = R;
-    SatCastParams p{src, (short*)dst, lds, ldd, R, C, Rpad, src_f32, transpose};
-    SAT_LAUNCH(sat_cast_kernel, dim3(sat_cdiv(C, 64), sat_cdiv(transpose ? Rpad : R, 64)), dim3(256), stream, p);
+    // 16-byte path: every row start 16-byte aligned on both sides
+    const long long salign = src_f32 ? 4 : 8;
+    const bool vec = ((unsigned long long)src % 16 == 0) && ((unsigned long long)dst % 16 == 0) && (lds % salign == 0) && (ldd % 8 == 0);
+    SatCastParams p{src, (short*)dst, lds, ldd, R, C, Rpad, src_f32, (transpose ? 1 : 0) | (vec ? 2 : 0)};
+    if (transpose) {
+        SAT_LAUNCH(sat_cast_kernel, dim3(sat_cdiv(C, 64), sat_cdiv(Rpad, 64)), dim3(256), stream, p);
+    } else {
+        const long long total = (long long)R * ((C + 7) / 8);
+        SAT_LAUNCH(sat_cast_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 8192 ? sat_cdivll(total, 256) : 8192)), dim3(256), stream, p);
+    }
     return sat_check_launch("sat_cast_bf16");
 }
 
