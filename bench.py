@@ -36,6 +36,7 @@ def parse():
                     help="items per GPU per step (default: 1 for vae_train and dit_sample, 4 for dit_train)")
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
     ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train"], default="vae_train",
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
@@ -79,7 +80,11 @@ class AttnProfiler:
             self.records["self" if nq == nk else "cross"].append((s, e, 4.0 * b * h * nq * nk * d))
             return rc
 
+        self._lib, self._orig = ops.lib, orig
         ops.lib.sat_attention_fwd = timed
+
+    def restore(self):
+        self._lib.sat_attention_fwd = self._orig
 
     def summary(self, which="self"):
         torch.cuda.synchronize()
@@ -101,27 +106,52 @@ class AttnProfiler:
 
 
 def dit_cpu_baseline(dcfg, latent_len, ctx_len):
-    """Oracle DiT forward (fp32, CFG batch of 2) on <=16 host threads: one model evaluation."""
+    """One sampler step's model evaluation (fp32, CFG batch of 2) on this box's host cores: the reference's own
+    DiffusionTransformer when /root/reference is importable (kind "reference"), the oracle port otherwise.  Thread count =
+    the faster of 16 / 32 (one probe each after a warm-up), then the median of 3."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dit_oracle
     from stable_audio_tools_amd.dit import DiffusionTransformer
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    model = DiffusionTransformer(**dcfg)
-    sd = {k: v.detach() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
     cross = torch.randn(1, ctx_len, dcfg["cond_token_dim"], generator=g)
     glob = torch.randn(1, dcfg["global_cond_dim"], generator=g)
     t = torch.tensor([0.5])
-    with torch.no_grad():
-        dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=6.0)   # warm-up
-        t0 = time.perf_counter()
-        dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=6.0)
-        dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 sampler step (oracle DiT forward, fp32, CFG batch 2, N={latent_len + 1}) in {dt:.2f} s"}
+    kind = "port"
+    if _reference_importable():
+        import contextlib
+        import refimport
+        with contextlib.redirect_stdout(sys.stderr):
+            refimport.import_reference()
+        from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
+        ref = RefDiT(**dcfg).float().train(False)
+        kind = "reference"
+
+        def step():
+            with torch.no_grad():
+                ref(x, t, cross_attn_cond=cross, global_embed=glob, cfg_scale=6.0, scale_phi=0.75)
+    else:
+        with torch.device("meta"):
+            shapes = {k: (tuple(v.shape), v.dtype) for k, v in DiffusionTransformer(**dcfg).state_dict().items()}
+        sd = {k: (torch.randn(sh) * 0.02 if dt.is_floating_point else torch.zeros(sh, dtype=dt)) for k, (sh, dt) in shapes.items()}
+        half = 32
+        sd["transformer.rotary_pos_emb.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, half, 2).float() / half))
+
+        def step():
+            with torch.no_grad():
+                dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=6.0, scale_phi=0.75)
+    ncpu = os.cpu_count() or 1
+    probes = {}
+    for cores in sorted({min(ncpu, c) for c in (16, 32)}):
+        torch.set_num_threads(cores)
+        probes[cores] = _median_time(step, reps=1)
+    cores = min(probes, key=probes.get)
+    torch.set_num_threads(cores)
+    dt = _median_time(step, reps=3)
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": kind,
+            "sample": f"1 sampler step = 1 model evaluation (fp32, CFG batch 2, N={latent_len + 1}): median of 3 after warm-up = {dt:.2f} s "
+                      f"at {cores} threads (probes: {', '.join(f'{c}: {v:.2f} s' for c, v in probes.items())})"}
 
 
 def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
@@ -150,6 +180,11 @@ def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
 
 
 def run_dit_sample(args):
+    line = dit_sample_line(args.dit_dtype, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
+    print(json.dumps(line), flush=True)
+
+
+def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
     """BASELINE.json configs[2]: Stable-Audio-Open-1.0 DiT, text-conditioned, v-DDIM sampling with CFG
     (batch doubled inside the model, dit.py:324-410).  One 'step' = one sampler step = one DiT evaluation
     at batch 2*B plus the DDIM update."""
@@ -160,7 +195,7 @@ def run_dit_sample(args):
     from stable_audio_tools_amd.sampling import sample_v_ddim
     cfg = json.load(open(os.path.join(ROOT, "stable_audio_tools_amd", "configs", "stable_audio_open_dit.json")))
     dcfg = cfg["diffusion"]["config"]
-    dtype = torch.bfloat16 if args.dit_dtype == "bf16" else torch.float32
+    dtype = torch.bfloat16 if dit_dtype == "bf16" else torch.float32
     torch.manual_seed(1234)
     model = DiffusionTransformer(**dcfg)
     with torch.no_grad():   # de-zero the branch outputs the reference zero-initialises
@@ -170,34 +205,37 @@ def run_dit_sample(args):
     model = model.to(device=dev, dtype=dtype).train(False)
     ops = O.get_ops()
     prof = AttnProfiler(ops)
-    b, tlat, m = args.batch, cfg["latent_length"], cfg["context_length"]
+    b, tlat, m = batch, cfg["latent_length"], cfg["context_length"]
     g = torch.Generator().manual_seed(0)
     noise = torch.randn(b, dcfg["io_channels"], tlat, generator=g).to(dev, dtype)
     cross = torch.randn(b, m, dcfg["cond_token_dim"], generator=g).to(dev, dtype)
     glob = torch.randn(b, dcfg["global_cond_dim"], generator=g).to(dev, dtype)
     kw = dict(cross_attn_cond=cross, global_embed=glob, cfg_scale=6.0, scale_phi=0.75)
-    sample_v_ddim(model, noise, max(args.warmup, 1), **kw)
+    sample_v_ddim(model, noise, max(warmup, 1), **kw)
     torch.cuda.synchronize()
     prof.enabled = True
     t0 = time.perf_counter()
-    out = sample_v_ddim(model, noise, args.steps, **kw)
+    out = sample_v_ddim(model, noise, steps, **kw)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof.enabled = False
-    peak = PEAK_BF16_MFMA_TFLOPS if args.dit_dtype == "bf16" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    prof.restore()
+    peak = PEAK_BF16_MFMA_TFLOPS if dit_dtype == "bf16" else PEAK_BF16_MFMA_TFLOPS / 3.0
     n = tlat + 1
     line = {
-        "metric": "DiT sampling steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dit_dtype, "data": "synthetic",
+        "metric": "DiT sampling steps/sec", "value": steps / elapsed, "unit": "steps/s", "n_gpus": 1,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dit_dtype, "data": "synthetic",
         "config": {"workload": "stable_audio_open_1_0 DiT (d=1536, 24 layers, 24x64 heads, GQA cross-attn to 130x768 context), "
                                "v-DDIM sampler with CFG scale 6 + rescale (model batch 2B), random init",
                    "latent_frames": tlat, "tokens": n, "context": m, "per_gpu_batch": b, "finite": bool(torch.isfinite(out.float()).all())},
         "roofline": prof.roofline(peak),
     }
-    if not args.no_cpu_baseline:
+    if with_cpu_baseline:
         line["cpu_baseline"] = dit_cpu_baseline(dcfg, tlat, m)
-    print(json.dumps(line), flush=True)
+    del model
+    torch.cuda.empty_cache()
+    return line
 
 
 class ConvProfiler:
@@ -215,7 +253,9 @@ class ConvProfiler:
         "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),
         "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
         "sat_conv_wgrad": ("sat_conv_wgrad_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
-        "sat_conv_wgrad7_bf16x3": ("sat_wgrad7_bf16x3_kernel", X3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
+        # N >= 64 input channels and T % 4 == 0 -> the 8-wave pipelined kernel (conv_wgrad_bf16x3.hip sat_wgrad7 plan)
+        "sat_conv_wgrad7_bf16x3": (lambda a: "sat_wgrad7_bf16x3_pipe_kernel" if (a[10] >= 64 and a[11] % 4 == 0) else "sat_wgrad7_bf16x3_kernel",
+                                   X3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
         "sat_conv_wgrad_bf16x3": ("sat_wgrad_small_bf16x3_kernel", X3, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
     }
 
@@ -273,38 +313,89 @@ def pmc_traffic(kernel, args):
         return None
 
 
-def cpu_baseline(cfg, nsamples):
-    """The oracle (CPU restatement of the reference path, oracle/*.py) timed on this box's host cores on a
-    bounded sample: ONE generator step (fwd + autograd bwd + torch AdamW) on a `nsamples`-long stereo crop;
-    the model is fully convolutional, so cost scales linearly with length."""
+def _reference_importable():
+    """The reference checkout exists only in the build container; on the GPU box the baseline is the oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import seeded
+    import refimport
+    return refimport.available()
+
+
+def _median_time(fn, reps=3):
+    fn()                                   # warm-up (allocator, thread pool, code paths)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline(cfg, nsamples):
+    """CPU baseline of the SAME workload on this box's host cores, on a bounded sample: ONE generator step (forward +
+    autograd backward + torch AdamW) on a `nsamples`-long stereo crop (the model is fully convolutional: cost is linear in
+    length), 1 warm-up + median of 3, at the thread count that measured fastest.  kind "reference": the reference's own
+    modules (stable_audio_tools.models.autoencoders + training/losses/auraloss.py) when /root/reference is importable;
+    "port": the oracle restatement (oracle/vae_oracle.py, oracle/stft_oracle.py) otherwise (the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import stft_oracle
     import vae_oracle
-    from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
-    # torch's CPU conv path degrades badly when oversubscribed (measured: 256 threads on the GPU box's host
-    # took 700 s for what 8 threads do in ~25 s) — use a bounded pool and report the threads actually used
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    # same random-init recipe as the GPU replica (reference-format state_dict consumed by the oracle)
-    torch.manual_seed(1234)
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in create_autoencoder_from_config(cfg).state_dict().items()}
-    opt = torch.optim.AdamW(list(sd.values()), lr=1.5e-4, betas=(0.8, 0.99), weight_decay=1e-3)
     g = torch.Generator().manual_seed(0)
     audio = 0.1 * torch.randn(1, 2, nsamples, generator=g)
     noise = torch.randn(1, cfg["model"]["latent_dim"], nsamples // cfg["model"]["downsampling_ratio"], generator=g)
     sc = cfg["training"]["loss_configs"]["spectral"]["config"]
-    t0 = time.perf_counter()
-    z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
-    dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
-    loss = stft_oracle.autoencoder_spectral_loss(audio, dec, sc, cfg["sample_rate"]) + 1e-4 * kl
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
+    kind = "port"
+    if _reference_importable():
+        import contextlib
+        import refimport
+        with contextlib.redirect_stdout(sys.stderr):       # the reference prints its optional-import notices to stdout
+            refimport.import_reference()
+            al = refimport.import_auraloss()
+        from stable_audio_tools.models.autoencoders import create_autoencoder_from_config as ref_create
+        torch.manual_seed(1234)
+        model = ref_create(cfg).float().train(True)
+        opt = torch.optim.AdamW(model.parameters(), lr=1.5e-4, betas=(0.8, 0.99), weight_decay=1e-3)
+        sd_loss = al.SumAndDifferenceSTFTLoss(sample_rate=cfg["sample_rate"], **sc)
+        lr_loss = al.MultiResolutionSTFTLoss(sample_rate=cfg["sample_rate"], **sc)
+        kind = "reference"
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            pre = model.encoder(audio)
+            mean, scale = pre.chunk(2, dim=1)
+            stdev = torch.nn.functional.softplus(scale) + 1e-4
+            z = noise * stdev + mean
+            kl = (mean * mean + stdev * stdev - torch.log(stdev * stdev) - 1).sum(1).mean()
+            dec = model.decode(z)
+            loss = sd_loss(audio, dec) + 0.5 * lr_loss(audio[:, 0:1], dec[:, 0:1]) + 0.5 * lr_loss(audio[:, 1:2], dec[:, 1:2]) + 1e-4 * kl
+            loss.backward()
+            opt.step()
+    else:
+        from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
+        torch.manual_seed(1234)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in create_autoencoder_from_config(cfg).state_dict().items()}
+        opt = torch.optim.AdamW(list(sd.values()), lr=1.5e-4, betas=(0.8, 0.99), weight_decay=1e-3)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
+            dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+            loss = stft_oracle.autoencoder_spectral_loss(audio, dec, sc, cfg["sample_rate"]) + 1e-4 * kl
+            loss.backward()
+            opt.step()
+    # torch's CPU conv path degrades when oversubscribed (256 hardware threads on the GPU box's host took 700 s for what 8
+    # do in ~25 s): try a few pool sizes, keep the fastest, report the threads actually used
+    ncpu = os.cpu_count() or 1
+    best = None
+    for cores in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(cores)
+        dt = _median_time(step)
+        if best is None or dt < best[0]:
+            best = (dt, cores)
+    dt, cores = best
     scale = SAMPLE_SIZE / nsamples
-    return {"value": 1.0 / (dt * scale), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 generator step (oracle fwd + autograd bwd + AdamW) on a {nsamples}-sample stereo crop "
-                      f"({dt:.2f} s), scaled x{scale:.0f} to {SAMPLE_SIZE} samples"}
+    return {"value": 1.0 / (dt * scale), "unit": "samples/s", "cores": cores, "kind": kind,
+            "sample": f"generator step (fwd + autograd bwd + AdamW) on a {nsamples}-sample stereo crop: median of 3 after 1 warm-up = "
+                      f"{dt:.2f} s at {cores} threads (fastest of 8/16/32), scaled x{scale:.0f} to {SAMPLE_SIZE} samples"}
 
 
 def run_dit_train(args):
@@ -379,8 +470,26 @@ def run_dit_train(args):
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's own
+    invocation sets WORLD_SIZE and lands in the normal path)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    if args.gpus != int(os.environ.get("WORLD_SIZE", 1)):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     if args.workload == "dit_train":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
@@ -451,7 +560,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32(bf16x3)", "data": "synthetic",
             "config": {"workload": "oobleck_vae_generator_train_step(encode+vae_sample+decode+mrstft_sumdiff_LR_7res_aweighted+kl,"
                                    " backward, dp_allreduce, fused_adamw_ema); stable_audio_2_0_vae architecture, random init;"
                                    " discriminator terms excluded (SURVEY.md 8 f-3)",
@@ -472,6 +581,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)
+        if world == 1 and not args.no_secondary:
+            # the second half of BASELINE.json's metric ("...; DiT sampling steps/sec"), measured in the same run: configs[2]
+            # (Stable Audio Open DiT, bf16, v-DDIM + CFG), with the self-attention kernel's MFMA roofline
+            del stepper, model, batches
+            torch.cuda.empty_cache()
+            sec = dit_sample_line("bf16", 1, 30, 5, with_cpu_baseline=not args.no_cpu_baseline)
+            line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")
+                                 if k in sec}
+            if "cpu_baseline" in sec:
+                line["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
