@@ -231,6 +231,13 @@ int sat_gate_residual_bwd_nchunks(int N);
 int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long long gstride, void* dx, float* part,
                           int B, int N, int D, int dtype, void* stream);
 
+/* Classifier-free-guidance combine + CFG rescale + sampler update in one pass — models/dit.py:400-410 (chunk, uncond +
+ * (cond - uncond) * scale, channel-std rescale with scale_phi) and inference/sampling.py:254-307 (v-DDIM), :98-135 (Euler).
+ * out2 (ncond*B, C, T): conditioned half first (ncond 2) or the plain output (ncond 1); v = guided(+rescaled) output;
+ * y0 = c0x*x + c0v*v (x NULL: y0 = v); y1 = c1x*x + c1v*v (optional).  dtype 0 fp32 / 1 bf16. */
+int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
+                 float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense projections of the DiT — models/transformer.py: to_qkv :362/:481, to_out :364/:534, to_q / to_kv :356-357,
  * GLU proj + x*silu(gate) :263-275, FeedForward linear_out :308, residual / gate updates :684-712; models/dit.py :49-77.

@@ -518,3 +518,68 @@ extern "C" int sat_gate_residual(const void* x, const void* gate, long long gstr
     else SAT_LAUNCH(sat_gate_residual_kernel<short>, dim3((unsigned)nb), dim3(256), stream, p);
     return sat_check_launch("sat_gate_residual");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Classifier-free-guidance combine + CFG rescale + sampler update in one pass
+// (reference: models/dit.py:400-410 — cond/uncond chunk, uncond + (cond - uncond) * scale, channel-std rescale with
+//  scale_phi; inference/sampling.py:254-307 v-DDIM update, :98-135 rectified-flow Euler update).
+//   out2: (ncond * B, C, T) model output, conditioned half first (ncond = 2), or the plain output (ncond = 1)
+//   v    = ncond == 2 ? rescale(uncond + (cond - uncond) * scale) : out2
+//   y0   = c0x * x + c0v * v           (x == NULL: y0 = v)
+//   y1   = c1x * x + c1v * v           (optional second output, e.g. DDIM's `pred` beside the next x)
+// One thread per (b, t) column, two passes over the C channels (unbiased channel std, as torch.std(dim=1)).
+// ------------------------------------------------------------------------------------------------
+struct SatCfgParams {
+    const void* out2;
+    const void* x;
+    void* y0;
+    void* y1;
+    int B, C, T, ncond;
+    float scale, phi, c0x, c0v, c1x, c1v;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_cfg_step_kernel(SatCfgParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.B * p.T) return;
+    const int b = (int)(i / p.T), t = (int)(i - (long long)b * p.T);
+    const long long cbase = (long long)b * p.C * p.T + t;
+    const long long ubase = cbase + (long long)p.B * p.C * p.T;
+    float ratio = 1.0f;
+    if (p.ncond == 2 && p.phi != 0.0f) {
+        float sc = 0.f, sc2 = 0.f, sg = 0.f, sg2 = 0.f;
+        for (int c = 0; c < p.C; ++c) {
+            const float cv = SatIO<T>::ld(p.out2, cbase + (long long)c * p.T), uv = SatIO<T>::ld(p.out2, ubase + (long long)c * p.T);
+            const float g = uv + (cv - uv) * p.scale;
+            sc += cv; sc2 += cv * cv; sg += g; sg2 += g * g;
+        }
+        const float n = (float)p.C, dn = (float)(p.C > 1 ? p.C - 1 : 1);
+        const float var_c = fmaxf(sc2 - sc * sc / n, 0.f) / dn, var_g = fmaxf(sg2 - sg * sg / n, 0.f) / dn;
+        ratio = p.phi * (sqrtf(var_c) / sqrtf(var_g)) + (1.0f - p.phi);
+    }
+    for (int c = 0; c < p.C; ++c) {
+        const long long o = cbase + (long long)c * p.T;
+        float v = SatIO<T>::ld(p.out2, o);
+        if (p.ncond == 2) {
+            const float uv = SatIO<T>::ld(p.out2, ubase + (long long)c * p.T);
+            v = (uv + (v - uv) * p.scale) * ratio;
+        }
+        if (p.x) {
+            const float xv = SatIO<T>::ld(p.x, o);
+            SatIO<T>::st(p.y0, o, p.c0x * xv + p.c0v * v);
+            if (p.y1) SatIO<T>::st(p.y1, o, p.c1x * xv + p.c1v * v);
+        } else {
+            SatIO<T>::st(p.y0, o, v);
+        }
+    }
+}
+extern "C" int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
+                            float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { sat_set_error("sat_cfg_step: bad shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_cfg_step: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    if (!out2 || !y0 || (y1 && !x)) { sat_set_error("sat_cfg_step: missing buffer"); return 1; }
+    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, c0x, c0v, c1x, c1v};
+    const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
+    if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_cfg_step");
+}

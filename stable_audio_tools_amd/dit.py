@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import functional as _fn
 from .linear import Linear
 from .transformer import ContinuousTransformer
 
@@ -33,6 +34,8 @@ class FourierFeatures(nn.Module):
 
 
 class DiffusionTransformer(nn.Module):
+    supports_fused_update = True      # forward(..., fused_update=...) — see sampling.py
+
     def __init__(self, io_channels=32, patch_size=1, embed_dim=768, cond_token_dim=0, project_cond_tokens=True,
                  global_cond_dim=0, project_global_cond=True, input_concat_dim=0, prepend_cond_dim=0, depth=12,
                  num_heads=8, transformer_type: tp.Literal["continuous_transformer"] = "continuous_transformer",
@@ -137,8 +140,12 @@ class DiffusionTransformer(nn.Module):
     def forward(self, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
                 negative_cross_attn_mask=None, input_concat_cond=None, global_embed=None, negative_global_embed=None,
                 prepend_cond=None, prepend_cond_mask=None, cfg_scale=1.0, cfg_dropout_prob=0.0, cfg_interval=(0, 1),
-                causal=False, scale_phi=0.0, mask=None, return_info=False, exit_layer_ix=None, **kwargs):
+                causal=False, scale_phi=0.0, mask=None, return_info=False, exit_layer_ix=None, fused_update=None, **kwargs):
+        """fused_update (native extension, never passed by reference callers): (c0x, c0v, c1x, c1v) — instead of the model
+        output v, return (c0x*x + c0v*v, c1x*x + c1v*v): the sampler's update of x folded into the guidance-combine kernel
+        (no-grad only)."""
         assert causal is False, "Causal mode is not supported for DiffusionTransformer"
+        x_in = x
         dt = next(self.parameters()).dtype
 
         def cast(a):
@@ -174,8 +181,12 @@ class DiffusionTransformer(nn.Module):
         use_cfg = cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None) \
             and (full_interval or bool(cfg_interval[0] <= sigma[0] <= cfg_interval[1]))
         if not use_cfg:
-            return self._forward(x, t, cross_attn_cond=cross_attn_cond, global_embed=global_embed, prepend_cond=prepend_cond,
-                                 prepend_cond_mask=prepend_cond_mask, **common)
+            out = self._forward(x, t, cross_attn_cond=cross_attn_cond, global_embed=global_embed, prepend_cond=prepend_cond,
+                                prepend_cond_mask=prepend_cond_mask, **common)
+            if fused_update is not None:
+                assert not return_info and not torch.is_grad_enabled()
+                return _fn._ops(None).cfg_step(out.contiguous(), 1, x=x_in.to(out.dtype).contiguous(), coef=fused_update, want_second=True)
+            return out
 
         # classifier-free guidance: conditioned and unconditioned halves in one batch (dit.py:328-395)
         def twice(a):
@@ -197,6 +208,13 @@ class DiffusionTransformer(nn.Module):
         info = None
         if return_info:
             out, info = out
+        if not torch.is_grad_enabled() and not return_info:
+            # inference: guidance combine, channel-std rescale and (optionally) the sampler update in ONE kernel (sat_cfg_step)
+            ops = _fn._ops(None)
+            if fused_update is not None:
+                return ops.cfg_step(out.contiguous(), 2, cfg_scale, scale_phi, x=x_in.to(out.dtype).contiguous(), coef=fused_update, want_second=True)
+            return ops.cfg_step(out.contiguous(), 2, cfg_scale, scale_phi)
+        assert fused_update is None
         cond_output, uncond_output = torch.chunk(out, 2, dim=0)
         cfg_output = uncond_output + (cond_output - uncond_output) * cfg_scale
         if scale_phi != 0.0:    # CFG rescale over the channel dim (dit.py:405-408)

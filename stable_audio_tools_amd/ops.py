@@ -500,6 +500,21 @@ class SatOps:
         dgate = torch.stack([self._reduce_rows(part[i], nch, d) for i in range(b)])
         return dx, dgate
 
+    def cfg_step(self, out2, ncond, cfg_scale=1.0, scale_phi=0.0, x=None, coef=None, want_second=False):
+        """Guidance combine (+rescale) of the batched model output and, with x/coef, the sampler update in the same pass:
+        out2 (ncond*B, C, T); returns v, or (c0x*x + c0v*v [, c1x*x + c1v*v]) for coef = (c0x, c0v, c1x, c1v)."""
+        dt = self._dt(out2, x)
+        if not out2.is_contiguous() or (x is not None and not x.is_contiguous()):
+            raise ValueError("cfg_step: contiguous tensors expected")
+        nb2, c, t = out2.shape
+        b = nb2 // ncond
+        y0 = torch.empty(b, c, t, dtype=out2.dtype, device=out2.device)
+        y1 = torch.empty_like(y0) if (want_second and x is not None) else None
+        c0x, c0v, c1x, c1v = coef if coef is not None else (0.0, 1.0, 0.0, 0.0)
+        self._chk(self.lib.sat_cfg_step(_ptr(out2), _ptr(x), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale), float(scale_phi),
+                                        float(c0x), float(c0v), float(c1x), float(c1v), dt, self._stream(out2)))
+        return (y0, y1) if y1 is not None else y0
+
     # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
     EPI_STORE, EPI_RES, EPI_GATE_RES, EPI_SWIGLU = 0, 1, 2, 3
     gemm_tile = None     # None: pick per shape; 0 = 128x128 (4 waves), 1 = 256x128 (8 waves)

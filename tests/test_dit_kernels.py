@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from golden_util import rel_err
+
 
 def _ln_case(ops, dev, dtype, b, n, d, ada, seed):
     gen = torch.Generator().manual_seed(seed)
@@ -101,3 +103,33 @@ def test_attention_sim(emu, case, dtype):
 def test_attention_gpu(hip, dtype):
     for case in ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130)]:
         _attn_case(hip, "cuda", dtype, case, seed=22)
+
+
+def _cfg_step_case(ops, dev):
+    """sat_cfg_step vs the reference formulas (models/dit.py:400-410 + the v-DDIM update of inference/sampling.py:254-307)."""
+    torch.manual_seed(3)
+    b, c, t = 2, 6, 37
+    out2 = torch.randn(2 * b, c, t).to(dev)
+    x = torch.randn(b, c, t).to(dev)
+    scale, phi = 6.0, 0.75
+    cond, uncond = torch.chunk(out2.cpu(), 2, dim=0)
+    g = uncond + (cond - uncond) * scale
+    ref = phi * (g * (cond.std(dim=1, keepdim=True) / g.std(dim=1, keepdim=True))) + (1 - phi) * g
+    assert rel_err(ops.cfg_step(out2, 2, scale, phi), ref) < 1e-5
+    assert rel_err(ops.cfg_step(out2, 2, scale, 0.0), g) < 1e-6
+    coef = (0.3, -0.7, 1.1, 0.2)
+    y0, y1 = ops.cfg_step(out2, 2, scale, phi, x=x, coef=coef, want_second=True)
+    assert rel_err(y0, coef[0] * x.cpu() + coef[1] * ref) < 1e-5 and rel_err(y1, coef[2] * x.cpu() + coef[3] * ref) < 1e-5
+    y0, y1 = ops.cfg_step(out2[:b].contiguous(), 1, x=x, coef=coef, want_second=True)
+    assert rel_err(y0, coef[0] * x.cpu() + coef[1] * out2[:b].cpu()) < 1e-6
+    ob = ops.cfg_step(out2.bfloat16(), 2, scale, phi)
+    assert ob.dtype == torch.bfloat16 and rel_err(ob.float(), ref) < 2e-2
+
+
+def test_cfg_step_simulator(emu):
+    _cfg_step_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_cfg_step_gpu(hip):
+    _cfg_step_case(hip, "cuda")

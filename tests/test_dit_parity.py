@@ -195,3 +195,33 @@ def test_sampler_v_ddim_simulator(emu_modules):
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_sampler_v_ddim_gpu(hip, use_graph):
     _sampler_case("cuda", use_graph)
+
+
+def _euler_case(device):
+    """Rectified-flow Euler sampler (reference inference/sampling.py:98-135) with the update fused into the guidance kernel,
+    vs the same loop around the CPU oracle's forward."""
+    from stable_audio_tools_amd.sampling import sample_discrete_euler
+    name, idx = "small_rf", 2
+    model, sd = _build(name, 700 + 10 * idx, device)
+    inp = dit_inputs(name)
+    kw = dict(cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], prepend_cond=inp.get("prepend_cond"),
+              prepend_cond_mask=inp.get("prepend_cond_mask"))
+    dkw = {k: (v.to(device) if v is not None else None) for k, v in kw.items()}
+    steps = 4
+    out = sample_discrete_euler(model, inp["x"].to(device), steps, cfg_scale=3.0, scale_phi=0.5, **dkw)
+    x = inp["x"]
+    t = torch.linspace(1.0, 0, steps + 1)
+    for tc, tp in zip(t[:-1], t[1:]):
+        v = dit_oracle.dit_forward(sd, seeded.DIT_CONFIGS[name], x, torch.ones(x.shape[0]) * tc, kw["cross_attn_cond"],
+                                   kw["global_embed"], kw.get("prepend_cond"), cfg_scale=3.0, scale_phi=0.5)
+        x = x + (tp - tc) * v
+    assert rel_err(out, x) < TOL
+
+
+def test_sampler_euler_fused_update_simulator(emu_modules):
+    _euler_case("cpu")
+
+
+@pytest.mark.gpu
+def test_sampler_euler_fused_update_gpu(hip):
+    _euler_case("cuda")
