@@ -71,34 +71,110 @@ class GradAllReduce:
 
     mode 'all_reduce'     : one all_reduce per bucket
     mode 'reduce_scatter' : reduce_scatter_tensor + all_gather_into_tensor per bucket (drives every
-                            xGMI link of the 8-GPU mesh in both phases; needs bucket % world == 0)"""
+                            xGMI link of the 8-GPU mesh in both phases; needs bucket % world == 0)
 
-    def __init__(self, flat: FlatParameters, group=None, bucket_bytes=512 << 20, mode="all_reduce"):
+    overlap=True (default): the exchange of a bucket is launched from autograd's post-accumulate hooks the moment the last
+    gradient of the bucket has landed, on a side stream fenced by an event — it runs under the backward of the layers
+    in front of it (what Lightning's DDP reducer does for the reference, train.py:138).  Gradients land in the flat
+    buffer from its END towards its start (backward visits the layers in reverse), so buckets are cut from the end and
+    fire in that order; `finish()` (called before the optimizer) launches whatever did not fire (parameters without a
+    gradient this step) and makes the compute stream wait for the side stream.  overlap=False: everything in finish()."""
+
+    def __init__(self, flat: FlatParameters, group=None, bucket_bytes=256 << 20, mode="all_reduce", overlap=True):
         self.flat = flat
         self.group = group
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
         n = flat.padded
         per = max(1, bucket_bytes // 4)
-        if mode == "reduce_scatter":
-            per = max(self.world, (per // self.world) * self.world)
-            if n % self.world != 0:
-                raise ValueError("FlatParameters(pad_to=world_size) is required for reduce_scatter mode")
-        self.buckets = [(s, min(s + per, n)) for s in range(0, n, per)]
+        per = max(self.world, (per // self.world) * self.world)
+        if mode == "reduce_scatter" and n % self.world != 0:
+            raise ValueError("FlatParameters(pad_to=world_size) is required for reduce_scatter mode")
+        # buckets from the END of the buffer (first to be complete during backward); bucket sizes are multiples of world
+        self.buckets = []
+        e = n
+        while e > 0:
+            s_ = max(0, e - per)
+            self.buckets.append((s_, e))
+            e = s_
         self.grad_scale = 1.0 / self.world
+        self.overlap = bool(overlap) and self.world > 1
+        self._handles = []
+        self._side = None
+        self._fired = [False] * len(self.buckets)
+        if self.overlap:
+            # parameter i covers [off, off+numel): it gates every bucket it overlaps
+            self._need = [0] * len(self.buckets)
+            self._of_param = []
+            off = 0
+            for p in flat.params:
+                lo, hi = off, off + p.numel()
+                mine = [bi for bi, (s_, e_) in enumerate(self.buckets) if lo < e_ and hi > s_]
+                for bi in mine:
+                    self._need[bi] += 1
+                self._of_param.append(mine)
+                off = hi
+            self._left = list(self._need)
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
 
-    def __call__(self):
+    def _make_hook(self, i):
+        def hook(param):
+            gv = self.flat._views[i]
+            if param.grad is not None and param.grad.data_ptr() != gv.data_ptr():      # autograd replaced the view: fold it back
+                gv.copy_(param.grad)
+                param.grad = gv
+            for bi in self._of_param[i]:
+                self._left[bi] -= 1
+                if self._left[bi] == 0:
+                    self._launch(bi)
+        return hook
+
+    def _exchange(self, chunk):
+        if self.mode == "reduce_scatter" and chunk.numel() % self.world == 0:
+            k = chunk.numel() // self.world
+            shard = chunk[self.rank * k:(self.rank + 1) * k]           # in place: output = this rank's slice of the input
+            try:
+                dist.reduce_scatter_tensor(shard, chunk, op=dist.ReduceOp.SUM, group=self.group)
+            except (RuntimeError, NotImplementedError):                # backend without reduce_scatter (gloo)
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            dist.all_gather_into_tensor(chunk, shard.clone(), group=self.group)
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _launch(self, bi):
+        if self._fired[bi]:
+            return
+        self._fired[bi] = True
+        s_, e_ = self.buckets[bi]
+        chunk = self.flat.grad[s_:e_]
+        if chunk.is_cuda and self.overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=chunk.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(chunk.device))      # the bucket's gradients are complete at this point
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._exchange(chunk)
+        else:
+            self._exchange(chunk)
+
+    def finish(self):
+        """All buckets exchanged and visible to the compute stream; re-arms the hooks' counters for the next step."""
         if self.world == 1:
             return
-        g = self.flat.grad
-        for s, e in self.buckets:
-            chunk = g[s:e]
-            if self.mode == "reduce_scatter" and (e - s) % self.world == 0:
-                shard = torch.empty((e - s) // self.world, dtype=g.dtype, device=g.device)
-                dist.reduce_scatter_tensor(shard, chunk, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_gather_into_tensor(chunk, shard, group=self.group)
-            else:
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        if self._side is not None:
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self._side)
+        self._fired = [False] * len(self.buckets)
+        if self.overlap:
+            self._left = list(self._need)
+
+    def __call__(self):
+        self.finish()
 
 
 def inverse_lr(step, base_lr, inv_gamma=1.0, power=1.0, warmup=0.0, final_lr=0.0):
@@ -147,7 +223,7 @@ class AutoencoderTrainStep:
     the loss is  w_mrstft * spectral(reals, decoded) + w_kl * kl  as in the no-discriminator
     configuration of the reference wrapper."""
 
-    def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=512 << 20):
+    def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True):
         from .auraloss import AutoencoderSpectralLoss
         tr = model_config["training"]
         self.model = autoencoder
@@ -174,7 +250,7 @@ class AutoencoderTrainStep:
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
-        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode)
+        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
         self.global_step = 0
 
     def current_lr(self):
@@ -212,14 +288,14 @@ class DiTTrainStep:
     the HIP kernels in bf16 with fp32 master weights (Lightning '--precision bf16-mixed')."""
 
     def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-3, cfg_dropout_prob=0.1, timestep_sampler="uniform",
-                 use_ema=True, autocast_dtype=None, ops=None, ddp_mode="all_reduce", bucket_bytes=512 << 20, seed=0):
+                 use_ema=True, autocast_dtype=None, ops=None, ddp_mode="all_reduce", bucket_bytes=256 << 20, seed=0, ddp_overlap=True):
         import math
         self._math = math
         self.model = model
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flat = FlatParameters(list(model.parameters()), pad_to=max(world, 1))
         self.opt = FusedAdamW(self.flat, lr, betas=betas, weight_decay=weight_decay, ops=ops, use_ema=use_ema)
-        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode)
+        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
         self.cfg_dropout_prob = cfg_dropout_prob
         self.timestep_sampler = timestep_sampler
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0

@@ -69,10 +69,10 @@ def _oracle_steps(cfg, batches, lr_fn):
     return {k: v.detach() for k, v in sd.items()}, losses
 
 
-def _native_steps(cfg, batches, device):
+def _native_steps(cfg, batches, device, **step_kw):
     from stable_audio_tools_amd.training import AutoencoderTrainStep
     model = build_native_ae(NAME, SEED, device)
-    stepper = AutoencoderTrainStep(model, cfg)
+    stepper = AutoencoderTrainStep(model, cfg, **step_kw)
     losses = []
     for audio, noise in batches:
         out = stepper(audio.to(device), noise=noise.to(device))
@@ -136,7 +136,7 @@ def test_generator_step_matches_oracle_gpu(hip, bf16x3):
     _check_against_oracle("cuda", hip, bf16x3)
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, ddp_mode="all_reduce", overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
@@ -151,7 +151,9 @@ def _ddp_worker(rank, world, port, q):
     try:
         cfg = _model_config()
         audio, noise = _batch(2, 950)           # global batch of 2, one item per rank
-        _, stepper, _ = _native_steps(cfg, [(audio[rank:rank + 1], noise[rank:rank + 1])], "cpu")
+        _, stepper, _ = _native_steps(cfg, [(audio[rank:rank + 1], noise[rank:rank + 1])], "cpu", ddp_mode=ddp_mode, ddp_overlap=overlap,
+                                      bucket_bytes=4096)          # tiny buckets: many of them fire from the hooks mid-backward
+        assert len(stepper.comm.buckets) > 4
         flat = stepper.flat.data.clone()
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
@@ -160,12 +162,13 @@ def _ddp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_step_gloo_world2(emu_modules):
+@pytest.mark.parametrize("ddp_mode,overlap", [("all_reduce", True), ("reduce_scatter", True), ("all_reduce", False)])
+def test_data_parallel_step_gloo_world2(emu_modules, ddp_mode, overlap):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + 7 * ["all_reduce", "reduce_scatter"].index(ddp_mode) + int(overlap)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, ddp_mode, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(2))
@@ -186,3 +189,43 @@ def test_data_parallel_step_gloo_world2(emu_modules):
     upd_ddp = r0[:n] - init
     upd_single = single[:n] - init
     assert float((upd_ddp - upd_single).norm() / upd_single.norm()) < 5e-2
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        cfg = _model_config()
+        audio, noise = _batch(2, 950)
+        _, stepper, _ = _native_steps(cfg, [(audio[rank:rank + 1], noise[rank:rank + 1])], f"cuda:{rank}", ddp_mode="reduce_scatter",
+                                      bucket_bytes=4096)
+        flat = stepper.flat.data.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        q.put((rank, bool(torch.equal(gathered[0], gathered[1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the single-GPU box runs the gloo twin on CPU")
+def test_data_parallel_step_rccl_world2(hip):
+    """The overlapped reduce-scatter / all-gather exchange on RCCL proper: two ranks, two GPUs, replicas must stay identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, 29700 + (os.getpid() % 200), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results.values())
