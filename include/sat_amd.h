@@ -266,6 +266,20 @@ int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, long long ldb
                       void* q_rm, void* k_rm, void* v_tr, const void* zeros, int nb, int ntok, int npad, int heads,
                       int K, int sec0, int nsec, int tile, void* stream);
 
+/* fp8 (OCP e4m3) forward projections for the long-context configuration (BASELINE.json configs[4], stable_audio_2_0.json:3):
+ * as sat_gemm_bf16 / sat_gemm_qkv_bf16 with A (M, K), B (N, K) in fp8 bytes (K, lda, ldb multiples of 16) on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B). */
+int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
+                 const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
+                 long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
+                 void* stream);
+int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
+                     void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
+                     int heads, int K, int sec0, int nsec, void* stream);
+/* dst (R, C) fp8 e4m3 = saturate_448(src * qscale[0]), round to nearest even; src fp32 | bf16; qscale a DEVICE scalar. */
+int sat_quant_fp8(const void* src, long long lds, void* dst, long long ldd, const float* qscale, int R, int C, int src_f32,
+                  void* stream);
+
 /* src (R, C) fp32 (src_f32 = 1) or bf16, row stride lds -> dst bf16: (R, C) row stride ldd; or, transpose = 1, (C, Rpad)
  * with columns R..Rpad-1 zero (reduction-dim padding of the weight-gradient GEMM). */
 int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int R, int C, int Rpad, int src_f32,

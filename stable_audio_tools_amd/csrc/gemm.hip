@@ -57,6 +57,7 @@ struct SatGemmParams {
     const void* gate;     // (M / rows_per_gate, ldg) dtype of C: v * sigmoid(1 - gate)   (transformer.py:684, :699)
     void* pre;            // SWIGLU: optional (M, ldp) copy of the pre-activation [x | gate] for the backward
     const short* zeros;   // >= 16 bytes of zeros: source of the k-chunks past K
+    const float* alpha;   // device scalar multiplied into the accumulators before the epilogue (fp8 de-quantisation), or null
     long long lda, ldb, ldc, ldr, ldg, ldp;
     int M, N, K;
     int rows_per_gate;
@@ -122,7 +123,7 @@ SAT_DEVICE void sat_store4(void* base, long long idx, f32x4 v) {
 }
 SAT_DEVICE float sat_gemm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE, int EPI, bool F32OUT>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE, int EPI, bool F32OUT, bool FP8 = false>
 __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams p) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -285,6 +286,33 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
         const char* As = smem + rd * STAGE;
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        if constexpr (FP8) {
+            // fp8 (e4m3) operands: the stage image is the same 128-byte-row layout, now 128 k-elements per row; one MX MFMA
+            // consumes 64 of them — lanes 0-31 the 32 bytes (two 16-byte chunks) at 64 ks, lanes 32-63 those at 64 ks + 32
+            static_assert(!FP8 || PIPE == 0, "the fp8 variant uses the plain loop");
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c0 = ks * 4 + (lane >> 5) * 2;
+                const char* Bs = As + ABYTES;
+                i32x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * (TM * 32) + i * 32 + (lane & 31);
+                    const u32x4 lo = __builtin_bit_cast(u32x4, sat_gemm_frag(As, row, c0)), hi4 = __builtin_bit_cast(u32x4, sat_gemm_frag(As, row, c0 + 1));
+                    a[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * (TN * 32) + j * 32 + (lane & 31);
+                    const u32x4 lo = __builtin_bit_cast(u32x4, sat_gemm_frag(Bs, row, c0)), hi4 = __builtin_bit_cast(u32x4, sat_gemm_frag(Bs, row, c0 + 1));
+                    b[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = sat_mfma_32x32x64_fp8(a[i], b[j], acc[i][j]);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if constexpr (PIPE != -2) {
@@ -293,10 +321,20 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
                 mfmas(a, b);
             }
         }
+        }
     }
     }
     SAT_RAW_BARRIER();         // stage buffers are free (no LDS-DMA is pending): each wave takes a private window for its epilogue
 
+    if (p.alpha) {
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= al;
+    }
     float* ep = (float*)(smem + wave * WIN);
     const int hi = lane >> 5, col = lane & 31;
 #pragma unroll
@@ -418,14 +456,14 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 
 static short* g_sat_zero_page = nullptr;   // set by the caller through sat_gemm_bf16's `zeros` argument (caller-owned)
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE, bool FP8 = false>
 static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
     p.ntm = sat_cdiv(p.M, BM);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
     dim3 grid(p.ntm * p.ntn, splits), block(WGM * WGN * 64);
 #define SAT_GEMM_CASE(E, F)                                                                          \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        SAT_LAUNCH((sat_gemm_kernel<BM, BN, WGM, WGN, NSTAGE, PIPE, E, F>), grid, block, stream, p);               \
+        SAT_LAUNCH((sat_gemm_kernel<BM, BN, WGM, WGN, NSTAGE, PIPE, E, F, FP8>), grid, block, stream, p);               \
         return sat_check_launch("sat_gemm_bf16");                                                    \
     }
     SAT_GEMM_CASE(SAT_EPI_STORE, false)
@@ -502,6 +540,116 @@ extern "C" int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, lo
     p.rope_cs = rope_cs; p.rope_off = rope_off; p.q_rm = (short*)q_rm; p.k_rm = (short*)k_rm; p.v_tr = (short*)v_tr;
     p.ntok = ntok; p.npad = npad; p.heads = heads; p.sec0 = sec0;
     return sat_gemm_dispatch(p, SAT_EPI_QKV, 0, 1, tile, stream);
+}
+
+// fp8 (OCP e4m3) variants of the two entry points above for the forward projections of the long-context configuration
+// (BASELINE.json configs[4]): A (M, K) and B (N, K) are fp8 bytes, K a multiple of 16, lda / ldb in elements (multiples of 16);
+// products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate, half the operand bytes);
+// alpha: device scalar = (de-quantisation scale of A) x (of B), multiplied into the fp32 accumulators before the epilogue.
+// Everything else (epilogues, output types) as sat_gemm_bf16 / sat_gemm_qkv_bf16; no split-K.
+extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
+                            const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
+                            long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
+                            void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) { sat_set_error("sat_gemm_fp8: empty shape"); return 1; }
+    if ((K & 15) || (lda & 15) || (ldb & 15) || (N & 7) || (ldc & 3)) { sat_set_error("sat_gemm_fp8: K, lda, ldb must be multiples of 16, N of 8"); return 1; }
+    if (!zeros || !alpha) { sat_set_error("sat_gemm_fp8: zeros page and alpha required"); return 1; }
+    if (epilogue < 0 || epilogue > 3) { sat_set_error("sat_gemm_fp8: bad epilogue"); return 1; }
+    if ((epilogue == SAT_EPI_RES || epilogue == SAT_EPI_GATE_RES) && !res) { sat_set_error("sat_gemm_fp8: residual missing"); return 1; }
+    if (epilogue == SAT_EPI_GATE_RES && (!gate || rows_per_gate <= 0)) { sat_set_error("sat_gemm_fp8: gate missing"); return 1; }
+    if (epilogue == SAT_EPI_SWIGLU && (N & 15)) { sat_set_error("sat_gemm_fp8: SwiGLU needs N = 2F with F % 8 == 0"); return 1; }
+    SatGemmParams p{};
+    // two fp8 elements = one "short" of the staging code: the kernel sees (M, K/2) x (N, K/2) 16-bit matrices
+    p.A = (const short*)A; p.B = (const short*)B; p.C = C; p.bias = bias; p.res = res; p.gate = gate; p.pre = pre;
+    p.zeros = (const short*)zeros; p.alpha = alpha;
+    p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc; p.ldr = ldr; p.ldg = ldg; p.ldp = ldp;
+    p.M = M; p.N = N; p.K = K / 2; p.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
+    p.klen = sat_cdiv(p.K, 64) * 64;
+    return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, epilogue, out_f32, 1, stream);
+}
+extern "C" int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
+                                void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
+                                int heads, int K, int sec0, int nsec, void* stream) {
+    if (nb <= 0 || ntok <= 0 || heads <= 0 || K <= 0 || npad < ntok) { sat_set_error("sat_gemm_qkv_fp8: bad shape"); return 1; }
+    if ((K & 15) || (lda & 15) || (ldb & 15)) { sat_set_error("sat_gemm_qkv_fp8: K, lda, ldb must be multiples of 16"); return 1; }
+    if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3 || !alpha) { sat_set_error("sat_gemm_qkv_fp8: bad section range / alpha"); return 1; }
+    SatGemmParams p{};
+    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros; p.alpha = alpha;
+    p.lda = lda / 2; p.ldb = ldb / 2;
+    p.M = nb * ntok; p.N = nsec * heads * 64; p.K = K / 2; p.rows_per_gate = 1;
+    p.klen = sat_cdiv(p.K, 64) * 64;
+    p.rope_cs = rope_cs; p.rope_off = rope_off; p.q_rm = (short*)q_rm; p.k_rm = (short*)k_rm; p.v_tr = (short*)v_tr;
+    p.ntok = ntok; p.npad = npad; p.heads = heads; p.sec0 = sec0;
+    return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, SAT_EPI_QKV, 0, 1, stream);
+}
+
+// Quantise to fp8 e4m3: dst[r][c] = sat_448(src[r][c] * qscale[0]) (round to nearest even); src fp32 or bf16 (R, C), row strides in
+// elements.  qscale is a DEVICE scalar (448 / amax, computed by the caller without a host round trip).
+struct SatQuantParams {
+    const void* src;
+    uint8_t* dst;
+    const float* qscale;
+    long long lds_, ldd;
+    int R, Cc, src_f32;
+};
+SAT_DEVICE uint32_t sat_f32x4_to_fp8(float a, float b, float c, float d) {
+#if defined(SAT_HIPEMU)
+    auto enc = [](float x) -> uint32_t {
+        if (x != x) return 0x7fu;
+        const uint32_t sign = x < 0.f ? 0x80u : 0u;
+        float ax = fabsf(x);
+        if (ax > 448.f) ax = 448.f;
+        if (ax < ldexpf(1.0f, -10)) return sign;                                  // below half the smallest subnormal (2^-9)
+        int e;
+        frexpf(ax, &e);                                                           // ax = f * 2^e, f in [0.5, 1)
+        int ue = e - 1;                                                           // unbiased exponent: ax in [2^ue, 2^(ue+1))
+        if (ue < -6) ue = -6;                                                     // subnormal range shares the exponent of 2^-6
+        const float q = ldexpf(1.0f, ue - 3);                                     // spacing of representable values
+        float m = nearbyintf(ax / q);                                             // RNE (default rounding mode)
+        float v = m * q;
+        if (v > 448.f) v = 448.f;
+        if (v == 0.f) return sign;
+        frexpf(v, &e);
+        ue = e - 1;
+        uint32_t bits;
+        if (ue < -6) bits = (uint32_t)nearbyintf(v / ldexpf(1.0f, -9));           // subnormal: mantissa only
+        else bits = ((uint32_t)(ue + 7) << 3) | ((uint32_t)nearbyintf(v / ldexpf(1.0f, ue - 3)) - 8u);
+        return sign | bits;
+    };
+    return enc(a) | (enc(b) << 8) | (enc(c) << 16) | (enc(d) << 24);
+#else
+    const float lim = 448.0f;
+    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+#endif
+}
+__global__ void __launch_bounds__(256) sat_quant_fp8_kernel(SatQuantParams p) {
+    const float qs = *p.qscale;
+    const int cch = p.Cc >> 2;
+    const long long total = (long long)p.R * cch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / cch), c = (int)(i % cch) * 4;
+        float x[4];
+        if (p.src_f32) {
+            const float* s = (const float*)p.src + (long long)r * p.lds_ + c;
+            for (int e = 0; e < 4; ++e) x[e] = s[e];
+        } else {
+            const short* s = (const short*)p.src + (long long)r * p.lds_ + c;
+            for (int e = 0; e < 4; ++e) x[e] = sat_bf16_to_f32(s[e]);
+        }
+        *(uint32_t*)(p.dst + (long long)r * p.ldd + c) = sat_f32x4_to_fp8(x[0] * qs, x[1] * qs, x[2] * qs, x[3] * qs);
+    }
+}
+extern "C" int sat_quant_fp8(const void* src, long long lds, void* dst, long long ldd, const float* qscale, int R, int C, int src_f32,
+                             void* stream) {
+    if (R <= 0 || C <= 0 || (C & 3) || (ldd & 3) || !qscale) { sat_set_error("sat_quant_fp8: C and ldd must be multiples of 4"); return 1; }
+    SatQuantParams p{src, (uint8_t*)dst, qscale, lds, ldd, R, C, src_f32};
+    const long long total = (long long)R * (C >> 2);
+    SAT_LAUNCH(sat_quant_fp8_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 8192 ? sat_cdivll(total, 256) : 8192)), dim3(256), stream, p);
+    return sat_check_launch("sat_quant_fp8");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

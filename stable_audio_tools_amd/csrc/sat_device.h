@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define SAT_WAVE 64
 
@@ -96,7 +97,42 @@ static inline f32x4 sat_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     }
     return d;
 }
+// OCP fp8 e4m3fn (gfx950's fp8; no infinities, 0x7f / 0xff = NaN, max 448)
+static inline float hipemu_e4m3_to_f32(uint8_t v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float f;
+    if (e == 15 && m == 7) f = NAN;
+    else if (e == 0) f = ldexpf((float)m, -9);
+    else f = ldexpf((float)(8 + m), e - 10);
+    return s ? -f : f;
+}
+// 32x32x64 fp8 x fp8 with unit block scales: lane l holds A[i = l & 31][k = 32 (l >> 5) + e], e = 0..31 (byte e of the 8 dwords),
+// B[k = 32 (l >> 5) + e][j = l & 31]; D as the other 32x32 shapes.
+static inline f32x16 sat_mfma_32x32x64_fp8(i32x8 a, i32x8 b, f32x16 c) {
+    struct { i32x8 a, b; } mine = {a, b};
+    const char* all = hipemu::wave_exchange(&mine, sizeof(mine));
+    const int l = hipemu::lane_id();
+    const int col = l & 31, hi = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g) {
+            uint8_t av[32], bv[32];
+            memcpy(av, all + (size_t)(row + 32 * g) * hipemu::kSlotBytes, 32);
+            memcpy(bv, all + (size_t)(col + 32 * g) * hipemu::kSlotBytes + 32, 32);
+            for (int e = 0; e < 32; ++e) acc += hipemu_e4m3_to_f32(av[e]) * hipemu_e4m3_to_f32(bv[e]);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
 #else
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both formats e4m3 (cbsz = blgp = 0) and unit E8M0 block scales (127 = 2^0): the MX
+// instruction is the only fp8 MFMA that runs at twice the bf16 rate on gfx950 (cdna_hip_programming.md section 3)
+SAT_DEVICE f32x16 sat_mfma_32x32x64_fp8(i32x8 a, i32x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+}
 SAT_DEVICE f32x16 sat_mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

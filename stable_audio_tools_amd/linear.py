@@ -66,6 +66,13 @@ class _WeightCache:
         return hit[1]
 
 
+def _fp8_operands(ops, x2, w, cache):
+    """(A, B, alpha) in fp8 e4m3 with per-tensor dynamic scales (activations quantised per call, weights once per version)."""
+    a, sa = ops.quant_fp8(x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2))
+    b, sb = cache.get(w, "fp8", lambda: ops.quant_fp8(_pad_rows8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
+    return a, b, sa * sb
+
+
 def _operands(ops, x2, w, cache, lowp):
     """GEMM operands (A, B) for y = x2 · w^T in the chosen precision mode."""
     if lowp:
@@ -87,7 +94,7 @@ class LinearFn(torch.autograd.Function):
     """y = epilogue(x · W^T + b).   mode: 'plain' | 'res' (y += res) | 'swiglu' (y = v * silu(g), W rows = [v | g])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, mode, lowp, cache):
+    def forward(ctx, x, weight, bias, res, mode, lowp, cache, fp8=False):
         ops = _ops()
         shp = x.shape
         k = shp[-1]
@@ -96,7 +103,11 @@ class LinearFn(torch.autograd.Function):
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
         out_dtype = torch.bfloat16 if lowp else torch.float32
-        a, b = _operands(ops, x2, weight, cache, lowp)
+        fp8 = bool(fp8) and lowp and k % 16 == 0
+        if fp8:
+            a, b, alpha = _fp8_operands(ops, x2, weight, cache)
+        else:
+            a, b = _operands(ops, x2, weight, cache, lowp)
         bias32 = None
         if bias is not None:
             bias32 = cache.get(bias, "bias32", lambda: torch.nn.functional.pad(bias.detach().float(), (0, (-n) % 8)).contiguous())
@@ -118,9 +129,15 @@ class LinearFn(torch.autograd.Function):
         if mode == "swiglu":
             if n % 16:
                 raise ValueError("SwiGLU projection needs 2F output rows with F % 8 == 0")
-            y = ops.gemm_bf16(a, b, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
+            if fp8:
+                y = ops.gemm_fp8(a, b, alpha, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
+            else:
+                y = ops.gemm_bf16(a, b, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
             if need_grad:
                 y, pre = y
+        elif fp8:
+            y = ops.gemm_fp8(a, b, alpha, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
+                             out=out2)
         else:
             y = ops.gemm_bf16(a, b, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
                               out=out2)
@@ -186,7 +203,7 @@ class LinearFn(torch.autograd.Function):
             dw = dw.to(wdt)
         if db is not None:
             db = db.to(bdt)
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def _lowp(x, weight):
@@ -215,6 +232,7 @@ class Linear(nn.Module):
         self.weight = ref.weight
         self.bias = ref.bias
         self._cache = _WeightCache()
+        self.fp8 = False          # forward products in fp8 e4m3 (set_fp8): BASELINE.json configs[4]; the backward stays bf16
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
@@ -230,4 +248,22 @@ class Linear(nn.Module):
         """mode None: x W^T + b [+ res];  'swiglu': value * silu(gate) over W rows = [value | gate]."""
         if mode is None:
             mode = "res" if res is not None else "plain"
-        return LinearFn.apply(x, self.weight, self.bias, res, mode, _lowp(x, self.weight), self._cache)
+        return LinearFn.apply(x, self.weight, self.bias, res, mode, _lowp(x, self.weight), self._cache, self.fp8)
+
+    def fp8_weight(self):
+        """(uint8 e4m3 weight, dequant scale) cached per weight version, or None when K % 16 != 0."""
+        if self.in_features % 16:
+            return None
+        w = self.weight
+        return self._cache.get(w, "fp8", lambda: _ops().quant_fp8(_pad_rows8(w.detach() if w.dtype == torch.bfloat16 else _ops().cast_bf16(w.detach()))))
+
+
+def set_fp8(module, enabled=True, min_features=256):
+    """Switch the forward GEMMs of every native Linear under `module` with in/out features >= min_features to fp8 e4m3
+    (per-tensor dynamic scaling, MX MFMA at twice the bf16 rate).  The tiny conditioning MLPs stay bf16."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, Linear) and min(m.in_features, m.out_features) >= min_features and m.in_features % 16 == 0:
+            m.fp8 = bool(enabled)
+            n += 1
+    return n

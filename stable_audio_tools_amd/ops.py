@@ -615,6 +615,53 @@ class SatOps:
                                              npq, npk, d, float(scale), 1, self._stream(q_rm)))
         return o
 
+    # ---- fp8 (e4m3) forward projections: per-tensor dynamic scaling, MX MFMA with unit block scales ----
+    def quant_fp8(self, src):
+        """src (R, C) fp32|bf16 -> (q (R, C) uint8 e4m3 bits, dequant scale = amax / 448 as a 0-dim device tensor)."""
+        dt = self._dt(src)
+        if src.dim() != 2 or src.stride(1) != 1 or src.shape[1] % 4:
+            raise ValueError("quant_fp8 takes a 2-D tensor with a contiguous last dim, C % 4 == 0")
+        amax = src.detach().abs().amax().float().clamp_min(1e-12)
+        qs = (448.0 / amax).contiguous()
+        q = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+        self._chk(self.lib.sat_quant_fp8(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(qs), src.shape[0], src.shape[1], int(dt == 0),
+                                         self._stream(src)))
+        return q, (amax / 448.0)
+
+    def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
+                 out=None):
+        """gemm_bf16 on fp8 operands: a (M, K), b (N, K) uint8 (quant_fp8), alpha = 0-dim fp32 device tensor (scale_a * scale_b)."""
+        if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[1] != b.shape[1]:
+            raise TypeError("gemm_fp8 takes (rows, K) uint8 operands")
+        m, k = a.shape
+        n = b.shape[0]
+        f32 = out_dtype == torch.float32
+        if bias is not None:
+            self._f32(bias)
+        nout = n // 2 if epilogue == self.EPI_SWIGLU else n
+        c = out if out is not None else torch.empty(m, nout, dtype=out_dtype, device=a.device)
+        pre = torch.empty(m, n, dtype=out_dtype, device=a.device) if (want_pre and epilogue == self.EPI_SWIGLU) else None
+        alpha = alpha.float().reshape(1).contiguous()
+        self._chk(self.lib.sat_gemm_fp8(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), nout, _ptr(bias),
+                                        _ptr(res), res.stride(0) if res is not None else 0, _ptr(gate), gate.stride(0) if gate is not None else 0,
+                                        rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), m, n, k, epilogue, int(f32),
+                                        self._stream(a)))
+        return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
+
+    def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None):
+        """gemm_heads_bf16 on fp8 operands (planes come out in bf16)."""
+        npad = (ntok + 63) // 64 * 64
+        out = {"n": ntok, "np": npad}
+        for i, (name, shape) in enumerate((("q", (nb, heads, npad, 64)), ("k", (nb, heads, npad, 64)), ("v_tr", (nb, heads, 64, npad)))):
+            if sec0 <= i < sec0 + nsec:
+                out[name] = (self._plane_cache((reuse, name, shape), shape, x.device) if reuse is not None
+                             else torch.zeros(shape, dtype=torch.int16, device=x.device))
+        alpha = alpha.float().reshape(1).contiguous()
+        self._chk(self.lib.sat_gemm_qkv_fp8(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
+                                            _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
+                                            _ptr(alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec, self._stream(x)))
+        return out
+
     def cast_bf16(self, src, transpose=False, row_pad=1, out=None):
         """src (R, C) fp32|bf16 (last dim contiguous) -> bf16 (R, C), or transposed (C, Rp) with Rp = R rounded up to row_pad
         (extra columns zero).  out: optional destination of that shape (row stride free)."""

@@ -249,6 +249,15 @@ class Attention(nn.Module):
         self.causal = False
         self.scale = dim_heads ** -0.5
 
+    @staticmethod
+    def _heads(ops, lin, x2, cs, heads, nb, ntok, sec0, nsec, tag):
+        """Input projection straight into attention operand planes (bf16, or fp8 operands when the layer is switched to fp8)."""
+        if lin.fp8 and lin.fp8_weight() is not None:
+            qx, sx = ops.quant_fp8(x2)
+            qw, sw = lin.fp8_weight()
+            return ops.gemm_heads_fp8(qx, qw, sx * sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag)
+        return ops.gemm_heads_bf16(x2, lin.lowp_weight(), cs, heads, nb, ntok, sec0, nsec, reuse=tag)
+
     def forward(self, x, context=None, rotary_pos_emb=None, causal=None, res=None, **unsupported):
         """res: the residual stream, added in the output projection's epilogue (x = x + attn(...), transformer.py:703-707)."""
         for k, v in unsupported.items():
@@ -272,12 +281,12 @@ class Attention(nn.Module):
                 m = kv_input.shape[1]
                 c2 = kv_input.reshape(b * m, -1)
                 c2 = c2 if c2.dtype == torch.bfloat16 else ops.cast_bf16(c2.contiguous())
-                pq = ops.gemm_heads_bf16(x2, self.to_q.lowp_weight(), None, h, b, n, 0, 1, reuse="cross")
-                pkv = ops.gemm_heads_bf16(c2, self.to_kv.lowp_weight(), None, kv_h, b, m, 1, 2, reuse="cross")
+                pq = self._heads(ops, self.to_q, x2, None, h, b, n, 0, 1, "cross")
+                pkv = self._heads(ops, self.to_kv, c2, None, kv_h, b, m, 1, 2, "cross")
                 out = ops.attention_planes(pq["q"], pkv["k"], pkv["v_tr"], n, m, self.scale)
             else:
                 cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
-                pl = ops.gemm_heads_bf16(x2, self.to_qkv.lowp_weight(), cs, h, b, n, 0, 3, reuse="self")
+                pl = self._heads(ops, self.to_qkv, x2, cs, h, b, n, 0, 3, "self")
                 out = ops.attention_planes(pl["q"], pl["k"], pl["v_tr"], n, n, self.scale)
             return self.to_out(out, res=res)
         if cross:
