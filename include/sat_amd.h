@@ -150,8 +150,9 @@ int sat_vae_sample_bwd(const float* pre, const float* noise, const float* dz, co
 int sat_fir(const float* x, const float* taps, float* y, int N, int T, int ntaps, int adjoint, void* stream);
 /* One resolution. x, y: (NI, C, T), C in {1,2}; views: (NV, 2) channel weights (sum/diff/left/right).
  * fwd writes partial[NI][NV][3][tile] = {sum(|Y|-|X|)^2, sum|Y|^2, sum|log|X|-log|Y||}, tile < sat_stft_tiles()  (sum over tiles: sat_rowsum).
- * bwd accumulates (atomics; caller zero-fills) dL/dy — or dL/dx if wrt_x — given coef[NI][NV][3] =
- * {c1, c2, c3}: dL/d|Y| = c1*((|Y|-|X|) - c2*|Y|) + c3*sign(log|Y|-log|X|)/|Y|.
+ * bwd writes dL/dy — or dL/dx if wrt_x — given coef[NI][NV][3] = {c1, c2, c3}: dL/d|Y| = c1*((|Y|-|X|) - c2*|Y|) +
+ * c3*sign(log|Y|-log|X|)/|Y|, as FOUR planes dy[4][NI][C][T] (even / odd workgroups x direct / reflected samples; the caller
+ * zero-fills them and sums them in a fixed order): plain stores, no atomics — the gradient is bit-reproducible.
  * Periodic Hann window of length n_fft, centre/reflect padding, hop, one-sided, unnormalised, power clamped at 1e-8. */
 int sat_stft_tiles(int n_fft, int hop, int T);
 int sat_stft_fwd(const float* x, const float* y, const float* views, float* partial, int NI, int C, int T, int NV,

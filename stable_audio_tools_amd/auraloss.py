@@ -79,13 +79,16 @@ class _MRSTFTFn(torch.autograd.Function):
         for which in (0, 1):          # 0: d/dx (first argument), 1: d/dy (second argument)
             if not ctx.needs_input_grad[which]:
                 continue
-            acc = torch.zeros_like(yf)
-            for (n, h), sums in zip(zip(fft_sizes, hop_sizes), sums_all):
+            # one set of 4 write-once planes per resolution (csrc/stft.hip: no atomics), summed in a fixed order: the
+            # gradient is bit-reproducible run to run
+            planes = torch.zeros((nres, 4) + tuple(yf.shape), dtype=yf.dtype, device=yf.device)
+            for ri, ((n, h), sums) in enumerate(zip(zip(fft_sizes, hop_sizes), sums_all)):
                 cnt = float(ni * (n // 2 + 1) * (1 + t // h))
                 sc = torch.sqrt(sums[..., 0] / sums[..., 1])
                 scale = (g * vw / nres).view(1, -1)                 # (1, NV)
                 coef = torch.stack([scale / (ni * sc * sums[..., 1]), sc * sc, (scale / cnt).expand_as(sc)], dim=-1).contiguous()
-                ops.stft_backward(xf, yf, views, coef, acc, n, h, wrt_x=(which == 0))
+                ops.stft_backward(xf, yf, views, coef, planes[ri], n, h, wrt_x=(which == 0))
+            acc = planes.sum(dim=(0, 1))
             if has_taps:
                 acc = ops.fir(acc.view(ni * c, t), taps, adjoint=True).view(ni, c, t)
             grads[which] = acc

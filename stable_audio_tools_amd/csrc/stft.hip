@@ -9,7 +9,9 @@
 //                   S3 = sum |log|X| - log|Y||.
 //   sat_stft_bwd    recomputes the FFT, forms dL/dY per bin from the three sums' coefficients,
 //                   runs the adjoint DFT in LDS, applies the window, overlap-adds a block's frames in
-//                   LDS and scatters into dL/d(filtered y) with one atomic per sample.
+//                   LDS (gathered per output sample) and writes dL/d(filtered y) as four planes (even /
+//                   odd workgroups, direct / reflected samples) with plain stores: no atomics anywhere,
+//                   the gradient is bit-reproducible.
 //
 // Two real signals ride in one complex FFT (z = x + i y), so one transform yields both spectra.
 // A "view" is a linear combination of an item's channels (sum / difference / left / right of a
@@ -87,7 +89,7 @@ struct SatStftParams {
     const float* views;   // (NV, 2) channel weights
     float* partial;       // fwd: [NI][NV][3][tiles]
     const float* coef;    // bwd: [NI][NV][3]  (c1, c2, c3)
-    float* dy;            // bwd: (NI, C, T) accumulated with atomics (caller zero-fills)
+    float* dy;            // bwd: (4, NI, C, T) planes [direct-even | direct-odd | mirror-even | mirror-odd], zero-filled by the caller; plain stores
     int NI, C, T, NV;
     int n, log2n, hop, nframes;
     int fb;               // frames transformed concurrently
@@ -310,31 +312,44 @@ __global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
             }
             __syncthreads();
             sat_fft_run(L, n, log2n, p.fb);
-            for (int i = threadIdx.x; i < p.fb * n; i += 256) {
-                const int fi = i >> log2n, j = i & (n - 1);
-                if (f0 + fi < p.nframes) {
-                    const float v = re[i] * sat_hann(L, j, n);
-                    const int o = (g * p.fb + fi) * p.hop + j;
-                    atomicAdd(&obuf_a[o], va * v);
-                    if (p.C > 1) atomicAdd(&obuf_b[o], vb * v);
+            // overlap-add of this group's fb frames into the per-channel LDS buffers, GATHERED: a thread owns output sample o and
+            // sums the (<= n/hop) frames that cover it in frame order — no LDS atomics, so the result does not depend on wave timing
+            {
+                const int gspan = (p.fb - 1) * p.hop + n;
+                const int obase = g * p.fb * p.hop;
+                for (int orel = threadIdx.x; orel < gspan; orel += 256) {
+                    int f_lo = (orel - n + p.hop) / p.hop;            // first frame with f*hop + n > orel  (ceil((orel - n + 1) / hop))
+                    if (orel - n + 1 <= 0) f_lo = 0;
+                    int f_hi = orel / p.hop;
+                    if (f_hi > p.fb - 1) f_hi = p.fb - 1;
+                    float v = 0.f;
+                    for (int fi = f_lo; fi <= f_hi; ++fi) {
+                        const int j = orel - fi * p.hop;
+                        if (f0 + fi < p.nframes) v += re[fi * n + j] * sat_hann(L, j, n);
+                    }
+                    obuf_a[obase + orel] += va * v;
+                    if (p.C > 1) obuf_b[obase + orel] += vb * v;
                 }
             }
             __syncthreads();
         }
     }
-    // scatter: obuf[i] belongs to padded-signal index fbase*hop + i  ->  sample (.. - n/2), reflected
-    float* d0 = p.dy + (size_t)item * p.C * p.T;
+    // write-out without atomics: obuf[i] belongs to padded-signal index fbase*hop + i -> sample (.. - n/2), reflected at the ends.
+    // Consecutive workgroups overlap by n - hop < their own stride, so a sample is touched by at most two NEIGHBOURING workgroups:
+    // even and odd workgroups write different planes; reflected ("mirror") samples get planes of their own (the reflection is
+    // one-to-one).  dy = 4 planes [direct-even | direct-odd | mirror-even | mirror-odd] of (NI, C, T), zero-filled by the caller,
+    // written with plain stores; the gradient is their sum (formed by the caller in a fixed order): bit-reproducible.
+    const size_t plane = (size_t)p.NI * p.C * p.T;
     const int last = (p.nframes - 1) * p.hop + n;  // one past the last padded index any frame touches
     for (int i = threadIdx.x; i < olen; i += 256) {
         const int pidx = fbase * p.hop + i;
         if (pidx < last) {
-            const int t = sat_reflect(pidx - (n >> 1), p.T);
-            const float a = obuf_a[i];
-            if (a != 0.f) atomicAdd(&d0[t], a);
-            if (p.C > 1) {
-                const float bch = obuf_b[i];
-                if (bch != 0.f) atomicAdd(&d0[p.T + t], bch);
-            }
+            const int traw = pidx - (n >> 1);
+            const int t = sat_reflect(traw, p.T);
+            const bool mirror = (traw < 0) || (traw >= p.T);
+            float* d0 = p.dy + (size_t)((mirror ? 2 : 0) + (blockIdx.x & 1)) * plane + (size_t)item * p.C * p.T;
+            d0[t] = obuf_a[i];
+            if (p.C > 1) d0[p.T + t] = obuf_b[i];
         }
     }
 }

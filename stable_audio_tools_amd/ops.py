@@ -326,13 +326,16 @@ class SatOps:
         self._chk(self.lib.sat_stft_fwd(_ptr(x), _ptr(y), _ptr(views), _ptr(partial), ni, c, t, nv, n_fft, hop, self._stream(x)))
         return self._sum_last(partial).view(ni, nv, 3)
 
-    def stft_backward(self, x, y, views, coef, dy, n_fft, hop, wrt_x=False):
-        """Accumulates dL/dy (or dL/dx with wrt_x) into `dy` (caller zero-initialised) for one resolution.
-        coef: (NI, NV, 3) = (c1, c2, c3) — see csrc/stft.hip."""
-        self._f32(x, y, views, coef, dy)
+    def stft_backward(self, x, y, views, coef, planes, n_fft, hop, wrt_x=False):
+        """dL/dy (or dL/dx with wrt_x) of one resolution, written WITHOUT atomics into `planes` (4, NI, C, T) — zero-filled by the
+        caller; [direct-even | direct-odd | mirror-even | mirror-odd] workgroup / reflection classes, plain stores — whose sum over
+        dim 0 is the gradient (bit-reproducible).  coef: (NI, NV, 3) = (c1, c2, c3) — see csrc/stft.hip."""
+        self._f32(x, y, views, coef, planes)
         ni, c, t = x.shape
         nv = views.shape[0]
-        self._chk(self.lib.sat_stft_bwd(_ptr(x), _ptr(y), _ptr(views), _ptr(coef), _ptr(dy), ni, c, t, nv, n_fft, hop,
+        if tuple(planes.shape) != (4, ni, c, t):
+            raise ValueError("stft_backward: planes must be (4, NI, C, T)")
+        self._chk(self.lib.sat_stft_bwd(_ptr(x), _ptr(y), _ptr(views), _ptr(coef), _ptr(planes), ni, c, t, nv, n_fft, hop,
                                         int(wrt_x), self._stream(x)))
 
     # ------------------------------------------------------------------ DiT operators

@@ -127,3 +127,27 @@ def test_stft_linearity_property_full_size_gpu(hip):
         assert rel_err(s2[..., 0], 4 * s[..., 0]) < 1e-4
         assert rel_err(s2[..., 1], 4 * s[..., 1]) < 1e-4
         assert rel_err(s2[..., 2], s[..., 2]) < 1e-3
+
+
+def _deterministic(device):
+    """The loss gradient is bit-reproducible: csrc/stft.hip's backward uses no atomics (LDS overlap-add gathered per sample,
+    global write-out as four write-once planes summed in a fixed order)."""
+    from stable_audio_tools_amd.auraloss import AutoencoderSpectralLoss
+    loss = AutoencoderSpectralLoss(44100, weight=1.0, **seeded.STFT_CFG).to(device)
+    reals = torch.from_numpy(seeded.seeded_array((2, 2, 6000), 500, scale=0.1)).to(device)
+    dec0 = (reals + torch.from_numpy(seeded.seeded_array((2, 2, 6000), 501, scale=0.01)).to(device))
+    grads = []
+    for _ in range(3):
+        d = dec0.clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(loss(reals, d), d)
+        grads.append(g)
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_stft_gradient_is_bit_reproducible_simulator(emu_modules):
+    _deterministic("cpu")
+
+
+@pytest.mark.gpu
+def test_stft_gradient_is_bit_reproducible_gpu(hip):
+    _deterministic("cuda")
