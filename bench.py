@@ -586,7 +586,7 @@ def main():
             # (Stable Audio Open DiT, bf16, v-DDIM + CFG), with the self-attention kernel's MFMA roofline
             del stepper, model, batches
             torch.cuda.empty_cache()
-            sec = dit_sample_line("bf16", 1, 30, 5, with_cpu_baseline=not args.no_cpu_baseline)
+            sec = dit_sample_line("bf16", 1, 50, 10, with_cpu_baseline=not args.no_cpu_baseline)
             line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")
                                  if k in sec}
             if "cpu_baseline" in sec:
