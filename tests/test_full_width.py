@@ -85,7 +85,9 @@ def _vae_bar(g, tag):
         return lambda n: TOL
     # 4 x the white-noise probe: the native forward deviation (bf16x3 rounding, 8e-6 of the peak) is not white — it is correlated
     # along time, i.e. richer in exactly the low-frequency bins the A-weighted log-magnitude term amplifies (measured: up to 3.0 x)
-    return lambda n: max(TOL, 3.0 * float(g[f"refdist_gen/{n}"]), 4.0 * float(g[f"sens_gen/{n}"]))
+    # floor: the reference's own worst float32-vs-float64 parameter-gradient distance on this loss (1.47e-3)
+    floor = max(float(v) for k, v in g.items() if k.startswith("refdist_gen/"))
+    return lambda n: max(TOL, floor, 3.0 * float(g[f"refdist_gen/{n}"]), 4.0 * float(g[f"sens_gen/{n}"]))
 
 
 def _vae_asserts(g, pre, z, kl, dec, loss_gen, loss_lin):
