@@ -36,6 +36,7 @@ def parse():
                     help="items per GPU per step (default: 1 for vae_train and dit_sample, 4 for dit_train)")
     ap.add_argument("--sample-size", type=int, default=SAMPLE_SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-real-step", action="store_true", help="skip the timing of the alternating discriminator / generator step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
     ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train"], default="vae_train",
@@ -523,8 +524,9 @@ def main():
         for n_, p in model.named_parameters():
             if n_.endswith("alpha") or n_.endswith("beta"):
                 p.normal_(0.0, 0.1)
-    stepper = AutoencoderTrainStep(model, cfg)
-    ops = O.get_ops()
+    stepper = AutoencoderTrainStep(model, cfg, use_discriminator=(world == 1 and not args.no_real_step))
+    stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
+    ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
     prof = ConvProfiler(ops)
 
     g = torch.Generator().manual_seed(rank)     # per-rank data (train.py:30-33 seeds ranks differently)
@@ -581,11 +583,31 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)
+        if stepper.discriminator is not None:
+            # the REAL autoencoder step of the reference (training/autoencoders.py:440-515): MS-STFT discriminator (5 scales, 64
+            # filters), updates alternating discriminator / generator — timed over 2 + 2 steps after one of each as warm-up
+            stepper.use_disc = True
+            stepper.global_step = 0
+            for i in range(2):
+                stepper(batches[i % 2])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(4):
+                out_r = stepper(batches[i % 2])
+            torch.cuda.synchronize()
+            dt_real = (time.perf_counter() - t1) / 4
+            line["config"]["real_step"] = {
+                "workload": "alternating MS-STFT-discriminator / generator updates (encodec discriminator: 5 scales n_fft 2048..128, 64 filters, "
+                            "hinge + feature matching; adversarial 0.1, feature_matching 5.0) on the same 47.55 s stereo items",
+                "ms_per_step": 1e3 * dt_real, "samples_per_s": args.batch / dt_real, "steps": 4,
+                "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "last_loss": float(out_r["loss"])}
+            stepper.use_disc = False
         if world == 1 and not args.no_secondary:
             # the second half of BASELINE.json's metric ("...; DiT sampling steps/sec"), measured in the same run: configs[2]
             # (Stable Audio Open DiT, bf16, v-DDIM + CFG), with the self-attention kernel's MFMA roofline
             del stepper, model, batches
             torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
             sec = dit_sample_line("bf16", 1, 50, 10, with_cpu_baseline=not args.no_cpu_baseline)
             line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")
                                  if k in sec}

@@ -239,6 +239,14 @@ int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long 
 int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
                  float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream);
 
+/* Complex spectrogram of the MS-STFT discriminator — models/encodec.py:73-76, :97-102 (torchaudio Spectrogram: periodic Hann,
+ * normalized by ||w||_2, center = False, onesided, power = None; real / imaginary parts concatenated on the channel axis, axes
+ * swapped to (frames, freq)).  x (NI, C, T), C in {1, 2} -> z (NI, 2C, frames, n_fft/2+1), frames = sat_spec_frames().
+ * sat_spec_bwd: dz -> dx as TWO planes dx[2][NI][C][T] (even / odd workgroups; caller zero-fills and sums): no atomics. */
+int sat_spec_frames(int n_fft, int hop, int T);
+int sat_spec_fwd(const float* x, float* z, int NI, int C, int T, int n_fft, int hop, void* stream);
+int sat_spec_bwd(const float* dz, float* dx, int NI, int C, int T, int n_fft, int hop, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense projections of the DiT — models/transformer.py: to_qkv :362/:481, to_out :364/:534, to_q / to_kv :356-357,
  * GLU proj + x*silu(gate) :263-275, FeedForward linear_out :308, residual / gate updates :684-712; models/dit.py :49-77.

@@ -169,6 +169,33 @@ def gen_dit(name, seed):
     print(f"dit_{name}: out {tuple(plain.shape)} |plain| {plain.abs().max():.3f} |guided| {guided.abs().max():.3f} params {sum(p.numel() for p in model.parameters())}")
 
 
+def gen_disc(name, seed, batch=2, length=1500):
+    """EncodecDiscriminator (models/discriminators.py:18-63 over models/encodec.py) through the reference classes: logits, feature
+    maps and the three losses on seeded stereo signals, with autograd gradients w.r.t. the fake signal and every parameter."""
+    from stable_audio_tools.models.discriminators import EncodecDiscriminator
+    cfg = seeded.DISC_CONFIGS[name]
+    disc = EncodecDiscriminator(**cfg).float()
+    shapes = {k: tuple(v.shape) for k, v in disc.state_dict().items()}
+    sd = seeded.seeded_state_dict(shapes, seed)
+    disc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    reals = torch.from_numpy(seeded.seeded_array((batch, cfg["in_channels"], length), seed + 1, scale=0.3))
+    fakes = (reals + torch.from_numpy(seeded.seeded_array((batch, cfg["in_channels"], length), seed + 2, scale=0.1))).requires_grad_(True)
+    logits, fmaps = disc(fakes)
+    dis, adv, fm = disc.loss(reals, fakes)
+    total = dis + 0.1 * adv + 5.0 * fm
+    names = [n for n, _ in disc.named_parameters()]
+    grads = torch.autograd.grad(total, [fakes] + list(disc.parameters()))
+    out = {"dis": dis.detach().numpy(), "adv": adv.detach().numpy(), "fm": fm.detach().numpy(), "grad/<fakes>": grads[0].numpy(),
+           "keys": np.array(sorted(disc.state_dict().keys()))}
+    for i, lg in enumerate(logits):
+        out[f"logits/{i}"] = lg.detach().numpy()
+        out[f"fmap_last/{i}"] = fmaps[i][-1].detach().numpy()
+    for n, g in zip(names, grads[1:]):
+        out["grad/" + n] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, f"disc_{name}.npz"), **out)
+    print(f"disc_{name}: dis {dis.item():.5f} adv {adv.item():.5f} fm {fm.item():.5f} params {sum(p.numel() for p in disc.parameters())}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refimport.import_reference()
@@ -180,6 +207,7 @@ def main():
     gen_vae("mono", batch=2, in_len=320, seed=300)
     gen_chunked("tiny", seed=400)
     gen_stft(seed=500)
+    gen_disc("tiny", seed=800)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "reference": "Stability-AI/stable-audio-tools v0.0.19 (/root/reference)",
                    "torch": torch.__version__, "numpy": np.__version__}, f, indent=1)

@@ -33,9 +33,29 @@ def install_stubs():
         def __init__(self, *a, **k):
             raise RuntimeError("stubbed third-party module (off the hot path)")
 
+    class _Spectrogram(torch.nn.Module):
+        """torchaudio.transforms.Spectrogram restated from its published algorithm for the one call site on the scoped path
+        (models/encodec.py:73-76: power=None, normalized=True, center=False, window_fn=torch.hann_window).  PARITY UNPINNED:
+        torchaudio itself is absent here (oracle/disc_oracle.py header)."""
+
+        def __init__(self, n_fft, hop_length, win_length, window_fn=torch.hann_window, normalized=False, center=True, pad_mode="reflect",
+                     power=2.0):
+            super().__init__()
+            assert power is None and not center
+            self.n_fft, self.hop_length, self.win_length, self.normalized = n_fft, hop_length, win_length, normalized
+            self.register_buffer("window", window_fn(win_length), persistent=False)
+
+        def forward(self, x):
+            shp = x.shape
+            z = torch.stft(x.reshape(-1, shp[-1]), self.n_fft, self.hop_length, self.win_length, self.window.to(x), center=False,
+                           return_complex=True)
+            if self.normalized:
+                z = z / self.window.to(x).pow(2.0).sum().sqrt()
+            return z.reshape(*shp[:-1], z.shape[-2], z.shape[-1])
+
     if "torchaudio" not in sys.modules:
         ta = _stub("torchaudio")
-        ta.transforms = _stub("torchaudio.transforms", Resample=_Unavailable)
+        ta.transforms = _stub("torchaudio.transforms", Resample=_Unavailable, Spectrogram=_Spectrogram)
         ta.functional = _stub("torchaudio.functional")
     if "alias_free_torch" not in sys.modules:
         _stub("alias_free_torch", Activation1d=_Unavailable)

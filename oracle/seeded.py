@@ -135,3 +135,9 @@ def probe_index(name, numel, count=FULL_PROBE):
     """Seeded sample of flat indices of a large gradient tensor (depends only on the parameter name and size)."""
     rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
     return np.sort(rs.choice(numel, size=min(count, numel), replace=False))
+
+
+# MS-STFT discriminator (training.loss_configs.discriminator.config of stable_audio_2_0_vae.json:80-87, scaled down)
+DISC_CONFIGS = {
+    "tiny": dict(filters=8, in_channels=2, n_ffts=[128, 64, 32], hop_lengths=[32, 16, 8], win_lengths=[128, 64, 32]),
+}

@@ -57,6 +57,9 @@ SIGNATURES = {
     "sat_stft_tiles": (_I, [_I, _I, _I]),
     "sat_stft_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sat_stft_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sat_spec_frames": (_I, [_I, _I, _I]),
+    "sat_spec_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sat_spec_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     # attention.hip
     "sat_attn_prepare": (_I, [_P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_attention_fwd": (_I, [_P] * 8 + [_I] * 8 + [_F, _I, _P]),

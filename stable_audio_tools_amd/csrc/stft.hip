@@ -400,3 +400,182 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     SAT_LAUNCH(sat_stft_bwd_kernel, grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Complex spectrogram for the MS-STFT discriminator (reference: stable_audio_tools/models/encodec.py:73-76, :97-102 —
+// torchaudio.transforms.Spectrogram(n_fft, hop, win_length = n_fft, hann window (periodic), normalized = True (by
+// sqrt(sum w^2)), center = False, power = None), real and imaginary parts concatenated on the channel axis and the
+// (freq, frame) axes swapped: z (NI, 2C, frames, n/2+1)).  torchaudio itself is not in the reference tree; its published
+// algorithm is torch.stft(..., center=False, onesided) / ||w||_2.
+//   sat_spec_fwd   x (NI, C, T), C in {1, 2}  ->  z[ni][c][f][k] = Re X_c, z[ni][C + c][f][k] = Im X_c,  X_c[f][k] =
+//                  sum_j w_j x_c[f hop + j] e^{-2 pi i jk/n} / ||w||;  frames = 1 + (T - n) / hop.  The two channels of a
+//                  stereo item ride in one complex FFT (as the loss kernels do).
+//   sat_spec_bwd   dz -> dx, adjoint of the above: one complex FFT per channel and frame, frames overlap-added by gathering per
+//                  output sample in LDS; even / odd workgroups write different planes dx[2][NI][C][T] (plain stores, the caller
+//                  zero-fills and sums them): no atomics.
+// ---------------------------------------------------------------------------------------------
+struct SatSpecParams {
+    const float* x;     // fwd in (NI, C, T)
+    float* z;           // fwd out / bwd in (NI, 2C, frames, nb)
+    float* dx;          // bwd out (2, NI, C, T)
+    int NI, C, T, n, log2n, hop, nframes, fb;
+};
+
+__global__ void __launch_bounds__(256) sat_spec_fwd_kernel(SatSpecParams p) {
+    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
+    __shared__ float wsum[4];
+    const SatFftLds L{re, im, twr, twi};
+    const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
+    const int item = blockIdx.y;
+    sat_fft_init_twiddles(L, n);
+    __syncthreads();
+    // ||w||^2 of the periodic Hann window = 3n/8 for n >= 4; computed from the table so that it matches the window used
+    float ws = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) { const float w = sat_hann(L, j, n); ws += w * w; }
+    ws = sat_wave_sum(ws);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    const float inv_norm = 1.0f / sqrtf(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    const float* x0 = p.x + (size_t)item * p.C * p.T;
+    for (int g = 0; g < SAT_STFT_NG; ++g) {
+        const int f0 = (blockIdx.x * SAT_STFT_NG + g) * p.fb;
+        if (f0 >= p.nframes) break;
+        for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+            const int fi = i >> log2n, j = i & (n - 1);
+            const int f = f0 + fi;
+            float a = 0.f, b = 0.f;
+            if (f < p.nframes) {
+                const int t = f * p.hop + j;
+                const float w = sat_hann(L, j, n) * inv_norm;
+                a = w * x0[t];
+                if (p.C > 1) b = w * x0[p.T + t];
+            }
+            const int jr = (int)(sat_brev((unsigned)j) >> (32 - log2n));
+            re[fi * n + jr] = a;
+            im[fi * n + jr] = b;
+        }
+        __syncthreads();
+        sat_fft_run(L, n, log2n, p.fb);
+        for (int i = threadIdx.x; i < p.fb * nb; i += 256) {
+            const int fi = i / nb, k = i - fi * nb;
+            const int f = f0 + fi;
+            if (f < p.nframes) {
+                float ar, ai, br, bi;
+                sat_unpack_bins(L, n, fi, k, &ar, &ai, &br, &bi);
+                float* zo = p.z + (((size_t)item * 2 * p.C) * p.nframes + f) * nb + k;
+                const size_t cs = (size_t)p.nframes * nb;
+                zo[0] = ar;
+                if (p.C > 1) {
+                    zo[cs] = br;
+                    zo[2 * cs] = ai;
+                    zo[3 * cs] = bi;
+                } else {
+                    zo[cs] = ai;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) sat_spec_bwd_kernel(SatSpecParams p) {
+    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
+    __shared__ float obuf[SAT_STFT_OBUF];
+    __shared__ float wsum[4];
+    const SatFftLds L{re, im, twr, twi};
+    const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
+    const int item = blockIdx.y;
+    sat_fft_init_twiddles(L, n);
+    __syncthreads();
+    float ws = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) { const float w = sat_hann(L, j, n); ws += w * w; }
+    ws = sat_wave_sum(ws);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    const float inv_norm = 1.0f / sqrtf(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    const int fpb = SAT_STFT_NG * p.fb;
+    const int olen = (fpb - 1) * p.hop + n;
+    const int fbase = blockIdx.x * fpb;
+    const size_t cs = (size_t)p.nframes * nb;
+    for (int c = 0; c < p.C; ++c) {
+        for (int i = threadIdx.x; i < olen; i += 256) obuf[i] = 0.f;
+        __syncthreads();
+        const float* gre = p.z + ((size_t)item * 2 * p.C + c) * cs;
+        const float* gim = p.z + ((size_t)item * 2 * p.C + p.C + c) * cs;
+        for (int g = 0; g < SAT_STFT_NG; ++g) {
+            const int f0 = fbase + g * p.fb;
+            if (f0 >= p.nframes) break;
+            for (int i = threadIdx.x; i < p.fb * n; i += 256) {
+                re[i] = 0.f;
+                im[i] = 0.f;
+            }
+            __syncthreads();
+            // dx_j = w_j Re( sum_{k <= n/2} G_k e^{+2 pi i jk/n} ) = w_j Re( DFT(conj G)[j] )
+            for (int i = threadIdx.x; i < p.fb * nb; i += 256) {
+                const int fi = i / nb, k = i - fi * nb;
+                const int f = f0 + fi;
+                if (f < p.nframes) {
+                    const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
+                    re[fi * n + kr] = gre[(size_t)f * nb + k];
+                    im[fi * n + kr] = -gim[(size_t)f * nb + k];
+                }
+            }
+            __syncthreads();
+            sat_fft_run(L, n, log2n, p.fb);
+            const int gspan = (p.fb - 1) * p.hop + n;
+            const int obase = g * p.fb * p.hop;
+            for (int orel = threadIdx.x; orel < gspan; orel += 256) {
+                int f_lo = (orel - n + p.hop) / p.hop;
+                if (orel - n + 1 <= 0) f_lo = 0;
+                int f_hi = orel / p.hop;
+                if (f_hi > p.fb - 1) f_hi = p.fb - 1;
+                float v = 0.f;
+                for (int fi = f_lo; fi <= f_hi; ++fi) {
+                    const int j = orel - fi * p.hop;
+                    if (f0 + fi < p.nframes) v += re[fi * n + j] * sat_hann(L, j, n);
+                }
+                obuf[obase + orel] += v * inv_norm;
+            }
+            __syncthreads();
+        }
+        const int last = (p.nframes - 1) * p.hop + n;     // one past the last sample any frame touches (<= T)
+        float* d0 = p.dx + (size_t)(blockIdx.x & 1) * p.NI * p.C * p.T + ((size_t)item * p.C + c) * p.T;
+        for (int i = threadIdx.x; i < olen; i += 256) {
+            const int t = fbase * p.hop + i;
+            if (t < last) d0[t] = obuf[i];
+        }
+        __syncthreads();
+    }
+}
+
+static int sat_spec_plan(int n, int hop, int T, SatSpecParams* p) {
+    SatStftParams q;
+    if (T < n) return 1;
+    if (sat_stft_plan(n, hop, T > n / 2 ? T : n, &q)) return 1;
+    p->n = q.n; p->log2n = q.log2n; p->hop = hop; p->fb = q.fb;
+    p->nframes = 1 + (T - n) / hop;
+    return 0;
+}
+extern "C" int sat_spec_frames(int n_fft, int hop, int T) {
+    SatSpecParams p;
+    if (sat_spec_plan(n_fft, hop, T, &p)) return -1;
+    return p.nframes;
+}
+extern "C" int sat_spec_fwd(const float* x, float* z, int NI, int C, int T, int n_fft, int hop, void* stream) {
+    SatSpecParams p{};
+    if (NI <= 0 || (C != 1 && C != 2)) { sat_set_error("sat_spec_fwd: bad shape (C must be 1 or 2)"); return 1; }
+    if (sat_spec_plan(n_fft, hop, T, &p)) { sat_set_error("sat_spec_fwd: unsupported n_fft/hop/T (n_fft power of two in [8, 2048], hop <= n_fft <= T)"); return 1; }
+    p.x = x; p.z = z; p.NI = NI; p.C = C; p.T = T;
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI);
+    SAT_LAUNCH(sat_spec_fwd_kernel, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_spec_fwd");
+}
+extern "C" int sat_spec_bwd(const float* dz, float* dx, int NI, int C, int T, int n_fft, int hop, void* stream) {
+    SatSpecParams p{};
+    if (NI <= 0 || (C != 1 && C != 2)) { sat_set_error("sat_spec_bwd: bad shape (C must be 1 or 2)"); return 1; }
+    if (sat_spec_plan(n_fft, hop, T, &p)) { sat_set_error("sat_spec_bwd: unsupported n_fft/hop/T"); return 1; }
+    p.z = const_cast<float*>(dz); p.dx = dx; p.NI = NI; p.C = C; p.T = T;
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI);
+    SAT_LAUNCH(sat_spec_bwd_kernel, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_spec_bwd");
+}

@@ -1,0 +1,199 @@
+"""MS-STFT discriminator of the autoencoder training step on the native kernels.
+
+Mirror of stable_audio_tools/models/encodec.py (NormConv2d :19-28, get_2d_padding :34-35, DiscriminatorSTFT :37-106,
+MultiScaleSTFTDiscriminator :108-138) and stable_audio_tools/models/discriminators.py (get_hinge_losses :13-16,
+EncodecDiscriminator :18-63): same class names, constructor kwargs and state_dict keys
+(`discriminators.discriminators.{i}.convs.{j}.conv.{weight_g,weight_v,bias}`, `...conv_post.conv.*`).
+
+Execution
+  * spectrogram: csrc/stft.hip `sat_spec_fwd/bwd` — LDS FFT per frame (both stereo channels in one complex transform), normalised
+    by ||w||, real/imag planes written directly in the (B, 2C, frames, freq) layout the convs read; backward without atomics.
+    (torchaudio's Spectrogram is not in the reference tree: restated from its published algorithm, torch.stft(center=False)/||w||.)
+  * Conv2d (3 x 9 / 3 x 3 kernels, dilation along frames, stride 1 — DiscriminatorSTFT's default, the only one the reference
+    configures): run as stride-1 Conv1d over "virtual channels" on the conv stack's bf16x3 MFMA kernels (csrc/conv1d_bf16x3*.hip,
+    conv_wgrad*): the kh frame taps become channels (time-shifted copies), and the (frames x freq) plane is laid out as one long
+    sequence of zero-separated rows, so the 1-D kernels see the same regime as the VAE convs (C' = 192 channels, millions of
+    steps) instead of thousands of short rows; a 9-tap kernel is taps 1..7 on the 7-tap kernels + taps {0, 8} as a dilated 2-tap conv.
+    The rearrangement itself is torch data movement (autograd-tracked pad / stack / view); all arithmetic is in the HIP kernels.
+  * weight norm: functional.WeightNormFn (sat_wn_fold / sat_wn_grad), as for the 1-D convs.
+"""
+import typing as tp
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import functional as _fn
+from .functional import SnakeConv1dFn, WeightNormFn
+
+
+def get_2d_padding(kernel_size, dilation=(1, 1)):
+    return (((kernel_size[0] - 1) * dilation[0]) // 2, ((kernel_size[1] - 1) * dilation[1]) // 2)
+
+
+class _SpecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_fft, hop):
+        ops = _fn._ops(None)
+        x = x.contiguous()
+        ctx.meta = (ops, x.shape[1], x.shape[2], n_fft, hop)
+        return ops.spec_fwd(x, n_fft, hop)
+
+    @staticmethod
+    def backward(ctx, dz):
+        ops, c, t, n_fft, hop = ctx.meta
+        return ops.spec_bwd(dz.contiguous(), c, t, n_fft, hop), None, None
+
+
+def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
+    """F.conv2d(x, w, bias, stride=1, dilation=(dil_t, 1), padding=(pad_t, (kw-1)//2)) on the 1-D conv kernels ("same" along the
+    frequency axis, as get_2d_padding gives).  x (B, Cin, T, W); w (Cout, Cin, kh, kw), kw odd.
+
+    Layout: the kh frame taps become channels (time-shifted copies: C' = Cin*kh), and the (T x W) plane becomes one sequence of rows
+    [pad zeros | W samples | pad zeros] of pitch W + kw - 1 — a "same" 1-D conv of that sequence never mixes two rows' samples, and
+    its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel with C' >= 16 is split as taps 1..7 (a 7-tap conv: the
+    k7 forward / data-gradient / weight-gradient kernels of the conv stack) + taps {0, 8} (a 2-tap conv with dilation 8, added
+    through the residual input of the second launch)."""
+    b, cin, t, wd = x.shape
+    cout, _, kh, kw = w.shape
+    if kw % 2 != 1:
+        raise NotImplementedError("conv2d_virtual: odd frequency kernel")
+    pad_w = (kw - 1) // 2
+    xp = F.pad(x, (0, 0, pad_t, pad_t)) if pad_t else x
+    x3 = torch.stack([xp[:, :, kt * dil_t: kt * dil_t + t, :] for kt in range(kh)], dim=2)              # (B, Cin, kh, T, W)
+    pitch = wd + 2 * pad_w
+    seq = F.pad(x3, (pad_w, pad_w)).reshape(b, cin * kh, t * pitch)
+    w1 = w.reshape(cout, cin * kh, kw)
+    if kw == 9 and split_wide and cin * kh >= 16:
+        y = SnakeConv1dFn.apply(seq, None, None, w1[..., 1:8].contiguous(), bias, None, 1, 1, 3, False)
+        y = SnakeConv1dFn.apply(seq, None, None, w1[..., 0::8].contiguous(), None, y, 1, 8, 4, False)
+    else:
+        y = SnakeConv1dFn.apply(seq, None, None, w1.contiguous(), bias, None, 1, 1, pad_w, False)
+    return y.view(b, cout, t, pitch)[..., pad_w:pad_w + wd].contiguous()
+
+
+class _WNConv2d(nn.Module):
+    """weight_norm(nn.Conv2d) parameters (old-style names weight_g / weight_v / bias, models/encodec.py:25) + the virtual-channel run."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=(1, 1), dilation=(1, 1), padding=(0, 0)):
+        super().__init__()
+        ref = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, padding=padding)
+        self.weight_v = nn.Parameter(ref.weight.detach().clone())
+        self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1, 1).clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+        self.kernel_size, self.stride, self.dilation, self.padding = tuple(kernel_size), tuple(stride), tuple(dilation), tuple(padding)
+        if self.stride != (1, 1) or self.dilation[1] != 1 or self.padding != get_2d_padding(self.kernel_size, self.dilation):
+            raise NotImplementedError("only stride (1, 1), frequency dilation 1 and 'same' padding (the MS-STFT discriminator as "
+                                      "stable-audio-tools configures it: DiscriminatorSTFT(stride=(1, 1)), models/encodec.py:58)")
+
+    def forward(self, x):
+        w = WeightNormFn.apply(self.weight_v, self.weight_g)
+        return conv2d_virtual(x, w, self.bias, dil_t=self.dilation[0], pad_t=self.padding[0])
+
+
+class NormConv2d(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.conv = _WNConv2d(*args, **kwargs)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class DiscriminatorSTFT(nn.Module):
+    def __init__(self, filters, in_channels=1, out_channels=1, n_fft=1024, hop_length=256, win_length=1024, max_filters=1024,
+                 filters_scale=1, kernel_size=(3, 9), dilations=[1, 2, 4], stride=(1, 1), normalized=True, activation="LeakyReLU",
+                 activation_params={"negative_slope": 0.2}, spec_scale_pow=0.0, **kwargs):
+        super().__init__()
+        if win_length != n_fft or not normalized or spec_scale_pow != 0.0 or in_channels not in (1, 2):
+            raise NotImplementedError("DiscriminatorSTFT: win_length == n_fft, normalized, spec_scale_pow == 0, mono/stereo only")
+        self.filters, self.in_channels, self.out_channels = filters, in_channels, out_channels
+        self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
+        self.activation = getattr(torch.nn, activation)(**activation_params)
+        spec_channels = 2 * in_channels
+        self.convs = nn.ModuleList()
+        self.convs.append(NormConv2d(spec_channels, filters, kernel_size=kernel_size, padding=get_2d_padding(kernel_size)))
+        in_chs = min(filters_scale * filters, max_filters)
+        for i, dilation in enumerate(dilations):
+            out_chs = min((filters_scale ** (i + 1)) * filters, max_filters)
+            self.convs.append(NormConv2d(in_chs, out_chs, kernel_size=kernel_size, stride=stride, dilation=(dilation, 1),
+                                         padding=get_2d_padding(kernel_size, (dilation, 1))))
+            in_chs = out_chs
+        out_chs = min((filters_scale ** (len(dilations) + 1)) * filters, max_filters)
+        k0 = (kernel_size[0], kernel_size[0])
+        self.convs.append(NormConv2d(in_chs, out_chs, kernel_size=k0, padding=get_2d_padding(k0)))
+        self.conv_post = NormConv2d(out_chs, out_channels, kernel_size=k0, padding=get_2d_padding(k0))
+
+    def forward(self, x):
+        fmap = []
+        z = _SpecFn.apply(x, self.n_fft, self.hop_length)          # (B, 2C, frames, freq) = cat(real, imag) + 'b c w t -> b c t w'
+        for layer in self.convs:
+            z = self.activation(layer(z))
+            fmap.append(z)
+        return self.conv_post(z), fmap
+
+
+class MultiScaleSTFTDiscriminator(nn.Module):
+    def __init__(self, filters, in_channels=1, out_channels=1, n_ffts=[1024, 2048, 512], hop_lengths=[256, 512, 128],
+                 win_lengths=[1024, 2048, 512], **kwargs):
+        super().__init__()
+        assert len(n_ffts) == len(hop_lengths) == len(win_lengths)
+        self.discriminators = nn.ModuleList([
+            DiscriminatorSTFT(filters, in_channels=in_channels, out_channels=out_channels, n_fft=n_ffts[i], win_length=win_lengths[i],
+                              hop_length=hop_lengths[i], **kwargs) for i in range(len(n_ffts))])
+        self.num_discriminators = len(self.discriminators)
+
+    def forward(self, x):
+        logits, fmaps = [], []
+        for disc in self.discriminators:
+            logit, fmap = disc(x)
+            logits.append(logit)
+            fmaps.append(fmap)
+        return logits, fmaps
+
+
+def get_hinge_losses(score_real, score_fake):
+    gen_loss = -score_fake.mean()
+    dis_loss = torch.relu(1 - score_real).mean() + torch.relu(1 + score_fake).mean()
+    return dis_loss, gen_loss
+
+
+class EncodecDiscriminator(nn.Module):
+    def __init__(self, normalize_losses=False, loss_type: tp.Literal["hinge", "rpgan"] = "hinge", *args, **kwargs):
+        super().__init__()
+        if loss_type != "hinge":
+            raise NotImplementedError("only the hinge loss (the configured default) is restated")
+        self.discriminators = MultiScaleSTFTDiscriminator(*args, **kwargs)
+        self.normalize_losses = normalize_losses
+        self.fm_reduction = (lambda x, y: abs(x - y).mean() / (abs(x).mean() + 1e-3)) if normalize_losses else (lambda x, y: abs(x - y).mean())
+        self.loss_type = loss_type
+
+    def forward(self, x):
+        return self.discriminators(x)
+
+    def scale_losses(self, i, reals, fakes):
+        """The terms scale i contributes to loss(): (dis_i, adv_i, fm_i), each already divided by the number of scales.  The training
+        step back-propagates scale by scale (one scale's activations alive at a time: a 47 s stereo item makes ~23 GB of them per
+        scale and branch) instead of holding all five graphs."""
+        d = self.discriminators.discriminators[i]
+        n = self.discriminators.num_discriminators
+        logit_t, feat_t = d(reals)
+        logit_f, feat_f = d(fakes)
+        fm = sum(map(self.fm_reduction, feat_t, feat_f)) / len(feat_t)
+        dis, adv = get_hinge_losses(logit_t, logit_f)
+        return dis / n, adv / n, fm / n
+
+    def loss(self, reals, fakes):
+        """(dis_loss, adv_loss, feature_matching_distance) / num_scales — models/discriminators.py:31-63."""
+        feature_matching_distance = torch.tensor(0., device=reals.device)
+        dis_loss = torch.tensor(0., device=reals.device)
+        adv_loss = torch.tensor(0., device=reals.device)
+        logits_true, feature_true = self.forward(reals)
+        logits_fake, feature_fake = self.forward(fakes)
+        for i, (scale_true, scale_fake) in enumerate(zip(feature_true, feature_fake)):
+            feature_matching_distance = feature_matching_distance + sum(map(self.fm_reduction, scale_true, scale_fake)) / len(scale_true)
+            _dis, _adv = get_hinge_losses(logits_true[i], logits_fake[i])
+            dis_loss = dis_loss + _dis
+            adv_loss = adv_loss + _adv
+        n = len(logits_true)
+        return dis_loss / n, adv_loss / n, feature_matching_distance / n

@@ -338,6 +338,26 @@ class SatOps:
         self._chk(self.lib.sat_stft_bwd(_ptr(x), _ptr(y), _ptr(views), _ptr(coef), _ptr(planes), ni, c, t, nv, n_fft, hop,
                                         int(wrt_x), self._stream(x)))
 
+    # ------------------------------------------------------------------ discriminator spectrogram
+    def spec_fwd(self, x, n_fft, hop):
+        """x (NI, C, T), C in {1, 2} -> (NI, 2C, frames, n_fft/2+1): [Re X_c | Im X_c] of the normalised, un-centred STFT."""
+        self._f32(x)
+        ni, c, t = x.shape
+        frames = self.lib.sat_spec_frames(n_fft, hop, t)
+        if frames < 0:
+            raise RuntimeError(f"sat_spec: unsupported n_fft={n_fft} hop={hop} T={t}")
+        z = torch.empty(ni, 2 * c, frames, n_fft // 2 + 1, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_spec_fwd(_ptr(x), _ptr(z), ni, c, t, n_fft, hop, self._stream(x)))
+        return z
+
+    def spec_bwd(self, dz, c, t, n_fft, hop):
+        """Adjoint of spec_fwd: dz (NI, 2C, frames, bins) -> dx (NI, C, T) (two write-once planes summed here)."""
+        self._f32(dz)
+        ni = dz.shape[0]
+        planes = torch.zeros(2, ni, c, t, dtype=torch.float32, device=dz.device)
+        self._chk(self.lib.sat_spec_bwd(_ptr(dz), _ptr(planes), ni, c, t, n_fft, hop, self._stream(dz)))
+        return planes[0] + planes[1]
+
     # ------------------------------------------------------------------ DiT operators
     def _dt(self, *tensors):
         """dtype code for the DiT kernels: 0 = fp32, 1 = bf16 (all given tensors must agree)."""

@@ -218,12 +218,20 @@ class FusedAdamW:
 
 
 class AutoencoderTrainStep:
-    """One generator optimisation step of the Oobleck VAE, data-parallel over the default process
-    group.  Discriminator / feature-matching terms are out of scope this round:
-    the loss is  w_mrstft * spectral(reals, decoded) + w_kl * kl  as in the no-discriminator
-    configuration of the reference wrapper."""
+    """The optimisation step of the Oobleck VAE, data-parallel over the default process group — restated from
+    AutoencoderTrainingWrapper.training_step (training/autoencoders.py:367-527).
 
-    def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True):
+    Without a discriminator (`use_discriminator=False`, or no `loss_configs.discriminator` block): every step is a generator
+    step on  w_mrstft * spectral(reals, decoded) + w_kl * kl.
+    With the MS-STFT discriminator (loss_configs.discriminator of type "encodec", :440-454): steps ALTERNATE as in the reference
+    (:476-483, manual optimisation) — odd global steps update the discriminator on its hinge loss, even steps update the
+    autoencoder on  spectral + kl + w_adv * adversarial + w_fm * feature_matching  (:165-194).  Two restatement choices that do not
+    change any update: in a discriminator step the autoencoder runs under no_grad (the reference back-propagates loss_dis into the
+    autoencoder too and discards those gradients at the next opt_gen.zero_grad()), and in a generator step the discriminator's
+    parameters do not require grad (the reference computes and discards their gradients the same way)."""
+
+    def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True,
+                 use_discriminator=True):
         from .auraloss import AutoencoderSpectralLoss
         tr = model_config["training"]
         self.model = autoencoder
@@ -231,15 +239,7 @@ class AutoencoderTrainStep:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flat = FlatParameters(list(autoencoder.parameters()), pad_to=max(world, 1))
         oc = tr["optimizer_configs"]["autoencoder"]
-        if oc["optimizer"]["type"] != "AdamW":
-            raise NotImplementedError("only AdamW (the configured optimizer) has a fused HIP step")
-        ocfg = dict(oc["optimizer"]["config"])
-        self.base_lr = ocfg.pop("lr", tr.get("learning_rate", 1e-4))
-        self.opt = FusedAdamW(self.flat, self.base_lr, betas=ocfg.pop("betas", (0.9, 0.999)), eps=ocfg.pop("eps", 1e-8),
-                              weight_decay=ocfg.pop("weight_decay", 1e-2), ops=ops, use_ema=bool(tr.get("use_ema", False)))
-        self.sched = oc.get("scheduler")
-        if self.sched is not None and self.sched["type"] != "InverseLR":
-            raise NotImplementedError("only the InverseLR scheduler is restated")
+        self.opt, self.base_lr, self.sched = self._make_opt(self.flat, oc, tr, ops, use_ema=bool(tr.get("use_ema", False)))
         lc = tr["loss_configs"]
         self.w_kl = lc.get("bottleneck", {}).get("weights", {}).get("kl", 1e-6)      # wrapper default: training/autoencoders.py:644-647
         tw = lc.get("time", {}).get("weights", {})
@@ -247,34 +247,113 @@ class AutoencoderTrainStep:
             raise NotImplementedError("time-domain l1/l2 loss terms are not restated on the HIP path")
         if float(tr.get("clip_grad_norm", 0.0)) > 0:
             raise NotImplementedError("clip_grad_norm is not restated on the HIP path")
+        if int(tr.get("warmup_steps", 0)) > 0:
+            raise NotImplementedError("discriminator warm-up (warmup_steps > 0) is not restated")
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
         self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
+        self.discriminator = None
+        dcfg = lc.get("discriminator")
+        if use_discriminator and dcfg is not None:
+            if dcfg.get("type") != "encodec":
+                raise NotImplementedError("only the 'encodec' MS-STFT discriminator is on the HIP path")
+            from .discriminators import EncodecDiscriminator
+            dev = self.flat.data.device
+            # training/autoencoders.py:83-84: EncodecDiscriminator(in_channels=self.autoencoder.out_channels, **config)
+            self.discriminator = EncodecDiscriminator(in_channels=autoencoder.out_channels, **dcfg["config"]).to(dev)
+            self.w_adv = float(dcfg["weights"]["adversarial"])
+            self.w_fm = float(dcfg["weights"]["feature_matching"])
+            self.flat_d = FlatParameters(list(self.discriminator.parameters()), pad_to=max(world, 1))
+            self.opt_d, self.base_lr_d, self.sched_d = self._make_opt(self.flat_d, tr["optimizer_configs"]["discriminator"], tr, ops, use_ema=False)
+            self.comm_d = GradAllReduce(self.flat_d, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
         self.global_step = 0
+        self.gen_steps = self.disc_steps = 0
+        self.use_disc = self.discriminator is not None      # switchable (bench.py times the generator-only step and the real step)
+
+    @staticmethod
+    def _make_opt(flat, oc, tr, ops, use_ema):
+        if oc["optimizer"]["type"] != "AdamW":
+            raise NotImplementedError("only AdamW (the configured optimizer) has a fused HIP step")
+        ocfg = dict(oc["optimizer"]["config"])
+        base_lr = ocfg.pop("lr", tr.get("learning_rate", 1e-4))
+        opt = FusedAdamW(flat, base_lr, betas=ocfg.pop("betas", (0.9, 0.999)), eps=ocfg.pop("eps", 1e-8),
+                         weight_decay=ocfg.pop("weight_decay", 1e-2), ops=ops, use_ema=use_ema)
+        sched = oc.get("scheduler")
+        if sched is not None and sched["type"] != "InverseLR":
+            raise NotImplementedError("only the InverseLR scheduler is restated")
+        return opt, base_lr, sched
 
     def current_lr(self):
         if self.sched is None:
             return self.base_lr
-        return inverse_lr(self.global_step, self.base_lr, **self.sched["config"])
+        return inverse_lr(self.gen_steps, self.base_lr, **self.sched["config"])      # the scheduler steps with its optimizer (:513-515)
+
+    def _trim(self, decoded, reals):
+        n = min(decoded.shape[-1], reals.shape[-1])          # trim_to_shortest (training/autoencoders.py:418)
+        if decoded.shape[-1] != n or reals.shape[-1] != n:
+            decoded, reals = decoded[..., :n], reals[..., :n].contiguous()
+        return decoded, reals
 
     def __call__(self, reals, noise=None):
         """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
         m = self.model
+        kw = {"noise": noise} if noise is not None else {}
+        if self.use_disc and self.global_step % 2 == 1:
+            # ---- discriminator step (:484-497) ----
+            self.flat_d.zero_grad()
+            with torch.no_grad():
+                latents = m.encode(reals, **kw)
+                decoded, reals_t = self._trim(m.decode(latents), reals)
+            # scale by scale: one scale's graph alive at a time (the sum of the per-scale terms is loss(): discriminators.py:42-63)
+            decoded = decoded.contiguous()
+            loss_dis = torch.zeros((), device=reals.device)
+            for i in range(self.discriminator.discriminators.num_discriminators):
+                dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded)
+                dis_i.backward()
+                loss_dis = loss_dis + dis_i.detach()
+            self.flat_d.gather_grads()
+            self.comm_d()
+            lr = self.base_lr_d if self.sched_d is None else inverse_lr(self.disc_steps, self.base_lr_d, **self.sched_d["config"])
+            self.opt_d.step(lr=lr, grad_scale=self.comm_d.grad_scale)
+            self.disc_steps += 1
+            self.global_step += 1
+            return {"loss": loss_dis.detach(), "discriminator_loss": loss_dis.detach()}
+        # ---- generator step (:498-515) ----
         self.flat.zero_grad()
-        latents, info = m.encode(reals, return_info=True, noise=noise) if noise is not None else m.encode(reals, return_info=True)
-        decoded = m.decode(latents)
-        n = min(decoded.shape[-1], reals.shape[-1])          # trim_to_shortest (training/autoencoders.py:418)
-        if decoded.shape[-1] != n or reals.shape[-1] != n:
-            decoded, reals = decoded[..., :n], reals[..., :n].contiguous()
-        mrstft = self.spectral(reals, decoded)
+        latents, info = m.encode(reals, return_info=True, **kw)
+        decoded, reals_t = self._trim(m.decode(latents), reals)
+        mrstft = self.spectral(reals_t, decoded)
         loss = mrstft + self.w_kl * info["kl"]
-        loss.backward()
+        out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
+        if self.use_disc:
+            # adversarial + feature-matching terms: their gradient w.r.t. the decoded audio is collected scale by scale on a detached
+            # leaf (one scale's activations alive at a time), then enters the autoencoder's single backward pass below
+            leaf = decoded.detach().contiguous().requires_grad_(True)
+            loss_adv = torch.zeros((), device=reals.device)
+            fm = torch.zeros((), device=reals.device)
+            for p in self.flat_d.params:
+                p.requires_grad_(False)
+            try:
+                for i in range(self.discriminator.discriminators.num_discriminators):
+                    _, adv_i, fm_i = self.discriminator.scale_losses(i, reals_t, leaf)
+                    (self.w_adv * adv_i + self.w_fm * fm_i).backward()
+                    loss_adv, fm = loss_adv + adv_i.detach(), fm + fm_i.detach()
+            finally:
+                for p in self.flat_d.params:
+                    p.requires_grad_(True)
+            torch.autograd.backward([loss, decoded], [torch.ones_like(loss), leaf.grad])
+            loss = loss.detach() + self.w_adv * loss_adv + self.w_fm * fm
+            out.update(loss_adv=(self.w_adv * loss_adv).detach(), feature_matching=(self.w_fm * fm).detach())
+        else:
+            loss.backward()
         self.flat.gather_grads()
         self.comm()
         self.opt.step(lr=self.current_lr(), grad_scale=self.comm.grad_scale)
+        self.gen_steps += 1
         self.global_step += 1
-        return {"loss": loss.detach(), "mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
+        out["loss"] = loss.detach()
+        return out
 
 
 class DiTTrainStep:

@@ -229,3 +229,80 @@ def test_data_parallel_step_rccl_world2(hip):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results.values())
+
+
+# ---- the real autoencoder step: MS-STFT discriminator, alternating discriminator / generator updates ----
+def _disc_config():
+    cfg = _model_config()
+    tr = cfg["training"]
+    tr["optimizer_configs"]["discriminator"] = {
+        "optimizer": {"type": "AdamW", "config": {"betas": [0.8, 0.99], "lr": 2e-3, "weight_decay": 1e-3, "eps": 1e-3}},
+        "scheduler": {"type": "InverseLR", "config": {"inv_gamma": 200000, "power": 0.5, "warmup": 0.9}}}
+    tr["loss_configs"]["discriminator"] = {"type": "encodec", "config": {"filters": 4, "n_ffts": [64, 32], "hop_lengths": [16, 8],
+                                                                         "win_lengths": [64, 32]},
+                                           "weights": {"adversarial": 0.1, "feature_matching": 5.0}}
+    return cfg
+
+
+def _alternating(device):
+    """Step 0 (even): generator update on spectral + kl + 0.1 adversarial + 5 feature-matching; step 1 (odd): discriminator update on
+    its hinge loss with the UPDATED autoencoder (training/autoencoders.py:440-515).  Against a plain-torch restatement built from
+    the oracles (vae_oracle, stft_oracle, disc_oracle) with torch.optim.AdamW."""
+    import disc_oracle
+    from stable_audio_tools_amd.training import AutoencoderTrainStep, inverse_lr
+    cfg = _disc_config()
+    torch.manual_seed(7)
+    model = build_native_ae(NAME, SEED, device)
+    stepper = AutoencoderTrainStep(model, cfg)
+    dsd0 = {k: v.detach().cpu().clone() for k, v in stepper.discriminator.state_dict().items()}
+    batches = [_batch(2, 900), _batch(2, 910)]
+    out = [stepper(a.to(device), noise=n.to(device)) for a, n in batches]
+    assert stepper.gen_steps == 1 and stepper.disc_steps == 1 and "feature_matching" in out[0] and "discriminator_loss" in out[1]
+
+    # oracle side
+    from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
+    shapes = {k: tuple(v.shape) for k, v in create_autoencoder_from_config(cfg).state_dict().items()}
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in seeded.seeded_state_dict(shapes, SEED).items()}
+    dsd = {("discriminators." + k if not k.startswith("discriminators.") else k): v.clone().requires_grad_(True) for k, v in dsd0.items()}
+    tr = cfg["training"]
+    oa, od = tr["optimizer_configs"]["autoencoder"], tr["optimizer_configs"]["discriminator"]
+    opt_g = torch.optim.AdamW(list(sd.values()), lr=inverse_lr(0, oa["optimizer"]["config"]["lr"], **oa["scheduler"]["config"]),
+                              betas=(0.8, 0.99), weight_decay=1e-3, eps=1e-3)
+    opt_d = torch.optim.AdamW(list(dsd.values()), lr=inverse_lr(0, od["optimizer"]["config"]["lr"], **od["scheduler"]["config"]),
+                              betas=(0.8, 0.99), weight_decay=1e-3, eps=1e-3)
+    dc = tr["loss_configs"]["discriminator"]["config"]
+    sc = tr["loss_configs"]["spectral"]["config"]
+    (a0, n0), (a1, n1) = batches
+    z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], a0, n0)
+    dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+    _, adv, fm = disc_oracle.discriminator_losses(dsd, a0, dec, dc["n_ffts"], dc["hop_lengths"], dc["win_lengths"])
+    loss_g = stft_oracle.autoencoder_spectral_loss(a0, dec, sc, cfg["sample_rate"]) + 1e-4 * kl + 0.1 * adv + 5.0 * fm
+    opt_g.zero_grad()
+    opt_d.zero_grad()
+    loss_g.backward()
+    opt_g.step()
+    with torch.no_grad():
+        z, _, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], a1, n1)
+        dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+    opt_d.zero_grad()
+    loss_d, _, _ = disc_oracle.discriminator_losses(dsd, a1, dec, dc["n_ffts"], dc["hop_lengths"], dc["win_lengths"])
+    loss_d.backward()
+    opt_d.step()
+    assert abs(float(out[0]["loss"]) - float(loss_g)) <= 1e-3 * abs(float(loss_g)), (float(out[0]["loss"]), float(loss_g))
+    assert abs(float(out[1]["loss"]) - float(loss_d)) <= 1e-3 * abs(float(loss_d)), (float(out[1]["loss"]), float(loss_d))
+    # the discriminator update itself (direction of the step; its size is ~lr per element with Adam)
+    ups, refs = [], []
+    for k, v in stepper.discriminator.state_dict().items():
+        ups.append((v.detach().cpu() - dsd0[k]).reshape(-1))
+        refs.append((dsd[k].detach() - dsd0[k]).reshape(-1))
+    cos = float(torch.nn.functional.cosine_similarity(torch.cat(ups), torch.cat(refs), dim=0))
+    assert cos >= 0.995, cos
+
+
+def test_alternating_discriminator_generator_steps_simulator(emu_modules):
+    _alternating("cpu")
+
+
+@pytest.mark.gpu
+def test_alternating_discriminator_generator_steps_gpu(hip):
+    _alternating("cuda")
