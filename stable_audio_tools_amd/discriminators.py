@@ -13,7 +13,8 @@ Execution
     configures): run as stride-1 Conv1d over "virtual channels" on the conv stack's bf16x3 MFMA kernels (csrc/conv1d_bf16x3*.hip,
     conv_wgrad*): the kh frame taps become channels (time-shifted copies), and the (frames x freq) plane is laid out as one long
     sequence of zero-separated rows, so the 1-D kernels see the same regime as the VAE convs (C' = 192 channels, millions of
-    steps) instead of thousands of short rows; a 9-tap kernel is taps 1..7 on the 7-tap kernels + taps {0, 8} as a dilated 2-tap conv.
+    steps) instead of thousands of short rows; a 9-tap kernel is taps 1..7 on the 7-tap kernels + taps 0 and 8 as 1-tap convs on
+    offset views of the same buffer.
     The rearrangement itself is torch data movement (autograd-tracked pad / stack / view); all arithmetic is in the HIP kernels.
   * weight norm: functional.WeightNormFn (sat_wn_fold / sat_wn_grad), as for the 1-D convs.
 """
@@ -52,8 +53,8 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
     Layout: the kh frame taps become channels (time-shifted copies: C' = Cin*kh), and the (T x W) plane becomes one sequence of rows
     [pad zeros | W samples | pad zeros] of pitch W + kw - 1 — a "same" 1-D conv of that sequence never mixes two rows' samples, and
     its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel with C' >= 16 is split as taps 1..7 (a 7-tap conv: the
-    k7 forward / data-gradient / weight-gradient kernels of the conv stack) + taps {0, 8} (a 2-tap conv with dilation 8, added
-    through the residual input of the second launch)."""
+    k7 forward / data-gradient / weight-gradient kernels of the conv stack) + tap 0 + tap 8 (1-tap convs on the sequence shifted by
+    -+4 samples — offset views of one buffer — added through the residual input of their launches)."""
     b, cin, t, wd = x.shape
     cout, _, kh, kw = w.shape
     if kw % 2 != 1:
@@ -61,13 +62,23 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
     pad_w = (kw - 1) // 2
     xp = F.pad(x, (0, 0, pad_t, pad_t)) if pad_t else x
     x3 = torch.stack([xp[:, :, kt * dil_t: kt * dil_t + t, :] for kt in range(kh)], dim=2)              # (B, Cin, kh, T, W)
-    pitch = wd + 2 * pad_w
-    seq = F.pad(x3, (pad_w, pad_w)).reshape(b, cin * kh, t * pitch)
-    w1 = w.reshape(cout, cin * kh, kw)
-    if kw == 9 and split_wide and cin * kh >= 16:
+    pitch = (wd + 2 * pad_w + 3) // 4 * 4          # multiple of 4: 16-byte epilogues and the pipelined weight-gradient kernel
+    cp = cin * kh
+    L = t * pitch
+    w1 = w.reshape(cout, cp, kw)
+    if kw == 9 and split_wide and cp >= 16:
+        # the sequence sits in a buffer with 4 elements of slack on both sides, so that "the sequence shifted by +-4 samples" is a
+        # VIEW (same strides, storage offset -+4): taps 0 and 8 become two 1-tap convs on those views (the k1 kernels), chained
+        # through the residual input — no dilated conv, no shifted copies.  Positions where a shifted view reads across a channel
+        # boundary are row-padding positions, whose outputs are discarded (and carry zero gradient).
+        buf = F.pad(F.pad(x3, (pad_w, pitch - wd - pad_w)).reshape(b * cp * L), (4, 4))
+        strides = (cp * L, L, 1)
+        seq = buf.as_strided((b, cp, L), strides, 4)
         y = SnakeConv1dFn.apply(seq, None, None, w1[..., 1:8].contiguous(), bias, None, 1, 1, 3, False)
-        y = SnakeConv1dFn.apply(seq, None, None, w1[..., 0::8].contiguous(), None, y, 1, 8, 4, False)
+        y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 0), None, None, w1[..., 0:1].contiguous(), None, y, 1, 1, 0, False)
+        y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 8), None, None, w1[..., 8:9].contiguous(), None, y, 1, 1, 0, False)
     else:
+        seq = F.pad(x3, (pad_w, pitch - wd - pad_w)).reshape(b, cp, L)
         y = SnakeConv1dFn.apply(seq, None, None, w1.contiguous(), bias, None, 1, 1, pad_w, False)
     return y.view(b, cout, t, pitch)[..., pad_w:pad_w + wd].contiguous()
 
