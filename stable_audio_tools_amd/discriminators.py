@@ -52,7 +52,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
 
     Layout: the kh frame taps become channels (time-shifted copies: C' = Cin*kh), and the (T x W) plane becomes one sequence of rows
     [pad zeros | W samples | pad zeros] of pitch W + kw - 1 — a "same" 1-D conv of that sequence never mixes two rows' samples, and
-    its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel with C' >= 16 is split as taps 1..7 (a 7-tap conv: the
+    its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel is split as taps 1..7 (a 7-tap conv: the
     k7 forward / data-gradient / weight-gradient kernels of the conv stack) + tap 0 + tap 8 (1-tap convs on the sequence shifted by
     -+4 samples — offset views of one buffer — added through the residual input of their launches)."""
     b, cin, t, wd = x.shape
@@ -66,7 +66,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
     cp = cin * kh
     L = t * pitch
     w1 = w.reshape(cout, cp, kw)
-    if kw == 9 and split_wide and cp >= 16:
+    if kw == 9 and split_wide:
         # the sequence sits in a buffer with 4 elements of slack on both sides, so that "the sequence shifted by +-4 samples" is a
         # VIEW (same strides, storage offset -+4): taps 0 and 8 become two 1-tap convs on those views (the k1 kernels), chained
         # through the residual input — no dilated conv, no shifted copies.  Positions where a shifted view reads across a channel
@@ -79,7 +79,13 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
         y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 8), None, None, w1[..., 8:9].contiguous(), None, y, 1, 1, 0, False)
     else:
         seq = F.pad(x3, (pad_w, pitch - wd - pad_w)).reshape(b, cp, L)
-        y = SnakeConv1dFn.apply(seq, None, None, w1.contiguous(), bias, None, 1, 1, pad_w, False)
+        if kw < 7 and split_wide and cout >= 16 and cp >= 64 and torch.is_grad_enabled():
+            # training: zero-pad the 3-tap kernel to 7 taps — the k7 kernels process 8 tap groups per chunk either way, and the 7-tap
+            # weight-gradient kernel (bf16x3, pipelined) is ~4x faster than the generic one a 3-tap conv would fall back to
+            ext = (7 - kw) // 2
+            y = SnakeConv1dFn.apply(seq, None, None, F.pad(w1, (ext, ext)).contiguous(), bias, None, 1, 1, 3, False)
+        else:
+            y = SnakeConv1dFn.apply(seq, None, None, w1.contiguous(), bias, None, 1, 1, pad_w, False)
     return y.view(b, cout, t, pitch)[..., pad_w:pad_w + wd].contiguous()
 
 
