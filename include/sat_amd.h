@@ -275,6 +275,11 @@ int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, long long ldb
                       void* q_rm, void* k_rm, void* v_tr, const void* zeros, int nb, int ntok, int npad, int heads,
                       int K, int sec0, int nsec, int tile, void* stream);
 
+/* Second half of a split-K projection (sat_gemm_bf16 with splits > 1 writes fp32 slabs): out = sum_z slabs[z] (+ bias) (+ res),
+ * in bf16 or fp32 — used for the few-tile / long-K projections (FF2), where cutting K doubles the workgroups on the chip. */
+int sat_splitk_epilogue(const float* slabs, int S, const float* bias, const void* res, long long ldr, void* out, long long ldo,
+                        int M, int N, int out_f32, void* stream);
+
 /* fp8 (OCP e4m3) forward projections for the long-context configuration (BASELINE.json configs[4], stable_audio_2_0.json:3):
  * as sat_gemm_bf16 / sat_gemm_qkv_bf16 with A (M, K), B (N, K) in fp8 bytes (K, lda, ldb multiples of 16) on
  * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B). */

@@ -542,6 +542,40 @@ extern "C" int sat_gemm_qkv_bf16(const void* A, long long lda, const void* B, lo
     return sat_gemm_dispatch(p, SAT_EPI_QKV, 0, 1, tile, stream);
 }
 
+// Second half of a split-K projection: out[m][n] = sum_z slabs[z][m][n] (+ bias[n]) (+ res[m][n]), written in the output dtype.
+// For the few-tile / long-K projections (FF2: 6144 -> 1536 at M = 2050 is 204 tiles of 96 K-steps on 256 CUs) cutting K in two
+// doubles the workgroups; the slabs (fp32, 12.6 MB each) stay in the Infinity Cache between the two launches.
+struct SatSplitEpiParams {
+    const float* slabs;
+    const float* bias;
+    const void* res;
+    void* out;
+    long long ldr, ldo;
+    int M, N, S, f32;
+};
+__global__ void __launch_bounds__(256) sat_splitk_epilogue_kernel(SatSplitEpiParams p) {
+    const int nq = p.N >> 2;
+    const long long total = (long long)p.M * nq;
+    const long long slab = (long long)p.M * p.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+        f32x4 v = *(const f32x4*)(p.slabs + (long long)m * p.N + n);
+        for (int z = 1; z < p.S; ++z) v += *(const f32x4*)(p.slabs + z * slab + (long long)m * p.N + n);
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.res) v += p.f32 ? sat_load4<true>(p.res, (long long)m * p.ldr + n) : sat_load4<false>(p.res, (long long)m * p.ldr + n);
+        if (p.f32) sat_store4<true>(p.out, (long long)m * p.ldo + n, v);
+        else sat_store4<false>(p.out, (long long)m * p.ldo + n, v);
+    }
+}
+extern "C" int sat_splitk_epilogue(const float* slabs, int S, const float* bias, const void* res, long long ldr, void* out, long long ldo,
+                                   int M, int N, int out_f32, void* stream) {
+    if (M <= 0 || N <= 0 || S < 1 || (N & 3)) { sat_set_error("sat_splitk_epilogue: bad shape (N % 4 == 0)"); return 1; }
+    SatSplitEpiParams p{slabs, bias, res, out, ldr, ldo, M, N, S, out_f32};
+    const long long total = (long long)M * (N >> 2);
+    SAT_LAUNCH(sat_splitk_epilogue_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 4096 ? sat_cdivll(total, 256) : 4096)), dim3(256), stream, p);
+    return sat_check_launch("sat_splitk_epilogue");
+}
+
 // fp8 (OCP e4m3) variants of the two entry points above for the forward projections of the long-context configuration
 // (BASELINE.json configs[4]): A (M, K) and B (N, K) are fp8 bytes, K a multiple of 16, lda / ldb in elements (multiples of 16);
 // products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate, half the operand bytes);

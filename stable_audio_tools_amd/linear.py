@@ -138,6 +138,8 @@ class LinearFn(torch.autograd.Function):
         elif fp8:
             y = ops.gemm_fp8(a, b, alpha, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
                              out=out2)
+        elif lowp and out2 is not None and ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]) > 1:
+            y = ops.gemm_bf16_splitk(a, b, ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]), bias=bias32, res=r2, out_dtype=out_dtype, out=out2)
         else:
             y = ops.gemm_bf16(a, b, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
                               out=out2)

@@ -603,6 +603,37 @@ class SatOps:
             cache[key] = t
         return t
 
+    def gemm_bf16_splitk(self, a, b, splits, bias=None, res=None, out_dtype=torch.bfloat16, out=None):
+        """gemm_bf16 (epilogue: [+bias] [+res]) with K cut into `splits` ranges: fp32 slabs from the GEMM kernel, summed with the
+        bias / residual by sat_splitk_epilogue.  For few-tile / long-K projections (more workgroups than tiles)."""
+        m, n = a.shape[0], b.shape[0]
+        key = ("splitk", splits, m, n)
+        slabs = self.__dict__.setdefault("_planes", {}).get(key)
+        if slabs is None or slabs.device != a.device:
+            slabs = torch.empty(splits, m, n, dtype=torch.float32, device=a.device)
+            self._planes[key] = slabs
+        self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(slabs), n, None, None, 0, None, 0, 0, None, 0,
+                                         _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits, self._pick_tile(m, n),
+                                         self._stream(a)))
+        c = out if out is not None else torch.empty(m, n, dtype=out_dtype, device=a.device)
+        if bias is not None:
+            self._f32(bias)
+        self._chk(self.lib.sat_splitk_epilogue(_ptr(slabs), splits, _ptr(bias), _ptr(res), res.stride(0) if res is not None else 0, _ptr(c), n,
+                                               m, n, int(out_dtype == torch.float32), self._stream(a)))
+        return c
+
+    def splitk_for(self, m, n, k):
+        """Split count for a projection: > 1 only when the 128 x 128 tiles leave most of the 512 workgroup slots empty AND K is long
+        enough that the slab round trip (fp32, M x N x 4 B per slice) is cheap next to the saving."""
+        if self.gemm_splitk is not None:
+            return self.gemm_splitk
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        if tiles > 256 or k < 4096:
+            return 1
+        return 2
+
+    gemm_splitk = None
+
     def gemm_heads_bf16(self, x, w, cs, heads, nb, ntok, sec0, nsec, reuse=None):
         """Attention input projection with head split / rotary / plane layout fused (sat_gemm_qkv_bf16): x (nb*ntok, K) bf16,
         w (nsec*heads*64, K) bf16, cs (>= ntok, 16, 2) fp32 rotary table or None.  Sections sec0 .. sec0+nsec-1 of (q, k, v).

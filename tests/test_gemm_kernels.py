@@ -37,6 +37,12 @@ def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3)):
                     assert rel_err(pre, full) < 1e-5
                     assert rel_err(c, full[:, :n // 2] * torch.nn.functional.silu(full[:, n // 2:])) < 1e-5
                 assert rel_err(ops.gemm_bf16(a, b, out_dtype=torch.float32, splits=2), ref) < 1e-5
+                # split-K with the bias / residual applied by sat_splitk_epilogue (the few-tile / long-K FF2 projection)
+                if n % 4 == 0:
+                    for s_ in (2, 3):
+                        assert rel_err(ops.gemm_bf16_splitk(a, b, s_, bias=bias, res=res.float(), out_dtype=torch.float32),
+                                       ref + bias.cpu() + res.float().cpu()) < 1e-5
+                        assert rel_err(ops.gemm_bf16_splitk(a, b, s_, bias=bias, res=res).float(), ref + bias.cpu() + res.float().cpu()) < 6e-3
             finally:
                 ops.gemm_tile = None
 
