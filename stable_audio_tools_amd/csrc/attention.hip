@@ -24,12 +24,14 @@
 // (slot (hi,e) of step u <-> row 16u + 4hi + (e&3) + 8(e>>2)) and the LDS-side operand is read in that
 // same order.
 #include "sat_device.h"
+#include <stdlib.h>
 
 #define SAT_ATT_D 64
 #define SAT_ATT_T 64              // tile width (keys in fwd/dQ, queries in dK/dV)
 #define SAT_ATT_ROW 72            // bf16 per LDS row (64 + 8 pad -> 144 B stride, conflict-free b128/b64)
 
 typedef short s4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 // prepare: strided source -> bf16 planes
@@ -158,6 +160,15 @@ SAT_DEVICE bf16x8 sat_att_frag_acc(short (*t)[LROW], int row, int kofs) {
 }
 template <int NP>
 SAT_DEVICE void sat_att_pack(const f32x16& acc, int u, bf16x8 (&out)[NP]) {
+#if !defined(SAT_HIPEMU)
+    if (NP == 1) {   // one 8-wide convert: four v_cvt_pk_bf16_f32 straight into the operand's register quad
+        typedef __bf16 sat_bf8 __attribute__((ext_vector_type(8)));
+        typedef float sat_f8 __attribute__((ext_vector_type(8)));
+        const sat_f8 v = {acc[8 * u], acc[8 * u + 1], acc[8 * u + 2], acc[8 * u + 3], acc[8 * u + 4], acc[8 * u + 5], acc[8 * u + 6], acc[8 * u + 7]};
+        out[0] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v, sat_bf8));
+        return;
+    }
+#endif
     uint32_t wh[4], wl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                        // packed RNE converts
@@ -213,6 +224,98 @@ template <> struct SatOut<short> { static SAT_DEVICE void put(void* p, long long
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+// K row read by lane l31 as MFMA row a = l31 of S^T = K Q^T: key(a) = a with bits 2 and 3 exchanged.  A free per-lane choice that makes
+// accumulator registers [8u, 8u+8) of a lane 8 CONSECUTIVE keys (16u + 8 hi + e): the B-operand k-slots of the P V MFMA then line up
+// with V^T in natural key order and the V^T fragments are single conflict-free 16-byte reads.
+SAT_DEVICE int sat_att_kperm(int a) { return (a & 0x13) | ((a & 4) << 1) | ((a & 8) >> 1); }
+// max over the two 32-lane halves, in every lane
+SAT_DEVICE float sat_att_halfmax(float x) {
+#if defined(SAT_HIPEMU)
+    return fmaxf(x, __shfl_xor(x, 32));
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+#endif
+}
+// The running max is only moved when some row of the wave outgrows it by more than 2^SAT_ATT_DEFER (in the exp2 domain): P is then
+// bounded by 2^SAT_ATT_DEFER instead of 1 — harmless in fp32 / bf16 — and the O-wide rescale pass runs on the first tiles only.
+#define SAT_ATT_DEFER 4.0f
+
+// one 64-key tile (NKB = 2) or its first 32 keys (NKB = 1): S^T = K Q^T, online softmax, O^T += V^T P^T
+template <int NP, int NKB, bool MASK>
+SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW], const bf16x8 (&qf)[4][NP],
+                                  f32x16 (&oacc)[2], float& m_run, float& l_run, float sl2, int l31, int hi, int kperm, int nvalid) {
+    f32x16 sacc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ka[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + kperm, 16 * s + 8 * hi);
+            sacc[kb] = sat_att_mma<NP>(ka, qf[s], sacc[kb]);
+        }
+    }
+    if (MASK) {                                       // only the last tile holds padded keys (block-uniform)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 7) + 8 * hi + 16 * (r >> 3);
+                if (key >= nvalid) sacc[kb][r] = -INFINITY;
+            }
+    }
+    float tmax = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
+    tmax = sat_att_halfmax(tmax);
+    if (sat_wave_any((tmax - m_run) * sl2 > SAT_ATT_DEFER)) {
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = sat_exp2((m_run - m_new) * sl2);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
+    const float mb = m_run * sl2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sl2v = {sl2, sl2}, mbv = {mb, mb};
+    f32x2 ps = {0.0f, 0.0f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                  // packed fp32: scale-and-subtract and the row sum two scores at a time
+            f32x2 t = {sacc[kb][2 * j], sacc[kb][2 * j + 1]};
+            t = t * sl2v - mbv;
+            t[0] = sat_exp2(t[0]);
+            t[1] = sat_exp2(t[1]);
+            ps += t;
+            sacc[kb][2 * j] = t[0];
+            sacc[kb][2 * j + 1] = t[1];
+        }
+    l_run += ps[0] + ps[1];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 pb[NP];
+            sat_att_pack<NP>(sacc[kb], u, pb);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 va[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) va[pl] = sat_att_frag_rm(v_lds[pl], t * 32 + l31, kb * 32 + 16 * u + 8 * hi);
+                oacc[t] = sat_att_mma<NP>(va, pb, oacc[t]);
+            }
+        }
+}
+
 template <typename T, int NP>
 __global__ void __launch_bounds__(256)
 #if !defined(SAT_HIPEMU)
@@ -224,11 +327,13 @@ sat_attn_fwd_kernel(SatAttnParams p) {
     __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][plane][d][key]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = sat_att_kperm(l31);
     const int b = blockIdx.z, h = blockIdx.y;
     const int hk = h / (p.H / p.Hkv);
     const int qrow = blockIdx.x * 128 + wave * 32 + l31;     // < Nqp (grid covers Nqp in steps of 128 only when present)
     const bool q_in = qrow < p.Nqp;
     const bool q_ok = qrow < p.Nq;
+    const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;   // wave-uniform: this wave owns a valid query
     const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
     const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
 
@@ -278,89 +383,35 @@ sat_attn_fwd_kernel(SatAttnParams p) {
     tile_store(0);
     if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
-        short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW] = k_lds2[buf];
-        short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW] = v_lds2[buf];
+    int buf = 0, k0 = 0;
+    // full tiles: ONE straight-line body, so that the accumulators keep their registers around the loop; the ragged last tile is peeled
+    for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
         if (k0 + SAT_ATT_T < p.Nk) {
             tile_store(buf ^ 1);                                         // tile k+1: registers -> the other buffer
             if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);   // tile k+2 -> registers (lands during this tile's math)
         }
-
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 ka[NP];
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + l31, 16 * s + 8 * hi);
-                sacc[kb] = sat_att_mma<NP>(ka, qf[s], sacc[kb]);
-            }
-        }
-        float tmax = -INFINITY;
-        if (k0 + SAT_ATT_T > p.Nk) {                      // only the last tile holds padded keys (block-uniform)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.Nk) sacc[kb][r] = -INFINITY;
-                }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = sat_exp2((m_run - m_new) * sl2);
-        m_run = m_new;
-        const float mb = m_new * sl2;
-        float psum = 0.0f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = sat_exp2(fmaf(sacc[kb][r], sl2, -mb));
-                sacc[kb][r] = pv;
-                psum += pv;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bf16x8 pb[NP];
-                sat_att_pack<NP>(sacc[kb], u, pb);
-                const int kofs = kb * 32 + 16 * u + 4 * hi;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    bf16x8 va[NP];
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) va[pl] = sat_att_frag_acc(v_lds[pl], t * 32 + l31, kofs);
-                    oacc[t] = sat_att_mma<NP>(va, pb, oacc[t]);
-                }
-            }
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, SAT_ATT_T);
         __syncthreads();
+    }
+    if (k0 < p.Nk && w_ok) {
+        const int rem = p.Nk - k0;
+        if (rem > 32) sat_attn_fwd_tile<NP, 2, true>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, rem);
+        else sat_attn_fwd_tile<NP, 1, true>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, rem);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
     if (q_ok) {
+        // lane (q, hi) holds d = 32 t + 8 g + 4 hi + {0..3} in registers 4 g + {0..3}: 8-byte (bf16) / 16-byte (fp32) stores
         const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * SAT_ATT_D) + (long long)h * SAT_ATT_D;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                SatOut<T>::put(p.o, obase + d, oacc[t][r] * inv_l);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oacc[t][4 * g] * inv_l, oacc[t][4 * g + 1] * inv_l, oacc[t][4 * g + 2] * inv_l, oacc[t][4 * g + 3] * inv_l};
+                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                if (sizeof(T) == 4) *(f32x4*)((float*)p.o + idx) = v;
+                else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
             }
         if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = m_run * p.scale + logf(l_tot);
     }

@@ -22,29 +22,6 @@
 #include "sat_device.h"
 #include <type_traits>
 
-#if defined(SAT_HIPEMU)
-static inline void sat_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::lane_id(), g, 16); }
-#define SAT_WAIT_VMCNT(n)
-#define SAT_RAW_BARRIER() hipemu::block_barrier()
-#define SAT_WAIT_LGKM0()
-#define SAT_SCHED_FENCE()
-static inline void sat_wave_sync() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
-#define SAT_SETPRIO(x)
-#else
-// LDS destination = wave-uniform base + lane * 16 (cdna_hip_programming.md §5)
-SAT_DEVICE void sat_glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-// counted wait on this wave's LDS-DMA queue + a bare s_barrier: tiles further down the ring stay in flight across the barrier
-// (__syncthreads() would drain them: an LDS-DMA is a pending LDS write on the VM counter)
-#define SAT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define SAT_RAW_BARRIER() __builtin_amdgcn_s_barrier()
-#define SAT_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define SAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-SAT_DEVICE void sat_wave_sync() { __builtin_amdgcn_wave_barrier(); }
-#define SAT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 
 enum { SAT_EPI_STORE = 0, SAT_EPI_RES = 1, SAT_EPI_GATE_RES = 2, SAT_EPI_SWIGLU = 3, SAT_EPI_QKV = 4 };
 

@@ -273,6 +273,40 @@ SAT_DEVICE float sat_snake(float x, float a, float ib) {
 
 // ---------------------------------------------------------------------------------------------
 // Launch + status plumbing shared by every C-ABI entry point.
+// ---- LDS-DMA staging, counted waits, scheduling hints (gemm.hip, attention_fwd64.h) ----
+#if defined(SAT_HIPEMU)
+static inline void sat_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::lane_id(), g, 16); }
+#define SAT_WAIT_VMCNT(n)
+#define SAT_RAW_BARRIER() hipemu::block_barrier()
+#define SAT_WAIT_LGKM0()
+#define SAT_SCHED_FENCE()
+static inline void sat_wave_sync() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
+#define SAT_SETPRIO(x)
+#define SAT_SCHED_GROUP(mask, n)
+static inline bool sat_wave_any(bool v) {
+    int x = v ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) x |= __shfl_xor(x, m);
+    return x != 0;
+}
+#else
+// LDS destination = wave-uniform base + lane * 16 (cdna_hip_programming.md §5)
+SAT_DEVICE void sat_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// counted wait on this wave's LDS-DMA queue + a bare s_barrier: tiles further down the ring stay in flight across the barrier
+// (__syncthreads() would drain them: an LDS-DMA is a pending LDS write on the VM counter)
+#define SAT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define SAT_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+#define SAT_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+SAT_DEVICE void sat_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#define SAT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+// scheduling group: the next `n` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x100 DS read, ...) in program order
+#define SAT_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+SAT_DEVICE bool sat_wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 void sat_set_error(const char* msg);
 int sat_check_launch(const char* what);

@@ -66,11 +66,14 @@ ATT_CASES = [  # (B, H, Hkv, Nq, Nk)
 ]
 
 
-def _attn_case(ops, dev, dtype, case, seed):
+def _attn_case(ops, dev, dtype, case, seed, spikes=()):
     b, h, hkv, nq, nk = case
     gen = torch.Generator().manual_seed(seed)
-    q = torch.randn(b, h, nq, 64, generator=gen).to(dev).to(dtype)
-    k = torch.randn(b, hkv, nk, 64, generator=gen).to(dev).to(dtype)
+    q = torch.randn(b, h, nq, 64, generator=gen)
+    k = torch.randn(b, hkv, nk, 64, generator=gen)
+    for (qi, ki, gain) in spikes:        # key ki lines up with query qi: its score jumps by gain * |q|^2 / 8 at that key tile
+        k[:, :, ki] = gain * q[:, ::h // hkv, qi]
+    q, k = q.to(dev).to(dtype), k.to(dev).to(dtype)
     v = torch.randn(b, hkv, nk, 64, generator=gen).to(dev).to(dtype)
     do = torch.randn(b, nq, h * 64, generator=gen).to(dev).to(dtype)
     o, lse, planes = ops.attention(q, k, v, 0.125, return_planes=True)
@@ -96,6 +99,24 @@ def _attn_case(ops, dev, dtype, case, seed):
 @pytest.mark.parametrize("case", ATT_CASES)
 def test_attention_sim(emu, case, dtype):
     _attn_case(emu, "cpu", dtype, case, seed=21)
+
+
+# The forward moves its running max only when a row outgrows it by more than 2^4 (deferred rescale): rows whose max jumps far past the
+# threshold late in the sequence (the branch), rows that grow by less than it (stale max, P > 1), and both in one wave.
+SPIKES = [(5, 150, 6.0), (7, 100, 0.3), (40, 190, 0.5), (41, 70, 3.0), (64, 192, 8.0)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_deferred_max_sim(emu, dtype):
+    _attn_case(emu, "cpu", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES)
+    _attn_case(emu, "cpu", dtype, (1, 4, 2, 70, 200), seed=24, spikes=SPIKES[:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_deferred_max_gpu(hip, dtype):
+    _attn_case(hip, "cuda", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES)
+    _attn_case(hip, "cuda", dtype, (2, 24, 24, 1025, 1025), seed=25, spikes=SPIKES + [(1000, 1024, 5.0), (1024, 3, 4.0)])
 
 
 @pytest.mark.gpu
