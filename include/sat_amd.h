@@ -70,6 +70,19 @@ int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, co
                         const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
                         int K, int stride, int pad, int tanh_out, void* stream);
 int sat_conv1d_bf16x3_partial_rows(int B, int Tout, int K, int stride);
+
+/* The stride-1, 5 <= K <= 8 convolutions (the k = 7 convs of the ResidualUnits, autoencoders.py:58-83, and their data-gradients) with
+ * the activated input converted ONCE into bf16 hi / lo planes [B][ceil(Cin/8)][rows][8 channels] (row = 32 + t, zero rows around the
+ * sequence) instead of per workgroup while staging: sat_conv1d_k7_planes writes the planes (SnakeBeta with pre-exponentiated constants
+ * or no activation), sat_conv1d_bf16x3_planes is sat_conv1d_bf16x3 reading them by LDS-DMA.  rows = sat_conv1d_k7_plane_rows(...)
+ * (-1: pad > 32 is not supported). */
+int sat_conv1d_k7_plane_rows(int Tin, int Tout, int pad);
+int sat_conv1d_k7_planes(const float* x, const float* snake_a, const float* snake_ib, short* xp_hi, short* xp_lo, int B, int Cin, int Tin,
+                         int rows, void* stream);
+int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo, const float* bias,
+                             const float* res, float* y, const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                             float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int tanh_out,
+                             void* stream);
 int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
 int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
 long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);

@@ -33,6 +33,10 @@ struct SatConvBfLaunch {
     int sout_log2;         // depth-to-space of the output: y[co][q*S + r - out_shift] = y'[co*S + r][q]  (transposed conv)
     int in_shift, out_shift;
     int nq;                // virtual output positions
+    // conv1d_bf16x3_k7p.h: the activation as pre-split planes [B][xp_c8][xp_rows][8] (null: convert from p.x while staging)
+    const short* xp_hi = nullptr;
+    const short* xp_lo = nullptr;
+    int xp_rows = 0, xp_c8 = 0;
 };
 
 SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
@@ -471,10 +475,12 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
 }
 
 #include "conv1d_bf16x3_k7.h"     // the pipelined kernel of the (8, 1) plan
+#include "conv1d_bf16x3_k7p.h"    // the same plan fed from pre-split activation planes by LDS-DMA
 
 static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
     if (pl.ng == 8 && pl.cs == 1 && a.sin_log2 == 0 && a.sout_log2 == 0) {
-        sat_bf_launch_k7(a, stream);
+        if (a.xp_hi) sat_bf_launch_k7p(a, stream);
+        else sat_bf_launch_k7(a, stream);
         return sat_check_launch(what);
     }
     dim3 grid(sat_cdiv(a.nq, SAT_T_T), a.cout_pad / SAT_CO_T, a.p.B);
@@ -517,6 +523,56 @@ extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short*
     a.out_shift = 0;
     a.nq = Tout;
     return sat_bf_launch("sat_conv1d_bf16x3", a, pl, stream);
+}
+
+// ---- the k = 5..8 stride-1 convs from pre-split activation planes (conv1d_bf16x3_k7p.h) ----
+// rows of one (batch, 8-channel chunk) plane: 32 zero rows, the sequence, zero rows up to the last window's halo
+extern "C" int sat_conv1d_k7_plane_rows(int Tin, int Tout, int pad) {
+    if (Tin <= 0 || Tout <= 0 || pad < 0 || pad > SAT_K7P_LEAD) return -1;
+    const int need = sat_cdiv(Tout, SAT_K7_T) * SAT_K7_T - pad + SAT_K7_AROWS;   // last window: rows [t0 - pad, t0 - pad + 320)
+    const int body = need > Tin ? need : Tin;
+    return SAT_K7P_LEAD + sat_cdiv(body, 64) * 64;
+}
+// x (B, Cin, Tin) fp32 -> act(x) as bf16 hi / lo planes [B][ceil(Cin/8)][rows][8]  (act = SnakeBeta with pre-exponentiated constants, or none)
+extern "C" int sat_conv1d_k7_planes(const float* x, const float* snake_a, const float* snake_ib, short* xp_hi, short* xp_lo, int B,
+                                    int Cin, int Tin, int rows, void* stream) {
+    if (B <= 0 || Cin <= 0 || Tin <= 0 || rows < SAT_K7P_LEAD + Tin) { sat_set_error("sat_conv1d_k7_planes: bad shape"); return 1; }
+    if ((snake_a == nullptr) != (snake_ib == nullptr)) { sat_set_error("sat_conv1d_k7_planes: snake constants must both be given"); return 1; }
+    SatK7PlaneParams p{x, snake_a, snake_ib, xp_hi, xp_lo, B, Cin, Tin, rows, sat_cdiv(Cin, 8)};
+    SAT_LAUNCH(sat_k7_planes_kernel, dim3(sat_cdiv(rows, 256), p.c8, B), dim3(256), stream, p);
+    return sat_check_launch("sat_conv1d_k7_planes");
+}
+// sat_conv1d_bf16x3 for stride 1, 5 <= K <= 8, with the (activated) input given as sat_conv1d_k7_planes planes
+extern "C" int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo,
+                                        const float* bias, const float* res, float* y, const float* x2, const float* alpha2,
+                                        const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
+                                        int K, int dil, int pad, int tanh_out, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3_planes: empty shape"); return 1; }
+    SatBfPlan pl;
+    if (!sat_bf_plan(K, 1, 0, &pl) || !(pl.ng == 8 && pl.cs == 1) || dil < 1 || (pl.kv - 1) * dil > 62) {
+        sat_set_error("sat_conv1d_bf16x3_planes: needs stride 1, 5 <= K <= 8, (K-1)*dil <= 62");
+        return 1;
+    }
+    if (rows != sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planes: rows must be sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
+    if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3_planes: backward epilogue needs alpha2/beta2/partials"); return 1; }
+    SatConvBfLaunch a;
+    a.p = SatConvParams{nullptr, nullptr, bias, nullptr, nullptr, res, y, x2, alpha2, beta2, part_da, part_db,
+                        B, Cin, Cout, Tin, Tout, pl.kv, 1, dil, pad, tanh_out};
+    a.w_hi = w_hi;
+    a.w_lo = w_lo;
+    a.cout_v = Cout;
+    a.cout_pad = sat_cdiv(Cout, SAT_CO_T) * SAT_CO_T;
+    a.cin_v = Cin;
+    a.sin_log2 = 0;
+    a.sout_log2 = 0;
+    a.in_shift = 0;
+    a.out_shift = 0;
+    a.nq = Tout;
+    a.xp_hi = xp_hi;
+    a.xp_lo = xp_lo;
+    a.xp_rows = rows;
+    a.xp_c8 = sat_cdiv(Cin, 8);
+    return sat_bf_launch("sat_conv1d_bf16x3_planes", a, pl, stream);
 }
 
 // Same contract as sat_convtr1d (y[co][q*stride + k - pad] += W[ci][co][k] act(x)[ci][q], K == 2*stride, power-of-two

@@ -5,6 +5,7 @@ device pointers + shapes to the HIP library on ``torch.cuda.current_stream()``; 
 PyTorch caching allocator) owns all buffers including workspaces.
 """
 import ctypes
+import os
 
 import torch
 
@@ -172,8 +173,44 @@ class SatOps:
         if tout is None:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
         rows = self.lib.sat_conv1d_bf16x3_partial_rows(b, tout, k, stride)
+        if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
+            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
                                  bias, snake, res, tanh_out, dsnake)
+
+    # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
+    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen.
+    k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
+    k7_planes_min_cin = 512      # measured (tools/k7_bench.py): the pre-pass pays from C = 512 up (-4..-12 %), costs +1..+15 % below
+
+    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake):
+        b, cin, tin = x.shape
+        self._f32(x, bias, res)
+        sa = sib = None
+        if snake is not None:
+            sa, sib = self.snake_consts(snake[0], snake[1])
+        rows = self.lib.sat_conv1d_k7_plane_rows(tin, tout, pad)
+        c8 = (cin + 7) // 8
+        need = 2 * b * c8 * rows * 8
+        ws = self.__dict__.setdefault("_planes", {}).get(("k7p", x.device))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.int16, device=x.device)
+            self._planes[("k7p", x.device)] = ws
+        hi, lo = ws[:need // 2], ws[need // 2:need]
+        st = self._stream(x)
+        self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
+        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        x2 = a2 = b2 = pda = pdb = None
+        if dsnake is not None:
+            x2, a2, b2 = dsnake
+            self._f32(x2, a2, b2)
+            pda, pdb = torch.empty(2, cout, prows, dtype=torch.float32, device=x.device).unbind(0)
+        self._chk(self.lib.sat_conv1d_bf16x3_planes(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
+                                                    _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
+                                                    k, dil, pad, int(tanh_out), st))
+        if dsnake is not None:
+            return (y, *self._sum_pair(pda, pdb))
+        return y
 
     def convtr1d_bf16x3(self, x, w_planes, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
                         tanh_out=False, dsnake=None):

@@ -119,6 +119,44 @@ def test_conv_up_sim(emu, case):
     _run_up(emu, "cpu", case, True)
 
 
+def _run_planes(ops, dev, cases):
+    """The k = 7 convs fed from pre-split activation planes (conv1d_bf16x3_k7p.h: sat_conv1d_k7_planes + sat_conv1d_bf16x3_planes) —
+    the path the C >= 512 levels take — forced on for every channel count: forward and all gradients vs torch, and bit-identical
+    outputs to the direct kernel (same split, same MFMA order)."""
+    keep = (ops.k7_planes, ops.k7_planes_min_cin)
+    try:
+        for case in cases:
+            ops.k7_planes, ops.k7_planes_min_cin = True, 1
+            _run_s1(ops, dev, case, True)
+            B, Cin, Cout, T, K, dil = case
+            gen = torch.Generator().manual_seed(7)
+            x = torch.randn(B, Cin, T, generator=gen).to(dev)
+            w = (torch.randn(Cout, Cin, K, generator=gen) * .2).to(dev)
+            la, lb = (torch.randn(Cin, generator=gen) * .3).to(dev), (torch.randn(Cin, generator=gen) * .3).to(dev)
+            x2 = torch.randn(B, Cout, T, generator=gen).to(dev)
+            a2, b2 = (torch.randn(Cout, generator=gen) * .3).to(dev), (torch.randn(Cout, generator=gen) * .3).to(dev)
+            wp = ops.pack_bf16x3(w, 0, 1)
+            pad = dil * (K - 1) // 2
+            outs = []
+            for flag in (True, False):
+                ops.k7_planes = flag
+                outs.append((ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, snake=(la, lb)),
+                             *ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2))))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
+    finally:
+        ops.k7_planes, ops.k7_planes_min_cin = keep
+
+
+def test_conv_k7_planes_sim(emu):
+    _run_planes(emu, "cpu", [c for c in S1_CASES if c[4] == 7][:6] + [(1, 20, 5, 90, 5, 2), (2, 16, 130, 517, 7, 3)])
+
+
+@pytest.mark.gpu
+def test_conv_k7_planes_gpu(hip):
+    _run_planes(hip, "cuda", [c for c in S1_CASES if c[4] == 7] + [(1, 128, 128, 8192, 7, 9), (1, 1024, 1024, 512, 7, 3), (2, 512, 512, 1000, 7, 1)])
+
+
 def test_conv_fp32_kernels_sim(emu):
     _run_s1(emu, "cpu", S1_CASES[1], False)
     _run_s1(emu, "cpu", S1_CASES[7], False)
