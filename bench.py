@@ -251,6 +251,7 @@ class ConvProfiler:
         "sat_conv1d": ("sat_conv1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * a[17] * a[16]),
         "sat_conv1d_bf16x3": (lambda a: "sat_conv1d_bf16x3_k7_kernel" if (a[18] >= 5 and a[19] == 1) else "sat_conv1d_bf16x3_kernel",
                               X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_conv1d_bf16x3_planes": ("sat_conv1d_bf16x3_k7p_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),
         "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
         "sat_conv_wgrad": ("sat_conv_wgrad_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
@@ -308,8 +309,13 @@ def pmc_traffic(kernel, args):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))
-        return doc["kernels"][kernel]["hbm_bytes_per_launch"]
+        for name in ("r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                doc = json.load(open(path))
+                if kernel in doc["kernels"]:
+                    return doc["kernels"][kernel]["hbm_bytes_per_launch"]
+        return None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -578,7 +584,7 @@ def main():
                                  "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
                                  "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
                                  "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
-                                 "same command (profiles/r01g_pmc_traffic.json; null for a non-default workload size)",
+                                 "same command (profiles/r02_pmc_traffic.json; null for a non-default workload size)",
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,27 +1,31 @@
 #!/bin/bash
-# Collects the round's committed evidence on the GPU box (run from the repo root):
-#   gpurun_out/final/vae_stats.csv        rocprofv3 --kernel-trace --stats of `bench.py` (VAE train step)
+# Collects the round's committed evidence on the GPU box (run from the repo root; TAG names the round, e.g. r02):
+#   gpurun_out/final/vae_stats.csv        rocprofv3 --kernel-trace --stats of `bench.py` (VAE generator train step only)
+#   gpurun_out/final/real_stats.csv       the same with the alternating discriminator / generator step
 #   gpurun_out/final/dit_{sample,train}_stats.csv
-#   gpurun_out/final/pmc_{FETCH,WRITE}_SIZE.txt   per-kernel HBM counters of the same bench command (separate passes)
+#   gpurun_out/final/pmc_{FETCH,WRITE}_SIZE.txt + pmc_traffic.json   per-kernel HBM counters of the same bench command (separate passes)
 #   gpurun_out/final/bench_*.json         the bench lines themselves (with cpu_baseline)
 set -u
 R=$(pwd)
 OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/vae_prof.log 2>&1
+GEN="--no-cpu-baseline --no-real-step --no-secondary"
+rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 $GEN > $OUT/vae_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/real_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_sample -- python $R/bench.py --workload dit_sample --steps 10 --warmup 2 --no-cpu-baseline > $OUT/dit_sample_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_train -- python $R/bench.py --workload dit_train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/dit_train_prof.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python $R/bench.py --steps 1 --warmup 1 $GEN > /dev/null 2>&1
 done
 cd $R
-for w in vae dit_sample dit_train; do python tools/rocpd_stats.py $(ls $OUT/$w/*/*.db | head -1) $OUT/${w}_stats.csv; done
+for w in vae real dit_sample dit_train; do python tools/rocpd_stats.py $(ls $OUT/$w/*/*.db | head -1) $OUT/${w}_stats.csv; done
 for ctr in FETCH_SIZE WRITE_SIZE; do python tools/pmc_summary.py $OUT/pmc_$ctr sat_ > $OUT/pmc_$ctr.txt 2>&1; done
+python tools/pmc_traffic_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 $GEN, MI355X (tools/collect_profiles.sh)" > $OUT/pmc_traffic.log 2>&1
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
-rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/dit_sample $OUT/dit_train
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/real $OUT/dit_sample $OUT/dit_train
 python bench.py > $OUT/bench_vae_train.json 2> $OUT/bench_vae_train.err
 python bench.py --workload dit_sample > $OUT/bench_dit_sample.json 2> /dev/null
 python bench.py --workload dit_train > $OUT/bench_dit_train.json 2> /dev/null
-tail -c 1500 $OUT/bench_vae_train.json
+tail -c 3000 $OUT/bench_vae_train.json
