@@ -24,7 +24,7 @@ import sys
 
 
 def _registry():
-    from . import auraloss, autoencoders, bottleneck, dit, pretransforms, transformer
+    from . import auraloss, autoencoders, bottleneck, discriminators, dit, pretransforms, transformer
     return [
         # (reference module, attribute, native object)
         ("models.dit", "DiffusionTransformer", dit.DiffusionTransformer),
@@ -43,6 +43,10 @@ def _registry():
         ("training.losses", "SumAndDifferenceSTFTLoss", auraloss.SumAndDifferenceSTFTLoss),
         ("training.autoencoders", "MultiResolutionSTFTLoss", auraloss.MultiResolutionSTFTLoss),
         ("training.autoencoders", "SumAndDifferenceSTFTLoss", auraloss.SumAndDifferenceSTFTLoss),
+        # the MS-STFT discriminator of the autoencoder training step
+        ("models.discriminators", "EncodecDiscriminator", discriminators.EncodecDiscriminator),
+        ("training.autoencoders", "EncodecDiscriminator", discriminators.EncodecDiscriminator),
+        ("models.encodec", "MultiScaleSTFTDiscriminator", discriminators.MultiScaleSTFTDiscriminator),
     ]
 
 
