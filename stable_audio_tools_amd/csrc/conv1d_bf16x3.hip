@@ -52,7 +52,12 @@ SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
 // channel index wave-uniform (scalar address arithmetic, s_load for the snake constants): a wave owns one sub-block
 // (CS > 1) and its lanes are time rows; the (K'-1) halo rows of a CS > 1 chunk are staged one ELEMENT per lane.
 template <int NG, int CS, bool GATHER>
-__global__ void __launch_bounds__(256) sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+// the k = 1 plan (NG = 4) is bound by bytes in flight (3 streams of 4*C*T bytes, 48 MFMAs per wave and tile-chunk): three workgroups per CU
+__attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : 2)))
+#endif
+sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
     constexpr int KT = NG / CS;
     constexpr int KROW = NG * 8 + 8;                      // bf16 per weight row in LDS (+8 pad: conflict-free b128 reads)
     constexpr int AROWS = (CS == 1) ? SAT_BF_AROWS1 : SAT_BF_AROWSN;
