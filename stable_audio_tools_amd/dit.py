@@ -85,6 +85,19 @@ class DiffusionTransformer(nn.Module):
         self.postprocess_conv = nn.Conv1d(io_channels, io_channels, 1, bias=False)
         nn.init.zeros_(self.postprocess_conv.weight)
 
+    def _embed_cond(self, cond):
+        """to_cond_embed(cond); in inference the result is cached per (cond object, version, weights version): a sampler passes the
+        same conditioning tensor at every step, and returning the same embedded tensor lets every cross-attention layer keep its
+        K / V planes (transformer.Attention) instead of re-projecting the context at each step."""
+        if torch.is_grad_enabled():
+            return self.to_cond_embed(cond)
+        key = (cond._version, cond.dtype, tuple(cond.shape)) + tuple((q._version, q.data_ptr()) for q in self.to_cond_embed.parameters())
+        if getattr(self, "_cond_src", None) is cond and self._cond_key == key:
+            return self._cond_out
+        out = self.to_cond_embed(cond)
+        self._cond_src, self._cond_key, self._cond_out = cond, key, out
+        return out
+
     @staticmethod
     def _conv1x1_residual(conv, x):
         # Conv1d(k=1, bias=False)(x) + x on a (B, C<=64+, T) latent: one small GEMM (dit.py:193, :224)
@@ -94,7 +107,7 @@ class DiffusionTransformer(nn.Module):
                  global_embed=None, prepend_cond=None, prepend_cond_mask=None, return_info=False, exit_layer_ix=None,
                  **kwargs):
         if cross_attn_cond is not None:
-            cross_attn_cond = self.to_cond_embed(cross_attn_cond)
+            cross_attn_cond = self._embed_cond(cross_attn_cond)
         if global_embed is not None:
             global_embed = self.to_global_embed(global_embed)
         prepend_inputs = None
@@ -151,6 +164,7 @@ class DiffusionTransformer(nn.Module):
         def cast(a):
             return a.to(dt) if a is not None else None
         x, t = x.to(dt), t.to(dt)
+        cond_in, neg_in = cross_attn_cond, negative_cross_attn_cond          # the caller's objects: keys of the inference caches
         cross_attn_cond, negative_cross_attn_cond = cast(cross_attn_cond), cast(negative_cross_attn_cond)
         input_concat_cond, global_embed, prepend_cond = cast(input_concat_cond), cast(global_embed), cast(prepend_cond)
         cross_attn_cond_mask = None      # conditioning masks are disabled in the reference (dit.py:283)
@@ -193,13 +207,23 @@ class DiffusionTransformer(nn.Module):
             return torch.cat([a, a], dim=0) if a is not None else None
         batch_cond = None
         if cross_attn_cond is not None:
-            null = torch.zeros_like(cross_attn_cond)
-            if negative_cross_attn_cond is not None:
-                if negative_cross_attn_mask is not None:
-                    negative_cross_attn_cond = torch.where(negative_cross_attn_mask.to(torch.bool).unsqueeze(2), negative_cross_attn_cond, null)
-                batch_cond = torch.cat([cross_attn_cond, negative_cross_attn_cond], dim=0)
+            # inference: the batched conditioning of one (cond, negative cond, mask) triple is built once, so that _embed_cond and the
+            # cross-attention layers see the same tensor object at every sampler step
+            srcs = (cond_in, neg_in, negative_cross_attn_mask)
+            vers = tuple((a._version if a is not None else -1) for a in srcs) + (dt,)
+            cached = getattr(self, "_cfg_cond", None)
+            if not torch.is_grad_enabled() and cached is not None and all(a is b for a, b in zip(cached[0], srcs)) and cached[1] == vers:
+                batch_cond = cached[2]
             else:
-                batch_cond = torch.cat([cross_attn_cond, null], dim=0)
+                null = torch.zeros_like(cross_attn_cond)
+                if negative_cross_attn_cond is not None:
+                    if negative_cross_attn_mask is not None:
+                        negative_cross_attn_cond = torch.where(negative_cross_attn_mask.to(torch.bool).unsqueeze(2), negative_cross_attn_cond, null)
+                    batch_cond = torch.cat([cross_attn_cond, negative_cross_attn_cond], dim=0)
+                else:
+                    batch_cond = torch.cat([cross_attn_cond, null], dim=0)
+                if not torch.is_grad_enabled():
+                    self._cfg_cond = (srcs, vers, batch_cond)
         batch_prepend = torch.cat([prepend_cond, torch.zeros_like(prepend_cond)], dim=0) if prepend_cond is not None else None
         out = self._forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), cross_attn_cond=batch_cond,
                             mask=twice(mask), input_concat_cond=twice(input_concat_cond), global_embed=twice(global_embed),

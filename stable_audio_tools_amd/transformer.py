@@ -279,10 +279,19 @@ class Attention(nn.Module):
             x2 = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2.contiguous())
             if cross:
                 m = kv_input.shape[1]
-                c2 = kv_input.reshape(b * m, -1)
-                c2 = c2 if c2.dtype == torch.bfloat16 else ops.cast_bf16(c2.contiguous())
                 pq = self._heads(ops, self.to_q, x2, None, h, b, n, 0, 1, "cross")
-                pkv = self._heads(ops, self.to_kv, c2, None, kv_h, b, m, 1, 2, "cross")
+                # the conditioning is the same tensor at every sampler step (dit.py caches its embedding): its K / V planes are
+                # computed once per (context object, version, weight version) and kept in this layer's own buffers
+                w = self.to_kv.weight
+                key = (kv_input._version, w._version, w.data_ptr(), bool(self.to_kv.fp8), tuple(kv_input.shape), kv_input.dtype)
+                hit = getattr(self, "_kv_ctx", None) is kv_input and self._kv_key == key
+                if hit:
+                    pkv = self._kv_planes
+                else:
+                    c2 = kv_input.reshape(b * m, -1)
+                    c2 = c2 if c2.dtype == torch.bfloat16 else ops.cast_bf16(c2.contiguous())
+                    pkv = self._heads(ops, self.to_kv, c2, None, kv_h, b, m, 1, 2, ("crosskv", id(self)))
+                    self._kv_ctx, self._kv_key, self._kv_planes = kv_input, key, pkv
                 out = ops.attention_planes(pq["q"], pkv["k"], pkv["v_tr"], n, m, self.scale)
             else:
                 cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
