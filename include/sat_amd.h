@@ -71,6 +71,19 @@ int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, co
                         int K, int stride, int pad, int tanh_out, void* stream);
 int sat_conv1d_bf16x3_partial_rows(int B, int Tout, int K, int stride);
 
+/* Row packing for the Conv2d layers of the MS-STFT discriminator (models/encodec.py:37-106) run as 1-D convs over virtual channels:
+ * sat_rows_pack builds buf[lead + ((b*C*kh + c*kh + kt)*T + t)*pitch + pad_w + w] = x[b][c][t + kt*dil_t - pad_t][w] (zeros elsewhere,
+ * incl. `lead` floats before and after; pitch % 4 == 0, lead % 4 == 0), sat_rows_pack_bwd is its adjoint; sat_rows_unpack takes a conv
+ * output (B, C, T*pitch) back to (B, C, T, W) with LeakyReLU(slope) (slope 1: copy), sat_rows_unpack_bwd is its adjoint (`out` = the
+ * activated output, or NULL for slope 1). */
+int sat_rows_pack(const float* x, float* buf, int B, int C, int T, int W, int kh, int dil_t, int pad_t, int pad_w, int pitch, int lead,
+                  void* stream);
+int sat_rows_pack_bwd(const float* dbuf, float* dx, int B, int C, int T, int W, int kh, int dil_t, int pad_t, int pad_w, int pitch,
+                      int lead, void* stream);
+int sat_rows_unpack(const float* y, float* out, int B, int C, int T, int W, int pad_w, int pitch, float slope, void* stream);
+int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, int C, int T, int W, int pad_w, int pitch, float slope,
+                        void* stream);
+
 /* The stride-1, 5 <= K <= 8 convolutions (the k = 7 convs of the ResidualUnits, autoencoders.py:58-83, and their data-gradients) with
  * the activated input converted ONCE into bf16 hi / lo planes [B][ceil(Cin/8)][rows][8 channels] (row = 32 + t, zero rows around the
  * sequence) instead of per workgroup while staging: sat_conv1d_k7_planes writes the planes (SnakeBeta with pre-exponentiated constants

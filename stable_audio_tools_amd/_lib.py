@@ -25,6 +25,10 @@ SIGNATURES = {
     "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 10 + [_P]),
     "sat_convtr1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
     "sat_conv1d_bf16x3_partial_rows": (_I, [_I] * 4),
+    "sat_rows_pack": (_I, [_P, _P] + [_I] * 10 + [_P]),
+    "sat_rows_pack_bwd": (_I, [_P, _P] + [_I] * 10 + [_P]),
+    "sat_rows_unpack": (_I, [_P, _P] + [_I] * 6 + [_F, _P]),
+    "sat_rows_unpack_bwd": (_I, [_P, _P, _P] + [_I] * 6 + [_F, _P]),
     "sat_conv1d_k7_plane_rows": (_I, [_I] * 3),
     "sat_conv1d_k7_planes": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "sat_conv1d_bf16x3_planes": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),

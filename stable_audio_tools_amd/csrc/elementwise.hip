@@ -149,6 +149,137 @@ extern "C" int sat_pack_weights(const float* w, float* out, int D0, int D1, int 
 //   mean, scale = chunk(pre, 2, dim=1); stdev = softplus(scale) + 1e-4; z = noise*stdev + mean
 //   kl = (mean^2 + var - log var - 1).sum(1).mean()
 // The N(0,1) draw is an INPUT (torch.randn_like on the caller side) so results are reproducible.
+// ---------------------------------------------------------------------------------------------------------------------
+// Row packing for the 2-D convs of the MS-STFT discriminator (models/encodec.py:37-106) run as 1-D convs over virtual channels
+// (stable_audio_tools_amd/discriminators.py conv2d_virtual): one pass builds the (B, C*kh, T*pitch) sequence tensor — kh frame taps as
+// channels (time-shifted copies), rows [pad_w zeros | W samples | zeros] of `pitch` floats — instead of torch pad + stack + pad +
+// reshape (and their autograd adds / fills); one pass takes a conv output back to (B, C, T, W) and applies LeakyReLU.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SatRowsParams {
+    const float* src;
+    const float* aux;     // unpack backward: the activated output (sign of the pre-activation)
+    float* dst;
+    int B, C, T, W, kh, dil_t, pad_t, pad_w, pitch, lead;
+    float slope;
+};
+
+// buf[lead + ((b*C*kh + c*kh + kt)*T + t)*pitch + pad_w + w] = x[b][c][t + kt*dil_t - pad_t][w]; everything else (row padding,
+// frames outside [0, T), the `lead` floats before and after) = 0.  One thread = 4 consecutive floats of buf (pitch % 4 == 0).
+__global__ void __launch_bounds__(256) sat_rows_pack_kernel(SatRowsParams p) {
+    const int q4 = p.pitch >> 2;
+    const long long groups = (long long)p.B * p.C * p.kh * p.T * q4;
+    const long long lead4 = p.lead >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < groups + 2 * lead4; i += (long long)gridDim.x * 256) {
+        if (i >= groups) {                                  // the slack before / after the sequence
+            const long long k = i - groups;
+            float* d = (k < lead4) ? p.dst + 4 * k : p.dst + p.lead + 4 * groups + 4 * (k - lead4);
+            *reinterpret_cast<f32x4*>(d) = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const int j = (int)(i % q4);
+        long long r = i / q4;
+        const int t = (int)(r % p.T);
+        r /= p.T;
+        const int kt = (int)(r % p.kh);
+        r /= p.kh;                                          // r = b * C + c
+        const int ts = t + kt * p.dil_t - p.pad_t;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ts < (unsigned)p.T) {
+            const float* row = p.src + (r * p.T + ts) * p.W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int w = 4 * j + e - p.pad_w;
+                if ((unsigned)w < (unsigned)p.W) v[e] = row[w];
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.dst + p.lead + 4 * i) = v;
+    }
+}
+// adjoint: dx[b][c][t][w] = sum_kt dbuf[...(c*kh + kt), t - kt*dil_t + pad_t, pad_w + w]
+__global__ void __launch_bounds__(256) sat_rows_pack_bwd_kernel(SatRowsParams p) {
+    const long long total = (long long)p.B * p.C * p.T * p.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i % p.W);
+        long long r = i / p.W;
+        const int t = (int)(r % p.T);
+        r /= p.T;                                           // b * C + c
+        float s = 0.0f;
+        for (int kt = 0; kt < p.kh; ++kt) {
+            const int tb = t - kt * p.dil_t + p.pad_t;
+            if ((unsigned)tb < (unsigned)p.T) s += p.src[p.lead + ((r * p.kh + kt) * p.T + tb) * p.pitch + p.pad_w + w];
+        }
+        p.dst[i] = s;
+    }
+}
+// out[b][c][t][w] = leaky_relu(y[b][c][t*pitch + pad_w + w], slope)   (slope 1: plain copy)
+__global__ void __launch_bounds__(256) sat_rows_unpack_kernel(SatRowsParams p) {
+    const long long total = (long long)p.B * p.C * p.T * p.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i % p.W);
+        const long long r = i / p.W;                        // (b * C + c) * T + t
+        const float v = p.src[r * p.pitch + p.pad_w + w];
+        p.dst[i] = v > 0.0f ? v : v * p.slope;
+    }
+}
+// dy[b][c][t*pitch + col] = dout[b][c][t][col - pad_w] * (out > 0 ? 1 : slope) inside the row, 0 on the padding columns
+__global__ void __launch_bounds__(256) sat_rows_unpack_bwd_kernel(SatRowsParams p) {
+    const int q4 = p.pitch >> 2;
+    const long long groups = (long long)p.B * p.C * p.T * q4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % q4);
+        const long long r = i / q4;                         // (b * C + c) * T + t
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int w = 4 * j + e - p.pad_w;
+            if ((unsigned)w < (unsigned)p.W) {
+                const float g = p.src[r * p.W + w];
+                v[e] = (p.aux == nullptr || p.aux[r * p.W + w] > 0.0f) ? g : g * p.slope;
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.dst + 4 * i) = v;
+    }
+}
+
+static int sat_rows_check(const char* who, int B, int C, int T, int W, int kh, int pad_w, int pitch, int lead) {
+    if (B <= 0 || C <= 0 || T <= 0 || W <= 0 || kh < 1 || pad_w < 0 || (pitch & 3) || pitch < W + pad_w || (lead & 3) || lead < 0) {
+        sat_set_error(who);
+        return 1;
+    }
+    return 0;
+}
+static unsigned sat_rows_grid(long long n) {
+    const long long g = sat_cdivll(n, 256);
+    return (unsigned)(g < 65536 ? (g > 0 ? g : 1) : 65536);
+}
+extern "C" int sat_rows_pack(const float* x, float* buf, int B, int C, int T, int W, int kh, int dil_t, int pad_t, int pad_w, int pitch,
+                             int lead, void* stream) {
+    if (sat_rows_check("sat_rows_pack: bad shape (pitch % 4 == 0, pitch >= W + pad_w, lead % 4 == 0)", B, C, T, W, kh, pad_w, pitch, lead)) return 1;
+    SatRowsParams p{x, nullptr, buf, B, C, T, W, kh, dil_t, pad_t, pad_w, pitch, lead, 1.0f};
+    SAT_LAUNCH(sat_rows_pack_kernel, dim3(sat_rows_grid((long long)B * C * kh * T * (pitch >> 2) + (lead >> 1))), dim3(256), stream, p);
+    return sat_check_launch("sat_rows_pack");
+}
+extern "C" int sat_rows_pack_bwd(const float* dbuf, float* dx, int B, int C, int T, int W, int kh, int dil_t, int pad_t, int pad_w,
+                                 int pitch, int lead, void* stream) {
+    if (sat_rows_check("sat_rows_pack_bwd: bad shape", B, C, T, W, kh, pad_w, pitch, lead)) return 1;
+    SatRowsParams p{dbuf, nullptr, dx, B, C, T, W, kh, dil_t, pad_t, pad_w, pitch, lead, 1.0f};
+    SAT_LAUNCH(sat_rows_pack_bwd_kernel, dim3(sat_rows_grid((long long)B * C * T * W)), dim3(256), stream, p);
+    return sat_check_launch("sat_rows_pack_bwd");
+}
+extern "C" int sat_rows_unpack(const float* y, float* out, int B, int C, int T, int W, int pad_w, int pitch, float slope, void* stream) {
+    if (sat_rows_check("sat_rows_unpack: bad shape", B, C, T, W, 1, pad_w, pitch, 0)) return 1;
+    SatRowsParams p{y, nullptr, out, B, C, T, W, 1, 1, 0, pad_w, pitch, 0, slope};
+    SAT_LAUNCH(sat_rows_unpack_kernel, dim3(sat_rows_grid((long long)B * C * T * W)), dim3(256), stream, p);
+    return sat_check_launch("sat_rows_unpack");
+}
+extern "C" int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, int C, int T, int W, int pad_w, int pitch,
+                                   float slope, void* stream) {
+    if (sat_rows_check("sat_rows_unpack_bwd: bad shape", B, C, T, W, 1, pad_w, pitch, 0)) return 1;
+    SatRowsParams p{dout, out, dy, B, C, T, W, 1, 1, 0, pad_w, pitch, 0, slope};
+    SAT_LAUNCH(sat_rows_unpack_bwd_kernel, dim3(sat_rows_grid((long long)B * C * T * (pitch >> 2))), dim3(256), stream, p);
+    return sat_check_launch("sat_rows_unpack_bwd");
+}
+
 // ---------------------------------------------------------------------------------------------
 struct SatVaeParams {
     const float* pre;    // (B, 2C, T)

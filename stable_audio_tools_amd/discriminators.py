@@ -46,22 +46,59 @@ class _SpecFn(torch.autograd.Function):
         return ops.spec_bwd(dz.contiguous(), c, t, n_fft, hop), None, None
 
 
-def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
-    """F.conv2d(x, w, bias, stride=1, dilation=(dil_t, 1), padding=(pad_t, (kw-1)//2)) on the 1-D conv kernels ("same" along the
-    frequency axis, as get_2d_padding gives).  x (B, Cin, T, W); w (Cout, Cin, kh, kw), kw odd.
+class _PackRowsFn(torch.autograd.Function):
+    """(B, C, T, W) -> the flat virtual-channel sequence buffer (ops.rows_pack); backward = its adjoint, one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, kh, dil_t, pad_t, pad_w, pitch, lead):
+        ops = _fn._ops(None)
+        x = x.contiguous()
+        ctx.meta = (ops, tuple(x.shape), kh, dil_t, pad_t, pad_w, pitch, lead)
+        return ops.rows_pack(x, kh, dil_t, pad_t, pad_w, pitch, lead)
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        ops, shape, kh, dil_t, pad_t, pad_w, pitch, lead = ctx.meta
+        return ops.rows_pack_bwd(dbuf.contiguous(), shape, kh, dil_t, pad_t, pad_w, pitch, lead), None, None, None, None, None, None
+
+
+class _UnpackActFn(torch.autograd.Function):
+    """conv output (B, C, T*pitch) -> LeakyReLU(slope) of its sample positions as (B, C, T, W); slope 1 = no activation."""
+
+    @staticmethod
+    def forward(ctx, y, t, wd, pad_w, pitch, slope):
+        ops = _fn._ops(None)
+        out = ops.rows_unpack(y.contiguous(), t, wd, pad_w, pitch, slope)
+        ctx.meta = (ops, pad_w, pitch, slope)
+        if slope != 1.0:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops, pad_w, pitch, slope = ctx.meta
+        out = ctx.saved_tensors[0] if slope != 1.0 else None
+        return ops.rows_unpack_bwd(dout.contiguous(), out, pad_w, pitch, slope), None, None, None, None, None
+
+
+def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
+    """leaky_relu(F.conv2d(x, w, bias, stride=1, dilation=(dil_t, 1), padding=(pad_t, (kw-1)//2)), slope) on the 1-D conv kernels
+    ("same" along the frequency axis, as get_2d_padding gives; slope 1 = no activation).  x (B, Cin, T, W); w (Cout, Cin, kh, kw), kw odd.
 
     Layout: the kh frame taps become channels (time-shifted copies: C' = Cin*kh), and the (T x W) plane becomes one sequence of rows
     [pad zeros | W samples | pad zeros] of pitch W + kw - 1 — a "same" 1-D conv of that sequence never mixes two rows' samples, and
     its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel is split as taps 1..7 (a 7-tap conv: the
     k7 forward / data-gradient / weight-gradient kernels of the conv stack) + tap 0 + tap 8 (1-tap convs on the sequence shifted by
-    -+4 samples — offset views of one buffer — added through the residual input of their launches)."""
+    -+4 samples — offset views of one buffer — added through the residual input of their launches).
+    The sequence tensor is built by ONE kernel (sat_rows_pack; adjoint sat_rows_pack_bwd) and the output rows are un-pitched and
+    activated by one (sat_rows_unpack / _bwd): no torch pad / stack / slice / LeakyReLU passes and none of their autograd adds and fills."""
     b, cin, t, wd = x.shape
     cout, _, kh, kw = w.shape
     if kw % 2 != 1:
         raise NotImplementedError("conv2d_virtual: odd frequency kernel")
+    if pad_t * 2 != dil_t * (kh - 1):
+        raise NotImplementedError("conv2d_virtual: 'same' padding along frames (get_2d_padding)")
     pad_w = (kw - 1) // 2
-    xp = F.pad(x, (0, 0, pad_t, pad_t)) if pad_t else x
-    x3 = torch.stack([xp[:, :, kt * dil_t: kt * dil_t + t, :] for kt in range(kh)], dim=2)              # (B, Cin, kh, T, W)
     pitch = (wd + 2 * pad_w + 3) // 4 * 4          # multiple of 4: 16-byte epilogues and the pipelined weight-gradient kernel
     cp = cin * kh
     L = t * pitch
@@ -71,14 +108,14 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
         # VIEW (same strides, storage offset -+4): taps 0 and 8 become two 1-tap convs on those views (the k1 kernels), chained
         # through the residual input — no dilated conv, no shifted copies.  Positions where a shifted view reads across a channel
         # boundary are row-padding positions, whose outputs are discarded (and carry zero gradient).
-        buf = F.pad(F.pad(x3, (pad_w, pitch - wd - pad_w)).reshape(b * cp * L), (4, 4))
+        buf = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 4)
         strides = (cp * L, L, 1)
         seq = buf.as_strided((b, cp, L), strides, 4)
         y = SnakeConv1dFn.apply(seq, None, None, w1[..., 1:8].contiguous(), bias, None, 1, 1, 3, False)
         y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 0), None, None, w1[..., 0:1].contiguous(), None, y, 1, 1, 0, False)
         y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 8), None, None, w1[..., 8:9].contiguous(), None, y, 1, 1, 0, False)
     else:
-        seq = F.pad(x3, (pad_w, pitch - wd - pad_w)).reshape(b, cp, L)
+        seq = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 0).view(b, cp, L)
         if kw < 7 and split_wide and cout >= 16 and cp >= 64 and torch.is_grad_enabled():
             # training: zero-pad the 3-tap kernel to 7 taps — the k7 kernels process 8 tap groups per chunk either way, and the 7-tap
             # weight-gradient kernel (bf16x3, pipelined) is ~4x faster than the generic one a 3-tap conv would fall back to
@@ -86,7 +123,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True):
             y = SnakeConv1dFn.apply(seq, None, None, F.pad(w1, (ext, ext)).contiguous(), bias, None, 1, 1, 3, False)
         else:
             y = SnakeConv1dFn.apply(seq, None, None, w1.contiguous(), bias, None, 1, 1, pad_w, False)
-    return y.view(b, cout, t, pitch)[..., pad_w:pad_w + wd].contiguous()
+    return _UnpackActFn.apply(y, t, wd, pad_w, pitch, float(slope))
 
 
 class _WNConv2d(nn.Module):
@@ -103,9 +140,10 @@ class _WNConv2d(nn.Module):
             raise NotImplementedError("only stride (1, 1), frequency dilation 1 and 'same' padding (the MS-STFT discriminator as "
                                       "stable-audio-tools configures it: DiscriminatorSTFT(stride=(1, 1)), models/encodec.py:58)")
 
-    def forward(self, x):
+    def forward(self, x, slope=1.0):
+        """slope != 1: LeakyReLU(slope) of the conv output, fused into the pass that un-pitches it."""
         w = WeightNormFn.apply(self.weight_v, self.weight_g)
-        return conv2d_virtual(x, w, self.bias, dil_t=self.dilation[0], pad_t=self.padding[0])
+        return conv2d_virtual(x, w, self.bias, dil_t=self.dilation[0], pad_t=self.padding[0], slope=slope)
 
 
 class NormConv2d(nn.Module):
@@ -113,8 +151,8 @@ class NormConv2d(nn.Module):
         super().__init__()
         self.conv = _WNConv2d(*args, **kwargs)
 
-    def forward(self, x):
-        return self.conv(x)
+    def forward(self, x, slope=1.0):
+        return self.conv(x, slope)
 
 
 class DiscriminatorSTFT(nn.Module):
@@ -144,8 +182,10 @@ class DiscriminatorSTFT(nn.Module):
     def forward(self, x):
         fmap = []
         z = _SpecFn.apply(x, self.n_fft, self.hop_length)          # (B, 2C, frames, freq) = cat(real, imag) + 'b c w t -> b c t w'
+        leaky = isinstance(self.activation, torch.nn.LeakyReLU)
         for layer in self.convs:
-            z = self.activation(layer(z))
+            # z = activation(layer(z))  (models/encodec.py:101-103); LeakyReLU rides in the conv's output pass
+            z = layer(z, self.activation.negative_slope) if leaky else self.activation(layer(z))
             fmap.append(z)
         return self.conv_post(z), fmap
 

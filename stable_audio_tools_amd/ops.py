@@ -376,6 +376,37 @@ class SatOps:
                                         int(wrt_x), self._stream(x)))
 
     # ------------------------------------------------------------------ discriminator spectrogram
+    # ---- row packing for the discriminator's Conv2d layers as virtual-channel 1-D convs (discriminators.conv2d_virtual) ----
+    def rows_pack(self, x, kh, dil_t, pad_t, pad_w, pitch, lead):
+        """x (B, C, T, W) fp32 -> flat buffer of lead + B*C*kh*T*pitch + lead floats (see sat_rows_pack in sat_amd.h)."""
+        self._f32(x)
+        b, c, t, w = x.shape
+        buf = torch.empty(2 * lead + b * c * kh * t * pitch, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.sat_rows_pack(_ptr(x), _ptr(buf), b, c, t, w, kh, dil_t, pad_t, pad_w, pitch, lead, self._stream(x)))
+        return buf
+
+    def rows_pack_bwd(self, dbuf, shape, kh, dil_t, pad_t, pad_w, pitch, lead):
+        self._f32(dbuf)
+        b, c, t, w = shape
+        dx = torch.empty(shape, dtype=torch.float32, device=dbuf.device)
+        self._chk(self.lib.sat_rows_pack_bwd(_ptr(dbuf), _ptr(dx), b, c, t, w, kh, dil_t, pad_t, pad_w, pitch, lead, self._stream(dbuf)))
+        return dx
+
+    def rows_unpack(self, y, t, w, pad_w, pitch, slope):
+        """y (B, C, T*pitch) -> leaky_relu(y[..., t*pitch + pad_w + w], slope) as (B, C, T, W)."""
+        self._f32(y)
+        b, c = y.shape[0], y.shape[1]
+        out = torch.empty(b, c, t, w, dtype=torch.float32, device=y.device)
+        self._chk(self.lib.sat_rows_unpack(_ptr(y), _ptr(out), b, c, t, w, pad_w, pitch, float(slope), self._stream(y)))
+        return out
+
+    def rows_unpack_bwd(self, dout, out, pad_w, pitch, slope):
+        self._f32(dout, out)
+        b, c, t, w = dout.shape
+        dy = torch.empty(b, c, t * pitch, dtype=torch.float32, device=dout.device)
+        self._chk(self.lib.sat_rows_unpack_bwd(_ptr(dout), _ptr(out), _ptr(dy), b, c, t, w, pad_w, pitch, float(slope), self._stream(dout)))
+        return dy
+
     def spec_fwd(self, x, n_fft, hop):
         """x (NI, C, T), C in {1, 2} -> (NI, 2C, frames, n_fft/2+1): [Re X_c | Im X_c] of the normalised, un-centred STFT."""
         self._f32(x)

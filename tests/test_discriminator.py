@@ -68,6 +68,37 @@ def _case_inner(device, gtol, bf16x3):
     assert worst[1] < gtol, worst
 
 
+def _conv2d_cases(device):
+    """conv2d_virtual (row packing kernels + 1-D conv kernels + fused LeakyReLU un-pitch) vs F.leaky_relu(F.conv2d): values, input and
+    weight / bias gradients; 3 x 9 (split: taps 1..7 + 0 + 8), dilated 3 x 9, 3 x 3, ragged widths (pitch padding), slope 1 (conv_post)."""
+    import torch.nn.functional as F
+    from stable_audio_tools_amd.discriminators import conv2d_virtual
+    gen = torch.Generator().manual_seed(11)
+    for (b, cin, cout, t, wd, kh, kw, dil, slope) in [(2, 2, 8, 9, 33, 3, 9, 1, 0.2), (1, 8, 8, 11, 30, 3, 9, 2, 0.2),
+                                                       (1, 8, 6, 7, 17, 3, 3, 1, 0.2), (1, 24, 16, 6, 21, 3, 3, 1, 1.0)]:
+        x = torch.randn(b, cin, t, wd, generator=gen).to(device).requires_grad_(True)
+        w = (torch.randn(cout, cin, kh, kw, generator=gen) * 0.2).to(device).requires_grad_(True)
+        bias = torch.randn(cout, generator=gen).to(device).requires_grad_(True)
+        pad_t = dil * (kh - 1) // 2
+        y = conv2d_virtual(x, w, bias, dil_t=dil, pad_t=pad_t, slope=slope)
+        ref = F.leaky_relu(F.conv2d(x, w, bias, dilation=(dil, 1), padding=(pad_t, (kw - 1) // 2)), slope)
+        gy = torch.randn(ref.shape, generator=gen).to(device)
+        g1 = torch.autograd.grad(y, [x, w, bias], gy)
+        g2 = torch.autograd.grad(ref, [x, w, bias], gy)
+        assert rel_err(y.detach(), ref.detach()) < 2e-4
+        for a, r in zip(g1, g2):
+            assert rel_err(a, r) < 2e-4
+
+
+def test_conv2d_virtual_simulator(emu_modules):
+    _conv2d_cases("cpu")
+
+
+@pytest.mark.gpu
+def test_conv2d_virtual_gpu(hip):
+    _conv2d_cases("cuda")
+
+
 @pytest.mark.parametrize("bf16x3", [False, True])
 def test_discriminator_matches_reference_golden_simulator(emu_modules, bf16x3):
     _case("cpu", emu_modules, bf16x3)
