@@ -29,7 +29,10 @@ class FourierFeatures(nn.Module):
         self.weight = nn.Parameter(torch.randn([out_features // 2, in_features]) * std)
 
     def forward(self, input):
-        f = 2 * math.pi * input @ self.weight.T
+        if self.weight.shape[1] == 1:       # scalar input (the timestep): the product is an outer product — no GEMM, same values
+            f = 2 * math.pi * input * self.weight.T
+        else:
+            f = 2 * math.pi * input @ self.weight.T
         return torch.cat([f.cos(), f.sin()], dim=-1)
 
 
@@ -99,9 +102,15 @@ class DiffusionTransformer(nn.Module):
         return out
 
     @staticmethod
-    def _conv1x1_residual(conv, x):
-        # Conv1d(k=1, bias=False)(x) + x on a (B, C<=64+, T) latent: one small GEMM (dit.py:193, :224)
-        return torch.einsum("oc,bct->bot", conv.weight[:, :, 0], x) + x
+    def _conv1x1_residual_tokens(conv, xt):
+        """Conv1d(k=1, bias=False)(x) + x (dit.py:193, :224) on the token-major tensor xt = x^T (B, T, C): a projection with the
+        residual in its epilogue on the native GEMM (the conv weight (C, C, 1) read as a (C, C) matrix)."""
+        from .linear import LinearFn, _WeightCache, _lowp
+        cache = conv.__dict__.get("_sat_cache")
+        if cache is None:
+            cache = conv.__dict__["_sat_cache"] = _WeightCache()
+        w = conv.weight[:, :, 0]
+        return LinearFn.apply(xt, w, None, xt, "res", _lowp(xt, w), cache, False)
 
     def _forward(self, x, t, mask=None, cross_attn_cond=None, cross_attn_cond_mask=None, input_concat_cond=None,
                  global_embed=None, prepend_cond=None, prepend_cond_mask=None, return_info=False, exit_layer_ix=None,
@@ -128,8 +137,8 @@ class DiffusionTransformer(nn.Module):
             g = global_embed.unsqueeze(1)
             prepend_inputs = g if prepend_inputs is None else torch.cat([prepend_inputs, g], dim=1)
             prepend_length = prepend_inputs.shape[1]
-        x = self._conv1x1_residual(self.preprocess_conv, x)
-        x = x.transpose(1, 2)                                       # b c t -> b t c
+        x = x.transpose(1, 2).contiguous()                          # b c t -> b t c
+        x = self._conv1x1_residual_tokens(self.preprocess_conv, x)  # (the 1x1 conv commutes with the transposition)
         extra_args = {}
         if self.global_cond_type == "adaLN":
             extra_args["global_cond"] = global_embed
@@ -143,11 +152,14 @@ class DiffusionTransformer(nn.Module):
             output, info = output
         if exit_layer_ix is not None:
             return (output, info) if return_info else output
-        output = output.transpose(1, 2)[:, :, prepend_length:]      # b t c -> b c t, drop prepended tokens
         if self.patch_size > 1:
+            output = output.transpose(1, 2)[:, :, prepend_length:]  # b t c -> b c t, drop prepended tokens
             b, cp, tt = output.shape
             output = output.reshape(b, cp // self.patch_size, self.patch_size, tt).transpose(2, 3).reshape(b, cp // self.patch_size, tt * self.patch_size)
-        output = self._conv1x1_residual(self.postprocess_conv, output)
+            output = self._conv1x1_residual_tokens(self.postprocess_conv, output.transpose(1, 2).contiguous()).transpose(1, 2)
+        else:
+            # drop the prepended tokens, 1x1 conv + residual on the token-major tensor, then b t c -> b c t
+            output = self._conv1x1_residual_tokens(self.postprocess_conv, output[:, prepend_length:].contiguous()).transpose(1, 2)
         return (output, info) if return_info else output
 
     def forward(self, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
