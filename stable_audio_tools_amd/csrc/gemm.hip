@@ -338,11 +338,22 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
                     for (int e = 0; e < 4; ++e) o[e] = sat_f32_to_bf16(ep[d * 33 + tq + e]);
                     const int b = m / p.ntok, t = m - b * p.ntok;
                     short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
-                    if (m + 3 < p.M && t + 3 < p.ntok && ((t & 3) == 0)) {
-                        u32x2 u;
-                        u[0] = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
-                        u[1] = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-                        *(u32x2*)dst = u;
+                    if (m + 3 < p.M && t + 3 < p.ntok) {
+                        // 4 tokens of one batch item: the widest aligned stores their phase allows (ntok is odd for the DiT —
+                        // 1 + 1024 — so every batch item but the first starts its rows off the 8-byte grid)
+                        const uint32_t p01 = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+                        const uint32_t p12 = (uint32_t)(uint16_t)o[1] | ((uint32_t)(uint16_t)o[2] << 16);
+                        const uint32_t p23 = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+                        if ((t & 3) == 0) {
+                            *(u32x2*)dst = u32x2{p01, p23};
+                        } else if ((t & 1) == 0) {
+                            *(uint32_t*)dst = p01;
+                            *(uint32_t*)(dst + 2) = p23;
+                        } else {
+                            dst[0] = o[0];
+                            *(uint32_t*)(dst + 1) = p12;
+                            dst[3] = o[3];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
