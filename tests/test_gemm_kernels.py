@@ -102,6 +102,8 @@ def test_gemm_epilogues_simulator(emu):
 
 def test_gemm_heads_epilogue_simulator(emu):
     _heads_case(emu, "cpu", 2, 71, 3, 72)
+    _heads_case(emu, "cpu", 3, 70, 2, 64)      # token counts of every residue mod 4: each V^T store phase of the epilogue
+    _heads_case(emu, "cpu", 2, 69, 2, 64)
 
 
 def test_gemm_operand_preparation_simulator(emu):
@@ -122,6 +124,8 @@ def test_gemm_ff_shapes_gpu(hip):
 @pytest.mark.gpu
 def test_gemm_heads_epilogue_gpu(hip):
     _heads_case(hip, "cuda", 2, 71, 3, 72)
+    _heads_case(hip, "cuda", 3, 70, 2, 64)
+    _heads_case(hip, "cuda", 2, 69, 2, 64)
     _heads_case(hip, "cuda", 2, 1025, 24, 1536)
 
 
