@@ -116,37 +116,56 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7p_kernel(SatCon
             sat_glds16(src, base + SAT_K7P_WBYTES + (8 + wave) * 1024);
         }
     };
+    // Fragment reads run one k-step AHEAD of the MFMAs that consume them (two register sets): the LDS latency of a k-step's eight
+    // 16-byte reads is paid once per chunk instead of once per k-step — both waves of a SIMD run this same code in near lock-step, so
+    // a stall of one is not covered by the other.
+    struct Frags { bf16x8 wa[2][2], xa[2][2]; };       // [mi|ni][plane]
+    auto load_frags = [&](Frags& f, const char* wb, const char* ab, int ks) {
+        const int g = 2 * ks + hi;                     // k-slots 0-7 <- tap group 2ks (lanes 0-31), 8-15 <- group 2ks+1
+        const int tap = g < K ? g : K - 1;             // groups >= K are zero-weight pads; keep the row in range
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int r = co_w + mi * 32 + l31;
+                f.wa[mi][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 16384 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
+            }
+            f.xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 5120 + (t_w + l31 + tap * dil) * 16);
+            f.xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 5120 + (t_w + 32 + l31 + tap * dil) * 16);
+        }
+    };
+    auto mfma_frags = [&](const Frags& f) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][0], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][1], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
+    };
     auto mfma_phase = [&](int stage) {
         const char* wb = ring + stage * SAT_K7P_STAGE;
         const char* ab = wb + SAT_K7P_WBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int g = 2 * ks + hi;                     // k-slots 0-7 <- tap group 2ks (lanes 0-31), 8-15 <- group 2ks+1
-            const int tap = g < K ? g : K - 1;             // groups >= K are zero-weight pads; keep the row in range
-            bf16x8 wa[2][2], xa[2][2];                     // [mi|ni][plane]
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int r = co_w + mi * 32 + l31;
-                    wa[mi][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 16384 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
-                }
-                xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 5120 + (t_w + l31 + tap * dil) * 16);
-                xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 5120 + (t_w + 32 + l31 + tap * dil) * 16);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(wa[mi][0], xa[ni][0], acc[mi][ni]);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(wa[mi][0], xa[ni][1], acc[mi][ni]);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(wa[mi][1], xa[ni][0], acc[mi][ni]);
-        }
+        Frags f0, f1;
+        load_frags(f0, wb, ab, 0);
+        load_frags(f1, wb, ab, 1);
+        SAT_SCHED_FENCE();
+        mfma_frags(f0);
+        SAT_SCHED_FENCE();
+        load_frags(f0, wb, ab, 2);
+        SAT_SCHED_FENCE();
+        mfma_frags(f1);
+        SAT_SCHED_FENCE();
+        load_frags(f1, wb, ab, 3);
+        SAT_SCHED_FENCE();
+        mfma_frags(f0);
+        SAT_SCHED_FENCE();
+        mfma_frags(f1);
     };
 
     issue(0, 0);

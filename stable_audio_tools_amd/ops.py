@@ -181,7 +181,7 @@ class SatOps:
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen.
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
-    k7_planes_min_cin = 512      # measured (tools/k7_bench.py): the pre-pass pays from C = 512 up (-4..-12 %), costs +1..+15 % below
+    k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "256"))      # measured (tools/k7_bench.py, profiles/r02_k7_bench.jsonl): the pre-pass pays from C = 256 up
 
     def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake):
         b, cin, tin = x.shape

@@ -14,7 +14,8 @@ def timeit(f, n=10):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-shapes = [(128, 2097152, 1), (128, 2097152, 9), (256, 1048576, 3), (512, 262144, 3), (1024, 65536, 9), (2048, 8192, 1)]
+# the ResidualUnit levels of stable_audio_2_0_vae at 2 097 152 samples (encoder and decoder): (channels, time steps, dilation)
+shapes = [(128, 2097152, 1), (128, 2097152, 9), (128, 1048576, 3), (256, 262144, 3), (512, 65536, 9), (1024, 8192, 1)]
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 for (c, t, dil) in shapes:
