@@ -179,7 +179,9 @@ class SatOps:
                                  bias, snake, res, tanh_out, dsnake)
 
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
-    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen.
+    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen,
+    # shared by every conv of the device: correct because the pre-pass and its conv are enqueued back to back on ONE stream (the
+    # caller's current stream) — convs issued concurrently on several streams would need one workspace per stream.
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "256"))      # measured (tools/k7_bench.py, profiles/r02_k7_bench.jsonl): the pre-pass pays from C = 256 up
 
@@ -696,7 +698,7 @@ class SatOps:
         if self.gemm_splitk is not None:
             return self.gemm_splitk
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        if tiles > 256 or k < 4096:
+        if tiles > 256 or k < 4096 or n % 4:
             return 1
         return 2
 
