@@ -179,9 +179,8 @@ class SatOps:
                                  bias, snake, res, tanh_out, dsnake)
 
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
-    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen,
-    # shared by every conv of the device: correct because the pre-pass and its conv are enqueued back to back on ONE stream (the
-    # caller's current stream) — convs issued concurrently on several streams would need one workspace per stream.
+    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
+    # per (device, stream): the pre-pass and its conv are enqueued back to back on the caller's current stream.
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "256"))      # measured (tools/k7_bench.py, profiles/r02_k7_bench.jsonl): the pre-pass pays from C = 256 up
 
@@ -194,12 +193,13 @@ class SatOps:
         rows = self.lib.sat_conv1d_k7_plane_rows(tin, tout, pad)
         c8 = (cin + 7) // 8
         need = 2 * b * c8 * rows * 8
-        ws = self.__dict__.setdefault("_planes", {}).get(("k7p", x.device))
+        st = self._stream(x)
+        wkey = ("k7p", x.device, st.value if st is not None else 0)       # one workspace per (device, stream)
+        ws = self.__dict__.setdefault("_planes", {}).get(wkey)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.int16, device=x.device)
-            self._planes[("k7p", x.device)] = ws
+            self._planes[wkey] = ws
         hi, lo = ws[:need // 2], ws[need // 2:need]
-        st = self._stream(x)
         self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
         y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
         x2 = a2 = b2 = pda = pdb = None
