@@ -677,9 +677,10 @@ class SatOps:
         """gemm_bf16 (epilogue: [+bias] [+res]) with K cut into `splits` ranges: fp32 slabs from the GEMM kernel, summed with the
         bias / residual by sat_splitk_epilogue.  For few-tile / long-K projections (more workgroups than tiles)."""
         m, n = a.shape[0], b.shape[0]
-        key = ("splitk", splits, m, n)
+        st = self._stream(a)
+        key = ("splitk", splits, m, n, a.device, st.value if st is not None else 0)      # one slab set per (device, stream)
         slabs = self.__dict__.setdefault("_planes", {}).get(key)
-        if slabs is None or slabs.device != a.device:
+        if slabs is None:
             slabs = torch.empty(splits, m, n, dtype=torch.float32, device=a.device)
             self._planes[key] = slabs
         self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(slabs), n, None, None, 0, None, 0, 0, None, 0,
