@@ -251,6 +251,7 @@ class ConvProfiler:
         "sat_conv1d": ("sat_conv1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * a[17] * a[16]),
         "sat_conv1d_bf16x3": (lambda a: "sat_conv1d_bf16x3_k7_kernel" if (a[18] >= 5 and a[19] == 1) else "sat_conv1d_bf16x3_kernel",
                               X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_conv1d_k7_planes": ("sat_k7_planes_kernel", X3, lambda a: 0.0),     # the planes kernel's pre-pass: time, no flops of its own
         "sat_conv1d_bf16x3_planes": ("sat_conv1d_bf16x3_k7p_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),
         "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
@@ -301,6 +302,20 @@ class ConvProfiler:
                         "achieved": ach, "peak": peak, "frac": ach / peak})
         out.sort(key=lambda d: -d["total_ms"])
         return (out[0] if out else None), out
+
+
+def k7_family(allk):
+    """The k = 7 convs of the ResidualUnits run on two kernels since round 2 (direct staging below C = 256, pre-split planes above):
+    their combined algorithmic flops / combined HIP-event time (the planes pre-pass included), for continuity with the single-kernel
+    figure of round 1."""
+    fam = [d for d in allk if d["kernel"].startswith("sat_conv1d_bf16x3_k7") or d["kernel"] == "sat_k7_planes_kernel"]
+    if not fam:
+        return None
+    ms = sum(d["total_ms"] for d in fam)
+    fl = sum(d["achieved"] * d["total_ms"] for d in fam)        # TFLOP/s * ms
+    ach = fl / ms if ms > 0 else 0.0
+    return {"kernels": [d["kernel"] for d in fam], "launches": sum(d["launches"] for d in fam), "total_ms": round(ms, 3),
+            "achieved": round(ach, 2), "peak": fam[0]["peak"], "frac": round(ach / fam[0]["peak"], 4)}
 
 
 def pmc_traffic(kernel, args):
@@ -585,6 +600,7 @@ def main():
                                  "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
                                  "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
                                  "same command (profiles/r02_pmc_traffic.json; null for a non-default workload size)",
+                         "k7_family": k7_family(allk),
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
         if world == 1 and not args.no_cpu_baseline:
