@@ -123,28 +123,61 @@ SAT_DEVICE float sat_hann(const SatFftLds& L, int j, int n) {
     const float c = (j < h) ? L.twr[j] : -L.twr[j - h];
     return 0.5f - 0.5f * c;
 }
-// in-place radix-2 DIT over `fb` frames of length n stored bit-reversed; ends with a barrier
-SAT_DEVICE void sat_fft_run(const SatFftLds& L, int n, int log2n, int fb) {
-    const int halfn = n >> 1;
-    for (int s = 1; s <= log2n; ++s) {
-        const int half = 1 << (s - 1);
-        for (int i = threadIdx.x; i < fb * halfn; i += 256) {
-            const int fi = i >> (log2n - 1);
-            const int bi = i & (halfn - 1);
-            const int grp = bi >> (s - 1), pos = bi & (half - 1);
-            const int i0 = fi * n + (grp << s) + pos, i1 = i0 + half;
-            const int tw = pos << (log2n - s);
-            const float wr = L.twr[tw], wi = L.twi[tw];
-            const float br = L.re[i1], bim = L.im[i1];
-            const float tr = br * wr - bim * wi, ti = br * wi + bim * wr;
-            const float ar = L.re[i0], ai = L.im[i0];
-            L.re[i0] = ar + tr;
-            L.im[i0] = ai + ti;
-            L.re[i1] = ar - tr;
-            L.im[i1] = ai - ti;
+// K fused radix-2 stages (s .. s+K-1, half = 2^(s-1)) on 2^K points held in registers: the butterflies, their order and their
+// twiddles are exactly those of K single radix-2 DIT stages (bit-identical results), with one LDS round trip and one barrier instead of K.
+template <int K>
+SAT_DEVICE void sat_fft_pass(const SatFftLds& L, int n, int log2n, int fb, int s) {
+    constexpr int R = 1 << K;
+    const int half = 1 << (s - 1);
+    const int per_frame = n >> K;                         // items (groups of R points) per frame
+    const int lpf = log2n - K;
+    for (int i = threadIdx.x; i < fb * per_frame; i += 256) {
+        const int fi = i >> lpf;
+        const int bi = i & (per_frame - 1);
+        const int grp = bi >> (s - 1), pos = bi & (half - 1);
+        const int base = fi * n + (grp << (s - 1 + K)) + pos;
+        float xr[R], xi[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            xr[j] = L.re[base + j * half];
+            xi[j] = L.im[base + j * half];
         }
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int d = 1 << q;                          // butterfly distance in units of `half`
+#pragma unroll
+            for (int m = 0; m < d; ++m) {                  // position inside the stage's block: pos + m * half
+                const int tw = (pos + m * half) << (log2n - s - q);
+                const float wr = L.twr[tw], wi = L.twi[tw];
+#pragma unroll
+                for (int j0 = 0; j0 < R; j0 += 2 * d) {
+                    const int a = j0 + m, b = a + d;
+                    const float tr = xr[b] * wr - xi[b] * wi, ti = xr[b] * wi + xi[b] * wr;
+                    const float ar = xr[a], ai = xi[a];
+                    xr[a] = ar + tr;
+                    xi[a] = ai + ti;
+                    xr[b] = ar - tr;
+                    xi[b] = ai - ti;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            L.re[base + j * half] = xr[j];
+            L.im[base + j * half] = xi[j];
+        }
     }
+    __syncthreads();
+}
+// in-place radix-2 DIT over `fb` frames of length n stored bit-reversed, run as fused radix-8 / radix-4 passes; ends with a barrier
+SAT_DEVICE void sat_fft_run(const SatFftLds& L, int n, int log2n, int fb) {
+    int s = 1;
+    while (log2n - s + 1 >= 3) {
+        sat_fft_pass<3>(L, n, log2n, fb, s);
+        s += 3;
+    }
+    if (log2n - s + 1 == 2) sat_fft_pass<2>(L, n, log2n, fb, s);
+    else if (log2n - s + 1 == 1) sat_fft_pass<1>(L, n, log2n, fb, s);
 }
 
 SAT_DEVICE void sat_stft_load_frames(const SatStftParams& p, const SatFftLds& L, int item, int view, int f0) {
