@@ -81,6 +81,54 @@ class _UnpackActFn(torch.autograd.Function):
         return ops.rows_unpack_bwd(dout.contiguous(), out, pad_w, pitch, slope), None, None, None, None, None
 
 
+class _Conv9Fn(torch.autograd.Function):
+    """The 9-tap row conv on the packed sequence buffer as ONE autograd unit: taps 1..7 as a 7-tap conv on the sequence (storage offset
+    4) + taps 0 and 8 as 1-tap convs on the views at offsets 0 and 8, chained through the residual input.  The backward writes the
+    three data-gradients into ONE buffer of the packed layout — the 7-tap one with plain stores at offset 4, the two 1-tap ones
+    accumulated in place at offsets 0 and 8 (out = res) — so no autograd of offset views (zero-fill + copy + add per view) is left."""
+
+    @staticmethod
+    def forward(ctx, buf, w1, bias, b, cp, L):
+        ops = _fn._ops(None)
+        strides = (cp * L, L, 1)
+        v0, v4, v8 = (buf.as_strided((b, cp, L), strides, o) for o in (0, 4, 8))
+        w1 = w1.contiguous()
+        y = _fn._conv_fwd(ops, v4, w1[..., 1:8].contiguous(), 1, 1, 3, bias=bias)
+        y = _fn._conv_fwd(ops, v0, w1[..., 0:1].contiguous(), 1, 1, 0, res=y)
+        y = _fn._conv_fwd(ops, v8, w1[..., 8:9].contiguous(), 1, 1, 0, res=y)
+        ctx.meta = (ops, b, cp, L, bias is not None)
+        ctx.save_for_backward(buf, w1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, b, cp, L, has_bias = ctx.meta
+        buf, w1 = ctx.saved_tensors
+        dy = dy.contiguous()
+        strides = (cp * L, L, 1)
+        v0, v4, v8 = (buf.as_strided((b, cp, L), strides, o) for o in (0, 4, 8))
+        dw = dbias = None
+        if ctx.needs_input_grad[1]:
+            dw7 = _fn._conv_wgrad(ops, dy, v4, 7, 1, 1, 3, None, bias_grad=has_bias)
+            if has_bias:
+                dw7, dbias = dw7
+            dw0 = _fn._conv_wgrad(ops, dy, v0, 1, 1, 1, 0, None)
+            dw8 = _fn._conv_wgrad(ops, dy, v8, 1, 1, 1, 0, None)
+            dw = torch.cat([dw0, dw7, dw8], dim=2)
+        elif has_bias:
+            dbias = ops.rowsum(dy)
+        dbuf = None
+        if ctx.needs_input_grad[0]:
+            dbuf = torch.empty_like(buf)
+            dbuf[:4].zero_()                           # the slack before / after the sequence: read by the in-place accumulations
+            dbuf[-4:].zero_()
+            d0, d4, d8 = (dbuf.as_strided((b, cp, L), strides, o) for o in (0, 4, 8))
+            _fn._conv_dgrad(ops, dy, w1[..., 1:8].contiguous(), 7, 1, 1, 3, cp, L, None, out=d4)
+            _fn._conv_dgrad(ops, dy, w1[..., 0:1].contiguous(), 1, 1, 1, 0, cp, L, None, res=d0, out=d0)
+            _fn._conv_dgrad(ops, dy, w1[..., 8:9].contiguous(), 1, 1, 1, 0, cp, L, None, res=d8, out=d8)
+        return dbuf, dw, dbias, None, None, None
+
+
 def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
     """leaky_relu(F.conv2d(x, w, bias, stride=1, dilation=(dil_t, 1), padding=(pad_t, (kw-1)//2)), slope) on the 1-D conv kernels
     ("same" along the frequency axis, as get_2d_padding gives; slope 1 = no activation).  x (B, Cin, T, W); w (Cout, Cin, kh, kw), kw odd.
@@ -109,11 +157,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
         # through the residual input — no dilated conv, no shifted copies.  Positions where a shifted view reads across a channel
         # boundary are row-padding positions, whose outputs are discarded (and carry zero gradient).
         buf = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 4)
-        strides = (cp * L, L, 1)
-        seq = buf.as_strided((b, cp, L), strides, 4)
-        y = SnakeConv1dFn.apply(seq, None, None, w1[..., 1:8].contiguous(), bias, None, 1, 1, 3, False)
-        y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 0), None, None, w1[..., 0:1].contiguous(), None, y, 1, 1, 0, False)
-        y = SnakeConv1dFn.apply(buf.as_strided((b, cp, L), strides, 8), None, None, w1[..., 8:9].contiguous(), None, y, 1, 1, 0, False)
+        y = _Conv9Fn.apply(buf, w1, bias, b, cp, L)
     else:
         seq = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 0).view(b, cp, L)
         if kw < 7 and split_wide and cout >= 16 and cp >= 64 and torch.is_grad_enabled():

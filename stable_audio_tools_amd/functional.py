@@ -54,14 +54,17 @@ class WeightNormFn(torch.autograd.Function):
         return dv, dg.view(ctx.g_shape), None
 
 
-def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None):
-    """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K)."""
+def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out=None):
+    """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K).  out= (stride-1 kernels only): write into
+    the caller's tensor (it may alias `res`: accumulation in place)."""
     if stride == 1:
         if ops.bf16x3_ok(k, 1, dil):
             return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
-                                     dsnake=dsnake, res=res)
+                                     dsnake=dsnake, res=res, out=out)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
-        return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res)
+        return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res, out=out)
+    if out is not None:
+        raise NotImplementedError("_conv_dgrad(out=...) is only plumbed through the stride-1 kernels")
     if ops.bf16x3_ok(k, stride, dil, transposed=True):   # (Cout, Cin, K) is the [in][out][K] weight of the transposed conv
         return ops.convtr1d_bf16x3(dy, ops.pack_bf16x3(w, mode=2, stride=stride), cin, k, stride, pad, tout=tin,
                                    dsnake=dsnake, res=res)

@@ -93,7 +93,7 @@ class SatOps:
         return self.rowsum(partial.view(1, c, r))
 
     def conv1d(self, x, w_packed, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
-               tanh_out=False, dsnake=None):
+               tanh_out=False, dsnake=None, out=None):
         """y = conv(snake(x)) [+bias] [+res] ; or, with dsnake=(x2, alpha2, beta2):
         y = conv(x) * dsnake(x2) + res and returns (y, dlog_alpha2, dlog_beta2)."""
         b, cin, tin = x.shape
@@ -101,7 +101,7 @@ class SatOps:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
         alpha, beta = snake if snake is not None else (None, None)
         self._f32(x, w_packed, bias, alpha, beta, res)
-        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        y = self._conv_out(out, b, cout, tout, x.device)
         x2 = a2 = b2 = pda = pdb = None
         rows = 0
         if dsnake is not None:
@@ -147,13 +147,23 @@ class SatOps:
         self._chk(self.lib.sat_snake_consts(_ptr(alpha), _ptr(beta), _ptr(a), _ptr(ib), alpha.numel(), self._stream(alpha)))
         return a, ib
 
-    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake):
+    def _conv_out(self, out, b, cout, tout, device):
+        """The conv output tensor: a fresh one, or the caller's `out` (B, Cout, Tout) fp32 in dense layout — it may be a view at a
+        storage offset and may alias `res` element for element (in-place accumulation through the residual input)."""
+        if out is None:
+            return torch.empty(b, cout, tout, dtype=torch.float32, device=device)
+        if tuple(out.shape) != (b, cout, tout) or not out.is_contiguous():
+            raise ValueError("conv out= must be a dense (B, Cout, Tout) tensor")
+        self._f32(out)
+        return out
+
+    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake, out=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
         if snake is not None:
             sa, sib = self.snake_consts(snake[0], snake[1])
-        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        y = self._conv_out(out, b, cout, tout, x.device)
         x2 = a2 = b2 = pda = pdb = None
         if dsnake is not None:
             x2, a2, b2 = dsnake
@@ -167,16 +177,16 @@ class SatOps:
         return y
 
     def conv1d_bf16x3(self, x, w_planes, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
-                      tanh_out=False, dsnake=None):
+                      tanh_out=False, dsnake=None, out=None):
         """Same contract as conv1d; `snake` = (log-alpha, log-beta) as everywhere else."""
         b, cin, tin = x.shape
         if tout is None:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
         rows = self.lib.sat_conv1d_bf16x3_partial_rows(b, tout, k, stride)
         if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
-            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake)
+            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
-                                 bias, snake, res, tanh_out, dsnake)
+                                 bias, snake, res, tanh_out, dsnake, out)
 
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
@@ -184,7 +194,7 @@ class SatOps:
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "256"))      # measured (tools/k7_bench.py, profiles/r02_k7_bench.jsonl): the pre-pass pays from C = 256 up
 
-    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake):
+    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
@@ -201,7 +211,7 @@ class SatOps:
             self._planes[wkey] = ws
         hi, lo = ws[:need // 2], ws[need // 2:need]
         self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
-        y = torch.empty(b, cout, tout, dtype=torch.float32, device=x.device)
+        y = self._conv_out(out, b, cout, tout, x.device)
         x2 = a2 = b2 = pda = pdb = None
         if dsnake is not None:
             x2, a2, b2 = dsnake
