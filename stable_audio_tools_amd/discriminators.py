@@ -82,10 +82,10 @@ class _UnpackActFn(torch.autograd.Function):
 
 
 class _Conv9Fn(torch.autograd.Function):
-    """The 9-tap row conv on the packed sequence buffer as ONE autograd unit: taps 1..7 as a 7-tap conv on the sequence (storage offset
-    4) + taps 0 and 8 as 1-tap convs on the views at offsets 0 and 8, chained through the residual input.  The backward writes the
-    three data-gradients into ONE buffer of the packed layout — the 7-tap one with plain stores at offset 4, the two 1-tap ones
-    accumulated in place at offsets 0 and 8 (out = res) — so no autograd of offset views (zero-fill + copy + add per view) is left."""
+    """The 9-tap row conv on the packed sequence buffer as ONE autograd unit: taps 0..7 as an 8-tap conv on the sequence (storage offset
+    4) + tap 8 as a 1-tap conv on the view at offset 8, chained through the residual input.  The backward writes both data-gradients
+    into ONE buffer of the packed layout — the 8-tap one with plain stores at offset 4, the 1-tap one accumulated in place at offset 8
+    (out = res) — so no autograd of offset views (zero-fill + copy + add per view) is left."""
 
     @staticmethod
     def forward(ctx, buf, w1, bias, b, cp, L):
@@ -93,8 +93,10 @@ class _Conv9Fn(torch.autograd.Function):
         strides = (cp * L, L, 1)
         v0, v4, v8 = (buf.as_strided((b, cp, L), strides, o) for o in (0, 4, 8))
         w1 = w1.contiguous()
-        y = _fn._conv_fwd(ops, v4, w1[..., 1:8].contiguous(), 1, 1, 3, bias=bias)
-        y = _fn._conv_fwd(ops, v0, w1[..., 0:1].contiguous(), 1, 1, 0, res=y)
+        # forward and data-gradient: taps 0..7 in ONE launch (the k7 kernels process 8 tap groups per chunk — the 8th is a zero pad
+        # for a 7-tap conv) + tap 8 as a 1-tap conv on the view at offset 8; the weight-gradient keeps the 7 + 1 + 1 split (its
+        # pipelined kernel is 7-tap)
+        y = _fn._conv_fwd(ops, v4, w1[..., 0:8].contiguous(), 1, 1, 4, bias=bias, tout=L)
         y = _fn._conv_fwd(ops, v8, w1[..., 8:9].contiguous(), 1, 1, 0, res=y)
         ctx.meta = (ops, b, cp, L, bias is not None)
         ctx.save_for_backward(buf, w1)
@@ -122,9 +124,8 @@ class _Conv9Fn(torch.autograd.Function):
             dbuf = torch.empty_like(buf)
             dbuf[:4].zero_()                           # the slack before / after the sequence: read by the in-place accumulations
             dbuf[-4:].zero_()
-            d0, d4, d8 = (dbuf.as_strided((b, cp, L), strides, o) for o in (0, 4, 8))
-            _fn._conv_dgrad(ops, dy, w1[..., 1:8].contiguous(), 7, 1, 1, 3, cp, L, None, out=d4)
-            _fn._conv_dgrad(ops, dy, w1[..., 0:1].contiguous(), 1, 1, 1, 0, cp, L, None, res=d0, out=d0)
+            d4, d8 = (dbuf.as_strided((b, cp, L), strides, o) for o in (4, 8))
+            _fn._conv_dgrad(ops, dy, w1[..., 0:8].contiguous(), 8, 1, 1, 4, cp, L, None, out=d4)
             _fn._conv_dgrad(ops, dy, w1[..., 8:9].contiguous(), 1, 1, 1, 0, cp, L, None, res=d8, out=d8)
         return dbuf, dw, dbias, None, None, None
 
@@ -135,9 +136,10 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
 
     Layout: the kh frame taps become channels (time-shifted copies: C' = Cin*kh), and the (T x W) plane becomes one sequence of rows
     [pad zeros | W samples | pad zeros] of pitch W + kw - 1 — a "same" 1-D conv of that sequence never mixes two rows' samples, and
-    its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel is split as taps 1..7 (a 7-tap conv: the
-    k7 forward / data-gradient / weight-gradient kernels of the conv stack) + tap 0 + tap 8 (1-tap convs on the sequence shifted by
-    -+4 samples — offset views of one buffer — added through the residual input of their launches).
+    its outputs at the sample positions are the 2-D conv's.  A 9-tap kernel runs as taps 0..7 (one launch of the k7 kernels, which
+    process 8 tap groups per chunk) + tap 8 (a 1-tap conv on the sequence shifted by +4 samples — an offset view of the same buffer —
+    added through the residual input of its launch); its weight gradient as taps 1..7 (the pipelined 7-tap kernel) + tap 0 + tap 8
+    (_Conv9Fn).
     The sequence tensor is built by ONE kernel (sat_rows_pack; adjoint sat_rows_pack_bwd) and the output rows are un-pitched and
     activated by one (sat_rows_unpack / _bwd): no torch pad / stack / slice / LeakyReLU passes and none of their autograd adds and fills."""
     b, cin, t, wd = x.shape
@@ -153,7 +155,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
     w1 = w.reshape(cout, cp, kw)
     if kw == 9 and split_wide:
         # the sequence sits in a buffer with 4 elements of slack on both sides, so that "the sequence shifted by +-4 samples" is a
-        # VIEW (same strides, storage offset -+4): taps 0 and 8 become two 1-tap convs on those views (the k1 kernels), chained
+        # VIEW (same strides, storage offset -+4): the outer taps become 1-tap convs on those views (the k1 kernels), chained
         # through the residual input — no dilated conv, no shifted copies.  Positions where a shifted view reads across a channel
         # boundary are row-padding positions, whose outputs are discarded (and carry zero gradient).
         buf = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 4)
