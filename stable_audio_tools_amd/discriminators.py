@@ -13,9 +13,10 @@ Execution
     configures): run as stride-1 Conv1d over "virtual channels" on the conv stack's bf16x3 MFMA kernels (csrc/conv1d_bf16x3*.hip,
     conv_wgrad*): the kh frame taps become channels (time-shifted copies), and the (frames x freq) plane is laid out as one long
     sequence of zero-separated rows, so the 1-D kernels see the same regime as the VAE convs (C' = 192 channels, millions of
-    steps) instead of thousands of short rows; a 9-tap kernel is taps 1..7 on the 7-tap kernels + taps 0 and 8 as 1-tap convs on
-    offset views of the same buffer.
-    The rearrangement itself is torch data movement (autograd-tracked pad / stack / view); all arithmetic is in the HIP kernels.
+    steps) instead of thousands of short rows; a 9-tap kernel is taps 0..7 in one launch of the k7 kernels + tap 8 as a 1-tap conv on
+    an offset view of the same buffer (_Conv9Fn: one autograd unit); 3-tap kernels are zero-padded to 7 taps in training (the
+    pipelined 7-tap weight-gradient kernel).
+    The rearrangement is two kernels each way (sat_rows_pack / sat_rows_unpack with LeakyReLU, and their adjoints).
   * weight norm: functional.WeightNormFn (sat_wn_fold / sat_wn_grad), as for the 1-D convs.
 """
 import typing as tp
@@ -162,7 +163,7 @@ def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
         y = _Conv9Fn.apply(buf, w1, bias, b, cp, L)
     else:
         seq = _PackRowsFn.apply(x, kh, dil_t, pad_t, pad_w, pitch, 0).view(b, cp, L)
-        if kw < 7 and split_wide and cout >= 16 and cp >= 64 and torch.is_grad_enabled():
+        if kw < 7 and split_wide and cp >= 64 and torch.is_grad_enabled():
             # training: zero-pad the 3-tap kernel to 7 taps — the k7 kernels process 8 tap groups per chunk either way, and the 7-tap
             # weight-gradient kernel (bf16x3, pipelined) is ~4x faster than the generic one a 3-tap conv would fall back to
             ext = (7 - kw) // 2
