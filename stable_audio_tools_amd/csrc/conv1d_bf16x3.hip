@@ -18,6 +18,7 @@
 //     so a chunk's slab is a straight 16-byte-per-lane copy into padded LDS rows.
 #include "conv_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define SAT_BF_AROWS1 192  // CS == 1: max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
 #define SAT_BF_AROWSN 136  // CS  > 1: 128 + (taps-1) rows, taps <= 4, dil = 1

@@ -192,7 +192,7 @@ class SatOps:
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
     # per (device, stream): the pre-pass and its conv are enqueued back to back on the caller's current stream.
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
-    k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "256"))      # measured (tools/k7_bench.py, profiles/r02_k7_bench.jsonl): the pre-pass pays from C = 256 up
+    k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
 
     def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None):
         b, cin, tin = x.shape

@@ -152,6 +152,23 @@ def test_conv_k7_planes_sim(emu):
     _run_planes(emu, "cpu", [c for c in S1_CASES if c[4] == 7][:6] + [(1, 20, 5, 90, 5, 2), (2, 16, 130, 517, 7, 3)])
 
 
+def test_conv_k7_planes_persistent_sim(emu, monkeypatch):
+    """The planes kernel is persistent (a workgroup walks several tiles, requesting the next tile's first chunks before its epilogue):
+    with the workgroup count capped at 1 / 2 / 3 the same cases run 2..12 tiles per workgroup, incl. a change of channel tile."""
+    for cap in ("1", "2", "3"):
+        monkeypatch.setenv("SAT_K7P_MAX_WGS", cap)
+        _run_planes(emu, "cpu", [(2, 16, 130, 517, 7, 3), (1, 8, 8, 1300, 7, 9), (3, 24, 200, 300, 7, 1)])
+
+
+@pytest.mark.gpu
+def test_conv_k7_planes_persistent_gpu(hip, monkeypatch):
+    for cap in ("2", "7"):
+        monkeypatch.setenv("SAT_K7P_MAX_WGS", cap)
+        _run_planes(hip, "cuda", [(2, 16, 130, 517, 7, 3), (1, 128, 128, 8192, 7, 9), (3, 24, 200, 300, 7, 1)])
+    monkeypatch.delenv("SAT_K7P_MAX_WGS")
+    _run_planes(hip, "cuda", [(1, 128, 128, 300000, 7, 3)])      # 1172 tiles on 256 workgroups
+
+
 @pytest.mark.gpu
 def test_conv_k7_planes_gpu(hip):
     _run_planes(hip, "cuda", [c for c in S1_CASES if c[4] == 7] + [(1, 128, 128, 8192, 7, 9), (1, 1024, 1024, 512, 7, 3), (2, 512, 512, 1000, 7, 1)])
