@@ -9,9 +9,11 @@
 //   * per K-chunk (8 input channels x 8 tap groups) a stage holds the weight slab [2 planes][128 co][8 groups x 8] (32 KiB, 128-byte
 //     rows, 16-byte chunks XOR-swizzled through the DMA source address) and the activation slab [2 planes][320 rows][8] (10 KiB);
 //     both arrive by LDS-DMA (42 one-KiB pieces per chunk, 5-6 per wave), no staging registers, no VALU, no ds_write;
-//   * three stages in a ring: chunk c+2 is requested right after the barrier that publishes chunk c, counted s_waitcnt vmcnt keeps
-//     chunk c+1 in flight across it; ONE barrier per chunk;
-//   * the MFMA phase (48 per wave and chunk: 2x2 tiles x 4 k-steps x 3 products) and the epilogue are those of conv1d_bf16x3_k7.h.
+//   * two stages in a ring: chunk c+1 is requested right after the barrier that publishes chunk c; ONE barrier per chunk;
+//   * PERSISTENT workgroups (one per CU) walk the tiles of the XCD-aware order: the next tile's first two chunks are requested before
+//     the epilogue of the current one (which has its own LDS transposition space), its stores drain under the next K loop;
+//   * fragment reads run one k-step ahead of the MFMAs (two register sets);
+//   * the MFMA work (48 per wave and chunk: 2x2 tiles x 4 k-steps x 3 products) and the epilogue are those of conv1d_bf16x3_k7.h.
 #pragma once
 
 #define SAT_K7P_LEAD 32           // zero rows before t = 0 in a plane (>= pad)
