@@ -365,19 +365,39 @@ struct SatAdamParams {
     float ema_decay;  // ema = decay*ema + (1-decay)*p_before_step  (the wrapper calls ema.update()
                       // BEFORE optimizer.step(): training/autoencoders.py:504-515)
 };
+SAT_DEVICE void sat_adamw_one(const SatAdamParams& a, float g, float& p, float& m, float& v, float* ema) {
+    g *= a.gscale;
+    if (ema) *ema = a.ema_decay * *ema + (1.0f - a.ema_decay) * p;
+    p *= (1.0f - a.lr * a.wd);
+    m = a.b1 * m + (1.0f - a.b1) * g;
+    v = a.b2 * v + (1.0f - a.b2) * g * g;
+    const float denom = sqrtf(v) / a.bc2s + a.eps;
+    p -= (a.lr / a.bc1) * (m / denom);
+}
+// streaming update, 16-byte accesses (the flat buffers are 16-byte aligned; the < 4 leftover elements go one by one)
 __global__ void __launch_bounds__(256) sat_adamw_kernel(SatAdamParams a) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
-        const float g = a.g[i] * a.gscale;
-        float p = a.p[i];
-        if (a.ema) a.ema[i] = a.ema_decay * a.ema[i] + (1.0f - a.ema_decay) * p;
-        p *= (1.0f - a.lr * a.wd);
-        const float m = a.b1 * a.m[i] + (1.0f - a.b1) * g;
-        const float v = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        const float denom = sqrtf(v) / a.bc2s + a.eps;
-        p -= (a.lr / a.bc1) * (m / denom);
-        a.p[i] = p;
+    const long long n4 = a.n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i], m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+        if (a.ema) e = reinterpret_cast<f32x4*>(a.ema)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = p[j], mj = m[j], vj = v[j], ej = e[j];
+            sat_adamw_one(a, g[j], pj, mj, vj, a.ema ? &ej : nullptr);
+            p[j] = pj; m[j] = mj; v[j] = vj; e[j] = ej;
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+        if (a.ema) reinterpret_cast<f32x4*>(a.ema)[i] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        sat_adamw_one(a, a.g[i], p, m, v, a.ema ? a.ema + i : nullptr);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
     }
 }
 extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
@@ -386,7 +406,11 @@ extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long
     if (n <= 0 || step < 1) { sat_set_error("sat_adamw_step: empty buffer or step < 1"); return 1; }
     SatAdamParams a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                     1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), grad_scale, ema, ema_decay};
-    long long nb = sat_cdivll(n, 256);
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0) {
+        sat_set_error("sat_adamw_step: buffers must be 16-byte aligned");
+        return 1;
+    }
+    long long nb = sat_cdivll(sat_cdivll(n, 4), 256);
     if (nb > 4096) nb = 4096;
     SAT_LAUNCH(sat_adamw_kernel, dim3((unsigned)nb), dim3(256), stream, a);
     return sat_check_launch("sat_adamw_step");

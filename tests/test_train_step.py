@@ -306,3 +306,33 @@ def test_alternating_discriminator_generator_steps_simulator(emu_modules):
 @pytest.mark.gpu
 def test_alternating_discriminator_generator_steps_gpu(hip):
     _alternating("cuda")
+
+
+def _adamw_case(ops, dev):
+    """sat_adamw_step (16-byte vector body + scalar tail) against torch.optim.AdamW over three steps, sizes around the vector width,
+    with the gradient scale (1 / world) and the EMA shadow (updated from the parameters BEFORE the step, training/autoencoders.py:504-515)."""
+    for n in (1, 3, 4, 1030, 4099):
+        gen = torch.Generator().manual_seed(n)
+        p0 = torch.randn(n, generator=gen)
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.1)
+        p = p0.clone().to(dev)
+        m, v, ema = torch.zeros(n, device=dev), torch.zeros(n, device=dev), p0.clone().to(dev)
+        ema_ref = p0.clone()
+        for step in (1, 2, 3):
+            g = torch.randn(n, generator=gen)
+            ema_ref = 0.9 * ema_ref + 0.1 * ref.detach()
+            ref.grad = g.clone()
+            opt.step()
+            ops.adamw_step(p, (2.0 * g).to(dev), m, v, 1e-2, 0.8, 0.95, 1e-6, 0.1, step, grad_scale=0.5, ema=ema, ema_decay=0.9)
+            assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6), (n, step)
+            assert torch.allclose(ema.cpu(), ema_ref, rtol=1e-6, atol=1e-7), (n, step)
+
+
+def test_adamw_kernel_simulator(emu):
+    _adamw_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_adamw_kernel_gpu(hip):
+    _adamw_case(hip, "cuda")
