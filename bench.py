@@ -83,9 +83,47 @@ class AttnProfiler:
 
         self._lib, self._orig = ops.lib, orig
         ops.lib.sat_attention_fwd = timed
+        # the projection GEMMs (80 % of a sampler step's GPU time): same budgeted event timing, algorithmic flops 2*M*N*K
+        self.gemm = []
+        self.gemm_budget = 2 * max_launches     # (about two model evaluations: events cost host time in the measured loop)
+        self._gemm_orig = {}
+        specs = {"sat_gemm_bf16": lambda a: 2.0 * a[15] * a[16] * a[17],
+                 "sat_gemm_qkv_bf16": lambda a: 2.0 * (a[10] * a[11]) * (a[16] * a[13] * 64) * a[14]}
+        for name, fl in specs.items():
+            self._wrap_gemm(ops.lib, name, fl)
+
+    def _wrap_gemm(self, lib, name, flops):
+        orig = getattr(lib, name)
+        self._gemm_orig[name] = orig
+
+        def timed(*a):
+            if not self.enabled or self.gemm_budget <= 0:
+                return orig(*a)
+            self.gemm_budget -= 1
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig(*a)
+            e.record()
+            self.gemm.append((s, e, flops(a)))
+            return rc
+
+        setattr(lib, name, timed)
 
     def restore(self):
         self._lib.sat_attention_fwd = self._orig
+        for name, orig in self._gemm_orig.items():
+            setattr(self._lib, name, orig)
+
+    def gemm_summary(self, peak):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.gemm)
+        fl = sum(f for _, _, f in self.gemm)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"kernel": "sat_gemm_kernel", "launches": len(self.gemm), "total_ms": round(ms, 3), "achieved": round(ach, 1), "peak": peak,
+                "frac": round(ach / peak, 4),
+                "note": "every projection launch (sat_gemm_bf16 / sat_gemm_qkv_bf16) of the first model evaluations of the timed region: "
+                        "2*M*N*K over HIP-event time, epilogues (SwiGLU, residual, head split + rotary + plane layout) included"}
 
     def summary(self, which="self"):
         torch.cuda.synchronize()
@@ -102,6 +140,7 @@ class AttnProfiler:
                 "kernel": "sat_attn_fwd_kernel", "launches": nl, "avg_launch_ms": ms / nl if nl else None,
                 "cross_attention": {"launches": nc, "avg_launch_ms": msc / nc if nc else None,
                                     "achieved": flc / (msc * 1e-3) / 1e12 if msc > 0 else 0.0},
+                "projections": self.gemm_summary(peak),
                 "note": "self-attention launches (the first ~4 model evaluations of the timed region): algorithmic flops 4*N*N*64*H*B over HIP-event time on the launch stream; "
                         "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split); cross-attention (GQA, M=130 keys) apart"}
 
