@@ -249,17 +249,16 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
         }
         SAT_WAIT_LGKM0();
     } else {
-    // (PIPE < 0: ablation builds of this plain loop for profiling — -1 without the LDS-DMA staging, -2 without fragment reads / MFMAs)
     // ring of NSTAGE tiles: tiles kt .. kt+NSTAGE-2 are in flight when K-step kt starts
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk && PIPE != -1) stage(s, s);
+        if (s < nk) stage(s, s);
     int rd = 0, wr = NSTAGE - 1;
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's pieces of tile kt have landed (the NSTAGE-2 younger tiles may still be in flight; the tail drains) ...
         if (kt + NSTAGE - 2 < nk) { SAT_WAIT_VMCNT((NSTAGE - 2) * G); } else { SAT_WAIT_VMCNT(0); }
         SAT_RAW_BARRIER();     // ... everybody's have, and every wave is done reading the slot tile kt+NSTAGE-1 goes to
-        if (kt + NSTAGE - 1 < nk && PIPE != -1) stage(kt + NSTAGE - 1, wr);
+        if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, wr);
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
         const char* As = smem + rd * STAGE;
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
@@ -292,11 +291,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
         } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (PIPE != -2) {
-                bf16x8 a[TM], b[TN];
-                frags(As, ks, a, b);
-                mfmas(a, b);
-            }
+            bf16x8 a[TM], b[TN];
+            frags(As, ks, a, b);
+            mfmas(a, b);
         }
         }
     }
@@ -474,8 +471,7 @@ static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, 
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile == 4) return sat_gemm_launch<128, 128, 2, 2, 2, -1>(p, epi, f32out, splits, stream);
-    if (tile == 5) return sat_gemm_launch<128, 128, 2, 2, 2, -2>(p, epi, f32out, splits, stream);
+    if (tile < 0 || tile > 3) { sat_set_error("sat_gemm: tile must be 0..3"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
 }
 
