@@ -20,6 +20,15 @@ from .linear import Linear
 from .transformer import ContinuousTransformer
 
 
+def clear_inference_caches(module):
+    """Drop the no-grad caches under `module` (embedded conditioning / CFG batch in DiffusionTransformer, cross-attention K / V planes in
+    transformer.Attention).  They are keyed on tensor identity + version counters and never go stale; this only releases their memory
+    (e.g. before switching a long-lived model back to training)."""
+    for m in module.modules():
+        for k in ("_kv_ctx", "_kv_key", "_kv_planes", "_cond_src", "_cond_key", "_cond_out", "_cfg_cond"):
+            m.__dict__.pop(k, None)
+
+
 class FourierFeatures(nn.Module):
     """models/blocks.py:85-94: cat(cos(2 pi x W^T), sin(2 pi x W^T))."""
 

@@ -100,11 +100,11 @@ def _inference_caches(device):
     cross = [m for m in model.modules() if isinstance(m, Attention) and hasattr(m, "to_q")]
     assert cross
 
+    from stable_audio_tools_amd.dit import clear_inference_caches
+
     def run(c, fresh=False):
         if fresh:
-            for m in list(model.modules()):
-                for k in ("_kv_ctx", "_kv_key", "_kv_planes", "_cond_src", "_cond_key", "_cond_out", "_cfg_cond"):
-                    m.__dict__.pop(k, None)
+            clear_inference_caches(model)
         with torch.no_grad():
             return model(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=4.0, scale_phi=0.5).float().clone()
 
