@@ -193,6 +193,15 @@ def ema_decay(step, beta=0.9999, power=0.75, inv_gamma=1.0, update_after_step=1,
     return min(max(value, min_value), beta)
 
 
+def clip_flat_grads(flat, max_norm, grad_scale=1.0):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (training/autoencoders.py:491-492, :509-510) on a flat gradient buffer, without
+    a host sync: the buffer holds the SUM over ranks and grad_scale = 1 / world turns its norm into that of the mean gradient the
+    reference clips; the coefficient min(1, max_norm / (norm + 1e-6)) is multiplied in on the device.  Returns the (mean-gradient) norm."""
+    norm = torch.linalg.vector_norm(flat.grad) * grad_scale
+    flat.grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+    return norm
+
+
 class FusedAdamW:
     """torch.optim.AdamW semantics (decoupled weight decay, bias correction) over FlatParameters in
     one HIP launch (csrc/elementwise.hip sat_adamw_step)."""
@@ -245,8 +254,7 @@ class AutoencoderTrainStep:
         tw = lc.get("time", {}).get("weights", {})
         if any(float(tw.get(k, 0.0)) > 0 for k in ("l1", "l2")):
             raise NotImplementedError("time-domain l1/l2 loss terms are not restated on the HIP path")
-        if float(tr.get("clip_grad_norm", 0.0)) > 0:
-            raise NotImplementedError("clip_grad_norm is not restated on the HIP path")
+        self.clip_grad_norm = float(tr.get("clip_grad_norm", 0.0))      # wrapper kwarg, training/autoencoders.py:48, :491-492, :509-510
         if int(tr.get("warmup_steps", 0)) > 0:
             raise NotImplementedError("discriminator warm-up (warmup_steps > 0) is not restated")
         sample_rate = model_config["sample_rate"]
@@ -315,6 +323,8 @@ class AutoencoderTrainStep:
             self.flat_d.gather_grads()
             self.comm_d()
             lr = self.base_lr_d if self.sched_d is None else inverse_lr(self.disc_steps, self.base_lr_d, **self.sched_d["config"])
+            if self.clip_grad_norm > 0.0:
+                clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale)
             self.opt_d.step(lr=lr, grad_scale=self.comm_d.grad_scale)
             self.disc_steps += 1
             self.global_step += 1
@@ -349,6 +359,8 @@ class AutoencoderTrainStep:
             loss.backward()
         self.flat.gather_grads()
         self.comm()
+        if self.clip_grad_norm > 0.0:
+            clip_flat_grads(self.flat, self.clip_grad_norm, self.comm.grad_scale)
         self.opt.step(lr=self.current_lr(), grad_scale=self.comm.grad_scale)
         self.gen_steps += 1
         self.global_step += 1

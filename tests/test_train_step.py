@@ -336,3 +336,23 @@ def test_adamw_kernel_simulator(emu):
 @pytest.mark.gpu
 def test_adamw_kernel_gpu(hip):
     _adamw_case(hip, "cuda")
+
+
+def test_clip_flat_grads_matches_torch():
+    """training.clip_flat_grads == torch.nn.utils.clip_grad_norm_ (the reference's clipping, training/autoencoders.py:491-492, :509-510)
+    on the flat buffer, incl. the 1 / world scale of a summed multi-rank gradient and the no-clip case."""
+    from stable_audio_tools_amd.training import FlatParameters, clip_flat_grads
+    gen = torch.Generator().manual_seed(5)
+    for max_norm, world in ((0.5, 1), (1e3, 1), (0.25, 4)):
+        params = [torch.nn.Parameter(torch.randn(*shp, generator=gen)) for shp in ((7, 3), (5,), (2, 4, 6))]
+        refs = [torch.nn.Parameter(q.detach().clone()) for q in params]
+        flat = FlatParameters(params, pad_to=world)
+        for q, r in zip(params, refs):
+            g = torch.randn(q.shape, generator=gen)
+            q.grad.copy_(g * world)                 # the flat buffer holds the SUM over ranks
+            r.grad = g.clone()                      # the mean gradient the reference clips
+        total = torch.nn.utils.clip_grad_norm_(refs, max_norm)
+        norm = clip_flat_grads(flat, max_norm, grad_scale=1.0 / world)
+        assert torch.allclose(norm, total, rtol=1e-6)
+        for q, r in zip(params, refs):
+            assert torch.allclose(q.grad / world, r.grad, rtol=1e-5, atol=1e-7)
