@@ -252,11 +252,15 @@ class AutoencoderTrainStep:
         lc = tr["loss_configs"]
         self.w_kl = lc.get("bottleneck", {}).get("weights", {}).get("kl", 1e-6)      # wrapper default: training/autoencoders.py:644-647
         tw = lc.get("time", {}).get("weights", {})
-        if any(float(tw.get(k, 0.0)) > 0 for k in ("l1", "l2")):
-            raise NotImplementedError("time-domain l1/l2 loss terms are not restated on the HIP path")
+        self.w_l1, self.w_l2 = float(tw.get("l1", 0.0)), float(tw.get("l2", 0.0))    # L1Loss / MSELoss on (reals, decoded): :170-190
         self.clip_grad_norm = float(tr.get("clip_grad_norm", 0.0))      # wrapper kwarg, training/autoencoders.py:48, :491-492, :509-510
-        if int(tr.get("warmup_steps", 0)) > 0:
-            raise NotImplementedError("discriminator warm-up (warmup_steps > 0) is not restated")
+        # discriminator warm-up (training/autoencoders.py:40-57, :378-379, :394-398, :440-452, :476-483)
+        self.warmup_steps = int(tr.get("warmup_steps", 0))
+        self.warmup_mode = tr.get("warmup_mode", "adv")
+        if self.warmup_mode not in ("adv", "full"):
+            raise ValueError("warmup_mode must be 'adv' or 'full'")
+        self.encoder_freeze_on_warmup = bool(tr.get("encoder_freeze_on_warmup", False))
+        self.warmed_up = False
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
@@ -307,7 +311,9 @@ class AutoencoderTrainStep:
         """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
         m = self.model
         kw = {"noise": noise} if noise is not None else {}
-        if self.use_disc and self.global_step % 2 == 1:
+        if self.global_step >= self.warmup_steps:
+            self.warmed_up = True
+        if self.use_disc and self.global_step % 2 == 1 and ((self.warmup_mode == "full" and self.warmed_up) or self.warmup_mode == "adv"):
             # ---- discriminator step (:484-497) ----
             self.flat_d.zero_grad()
             with torch.no_grad():
@@ -331,12 +337,24 @@ class AutoencoderTrainStep:
             return {"loss": loss_dis.detach(), "discriminator_loss": loss_dis.detach()}
         # ---- generator step (:498-515) ----
         self.flat.zero_grad()
-        latents, info = m.encode(reals, return_info=True, **kw)
+        if self.warmed_up and self.encoder_freeze_on_warmup:
+            with torch.no_grad():
+                latents, info = m.encode(reals, return_info=True, **kw)
+        else:
+            latents, info = m.encode(reals, return_info=True, **kw)
         decoded, reals_t = self._trim(m.decode(latents), reals)
         mrstft = self.spectral(reals_t, decoded)
         loss = mrstft + self.w_kl * info["kl"]
         out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
-        if self.use_disc:
+        if self.w_l1 > 0.0:
+            l1 = (reals_t - decoded).abs().mean()
+            loss = loss + self.w_l1 * l1
+            out["l1_time_loss"] = (self.w_l1 * l1).detach()
+        if self.w_l2 > 0.0:
+            l2 = ((reals_t - decoded) ** 2).mean()
+            loss = loss + self.w_l2 * l2
+            out["l2_time_loss"] = (self.w_l2 * l2).detach()
+        if self.use_disc and self.warmed_up:      # before the warm-up ends the adversarial / feature-matching terms are zero (:441-452)
             # adversarial + feature-matching terms: their gradient w.r.t. the decoded audio is collected scale by scale on a detached
             # leaf (one scale's activations alive at a time), then enters the autoencoder's single backward pass below
             leaf = decoded.detach().contiguous().requires_grad_(True)

@@ -356,3 +356,32 @@ def test_clip_flat_grads_matches_torch():
         assert torch.allclose(norm, total, rtol=1e-6)
         for q, r in zip(params, refs):
             assert torch.allclose(q.grad / world, r.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_warmup_and_time_losses_simulator(emu_modules):
+    """warmup_steps = 1 (mode 'adv'): step 0 is a generator step WITHOUT adversarial / feature-matching terms but with the time-domain
+    L1 / MSE terms, step 1 a discriminator step, step 2 a generator step with them (training/autoencoders.py:378-379, :440-452, :476-483);
+    step 0's loss against the oracles."""
+    import copy as _copy
+    from stable_audio_tools_amd.training import AutoencoderTrainStep
+    cfg = _copy.deepcopy(_disc_config())
+    cfg["training"]["warmup_steps"] = 1
+    cfg["training"]["loss_configs"]["time"] = {"weights": {"l1": 0.5, "l2": 0.25}}
+    cfg["training"]["clip_grad_norm"] = 10.0
+    torch.manual_seed(7)
+    model = build_native_ae(NAME, SEED, "cpu")
+    stepper = AutoencoderTrainStep(model, cfg)
+    batches = [_batch(2, 900), _batch(2, 910), _batch(2, 920)]
+    out = [stepper(a, noise=n) for a, n in batches]
+    assert "feature_matching" not in out[0] and "l1_time_loss" in out[0] and "discriminator_loss" in out[1] and "feature_matching" in out[2]
+    assert stepper.gen_steps == 2 and stepper.disc_steps == 1
+    from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
+    shapes = {k: tuple(v.shape) for k, v in create_autoencoder_from_config(cfg).state_dict().items()}
+    sd = {k: torch.from_numpy(v).clone() for k, v in seeded.seeded_state_dict(shapes, SEED).items()}
+    a0, n0 = batches[0]
+    z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], a0, n0)
+    dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+    sc = cfg["training"]["loss_configs"]["spectral"]["config"]
+    ref = stft_oracle.autoencoder_spectral_loss(a0, dec, sc, cfg["sample_rate"]) + 1e-4 * kl \
+        + 0.5 * (a0 - dec).abs().mean() + 0.25 * ((a0 - dec) ** 2).mean()
+    assert abs(float(out[0]["loss"]) - float(ref)) <= 1e-3 * abs(float(ref)), (float(out[0]["loss"]), float(ref))
