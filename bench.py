@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-step", action="store_true", help="skip the timing of the alternating discriminator / generator step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check of the bench item (about one CPU-minute)")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
     ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train"], default="vae_train",
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
@@ -459,6 +460,45 @@ def cpu_baseline(cfg, nsamples):
                       f"{dt:.2f} s at {cores} threads (fastest of 8/16/32), scaled x{scale:.0f} to {SAMPLE_SIZE} samples"}
 
 
+def headline_parity(model, cfg, stepper, audio):
+    """Parity ON the bench item, outside the timed region: the native forward of the first full-length item of the timed
+    batches (encode with an explicit VAE draw -> decode -> MR-STFT generator loss), with the weights as the timed steps left them,
+    against the CPU oracle (oracle/vae_oracle.py, oracle/stft_oracle.py — the restatement pinned to the reference by
+    tests/test_full_width.py) run on this box's host cores.  rel err = max|a-b| / max|b| (the 1e-3 bar of BASELINE.json)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import stft_oracle
+    import vae_oracle
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    mc = cfg["model"]
+    x = audio[:1]
+    g = torch.Generator().manual_seed(4321)
+    noise = torch.randn(1, mc["latent_dim"], x.shape[-1] // mc["downsampling_ratio"], generator=g)
+    with torch.no_grad():
+        z, info = model.encode(x, return_info=True, noise=noise.to(x.device))
+        dec = model.decode(z)
+        loss = stepper.spectral(x, dec)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        z_o, kl_o, pre_o = vae_oracle.autoencoder_encode(sd, mc, x.cpu(), noise)
+        dec_o = vae_oracle.autoencoder_decode(sd, mc, z_o)
+        loss_o = stft_oracle.autoencoder_spectral_loss(x.cpu(), dec_o, cfg["training"]["loss_configs"]["spectral"]["config"], cfg["sample_rate"],
+                                                       weight=cfg["training"]["loss_configs"]["spectral"]["weights"]["mrstft"])
+    secs = time.perf_counter() - t0
+    out = {"pre_latents": rel(info["pre_bottleneck_latents"], pre_o), "z": rel(z, z_o), "kl": rel(info["kl"], kl_o), "decoded": rel(dec, dec_o),
+           "mrstft_loss": abs(float(loss) - float(loss_o)) / abs(float(loss_o))}
+    return {"rel_err": {k: float(f"{v:.3e}") for k, v in out.items()}, "tolerance": 1e-3, "ok": bool(max(out.values()) < 1e-3),
+            "samples": int(x.shape[-1]), "batch_item": 0, "oracle_seconds": round(secs, 1), "oracle_threads": cores,
+            "what": "native forward (encode, VAE sample with a given draw, decode, MR-STFT generator loss) of the bench item itself vs the CPU "
+                    "oracle (fp32) on this box, weights as left by the timed steps; max|a-b|/max|b|; outside the timed region "
+                    "(tests/test_headline_parity.py holds the same comparison plus dL/d(decoded) and the B = 2 offsets)"}
+
+
 def run_dit_train(args):
     """BASELINE.json configs[2]/[3]: Stable-Audio-Open-1.0 DiT training step (v-objective MSE on 1024 latent frames =
     47.55 s of audio, pre-encoded latents), bf16-mixed, data-parallel over RCCL.  samples/s = items/s."""
@@ -644,6 +684,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)
+        if world == 1 and not args.no_parity:
+            line["parity"] = headline_parity(model, cfg, stepper, batches[0])
         if stepper.discriminator is not None:
             # the REAL autoencoder step of the reference (training/autoencoders.py:440-515): MS-STFT discriminator (5 scales, 64
             # filters), updates alternating discriminator / generator — timed over 2 + 2 steps after one of each as warm-up

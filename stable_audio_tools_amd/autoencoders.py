@@ -12,10 +12,12 @@ it in *fusion units* (functional.py) so SnakeBeta, bias, residual add and tanh n
 trip through HBM, and both forward and backward run on the HIP kernels of csrc/.  There is no
 PyTorch conv fallback: without the gfx950 library these modules raise.
 """
+import copy
 import math
 
 import torch
 from torch import nn
+from torch.nn.utils.weight_norm import WeightNorm as _TorchWeightNorm
 
 from . import functional as Fn
 from .bottleneck import VAEBottleneck  # noqa: F401  (re-export, mirrors reference import surface)
@@ -45,9 +47,38 @@ class SnakeBeta(nn.Module):
         return Fn.SnakeConv1dFn.apply(x, self.alpha, self.beta, eye, None, None, 1, 1, 0, False)
 
 
+class _NativeWeightNorm(_TorchWeightNorm):
+    """The forward-pre-hook object torch.nn.utils.weight_norm leaves on a module, re-implemented for the native convs so that the
+    reference's `remove_weight_norm_from_model` (models/utils.py:31-37; train.py:73-81 `--remove-pretransform-weight-norm`) keeps
+    working unchanged: torch.nn.utils.remove_weight_norm looks for a WeightNorm hook named "weight" and calls its .remove().
+    Nothing happens per forward (the fold is a HIP launch inside the conv's fusion unit, or cached); .remove() turns the module into
+    its folded form: a plain `weight` parameter, no weight_g / weight_v — the state_dict layout of a checkpoint saved after removal."""
+
+    def __init__(self, name="weight", dim=0):
+        super().__init__(name, dim)
+
+    def compute_weight(self, module):
+        return module._fold_host()
+
+    def remove(self, module):
+        module._to_folded(module._fold_host().detach())
+
+    def __call__(self, module, inputs):
+        return None
+
+
+def _inference_pass(*tensors):
+    """True when no gradient can be asked of this call: derived weights may come from the layer's DerivedCache."""
+    return (not torch.is_grad_enabled()) or not any(t is not None and t.requires_grad for t in tensors)
+
+
 class _WNConvBase(nn.Module):
     """Old-style torch.nn.utils.weight_norm parametrisation (dim=0): parameters weight_g, weight_v
-    (+ bias) — the names the reference checkpoints carry (autoencoders.py:8, :23-27)."""
+    (+ bias) — the names the reference checkpoints carry (autoencoders.py:8, :23-27).
+
+    Two parameter layouts, as in the reference: weight-normed (weight_g, weight_v; `module.weight` reads as the folded tensor)
+    and, after torch.nn.utils.remove_weight_norm / remove_weight_norm_from_model or after loading a checkpoint that was saved
+    that way, folded (one `weight` parameter).  load_state_dict accepts either layout into either form."""
 
     transposed = False
 
@@ -71,16 +102,71 @@ class _WNConvBase(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
         else:
             self.register_parameter("bias", None)
+        self.register_forward_pre_hook(_NativeWeightNorm("weight", 0))
+        self.__dict__["_derived"] = Fn.DerivedCache()
+
+    # ---- the two parameter layouts ----
+    @property
+    def is_folded(self):
+        return "weight" in self._parameters
+
+    def __getattr__(self, name):
+        # weight-normed form: `module.weight` is the folded tensor, as the attribute old-style weight_norm keeps on the module
+        if name == "weight" and "weight_v" in self.__dict__.get("_parameters", ()):
+            return self._fold_host()
+        return super().__getattr__(name)
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = Fn.DerivedCache() if k == "_derived" else copy.deepcopy(v, memo)
+        return new
+
+    def _fold_host(self):
+        """w = g * v / ||v|| in plain torch: parameter management on whatever device the module is on (attribute access, weight-norm
+        removal, checkpoint conversion) — not the compute path, which folds inside the HIP fusion unit (folded_weight)."""
+        v, g = self._parameters["weight_v"], self._parameters["weight_g"]
+        return v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+
+    def _to_folded(self, w):
+        rg = self._parameters["weight_v"].requires_grad
+        del self._parameters["weight_g"], self._parameters["weight_v"]
+        self._parameters["weight"] = nn.Parameter(w.clone(), requires_grad=rg)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        kw, kg, kv = prefix + "weight", prefix + "weight_g", prefix + "weight_v"
+        if not self.is_folded and kw in state_dict and kv not in state_dict:
+            # a checkpoint saved after weight-norm removal: take the folded layout
+            self._to_folded(torch.empty_like(self._parameters["weight_v"]))
+        elif self.is_folded and kw not in state_dict and kv in state_dict and kg in state_dict:
+            # weight-normed checkpoint into a module whose weight norm was removed ("pre_load" order of train.py:73-76): fold on load
+            v, g = state_dict.pop(kv), state_dict.pop(kg)
+            state_dict[kw] = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def folded_weight(self):
-        return Fn.WeightNormFn.apply(self.weight_v, self.weight_g)
+        """The conv weight for this pass: the `weight` parameter (folded layout), or g * v / ||v|| by sat_wn_fold — inside autograd
+        when something is trained, from the layer's DerivedCache when nothing can ask for a gradient (no_grad, or a frozen layer)."""
+        if self.is_folded:
+            return self._parameters["weight"]
+        v, g = self.weight_v, self.weight_g
+        if _inference_pass(v, g):
+            return self._derived.get("folded", (v, g), lambda: Fn.WeightNormFn.apply(v.detach(), g.detach()))
+        return Fn.WeightNormFn.apply(v, g)
+
+    def derived_cache(self, *others):
+        """The layer's DerivedCache when this call trains nothing of the layer (nor `others`: the SnakeBeta in front of it)."""
+        ps = list(self._parameters.values()) + list(others)
+        return self._derived if _inference_pass(*ps) else None
 
 
 class WNConv1d(_WNConvBase):
     def forward(self, x, snake=None, res=None, tanh_out=False):
         a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
         return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias, res, self.stride, self.dilation,
-                                      self.padding, tanh_out)
+                                      self.padding, tanh_out, None, self.derived_cache(a, b))
 
 
 class WNConvTranspose1d(_WNConvBase):
@@ -88,7 +174,8 @@ class WNConvTranspose1d(_WNConvBase):
 
     def forward(self, x, snake=None):
         a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
-        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias, self.stride, self.padding)
+        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias, self.stride, self.padding, None,
+                                        self.derived_cache(a, b))
 
 
 def _require_snake(use_snake, antialias_activation=False):
@@ -100,6 +187,11 @@ def _require_snake(use_snake, antialias_activation=False):
 
 
 class ResidualUnit(nn.Module):
+    # activation recompute (the reference always checkpoints this unit in training, autoencoders.py:78-79): off by default — one
+    # 47.55 s stereo item per GPU needs 31 GB here and 288 GB are available — switch on (class-wide or per instance) to halve the
+    # unit's saved activations when the per-GPU batch does not fit; results are identical (tests/test_vae_parity.py)
+    checkpointing = False
+
     def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
         super().__init__()
         _require_snake(use_snake, antialias_activation)
@@ -114,8 +206,10 @@ class ResidualUnit(nn.Module):
 
     def forward(self, x):
         s1, c1, s2, c2 = self.layers
+        ca, cb = c1.derived_cache(s1.alpha, s1.beta), c2.derived_cache(s2.alpha, s2.beta)
         return Fn.ResidualUnitFn.apply(x, s1.alpha, s1.beta, c1.folded_weight(), c1.bias,
-                                       s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation)
+                                       s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation, None,
+                                       self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None)
 
 
 class EncoderBlock(nn.Module):

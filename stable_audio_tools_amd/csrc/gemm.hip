@@ -100,6 +100,130 @@ SAT_DEVICE void sat_store4(void* base, long long idx, f32x4 v) {
 }
 SAT_DEVICE float sat_gemm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- epilogue of one 32-row x 64-column window of a wave's accumulators ---------------------------------------------
+// The wave has put the window into its private LDS space `ep`: row-major [32][64] fp32 — or, for a window of v columns of the
+// fused QKV epilogue (sat_gemm_window_is_v), transposed [64 d][33].  A lane then owns 4 consecutive columns: bias / residual /
+// gate loads and the stores are 8- or 16-byte accesses that cover whole 128-byte row segments.
+template <int EPI>
+SAT_DEVICE bool sat_gemm_window_is_v(const SatGemmParams& p, int nwin) {
+    if constexpr (EPI == SAT_EPI_QKV) return nwin < p.N && nwin / (p.heads * 64) + p.sec0 == 2;
+    else return false;
+}
+
+template <int EPI, bool F32OUT>
+SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep, int mrow0, int nwin, int glu_col0, int glu_f, int lane) {
+    if constexpr (EPI == SAT_EPI_QKV) {
+        // a 64-column window is one head of q, k or v (wave-uniform).  v goes out TRANSPOSED (nb, H, 64, Np): the window was
+        // staged as [64 d][33] so that a lane reads 4 consecutive tokens of one head dim (odd stride: conflict free)
+        if (sat_gemm_window_is_v<EPI>(p, nwin)) {
+            const int h = (nwin % (p.heads * 64)) >> 6;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int d = pass * 8 + (lane >> 3), tq = (lane & 7) * 4;
+                const int m = mrow0 + tq;                 // 4 consecutive rows m .. m+3 (may straddle a batch item)
+                short o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = sat_f32_to_bf16(ep[d * 33 + tq + e]);
+                const int b = m / p.ntok, t = m - b * p.ntok;
+                short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
+                if (m + 3 < p.M && t + 3 < p.ntok) {
+                    // 4 tokens of one batch item: the widest aligned stores their phase allows (ntok is odd for the DiT —
+                    // 1 + 1024 — so every batch item but the first starts its rows off the 8-byte grid)
+                    const uint32_t p01 = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+                    const uint32_t p12 = (uint32_t)(uint16_t)o[1] | ((uint32_t)(uint16_t)o[2] << 16);
+                    const uint32_t p23 = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+                    if ((t & 3) == 0) {
+                        *(u32x2*)dst = u32x2{p01, p23};
+                    } else if ((t & 1) == 0) {
+                        *(uint32_t*)dst = p01;
+                        *(uint32_t*)(dst + 2) = p23;
+                    } else {
+                        dst[0] = o[0];
+                        *(uint32_t*)(dst + 1) = p12;
+                        dst[3] = o[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int me = m + e;
+                        if (me < p.M) {
+                            const int be = me / p.ntok, te = me - be * p.ntok;
+                            p.v_tr[(((long long)be * p.heads + h) * 64 + d) * p.npad + te] = o[e];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (EPI == SAT_EPI_SWIGLU) {
+        // window columns 0..31 = value, 32..63 = gate of output columns glu_col0 + (0..31)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rr = pass * 8 + (lane >> 3), cc = (lane & 7) * 4;
+            const int m = mrow0 + rr;
+            const int n = glu_col0 + cc;
+            f32x4 xv = *(const f32x4*)(ep + rr * 64 + cc);
+            f32x4 gv = *(const f32x4*)(ep + rr * 64 + 32 + cc);
+            if (m < p.M && n < glu_f) {
+                if (p.bias) {
+                    xv += *(const f32x4*)(p.bias + n);
+                    gv += *(const f32x4*)(p.bias + glu_f + n);
+                }
+                if (p.pre) {
+                    sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + n, xv);
+                    sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + glu_f + n, gv);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = xv[e] * gv[e] * sat_gemm_sigmoid(gv[e]);
+                sat_store4<F32OUT>(p.C, (long long)m * p.ldc + n, o);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int rr = pass * 4 + (lane >> 4), cc = (lane & 15) * 4;
+            const int m = mrow0 + rr;
+            const int n = nwin + cc;
+            f32x4 v = *(const f32x4*)(ep + rr * 64 + cc);
+            if (m < p.M && n < p.N) {
+                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                if constexpr (EPI == SAT_EPI_GATE_RES) {
+                    const f32x4 g = sat_load4<F32OUT>(p.gate, (long long)(m / p.rows_per_gate) * p.ldg + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= sat_gemm_sigmoid(1.0f - g[e]);
+                }
+                if constexpr (EPI == SAT_EPI_RES || EPI == SAT_EPI_GATE_RES) v += sat_load4<F32OUT>(p.res, (long long)m * p.ldr + n);
+                if constexpr (EPI == SAT_EPI_QKV) {
+                    // fused to_qkv epilogue (transformer.py:481-507): split heads, partial rotary on q and k (first 32 dims
+                    // of each 64-dim head, rotate_half pairs (d, d+16)), and emit the attention kernel's operand planes:
+                    // q, k row-major (nb, H, Np, 64), v transposed (nb, H, 64, Np).  A 64-column window is exactly one head.
+                    const int hd = p.heads * 64;
+                    const int which = n / hd + p.sec0, h = (n % hd) >> 6, d = n & 63;     // 0 q, 1 k, 2 v
+                    const int b = m / p.ntok, t = m % p.ntok;
+                    if (p.rope_cs && d < 32) {
+                        // partner column d ^ 16 lives 4 lanes away in this row's 16-lane group
+                        f32x4 o;
+                        const f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
+                        const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float c = cs[2 * e], s = cs[2 * e + 1];
+                            o[e] = (d < 16) ? v[e] * c - pv[e] * s : v[e] * c + pv[e] * s;
+                        }
+                        v = o;
+                    }
+                    short* dst = (which == 0) ? p.q_rm : p.k_rm;
+                    sat_store4<false>(dst, (((long long)b * p.heads + h) * p.npad + t) * 64 + d, v);
+                } else {
+                    sat_store4<F32OUT>(p.C, (long long)blockIdx.y * p.M * p.ldc + (long long)m * p.ldc + n, v);
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, int PIPE, int EPI, bool F32OUT, bool FP8 = false>
 __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams p) {
     constexpr int NW = WGM * WGN;
@@ -315,128 +439,210 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
     for (int i = 0; i < TM; ++i) {
         sat_wave_sync();
         const int mrow0 = m0 + wm * (TM * 32) + i * 32;
-        if constexpr (EPI == SAT_EPI_QKV) {
-            // a 64-column window is one head of q, k or v (wave-uniform).  v goes out TRANSPOSED (nb, H, 64, Np): stage the
-            // window as [64 d][33] so that a lane reads 4 consecutive tokens of one head dim (odd stride: conflict free)
-            const int nwin = n0 + wn * 64;
-            if (nwin < p.N && nwin / (p.heads * 64) + p.sec0 == 2) {
+        const int nwin = n0 + wn * 64;
+        if (sat_gemm_window_is_v<EPI>(p, nwin)) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
-                sat_wave_sync();
-                const int h = (nwin % (p.heads * 64)) >> 6;
-#pragma unroll
-                for (int pass = 0; pass < 8; ++pass) {
-                    const int d = pass * 8 + (lane >> 3), tq = (lane & 7) * 4;
-                    const int m = mrow0 + tq;                 // 4 consecutive rows m .. m+3 (may straddle a batch item)
-                    short o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = sat_f32_to_bf16(ep[d * 33 + tq + e]);
-                    const int b = m / p.ntok, t = m - b * p.ntok;
-                    short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
-                    if (m + 3 < p.M && t + 3 < p.ntok) {
-                        // 4 tokens of one batch item: the widest aligned stores their phase allows (ntok is odd for the DiT —
-                        // 1 + 1024 — so every batch item but the first starts its rows off the 8-byte grid)
-                        const uint32_t p01 = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
-                        const uint32_t p12 = (uint32_t)(uint16_t)o[1] | ((uint32_t)(uint16_t)o[2] << 16);
-                        const uint32_t p23 = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-                        if ((t & 3) == 0) {
-                            *(u32x2*)dst = u32x2{p01, p23};
-                        } else if ((t & 1) == 0) {
-                            *(uint32_t*)dst = p01;
-                            *(uint32_t*)(dst + 2) = p23;
-                        } else {
-                            dst[0] = o[0];
-                            *(uint32_t*)(dst + 1) = p12;
-                            dst[3] = o[3];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int me = m + e;
-                            if (me < p.M) {
-                                const int be = me / p.ntok, te = me - be * p.ntok;
-                                p.v_tr[(((long long)be * p.heads + h) * 64 + d) * p.npad + te] = o[e];
-                            }
-                        }
-                    }
-                }
-                continue;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
-        sat_wave_sync();
-        if constexpr (EPI == SAT_EPI_SWIGLU) {
-            // window columns 0..31 = value, 32..63 = gate of output columns glu_tile0 + wn*32 + (0..31)
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int rr = pass * 8 + (lane >> 3), cc = (lane & 7) * 4;
-                const int m = mrow0 + rr;
-                const int n = glu_tile0 + wn * 32 + cc;
-                f32x4 xv = *(const f32x4*)(ep + rr * 64 + cc);
-                f32x4 gv = *(const f32x4*)(ep + rr * 64 + 32 + cc);
-                if (m < p.M && n < glu_f) {
-                    if (p.bias) {
-                        xv += *(const f32x4*)(p.bias + n);
-                        gv += *(const f32x4*)(p.bias + glu_f + n);
-                    }
-                    if (p.pre) {
-                        sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + n, xv);
-                        sat_store4<F32OUT>(p.pre, (long long)m * p.ldp + glu_f + n, gv);
-                    }
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = xv[e] * gv[e] * sat_gemm_sigmoid(gv[e]);
-                    sat_store4<F32OUT>(p.C, (long long)m * p.ldc + n, o);
-                }
-            }
+                for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
         } else {
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int rr = pass * 4 + (lane >> 4), cc = (lane & 15) * 4;
-                const int m = mrow0 + rr;
-                const int n = n0 + wn * 64 + cc;
-                f32x4 v = *(const f32x4*)(ep + rr * 64 + cc);
-                if (m < p.M && n < p.N) {
-                    if (p.bias) v += *(const f32x4*)(p.bias + n);
-                    if constexpr (EPI == SAT_EPI_GATE_RES) {
-                        const f32x4 g = sat_load4<F32OUT>(p.gate, (long long)(m / p.rows_per_gate) * p.ldg + n);
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= sat_gemm_sigmoid(1.0f - g[e]);
-                    }
-                    if constexpr (EPI == SAT_EPI_RES || EPI == SAT_EPI_GATE_RES) v += sat_load4<F32OUT>(p.res, (long long)m * p.ldr + n);
-                    if constexpr (EPI == SAT_EPI_QKV) {
-                        // fused to_qkv epilogue (transformer.py:481-507): split heads, partial rotary on q and k (first 32 dims
-                        // of each 64-dim head, rotate_half pairs (d, d+16)), and emit the attention kernel's operand planes:
-                        // q, k row-major (nb, H, Np, 64), v transposed (nb, H, 64, Np).  A 64-column window is exactly one head.
-                        const int hd = p.heads * 64;
-                        const int which = n / hd + p.sec0, h = (n % hd) >> 6, d = n & 63;     // 0 q, 1 k, 2 v
-                        const int b = m / p.ntok, t = m % p.ntok;
-                        if (p.rope_cs && d < 32) {
-                            // partner column d ^ 16 lives 4 lanes away in this row's 16-lane group
-                            f32x4 o;
-                            const f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
-                            const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
+                for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
+        }
+        sat_wave_sync();
+        sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wn * 32, glu_f, lane);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves, BK = 64, eight barrier intervals per K-step — the large-tile schedule for the projections whose
+// tile count fills the chip (QKV, FF1; FF2 and the weight gradients through split-K).  cdna_hip_programming.md §5 ("256² 8-phase
+// template") is the structure; the 128 x 128 kernel above stays for the few-tile shapes.
+//
+//   * waves as 2 (M) x 4 (N): wave (wr, wc) owns rows wr*128 .. +128 and columns wc*64 .. +64 of the tile (8 x 4 accumulator
+//     tiles of v_mfma_f32_16x16x32_bf16).  A K-step is four PHASES; phase P multiplies the wave's row quadrant P (32 rows) by
+//     all of its 64 columns: 2 x 4 tiles x 2 k-sub-steps = 16 MFMAs.  The B fragments (8 ds_read_b128) are read in phase 0 and
+//     kept; each phase reads its own 4 A fragments.
+//   * a phase = [read section: fragment reads + the LDS-DMA of one HALF-TILE (128 rows x 128 B, 2 instructions per wave)]
+//     s_barrier [lgkmcnt(0), 16 MFMAs at raised priority] s_barrier.  The two wave rows run ONE BARRIER APART (wr = 1 takes an
+//     extra barrier before the loop, wr = 0 one after it): in every interval one wave of each SIMD is in its MFMA section and
+//     the other in its read section, so fragment reads and DMA issue sit beside the partner's matrix work.
+//   * staging order.  Two tile buffers of 64 KB ([A 256 x 128 B | B 256 x 128 B], rows swizzled as in the 128² kernel).
+//     Half-tile H = 4*tile + j, j = 0: B rows 0..127, 1: B rows 128..255, 2: A rows 0..127, 3: A rows 128..255; phase
+//     P' = 4t + P issues H = P' + 6: A of tile t+1 in phases 0, 1 and B of tile t+2 in phases 2, 3 — B(t) was last read in phase
+//     0 of K-step t and A(t-1) in phase 3 of K-step t-1, two or more intervals before the region is overwritten, and every
+//     half-tile has at least two phases to land.  ONE counted wait per K-step: vmcnt(4) in front of the MIDDLE barrier of phase
+//     3 (everything up to tile t+1 has landed, tile t+2's B halves stay in flight); the first read of tile t+1 is two barriers
+//     later for the waiting wave and one barrier after the other wave row's wait.
+// Rows of an M-tail tile beyond M are neither read nor multiplied (a 2050-row activation costs its ninth row tile the DMA
+// stream only).
+template <int EPI, bool F32OUT>
+__global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+    constexpr int WIN = 2 * STAGE / 8;           // per-wave epilogue window (16 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
+    const int wr = wave >> 2, wc = wave & 3;
+    int tm, tn;
+    sat_xcd_tile((int)blockIdx.x, p.ntm, p.ntn, &tm, &tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.klen;
+    const int kend = (kbeg + p.klen < p.K) ? kbeg + p.klen : p.K;
+    const int nk = (kend - kbeg + 63) >> 6;
+    constexpr bool GLU = (EPI == SAT_EPI_SWIGLU);
+    const int glu_f = p.N >> 1, glu_tile0 = tn * (BN / 2);
+    const int mv = p.M - m0 - wr * 128;          // valid rows of this wave's 128 (<= 0: none)
+
+    f32x4 acc[8][4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float c = cs[2 * e], s = cs[2 * e + 1];
-                                o[e] = (d < 16) ? v[e] * c - pv[e] * s : v[e] * c + pv[e] * s;
-                            }
-                            v = o;
-                        }
-                        short* dst = (which == 0) ? p.q_rm : p.k_rm;
-                        sat_store4<false>(dst, (((long long)b * p.heads + h) * p.npad + t) * 64 + d, v);
-                    } else {
-                        sat_store4<F32OUT>(p.C, (long long)blockIdx.y * p.M * p.ldc + (long long)m * p.ldc + n, v);
-                    }
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the wave's two LDS-DMA instructions of half-tile j (compile-time) of K-step kt
+    auto stage_half = [&](int kt, auto jc) {
+        constexpr int J = decltype(jc)::value;
+        char* s = smem + (kt & 1) * STAGE;
+        const int k0 = kbeg + kt * 64;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int piece = (J & 1) * 16 + wave + 8 * u;
+            if constexpr (J >= 2) sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, piece, lane, 0, 0);
+            else sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, piece, lane, glu_f, glu_tile0);
+        }
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+
+    // prologue: tile 0 complete, tile 1's B halves in flight
+    stage_half(0, J0{}); stage_half(0, J1{}); stage_half(0, J2{}); stage_half(0, J3{});
+    if (nk > 1) {
+        stage_half(1, J0{}); stage_half(1, J1{});
+        SAT_WAIT_VMCNT(4);
+    } else {
+        SAT_WAIT_VMCNT(0);
+    }
+    SAT_RAW_BARRIER();
+    if (wr == 1) SAT_RAW_BARRIER();              // the second wave row runs one barrier behind the first
+
+    bf16x8 bfr[4][2], afr[2][2];
+    const int frow = lane & 15, fkc = lane >> 4;
+    auto phase = [&](int t, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const char* As = smem + (t & 1) * STAGE;
+        const char* Bs = As + ABYTES;
+        const bool on0 = P * 32 < mv, on1 = P * 32 + 16 < mv;
+        // ---- read section ----
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 16 + frow, ks * 4 + fkc);
+        }
+        if (on0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) afr[i][ks] = sat_gemm_frag(As, wr * 128 + P * 32 + i * 16 + frow, ks * 4 + fkc);
+        }
+        if constexpr (P == 0) { if (t + 1 < nk) stage_half(t + 1, J2{}); }
+        if constexpr (P == 1) { if (t + 1 < nk) stage_half(t + 1, J3{}); }
+        if constexpr (P == 2) { if (t + 2 < nk) stage_half(t + 2, J0{}); }
+        if constexpr (P == 3) {
+            if (t + 2 < nk) { stage_half(t + 2, J1{}); SAT_WAIT_VMCNT(4); }
+            else { SAT_WAIT_VMCNT(0); }
+        }
+        SAT_RAW_BARRIER();
+        // ---- MFMA section ----
+        SAT_WAIT_LGKM0();
+        SAT_SCHED_FENCE();
+        if (on0) {
+            SAT_SETPRIO(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[P * 2][j] = sat_mfma_16x16x32_bf16(afr[0][ks], bfr[j][ks], acc[P * 2][j]);
+                if (on1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[P * 2 + 1][j] = sat_mfma_16x16x32_bf16(afr[1][ks], bfr[j][ks], acc[P * 2 + 1][j]);
                 }
             }
+            SAT_SETPRIO(0);
         }
+        SAT_SCHED_FENCE();
+        SAT_RAW_BARRIER();
+    };
+    for (int t = 0; t < nk; ++t) {
+        phase(t, std::integral_constant<int, 0>{});
+        phase(t, std::integral_constant<int, 1>{});
+        phase(t, std::integral_constant<int, 2>{});
+        phase(t, std::integral_constant<int, 3>{});
     }
+    if (wr == 0) SAT_RAW_BARRIER();              // pairs with the second wave row's last barrier: every LDS read is done
+    SAT_RAW_BARRIER();
+
+    if (p.alpha) {
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= al;
+    }
+    float* ep = (float*)(smem + wave * WIN);
+    const int nwin = n0 + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i * 32 >= mv) break;                 // (wave-uniform)
+        sat_wave_sync();
+        const int mrow0 = m0 + wr * 128 + i * 32;
+        // D of a 16 x 16 tile: register r of lane l is row 4 * (l >> 4) + r, column l & 15
+        if (sat_gemm_window_is_v<EPI>(p, nwin)) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ep[(j * 16 + frow) * 33 + rr * 16 + 4 * fkc + r] = acc[2 * i + rr][j][r];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ep[(rr * 16 + 4 * fkc + r) * 64 + j * 16 + frow] = acc[2 * i + rr][j][r];
+        }
+        sat_wave_sync();
+        sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wc * 32, glu_f, lane);
+    }
+}
+
+template <int DUMMY = 0>
+static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
+    p.ntm = sat_cdiv(p.M, 256);
+    p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
+    dim3 grid(p.ntm * p.ntn, splits), block(512);
+#define SAT_GEMM256_CASE(E, F)                                                                       \
+    if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
+        SAT_LAUNCH((sat_gemm256_kernel<E, F>), grid, block, stream, p);                              \
+        return sat_check_launch("sat_gemm_bf16 (256x256)");                                          \
+    }
+    SAT_GEMM256_CASE(SAT_EPI_STORE, false)
+    SAT_GEMM256_CASE(SAT_EPI_STORE, true)
+    SAT_GEMM256_CASE(SAT_EPI_RES, false)
+    SAT_GEMM256_CASE(SAT_EPI_RES, true)
+    SAT_GEMM256_CASE(SAT_EPI_GATE_RES, false)
+    SAT_GEMM256_CASE(SAT_EPI_GATE_RES, true)
+    SAT_GEMM256_CASE(SAT_EPI_SWIGLU, false)
+    SAT_GEMM256_CASE(SAT_EPI_SWIGLU, true)
+    SAT_GEMM256_CASE(SAT_EPI_QKV, false)
+#undef SAT_GEMM256_CASE
+    sat_set_error("sat_gemm_bf16: unsupported epilogue / output type");
+    return 1;
 }
 
 static short* g_sat_zero_page = nullptr;   // set by the caller through sat_gemm_bf16's `zeros` argument (caller-owned)
@@ -466,12 +672,14 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 }
 
 // tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
-// 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure)
+// 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure);
+// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 8 intervals per K-step (sat_gemm256_kernel)
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
+    if (tile == 4) return sat_gemm256_launch<>(p, epi, f32out, splits, stream);
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile < 0 || tile > 3) { sat_set_error("sat_gemm: tile must be 0..3"); return 1; }
+    if (tile < 0 || tile > 4) { sat_set_error("sat_gemm: tile must be 0..4"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
 }
 

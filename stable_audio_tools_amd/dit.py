@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _caches
 from . import functional as _fn
 from .linear import Linear
 from .transformer import ContinuousTransformer
@@ -22,8 +23,9 @@ from .transformer import ContinuousTransformer
 
 def clear_inference_caches(module):
     """Drop the no-grad caches under `module` (embedded conditioning / CFG batch in DiffusionTransformer, cross-attention K / V planes in
-    transformer.Attention).  They are keyed on tensor identity + version counters and never go stale; this only releases their memory
-    (e.g. before switching a long-lived model back to training)."""
+    transformer.Attention).  They are keyed on tensor identity + version counters + the invalidation epoch of _caches.py (bumped by every
+    optimizer step / EMA update / `invalidate_weight_caches()`), so they follow every weight update this process can see; this only
+    releases their memory (e.g. before switching a long-lived model back to training)."""
     for m in module.modules():
         for k in ("_kv_ctx", "_kv_key", "_kv_planes", "_cond_src", "_cond_key", "_cond_out", "_cfg_cond"):
             m.__dict__.pop(k, None)
@@ -101,9 +103,10 @@ class DiffusionTransformer(nn.Module):
         """to_cond_embed(cond); in inference the result is cached per (cond object, version, weights version): a sampler passes the
         same conditioning tensor at every step, and returning the same embedded tensor lets every cross-attention layer keep its
         K / V planes (transformer.Attention) instead of re-projecting the context at each step."""
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() or not _caches.trackable(cond):       # inference tensors carry no version counter: no caching
             return self.to_cond_embed(cond)
-        key = (cond._version, cond.dtype, tuple(cond.shape)) + tuple((q._version, q.data_ptr()) for q in self.to_cond_embed.parameters())
+        key = (cond._version, cond.dtype, tuple(cond.shape), _caches.weight_epoch()) \
+            + tuple((q._version, q.data_ptr()) for q in self.to_cond_embed.parameters())
         if getattr(self, "_cond_src", None) is cond and self._cond_key == key:
             return self._cond_out
         out = self.to_cond_embed(cond)
@@ -231,9 +234,10 @@ class DiffusionTransformer(nn.Module):
             # inference: the batched conditioning of one (cond, negative cond, mask) triple is built once, so that _embed_cond and the
             # cross-attention layers see the same tensor object at every sampler step
             srcs = (cond_in, neg_in, negative_cross_attn_mask)
-            vers = tuple((a._version if a is not None else -1) for a in srcs) + (dt,)
+            vers = tuple(_caches.version_of(a) for a in srcs) + (dt,)
             cached = getattr(self, "_cfg_cond", None)
-            if not torch.is_grad_enabled() and cached is not None and all(a is b for a, b in zip(cached[0], srcs)) and cached[1] == vers:
+            can_cache = not torch.is_grad_enabled() and _caches.trackable(*srcs)
+            if can_cache and cached is not None and all(a is b for a, b in zip(cached[0], srcs)) and cached[1] == vers:
                 batch_cond = cached[2]
             else:
                 null = torch.zeros_like(cross_attn_cond)
@@ -243,7 +247,7 @@ class DiffusionTransformer(nn.Module):
                     batch_cond = torch.cat([cross_attn_cond, negative_cross_attn_cond], dim=0)
                 else:
                     batch_cond = torch.cat([cross_attn_cond, null], dim=0)
-                if not torch.is_grad_enabled():
+                if can_cache:
                     self._cfg_cond = (srcs, vers, batch_cond)
         batch_prepend = torch.cat([prepend_cond, torch.zeros_like(prepend_cond)], dim=0) if prepend_cond is not None else None
         out = self._forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), cross_attn_cond=batch_cond,

@@ -35,6 +35,29 @@ def _ops(ops):
     return _ops_mod.get_ops()
 
 
+class DerivedCache:
+    """Derived copies of one conv layer's parameters (folded weight, packed bf16x3 planes, SnakeBeta constants) for the passes in
+    which nothing is trained: each entry is valid for one (storage, torch version counter, invalidation epoch) of its sources
+    (_caches.py explains the epoch).  A frozen pretransform (pretransforms.AutoencoderPretransform: requires_grad_(False).eval())
+    therefore launches no sat_wn_fold / sat_pack / sat_snake_consts after its first call."""
+
+    def __init__(self):
+        self.items = {}
+
+    def get(self, name, sources, make):
+        from . import _caches
+        key = tuple((t.data_ptr(), t._version, t.device) for t in sources if t is not None) + (_caches.weight_epoch(),)
+        hit = self.items.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make())
+            self.items[name] = hit
+        return hit[1]
+
+
+def _cached(cache, name, sources, make):
+    return make() if cache is None else cache.get(name, sources, make)
+
+
 class WeightNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, g, ops=None):
@@ -81,37 +104,43 @@ def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False):
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad)
 
 
-def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None):
+def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None, cache=None):
     """conv1d(snake(x), w) [+bias] [+res]: the bf16x3 split-MFMA kernel (fp32-accurate, csrc/conv1d_bf16x3.hip) where
-    its shape rules allow, else the fp32-MFMA kernel (csrc/conv1d.hip)."""
+    its shape rules allow, else the fp32-MFMA kernel (csrc/conv1d.hip).  cache: DerivedCache of the layer (no-grad / frozen
+    passes only) for the packed planes and the SnakeBeta constants."""
     cout, cin, k = w.shape
     if ops.bf16x3_ok(k, stride, dil):
-        return ops.conv1d_bf16x3(x, ops.pack_bf16x3(w, stride=stride), cout, k, stride, dil, pad, tout=tout, bias=bias,
-                                 snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake)
-    return ops.conv1d(x, ops.pack(w, PACK_CONV_FWD), cout, k, stride, dil, pad, tout=tout, bias=bias, snake=snake, res=res,
-                      tanh_out=tanh_out, dsnake=dsnake)
+        planes = _cached(cache, "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride))
+        sconsts = _cached(cache, "snake", snake, lambda: ops.snake_consts(snake[0], snake[1])) if snake is not None else None
+        return ops.conv1d_bf16x3(x, planes, cout, k, stride, dil, pad, tout=tout, bias=bias,
+                                 snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake, sconsts=sconsts)
+    return ops.conv1d(x, _cached(cache, "pack_fwd32", (w,), lambda: ops.pack(w, PACK_CONV_FWD)), cout, k, stride, dil, pad, tout=tout,
+                      bias=bias, snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake)
 
 
-def _convtr_fwd(ops, x, w, stride, pad, bias=None, snake=None):
+def _convtr_fwd(ops, x, w, stride, pad, bias=None, snake=None, cache=None):
     """conv_transpose1d(snake(x), w (Cin, Cout, K)) [+bias]."""
     cin, cout, k = w.shape
     if ops.bf16x3_ok(k, stride, 1, transposed=True):
-        return ops.convtr1d_bf16x3(x, ops.pack_bf16x3(w, mode=2, stride=stride), cout, k, stride, pad, bias=bias, snake=snake)
-    return ops.convtr1d(x, ops.pack(w, PACK_POLYPHASE, stride), cout, k, stride, pad, bias=bias, snake=snake)
+        planes = _cached(cache, "pack_tr", (w,), lambda: ops.pack_bf16x3(w, mode=2, stride=stride))
+        sconsts = _cached(cache, "snake", snake, lambda: ops.snake_consts(snake[0], snake[1])) if snake is not None else None
+        return ops.convtr1d_bf16x3(x, planes, cout, k, stride, pad, bias=bias, snake=snake, sconsts=sconsts)
+    return ops.convtr1d(x, _cached(cache, "pack_tr32", (w,), lambda: ops.pack(w, PACK_POLYPHASE, stride)), cout, k, stride, pad,
+                        bias=bias, snake=snake)
 
 
 class SnakeConv1dFn(torch.autograd.Function):
     """y = tanh?( conv1d(snake(x; alpha, beta), w, bias, stride, dil, pad) + res )."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None):
+    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None, cache=None):
         ops = _ops(ops)
         x = x.contiguous()
         w = w.contiguous()
         cout, cin, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
         y = _conv_fwd(ops, x, w, stride, dil, pad, bias=bias, snake=snake,
-                      res=res.contiguous() if res is not None else None, tanh_out=tanh_out)
+                      res=res.contiguous() if res is not None else None, tanh_out=tanh_out, cache=cache)
         ctx.ops = ops
         ctx.cfg = (stride, dil, pad, tanh_out, bias is not None, res is not None, alpha is not None)
         ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None)
@@ -140,20 +169,20 @@ class SnakeConv1dFn(torch.autograd.Function):
             dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
         elif ctx.needs_input_grad[0]:
             dx = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], None)
-        return dx, da, db, dw, dbias, dres, None, None, None, None, None
+        return dx, da, db, dw, dbias, dres, None, None, None, None, None, None
 
 
 class SnakeConvTr1dFn(torch.autograd.Function):
     """y = conv_transpose1d(snake(x), w (Cin, Cout, K=2*stride), bias, stride, pad)."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta, w, bias, stride, pad, ops=None):
+    def forward(ctx, x, alpha, beta, w, bias, stride, pad, ops=None, cache=None):
         ops = _ops(ops)
         x = x.contiguous()
         w = w.contiguous()
         cin, cout, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
-        y = _convtr_fwd(ops, x, w, stride, pad, bias=bias, snake=snake)
+        y = _convtr_fwd(ops, x, w, stride, pad, bias=bias, snake=snake, cache=cache)
         ctx.ops = ops
         ctx.cfg = (stride, pad, bias is not None, alpha is not None)
         ctx.save_for_backward(x, alpha, beta, w)
@@ -175,14 +204,17 @@ class SnakeConvTr1dFn(torch.autograd.Function):
             dx, da, db = _conv_fwd(ops, dy, w, stride, 1, pad, dsnake=(x, alpha, beta), tout=x.shape[2])
         elif ctx.needs_input_grad[0]:
             dx = _conv_fwd(ops, dy, w, stride, 1, pad, tout=x.shape[2])
-        return dx, da, db, dw, dbias, None, None, None
+        return dx, da, db, dw, dbias, None, None, None, None
 
 
 class ResidualUnitFn(torch.autograd.Function):
-    """y = x + conv1x1(snake2(conv7_dil(snake1(x))))  — one unit, one saved intermediate."""
+    """y = x + conv1x1(snake2(conv7_dil(snake1(x))))  — one unit, one saved intermediate (h = the k7 conv's output).
+    recompute=True: h is NOT kept; the backward runs the k7 conv again (what the reference's torch.utils.checkpoint around
+    `self.layers` does, autoencoders.py:78-79, minus the k1 conv it also repeats) — half the activation memory of the unit for
+    +1/3 of its forward flops.  caches = (DerivedCache of the k7 conv, of the k1 conv) or None."""
 
     @staticmethod
-    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None):
+    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None):
         ops = _ops(ops)
         x = x.contiguous()
         w1 = w1.contiguous()
@@ -190,28 +222,32 @@ class ResidualUnitFn(torch.autograd.Function):
         c = x.shape[1]
         k1 = w1.shape[2]
         pad = dil * (k1 - 1) // 2
-        h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1))
-        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x)
+        c1, c2 = caches if caches is not None else (None, None)
+        h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1), cache=c1)
+        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2)
         ctx.ops = ops
         ctx.dil = dil
-        ctx.save_for_backward(x, h, a1, b1, w1, a2, b2, w2)
+        ctx.recompute = bool(recompute)
+        ctx.save_for_backward(x, None if recompute else h, a1, b1, w1, a2, b2, w2, bias1 if recompute else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ops = ctx.ops
-        x, h, a1, b1, w1, a2, b2, w2 = ctx.saved_tensors
+        x, h, a1, b1, w1, a2, b2, w2, bias1 = ctx.saved_tensors
         dil = ctx.dil
         c = x.shape[1]
         k1, k2 = w1.shape[2], w2.shape[2]
         pad1 = dil * (k1 - 1) // 2
         t = x.shape[2]
         dy = dy.contiguous()
+        if ctx.recompute:
+            h = _conv_fwd(ops, x, w1, 1, dil, pad1, bias=bias1, snake=(a1, b1))
         dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
         dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2))
         dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
-        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None
+        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None
 
 
 class VaeSampleFn(torch.autograd.Function):

@@ -19,16 +19,9 @@ stored; the data gradient runs on the transposed weight copy and the weight grad
 import torch
 from torch import nn
 
+from . import _caches
 from . import functional as _fn
-
-_WEIGHT_EPOCH = 0
-
-
-def bump_weight_epoch():
-    """Called by the fused optimizer after it rewrote the flat parameter buffer in place (the HIP kernel does not touch
-    torch's version counters): drops every cached low-precision copy of a weight."""
-    global _WEIGHT_EPOCH
-    _WEIGHT_EPOCH += 1
+from ._caches import bump_weight_epoch  # noqa: F401  (re-export: training.FusedAdamW, tests)
 
 
 def _ops():
@@ -52,13 +45,14 @@ def _pad_rows8(t):
 
 class _WeightCache:
     """Low-precision / transposed / split copies of a module's parameters; each entry is valid for one
-    (storage, version, dtype, optimizer epoch) of the tensor it was made from."""
+    (storage, version, dtype, invalidation epoch) of the tensor it was made from — the epoch (_caches.py) covers the writers
+    torch's version counter does not see: the fused optimizer kernel and `.data` updates (ema_pytorch)."""
 
     def __init__(self):
         self.items = {}
 
     def get(self, w, name, make):
-        key = (w.data_ptr(), w._version, w.dtype, w.device, _WEIGHT_EPOCH)
+        key = (w.data_ptr(), w._version, w.dtype, w.device, _caches.weight_epoch())
         hit = self.items.get(name)
         if hit is None or hit[0] != key:
             hit = (key, make())

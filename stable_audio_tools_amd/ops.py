@@ -157,12 +157,12 @@ class SatOps:
         self._f32(out)
         return out
 
-    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake, out=None):
+    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
         if snake is not None:
-            sa, sib = self.snake_consts(snake[0], snake[1])
+            sa, sib = sconsts if sconsts is not None else self.snake_consts(snake[0], snake[1])
         y = self._conv_out(out, b, cout, tout, x.device)
         x2 = a2 = b2 = pda = pdb = None
         if dsnake is not None:
@@ -177,16 +177,17 @@ class SatOps:
         return y
 
     def conv1d_bf16x3(self, x, w_planes, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
-                      tanh_out=False, dsnake=None, out=None):
-        """Same contract as conv1d; `snake` = (log-alpha, log-beta) as everywhere else."""
+                      tanh_out=False, dsnake=None, out=None, sconsts=None):
+        """Same contract as conv1d; `snake` = (log-alpha, log-beta) as everywhere else; sconsts = snake_consts(*snake) if the
+        caller keeps them (frozen layers)."""
         b, cin, tin = x.shape
         if tout is None:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
         rows = self.lib.sat_conv1d_bf16x3_partial_rows(b, tout, k, stride)
         if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
-            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out)
+            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
-                                 bias, snake, res, tanh_out, dsnake, out)
+                                 bias, snake, res, tanh_out, dsnake, out, sconsts)
 
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
@@ -194,12 +195,12 @@ class SatOps:
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
 
-    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None):
+    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
         if snake is not None:
-            sa, sib = self.snake_consts(snake[0], snake[1])
+            sa, sib = sconsts if sconsts is not None else self.snake_consts(snake[0], snake[1])
         rows = self.lib.sat_conv1d_k7_plane_rows(tin, tout, pad)
         c8 = (cin + 7) // 8
         need = 2 * b * c8 * rows * 8
@@ -225,14 +226,14 @@ class SatOps:
         return y
 
     def convtr1d_bf16x3(self, x, w_planes, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
-                        tanh_out=False, dsnake=None):
+                        tanh_out=False, dsnake=None, sconsts=None):
         """Same contract as convtr1d."""
         b, cin, tin = x.shape
         if tout is None:
             tout = (tin - 1) * stride - 2 * pad + k
         rows = self.lib.sat_convtr1d_bf16x3_partial_rows(b, tout, stride, pad)
         return self._bf16x3_call(self.lib.sat_convtr1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, pad),
-                                 bias, snake, res, tanh_out, dsnake)
+                                 bias, snake, res, tanh_out, dsnake, None, sconsts)
 
     def convtr1d(self, x, w_packed, cout, k, stride, pad, tout=None, bias=None, snake=None, res=None,
                  tanh_out=False, dsnake=None):

@@ -86,6 +86,16 @@ def patch_reference(package="stable_audio_tools", import_missing=("models",)):
         handle._saved.append((mod, attr, getattr(mod, attr)))
         setattr(mod, attr, native)
         handle.applied.append((name, attr))
-    if not handle.applied:
+    # the reference's training wrappers keep EMA copies of the native models and update them through `.data` (ema_pytorch:
+    # training/diffusion.py:58, :240-247; training/autoencoders.py:262-270) — invisible to torch's version counters, so every
+    # EMA update also bumps the invalidation epoch of the derived-weight / inference caches (_caches.py)
+    try:
+        from ema_pytorch import EMA
+        from . import _caches
+        _caches.wrap_ema_update(EMA)
+        handle.applied.append(("ema_pytorch", "EMA.update"))
+    except ImportError:
+        handle.skipped.append(("ema_pytorch", "EMA.update"))
+    if not [a for a in handle.applied if a[0] != "ema_pytorch"]:
         raise RuntimeError(f"patch_reference: nothing to patch — is the reference package {package!r} importable?")
     return handle

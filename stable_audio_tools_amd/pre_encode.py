@@ -43,12 +43,12 @@ class PreEncoder:
                 json.dump(details if details is not None else {}, f)
 
     @torch.no_grad()
-    def encode_batch(self, audio, metadata, batch_idx):
+    def encode_batch(self, audio, metadata, batch_idx, **encode_kwargs):
         """audio (B, C, T) on the model's device; metadata: list of B dicts with at least `padding_mask` (T,) (tensor / list).
-        Returns the list of written latent paths."""
+        encode_kwargs go to model.encode (e.g. noise= for a reproducible VAE draw).  Returns the list of written latent paths."""
         if audio.ndim == 4 and audio.shape[0] == 1:                 # pre_encode.py:77-78
             audio = audio[0]
-        latents = self.model.encode(audio).float().cpu().numpy()
+        latents = self.model.encode(audio, **encode_kwargs).float().cpu().numpy()
         paths = []
         for i, latent in enumerate(latents):
             latent_id = f"{self.rank:03d}{batch_idx:06d}{i:04d}"

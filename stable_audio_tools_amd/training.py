@@ -73,6 +73,10 @@ class GradAllReduce:
     mode 'reduce_scatter' : reduce_scatter_tensor + all_gather_into_tensor per bucket (drives every
                             xGMI link of the 8-GPU mesh in both phases; needs bucket % world == 0)
 
+    Contract of overlap=True: exactly ONE backward pass accumulates into each parameter between two finish() calls (the hook of
+    a parameter firing twice raises); with gradient accumulation or several backward() calls per step use overlap=False.  close()
+    removes the hooks.
+
     overlap=True (default): the exchange of a bucket is launched from autograd's post-accumulate hooks the moment the last
     gradient of the bucket has landed, on a side stream fenced by an event — it runs under the backward of the layers
     in front of it (what Lightning's DDP reducer does for the reference, train.py:138).  Gradients land in the flat
@@ -100,7 +104,7 @@ class GradAllReduce:
             e = s_
         self.grad_scale = 1.0 / self.world
         self.overlap = bool(overlap) and self.world > 1
-        self._handles = []
+        self._hooks = []
         self._side = None
         self._fired = [False] * len(self.buckets)
         if self.overlap:
@@ -117,7 +121,7 @@ class GradAllReduce:
                 off = hi
             self._left = list(self._need)
             for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
     def _make_hook(self, i):
         def hook(param):
@@ -127,6 +131,10 @@ class GradAllReduce:
                 param.grad = gv
             for bi in self._of_param[i]:
                 self._left[bi] -= 1
+                if self._left[bi] < 0:
+                    raise RuntimeError("GradAllReduce: a parameter's gradient was accumulated twice before finish() — the overlapped "
+                                       "exchange supports ONE backward pass per step (use overlap=False for gradient accumulation "
+                                       "or several backward() calls into the same parameters)")
                 if self._left[bi] == 0:
                     self._launch(bi)
         return hook
@@ -140,7 +148,7 @@ class GradAllReduce:
             except (RuntimeError, NotImplementedError):                # backend without reduce_scatter (gloo)
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
                 return
-            dist.all_gather_into_tensor(chunk, shard.clone(), group=self.group)
+            dist.all_gather_into_tensor(chunk, shard, group=self.group)     # in place: rank r's input is slice r of the output
         else:
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -175,6 +183,13 @@ class GradAllReduce:
 
     def __call__(self):
         self.finish()
+
+    def close(self):
+        """Remove the autograd hooks (a second step object on the same parameters must not inherit live hooks)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.overlap = False
 
 
 def inverse_lr(step, base_lr, inv_gamma=1.0, power=1.0, warmup=0.0, final_lr=0.0):
@@ -250,6 +265,7 @@ class AutoencoderTrainStep:
         oc = tr["optimizer_configs"]["autoencoder"]
         self.opt, self.base_lr, self.sched = self._make_opt(self.flat, oc, tr, ops, use_ema=bool(tr.get("use_ema", False)))
         lc = tr["loss_configs"]
+        self._reject_unsupported(tr, lc)
         self.w_kl = lc.get("bottleneck", {}).get("weights", {}).get("kl", 1e-6)      # wrapper default: training/autoencoders.py:644-647
         tw = lc.get("time", {}).get("weights", {})
         self.w_l1, self.w_l2 = float(tw.get("l1", 0.0)), float(tw.get("l2", 0.0))    # L1Loss / MSELoss on (reals, decoded): :170-190
@@ -282,6 +298,23 @@ class AutoencoderTrainStep:
         self.global_step = 0
         self.gen_steps = self.disc_steps = 0
         self.use_disc = self.discriminator is not None      # switchable (bench.py times the generator-only step and the real step)
+
+    @staticmethod
+    def _reject_unsupported(tr, lc):
+        """Options of the reference wrapper (training/autoencoders.py:60-160, :367-470) that change the objective and are NOT
+        restated here must not be dropped silently."""
+        bad = []
+        for name in ("mrmel", "hubert"):                    # training/autoencoders.py:196-225
+            if float(lc.get(name, {}).get("weights", {}).get(name, 0.0)) > 0.0:
+                bad.append(f"loss_configs.{name}")
+        for blk in ("spectral", "time", "hubert"):          # LossModule.decay_weight (:170, :223, :231, :238)
+            if float(lc.get(blk, {}).get("decay", 1.0)) != 1.0:
+                bad.append(f"loss_configs.{blk}.decay != 1.0")
+        for key in ("latent_mask_ratio", "force_input_mono", "teacher_model"):
+            if tr.get(key):
+                bad.append(f"training.{key}")
+        if bad:
+            raise NotImplementedError("AutoencoderTrainStep does not restate: " + ", ".join(bad))
 
     @staticmethod
     def _make_opt(flat, oc, tr, ops, use_ema):

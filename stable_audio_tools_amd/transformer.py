@@ -6,21 +6,24 @@ ff.ff.0.proj / ff.ff.2, to_scale_shift_gate, project_in/out, rotary_pos_emb.inv_
 global_cond_embedder).
 
 Execution: LayerNorm(+adaLN modulate), partial rotary, attention (self and GQA cross), SwiGLU and the
-gate/residual epilogue are HIP kernels (csrc/dit_ops.hip, csrc/attention.hip); the plain bias-free /
-biased projections are nn.Linear (hipBLASLt — "plain library GEMMs").  Options of the reference that
+gate/residual epilogue are HIP kernels (csrc/dit_ops.hip, csrc/attention.hip); every projection is
+linear.Linear on the native MFMA GEMM (csrc/gemm.hip) with the head split / rotary / SwiGLU / gate /
+residual work of the block fused into the GEMM epilogues — no library GEMM.  Options of the reference that
 the Stable Audio DiT configs never enable (qk_norm, differential attention, conformer, layer_scale,
 memory tokens, sliding window, causal, flex-attention masks, abs/sinusoidal position embeddings)
 raise NotImplementedError.
 
 Forward AND backward run on the HIP kernels: every fused operator is a torch.autograd.Function whose
 backward calls the matching kernel (LayerNorm+adaLN, rotary transpose, attention dQ / dK,dV with
-probabilities recomputed from the saved log-sum-exp, SwiGLU, gate/residual); the projections'
-gradients are nn.Linear's own (hipBLASLt).  Per-layer activation checkpointing of the reference
-(transformer.py:28-30, :840-845) is not needed at these sizes on 288 GB and is not applied.
+probabilities recomputed from the saved log-sum-exp, SwiGLU, gate/residual); the projections' data and
+weight gradients run on the same native GEMM (linear.LinearFn.backward).  Per-layer activation checkpointing
+of the reference (transformer.py:28-30, :840-845) is optional here: off by default (288 GB of HBM), on with
+`use_checkpointing=True` / `ContinuousTransformer.checkpointing = True` when the batch does not fit.
 """
 import torch
 from torch import nn
 
+from . import _caches
 from . import functional as _fn
 from .linear import Linear, _lowp
 
@@ -79,7 +82,7 @@ class LayerNorm(nn.Module):
         t = getattr(self, name)
         if t.dtype == torch.float32:
             return t.detach()
-        key = (t.data_ptr(), t._version, t.device)
+        key = (t.data_ptr(), t._version, t.device, _caches.weight_epoch())
         hit = self._f32_cache.get(name)
         if hit is None or hit[0] != key:
             hit = (key, t.detach().float().contiguous())
@@ -283,15 +286,20 @@ class Attention(nn.Module):
                 # the conditioning is the same tensor at every sampler step (dit.py caches its embedding): its K / V planes are
                 # computed once per (context object, version, weight version) and kept in this layer's own buffers
                 w = self.to_kv.weight
-                key = (kv_input._version, w._version, w.data_ptr(), bool(self.to_kv.fp8), tuple(kv_input.shape), kv_input.dtype)
-                hit = getattr(self, "_kv_ctx", None) is kv_input and self._kv_key == key
+                can_cache = _caches.trackable(kv_input)       # an inference tensor carries no version counter: project it every call
+                key = (_caches.version_of(kv_input), w._version, w.data_ptr(), _caches.weight_epoch(), bool(self.to_kv.fp8),
+                       tuple(kv_input.shape), kv_input.dtype)
+                hit = can_cache and getattr(self, "_kv_ctx", None) is kv_input and self._kv_key == key
                 if hit:
                     pkv = self._kv_planes
                 else:
                     c2 = kv_input.reshape(b * m, -1)
                     c2 = c2 if c2.dtype == torch.bfloat16 else ops.cast_bf16(c2.contiguous())
                     pkv = self._heads(ops, self.to_kv, c2, None, kv_h, b, m, 1, 2, ("crosskv", id(self)))
-                    self._kv_ctx, self._kv_key, self._kv_planes = kv_input, key, pkv
+                    if can_cache:
+                        self._kv_ctx, self._kv_key, self._kv_planes = kv_input, key, pkv
+                    else:
+                        self.__dict__.pop("_kv_ctx", None)
                 out = ops.attention_planes(pq["q"], pkv["k"], pkv["v_tr"], n, m, self.scale)
             else:
                 cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
@@ -384,6 +392,7 @@ class ContinuousTransformer(nn.Module):
             self.global_cond_embedder = nn.Sequential(Linear(global_cond_dim, dim), nn.SiLU(), Linear(dim, dim * 6))
         self.final_cross_attn_ix = final_cross_attn_ix
         self.sliding_window = None
+        self.checkpointing = False      # opt-in activation recompute per layer (see forward)
         for i in range(depth):
             should_cross_attend = cross_attend and (final_cross_attn_ix == -1 or i <= final_cross_attn_ix)
             self.layers.append(TransformerBlock(dim, dim_heads=dim_heads, cross_attend=should_cross_attend,
@@ -392,7 +401,9 @@ class ContinuousTransformer(nn.Module):
 
     def forward(self, x, prepend_embeds=None, global_cond=None, return_info=False, use_checkpointing=True,
                 exit_layer_ix=None, **kwargs):
-        """use_checkpointing is accepted for API parity; activations are kept resident (288 GB HBM)."""
+        """Per-layer activation checkpointing (reference: transformer.py:28-30, :840-845, always on in training) is OPTIONAL here:
+        `self.checkpointing` (default False — a depth-24 N = 6145 step keeps 36 GiB at batch 1 on a 288 GB part) AND the reference's
+        `use_checkpointing` kwarg must both be true; results are identical either way (tests/test_boundary.py)."""
         model_dtype = next(self.parameters()).dtype
         x = x.to(model_dtype)
         info = {"hidden_states": []}
@@ -404,8 +415,12 @@ class ContinuousTransformer(nn.Module):
         if global_cond is not None and self.global_cond_embedder is not None:
             global_cond = self.global_cond_embedder(global_cond)
         x = x.contiguous()
+        ckpt = self.checkpointing and use_checkpointing and torch.is_grad_enabled()
         for layer_ix, layer in enumerate(self.layers):
-            x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, **kwargs)
+            if ckpt:
+                x = torch.utils.checkpoint.checkpoint(layer, x, rotary_pos_emb=rotary, global_cond=global_cond, use_reentrant=False, **kwargs)
+            else:
+                x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, **kwargs)
             if return_info:
                 info["hidden_states"].append(x)
             if exit_layer_ix is not None and layer_ix == exit_layer_ix:
