@@ -264,6 +264,10 @@ int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long 
  * y0 = c0x*x + c0v*v (x NULL: y0 = v); y1 = c1x*x + c1v*v (optional).  dtype 0 fp32 / 1 bf16. */
 int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
                  float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream);
+/* The same with (c0x, c0v, c1x, c1v) read from device memory (coef[4], fp32): the launch can be frozen in a HIP graph and replayed
+ * with new sampler coefficients (inference/sampling.py:254-307 changes them every step). */
+int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
+                     float phi, const float* coef, int dtype, void* stream);
 
 /* Complex spectrogram of the MS-STFT discriminator — models/encodec.py:73-76, :97-102 (torchaudio Spectrogram: periodic Hann,
  * normalized by ||w||_2, center = False, onesided, power = None; real / imaginary parts concatenated on the channel axis, axes

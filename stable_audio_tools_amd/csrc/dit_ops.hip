@@ -536,11 +536,13 @@ struct SatCfgParams {
     void* y1;
     int B, C, T, ncond;
     float scale, phi, c0x, c0v, c1x, c1v;
+    const float* coef;    // device (c0x, c0v, c1x, c1v) overriding the by-value ones (HIP-graph replay: the launch is frozen)
 };
 template <typename T>
 __global__ void __launch_bounds__(256) sat_cfg_step_kernel(SatCfgParams p) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)p.B * p.T) return;
+    if (p.coef) { p.c0x = p.coef[0]; p.c0v = p.coef[1]; p.c1x = p.coef[2]; p.c1v = p.coef[3]; }
     const int b = (int)(i / p.T), t = (int)(i - (long long)b * p.T);
     const long long cbase = (long long)b * p.C * p.T + t;
     const long long ubase = cbase + (long long)p.B * p.C * p.T;
@@ -577,9 +579,22 @@ extern "C" int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1,
     if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { sat_set_error("sat_cfg_step: bad shape"); return 1; }
     if (dtype != 0 && dtype != 1) { sat_set_error("sat_cfg_step: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
     if (!out2 || !y0 || (y1 && !x)) { sat_set_error("sat_cfg_step: missing buffer"); return 1; }
-    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, c0x, c0v, c1x, c1v};
+    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, c0x, c0v, c1x, c1v, nullptr};
     const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
     if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
     else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_cfg_step");
+}
+// The same with the four update coefficients read from DEVICE memory (coef[4] fp32): a sampler step captured into a HIP graph is
+// replayed with new coefficients by rewriting that buffer (sampling.GraphedDenoiser).
+extern "C" int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
+                                float phi, const float* coef, int dtype, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { sat_set_error("sat_cfg_step_dev: bad shape"); return 1; }
+    if (dtype != 0 && dtype != 1) { sat_set_error("sat_cfg_step_dev: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
+    if (!out2 || !y0 || !x || !coef) { sat_set_error("sat_cfg_step_dev: missing buffer"); return 1; }
+    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, 0.f, 1.f, 0.f, 0.f, coef};
+    const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
+    if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_cfg_step_dev");
 }

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
-    static_assert(TN == 2, "epilogue window is 64 columns wide");
+    static_assert(TN == 2 || TN == 4, "epilogue windows are 64 columns wide (one or two per wave)");
     constexpr int WIN = NSTAGE * STAGE / NW;     // per-wave epilogue window
     constexpr int G = (BM + BN) / 8 / NW;        // LDS-DMA instructions per wave per tile
     static_assert(WIN >= 64 * 33 * 4, "epilogue window (32 x 64 fp32, or 64 x 33 transposed) must fit");
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
         // goes out behind each k-substep's MFMAs instead of all of them in one burst right after the barrier (32 back-to-back
         // 1-KiB requests per workgroup stall the issuing waves on the memory pipeline's queue).  Slot of tile kt is drained at
         // the hand-over of K-step kt; tile kt+NSTAGE is issued in quarters: one right there, three during K-step kt+1.
-        static_assert(NSTAGE >= 3, "spread refill needs a third slot");
+        static_assert(NSTAGE >= 2, "spread refill: tile kt+NSTAGE-1 goes to the slot drained at the previous hand-over");
 #pragma unroll
         for (int s = 0; s < NSTAGE; ++s)
             if (s < nk) stage(s, s);
@@ -437,53 +437,59 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
     const int hi = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        sat_wave_sync();
-        const int mrow0 = m0 + wm * (TM * 32) + i * 32;
-        const int nwin = n0 + wn * 64;
-        if (sat_gemm_window_is_v<EPI>(p, nwin)) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int jh = 0; jh < TN / 2; ++jh) {          // 64-column windows of the wave's TN * 32 columns
+            sat_wave_sync();
+            const int mrow0 = m0 + wm * (TM * 32) + i * 32;
+            const int nwin = n0 + wn * (TN * 32) + jh * 64;
+            if (sat_gemm_window_is_v<EPI>(p, nwin)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
-        } else {
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                    for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][2 * jh + j][r];
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][2 * jh + j][r];
+            }
+            sat_wave_sync();
+            sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wn * (TN * 16) + jh * 32, glu_f, lane);
         }
-        sat_wave_sync();
-        sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wn * 32, glu_f, lane);
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves, BK = 64, eight barrier intervals per K-step — the large-tile schedule for the projections whose
-// tile count fills the chip (QKV, FF1; FF2 and the weight gradients through split-K).  cdna_hip_programming.md §5 ("256² 8-phase
-// template") is the structure; the 128 x 128 kernel above stays for the few-tile shapes.
+// 256 x 256 tile, 8 waves, BK = 64, two wave rows ONE BARRIER APART — the large-tile schedule for the projections whose tile
+// count fills the chip (QKV, FF1 and their data gradients).  cdna_hip_programming.md §5 ("256² 8-phase template") is the
+// structure, here with 32 x 32 x 16 MFMAs and four barrier intervals per K-step; the 128 x 128 kernel above stays for the
+// few-tile shapes (profiles/EXPERIMENTS.md round 3 has the A/B numbers, incl. the 16 x 16 x 32 / eight-interval and the
+// four-wave 128 x 128-per-wave variants that lost).
 //
-//   * waves as 2 (M) x 4 (N): wave (wr, wc) owns rows wr*128 .. +128 and columns wc*64 .. +64 of the tile (8 x 4 accumulator
-//     tiles of v_mfma_f32_16x16x32_bf16).  A K-step is four PHASES; phase P multiplies the wave's row quadrant P (32 rows) by
-//     all of its 64 columns: 2 x 4 tiles x 2 k-sub-steps = 16 MFMAs.  The B fragments (8 ds_read_b128) are read in phase 0 and
-//     kept; each phase reads its own 4 A fragments.
-//   * a phase = [read section: fragment reads + the LDS-DMA of one HALF-TILE (128 rows x 128 B, 2 instructions per wave)]
-//     s_barrier [lgkmcnt(0), 16 MFMAs at raised priority] s_barrier.  The two wave rows run ONE BARRIER APART (wr = 1 takes an
-//     extra barrier before the loop, wr = 0 one after it): in every interval one wave of each SIMD is in its MFMA section and
-//     the other in its read section, so fragment reads and DMA issue sit beside the partner's matrix work.
-//   * staging order.  Two tile buffers of 64 KB ([A 256 x 128 B | B 256 x 128 B], rows swizzled as in the 128² kernel).
-//     Half-tile H = 4*tile + j, j = 0: B rows 0..127, 1: B rows 128..255, 2: A rows 0..127, 3: A rows 128..255; phase
-//     P' = 4t + P issues H = P' + 6: A of tile t+1 in phases 0, 1 and B of tile t+2 in phases 2, 3 — B(t) was last read in phase
-//     0 of K-step t and A(t-1) in phase 3 of K-step t-1, two or more intervals before the region is overwritten, and every
-//     half-tile has at least two phases to land.  ONE counted wait per K-step: vmcnt(4) in front of the MIDDLE barrier of phase
-//     3 (everything up to tile t+1 has landed, tile t+2's B halves stay in flight); the first read of tile t+1 is two barriers
-//     later for the waiting wave and one barrier after the other wave row's wait.
+//   * waves as 2 (M) x 4 (N): wave (wr, wc) owns rows wr*128 .. +128 and columns wc*64 .. +64 of the tile (4 x 2 accumulator
+//     tiles of v_mfma_f32_32x32x16_bf16, the full-rate shape: 32 cycles per instruction and SIMD).  A K-step is TWO phases;
+//     phase P multiplies the wave's row half P (64 rows) by its 64 columns: 2 x 2 tiles x 4 k-sub-steps = 16 MFMAs = 512
+//     matrix-pipe cycles.
+//   * a phase = [read section: fragment reads, the LDS-DMA of two HALF-TILES (128 rows x 128 B each, 4 instructions per wave),
+//     lgkmcnt(0)] s_barrier [16 MFMAs at raised priority] s_barrier.  wr = 1 takes an extra barrier before the loop and wr = 0
+//     one after it: in every interval one wave of each SIMD is in its MFMA section and its partner in its read section, so
+//     fragment reads and DMA issue sit beside the partner's matrix work.
+//   * staging.  Two tile buffers of 64 KB ([A 256 x 128 B | B 256 x 128 B], rows swizzled as in the 128² kernel).  Phase 0 reads
+//     the B fragments (8 ds_read_b128, kept for both phases) and its 8 A fragments and issues A of tile t+1; phase 1 reads its A
+//     fragments and issues B of tile t+2, then waits vmcnt(4) (tile t+1 complete, B(t+2) in flight) in front of its middle
+//     barrier: the first read of tile t+1 is two barriers later for the waiting wave and one barrier after the other wave row's
+//     wait.  Fragment reads are retired BEFORE the middle barrier, so a region is overwritten by LDS-DMA at least one barrier
+//     after the last read of it completed (B(t): read in phase 0 of K-step t, overwritten from phase 1; A(t-1): read in phase 1
+//     of K-step t-1, overwritten from phase 0 of K-step t).
+//   * DMA source addresses: a per-lane offset (row, swizzled k-chunk) computed once + a wave-uniform base advanced by 128 B per
+//     K-step (one VALU add per instruction); the K tail (K % 64 != 0) takes the general path.
 // Rows of an M-tail tile beyond M are neither read nor multiplied (a 2050-row activation costs its ninth row tile the DMA
 // stream only).
 template <int EPI, bool F32OUT>
 __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
-    constexpr int WIN = 2 * STAGE / 8;           // per-wave epilogue window (16 KiB)
+    constexpr int WIN = 2 * STAGE / 8;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
@@ -498,31 +504,65 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     const int glu_f = p.N >> 1, glu_tile0 = tn * (BN / 2);
     const int mv = p.M - m0 - wr * 128;          // valid rows of this wave's 128 (<= 0: none)
 
-    f32x4 acc[8][4];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // the wave's two LDS-DMA instructions of half-tile j (compile-time) of K-step kt
-    auto stage_half = [&](int kt, auto jc) {
-        constexpr int J = decltype(jc)::value;
+    // per-lane source offsets (bytes, relative to the operand's base pointer) of this wave's 4 A pieces and 4 B pieces per tile:
+    // piece q of half h is tile rows (h*16 + wave + 8*q) * 8 .. +8; lane -> (row, 16-byte slot holding k-chunk slot ^ ((row>>1)&7))
+    long long aoff[4], boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = (q >> 1) * 16 + wave + 8 * (q & 1);
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int ga = m0 + r;
+        ga = ga < p.M ? ga : p.M - 1;
+        aoff[q] = ((long long)ga * p.lda + c * 8) * 2;
+        int gb;
+        if constexpr (GLU) gb = ((r >> 5) & 1) * glu_f + glu_tile0 + (r >> 6) * 32 + (r & 31);
+        else gb = n0 + r;
+        gb = gb < p.N ? gb : p.N - 1;
+        boff[q] = ((long long)gb * p.ldb + c * 8) * 2;
+    }
+    // half-tiles: AH = 0 / 1 -> A rows 0..127 / 128..255 (pieces q = 2*AH, 2*AH+1); same for B
+    auto stage_a = [&](int kt) {
         char* s = smem + (kt & 1) * STAGE;
         const int k0 = kbeg + kt * 64;
+        const bool full = k0 + 64 <= kend;
+        if (full) {
+            const char* base = (const char*)p.A + (long long)k0 * 2;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int piece = (J & 1) * 16 + wave + 8 * u;
-            if constexpr (J >= 2) sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, piece, lane, 0, 0);
-            else sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, piece, lane, glu_f, glu_tile0);
+            for (int q = 0; q < 4; ++q) sat_glds16(base + aoff[q], s + ((q >> 1) * 16 + wave + 8 * (q & 1)) * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, (q >> 1) * 16 + wave + 8 * (q & 1), lane, 0, 0);
         }
     };
-    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
-    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+    auto stage_b = [&](int kt) {
+        char* s = smem + (kt & 1) * STAGE + ABYTES;
+        const int k0 = kbeg + kt * 64;
+        const bool full = k0 + 64 <= kend;
+        if (full) {
+            const char* base = (const char*)p.B + (long long)k0 * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sat_glds16(base + boff[q], s + ((q >> 1) * 16 + wave + 8 * (q & 1)) * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s, p.zeros, (q >> 1) * 16 + wave + 8 * (q & 1), lane, glu_f, glu_tile0);
+        }
+    };
 
-    // prologue: tile 0 complete, tile 1's B halves in flight
-    stage_half(0, J0{}); stage_half(0, J1{}); stage_half(0, J2{}); stage_half(0, J3{});
+    // prologue: tile 0 complete, tile 1's B in flight
+    stage_b(0); stage_a(0);
     if (nk > 1) {
-        stage_half(1, J0{}); stage_half(1, J1{});
+        stage_b(1);
         SAT_WAIT_VMCNT(4);
     } else {
         SAT_WAIT_VMCNT(0);
@@ -530,46 +570,46 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     SAT_RAW_BARRIER();
     if (wr == 1) SAT_RAW_BARRIER();              // the second wave row runs one barrier behind the first
 
-    bf16x8 bfr[4][2], afr[2][2];
-    const int frow = lane & 15, fkc = lane >> 4;
+    bf16x8 bfr[2][4], afr[2][4];
+    const int frow = lane & 31, fkc = lane >> 5;
     auto phase = [&](int t, auto pc) {
         constexpr int P = decltype(pc)::value;
         const char* As = smem + (t & 1) * STAGE;
         const char* Bs = As + ABYTES;
-        const bool on0 = P * 32 < mv, on1 = P * 32 + 16 < mv;
+        const bool on0 = P * 64 < mv, on1 = P * 64 + 32 < mv;
         // ---- read section ----
         if constexpr (P == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 16 + frow, ks * 4 + fkc);
+                for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, ks * 2 + fkc);
         }
         if (on0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) afr[i][ks] = sat_gemm_frag(As, wr * 128 + P * 32 + i * 16 + frow, ks * 4 + fkc);
+            for (int ks = 0; ks < 4; ++ks) afr[0][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + frow, ks * 2 + fkc);
         }
-        if constexpr (P == 0) { if (t + 1 < nk) stage_half(t + 1, J2{}); }
-        if constexpr (P == 1) { if (t + 1 < nk) stage_half(t + 1, J3{}); }
-        if constexpr (P == 2) { if (t + 2 < nk) stage_half(t + 2, J0{}); }
-        if constexpr (P == 3) {
-            if (t + 2 < nk) { stage_half(t + 2, J1{}); SAT_WAIT_VMCNT(4); }
+        if (on1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) afr[1][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + 32 + frow, ks * 2 + fkc);
+        }
+        if constexpr (P == 0) { if (t + 1 < nk) stage_a(t + 1); }
+        if constexpr (P == 1) {
+            if (t + 2 < nk) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
             else { SAT_WAIT_VMCNT(0); }
         }
+        SAT_WAIT_LGKM0();
         SAT_RAW_BARRIER();
         // ---- MFMA section ----
-        SAT_WAIT_LGKM0();
         SAT_SCHED_FENCE();
         if (on0) {
             SAT_SETPRIO(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[P * 2][j] = sat_mfma_16x16x32_bf16(afr[0][ks], bfr[j][ks], acc[P * 2][j]);
+                for (int j = 0; j < 2; ++j) acc[P * 2][j] = sat_mfma_32x32x16_bf16(afr[0][ks], bfr[j][ks], acc[P * 2][j]);
                 if (on1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[P * 2 + 1][j] = sat_mfma_16x16x32_bf16(afr[1][ks], bfr[j][ks], acc[P * 2 + 1][j]);
+                    for (int j = 0; j < 2; ++j) acc[P * 2 + 1][j] = sat_mfma_32x32x16_bf16(afr[1][ks], bfr[j][ks], acc[P * 2 + 1][j]);
                 }
             }
             SAT_SETPRIO(0);
@@ -580,8 +620,6 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     for (int t = 0; t < nk; ++t) {
         phase(t, std::integral_constant<int, 0>{});
         phase(t, std::integral_constant<int, 1>{});
-        phase(t, std::integral_constant<int, 2>{});
-        phase(t, std::integral_constant<int, 3>{});
     }
     if (wr == 0) SAT_RAW_BARRIER();              // pairs with the second wave row's last barrier: every LDS read is done
     SAT_RAW_BARRIER();
@@ -589,39 +627,36 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     if (p.alpha) {
         const float al = *p.alpha;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] *= al;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= al;
     }
     float* ep = (float*)(smem + wave * WIN);
+    const int hi = lane >> 5, col = lane & 31;
     const int nwin = n0 + wc * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i * 32 >= mv) break;                 // (wave-uniform)
         sat_wave_sync();
         const int mrow0 = m0 + wr * 128 + i * 32;
-        // D of a 16 x 16 tile: register r of lane l is row 4 * (l >> 4) + r, column l & 15
         if (sat_gemm_window_is_v<EPI>(p, nwin)) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ep[(j * 16 + frow) * 33 + rr * 16 + 4 * fkc + r] = acc[2 * i + rr][j][r];
+                for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
         } else {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ep[(rr * 16 + 4 * fkc + r) * 64 + j * 16 + frow] = acc[2 * i + rr][j][r];
+                for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
         }
         sat_wave_sync();
         sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wc * 32, glu_f, lane);
     }
 }
 
-template <int DUMMY = 0>
 static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
@@ -673,9 +708,9 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 
 // tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
 // 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure);
-// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 8 intervals per K-step (sat_gemm256_kernel)
+// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel)
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
-    if (tile == 4) return sat_gemm256_launch<>(p, epi, f32out, splits, stream);
+    if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);

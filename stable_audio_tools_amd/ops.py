@@ -614,6 +614,13 @@ class SatOps:
         b = nb2 // ncond
         y0 = torch.empty(b, c, t, dtype=out2.dtype, device=out2.device)
         y1 = torch.empty_like(y0) if (want_second and x is not None) else None
+        if isinstance(coef, torch.Tensor):        # device coefficients (HIP-graph replay): 4 fp32 values read by the kernel
+            self._f32(coef)
+            if coef.numel() != 4 or x is None:
+                raise ValueError("cfg_step: device coef must hold (c0x, c0v, c1x, c1v) and needs x")
+            self._chk(self.lib.sat_cfg_step_dev(_ptr(out2), _ptr(x), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale), float(scale_phi),
+                                                _ptr(coef), dt, self._stream(out2)))
+            return (y0, y1) if y1 is not None else y0
         c0x, c0v, c1x, c1v = coef if coef is not None else (0.0, 1.0, 0.0, 0.0)
         self._chk(self.lib.sat_cfg_step(_ptr(out2), _ptr(x), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale), float(scale_phi),
                                         float(c0x), float(c0v), float(c1x), float(c1v), dt, self._stream(out2)))
@@ -621,7 +628,7 @@ class SatOps:
 
     # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
     EPI_STORE, EPI_RES, EPI_GATE_RES, EPI_SWIGLU = 0, 1, 2, 3
-    gemm_tile = None     # None: pick per shape; 0 = 128x128 (4 waves), 1 = 256x128 (8 waves)
+    gemm_tile = None     # None: pick per shape; 0 = 128x128 (4 waves, 2 workgroups per CU), 1..3 = experiments, 4 = 256x256 (8 waves)
 
     def _zeros_page(self, device):
         z = getattr(self, "_zpage", None)
@@ -630,9 +637,14 @@ class SatOps:
             self._zpage = z
         return z
 
-    def _pick_tile(self, m, n):
+    def _pick_tile(self, m, n, splits=1):
+        """256 x 256 tiles (sat_gemm256_kernel) when they fill most of the 256 CUs, 128 x 128 (two workgroups per CU) otherwise —
+        measured at M = 2050 / 4100 (profiles/r03_gemm_bench.jsonl): QKV 49.7 -> 42.6 us, FF1 + SwiGLU 111 -> 93 us; the few-tile
+        projections (1536 -> 1536, 6144 -> 1536) stay on the small tile (+ split-K)."""
         if self.gemm_tile is not None:
             return self.gemm_tile
+        if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
+            return 4
         return 0
 
     def gemm_bf16(self, a, b, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
@@ -669,7 +681,7 @@ class SatOps:
                                          _ptr(res), res.stride(0) if res is not None else 0,
                                          _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_gate,
                                          _ptr(pre), n, _ptr(self._zeros_page(a.device)), m, n, k, epilogue, int(f32), splits,
-                                         self._pick_tile(m, n), self._stream(a)))
+                                         self._pick_tile(m, nout if epilogue == self.EPI_SWIGLU else n, splits), self._stream(a)))
         if splits > 1:
             c = self._reduce_rows(c.view(splits, m * nout), splits, m * nout).view(m, nout)
         return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
@@ -695,7 +707,7 @@ class SatOps:
             slabs = torch.empty(splits, m, n, dtype=torch.float32, device=a.device)
             self._planes[key] = slabs
         self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(slabs), n, None, None, 0, None, 0, 0, None, 0,
-                                         _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits, self._pick_tile(m, n),
+                                         _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits, self._pick_tile(m, n, splits),
                                          self._stream(a)))
         c = out if out is not None else torch.empty(m, n, dtype=out_dtype, device=a.device)
         if bias is not None:

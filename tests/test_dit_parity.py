@@ -244,7 +244,7 @@ def test_sampler_v_ddim_gpu(hip, use_graph):
     _sampler_case("cuda", use_graph)
 
 
-def _euler_case(device):
+def _euler_case(device, use_graph=False):
     """Rectified-flow Euler sampler (reference inference/sampling.py:98-135) with the update fused into the guidance kernel,
     vs the same loop around the CPU oracle's forward."""
     from stable_audio_tools_amd.sampling import sample_discrete_euler
@@ -255,7 +255,7 @@ def _euler_case(device):
               prepend_cond_mask=inp.get("prepend_cond_mask"))
     dkw = {k: (v.to(device) if v is not None else None) for k, v in kw.items()}
     steps = 4
-    out = sample_discrete_euler(model, inp["x"].to(device), steps, cfg_scale=3.0, scale_phi=0.5, **dkw)
+    out = sample_discrete_euler(model, inp["x"].to(device), steps, use_graph=use_graph, cfg_scale=3.0, scale_phi=0.5, **dkw)
     x = inp["x"]
     t = torch.linspace(1.0, 0, steps + 1)
     for tc, tp in zip(t[:-1], t[1:]):
@@ -270,5 +270,6 @@ def test_sampler_euler_fused_update_simulator(emu_modules):
 
 
 @pytest.mark.gpu
-def test_sampler_euler_fused_update_gpu(hip):
-    _euler_case("cuda")
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sampler_euler_fused_update_gpu(hip, use_graph):
+    _euler_case("cuda", use_graph)

@@ -24,7 +24,8 @@ def timeit(fn, reps=30, warm=5):
     return s.elapsed_time(e) / reps * 1e3   # us
 
 
-TILES = tuple(int(t) for t in os.environ.get('SAT_TILES', '0,1,2,3').split(','))
+TILES = tuple(int(t) for t in os.environ.get('SAT_TILES', '0,4').split(','))
+SPLITS = tuple(int(t) for t in os.environ.get('SAT_SPLITS', '2,3,4,5,6').split(','))
 
 
 def main():
@@ -51,6 +52,9 @@ def main():
                     row[f"native_t{tile}_res_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, res=res, epilogue=ops.EPI_RES)), 1)
                 if name == "ff1":
                     row[f"native_t{tile}_swiglu_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, epilogue=ops.EPI_SWIGLU)), 1)
+                if name in ("out", "ff2"):
+                    for sp in SPLITS:      # split-K slabs + fused bias / residual epilogue kernel
+                        row[f"native_t{tile}_splitk{sp}_res_us"] = round(timeit(lambda: ops.gemm_bf16_splitk(a, b, sp, res=res)), 1)
             ops.gemm_tile = None
             print(json.dumps(row), flush=True)
 
