@@ -96,6 +96,16 @@ int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, int rows, c
                              const float* res, float* y, const float* x2, const float* alpha2, const float* beta2, float* part_da,
                              float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int tanh_out,
                              void* stream);
+/* Third-generation kernel for the same convs (csrc/conv1d_bf16x3_k7q.h: 16-channel K-chunks with one tap per MFMA k-step, two wave rows
+ * one barrier apart), 5 <= K <= 7: same arguments, the weight planes packed by sat_pack_weights_k7q
+ * ([chunk of 16 in-channels][tap][8-channel group][out channel padded to 128][8]; mode 0 = conv weight [out][in][K], mode 1 = the
+ * data-gradient of a stride-1 conv).  sat_pack_weights_k7q_size = elements per plane (-1: unsupported). */
+long long sat_pack_weights_k7q_size(int D0, int D1, int K, int mode);
+int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream);
+int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo, const float* bias,
+                             const float* res, float* y, const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                             float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int tanh_out,
+                             void* stream);
 int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
 int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
 long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);

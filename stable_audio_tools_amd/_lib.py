@@ -32,6 +32,9 @@ SIGNATURES = {
     "sat_conv1d_k7_plane_rows": (_I, [_I] * 3),
     "sat_conv1d_k7_planes": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "sat_conv1d_bf16x3_planes": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),
+    "sat_conv1d_bf16x3_planesq": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),
+    "sat_pack_weights_k7q": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sat_pack_weights_k7q_size": (_L, [_I, _I, _I, _I]),
     "sat_convtr1d_bf16x3_partial_rows": (_I, [_I] * 4),
     "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I, _I]),

@@ -38,6 +38,7 @@ struct SatConvBfLaunch {
     const short* xp_hi = nullptr;
     const short* xp_lo = nullptr;
     int xp_rows = 0, xp_c8 = 0;
+    int wq = 0;            // conv1d_bf16x3_k7q.h: the weight planes are in sat_pack_weights_k7q layout ([chunk16][tap][group][co][8])
 };
 
 SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
@@ -482,10 +483,12 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
 
 #include "conv1d_bf16x3_k7.h"     // the pipelined kernel of the (8, 1) plan
 #include "conv1d_bf16x3_k7p.h"    // the same plan fed from pre-split activation planes by LDS-DMA
+#include "conv1d_bf16x3_k7q.h"    // planes, 16-channel chunks (one tap per MFMA k-step), two wave rows one barrier apart
 
 static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
     if (pl.ng == 8 && pl.cs == 1 && a.sin_log2 == 0 && a.sout_log2 == 0) {
-        if (a.xp_hi) sat_bf_launch_k7p(a, stream);
+        if (a.xp_hi && a.wq) sat_bf_launch_k7q(a, stream);
+        else if (a.xp_hi) sat_bf_launch_k7p(a, stream);
         else sat_bf_launch_k7(a, stream);
         return sat_check_launch(what);
     }
@@ -579,6 +582,39 @@ extern "C" int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, 
     a.xp_rows = rows;
     a.xp_c8 = sat_cdiv(Cin, 8);
     return sat_bf_launch("sat_conv1d_bf16x3_planes", a, pl, stream);
+}
+// The same with the weights packed by sat_pack_weights_k7q (mode 0, or mode 1 for a data-gradient): conv1d_bf16x3_k7q.h, 5 <= K <= 7.
+extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo,
+                                         const float* bias, const float* res, float* y, const float* x2, const float* alpha2,
+                                         const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
+                                         int K, int dil, int pad, int tanh_out, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3_planesq: empty shape"); return 1; }
+    if (K < 5 || K > SAT_K7Q_TAPS || dil < 1 || (K - 1) * dil > 62) {
+        sat_set_error("sat_conv1d_bf16x3_planesq: needs stride 1, 5 <= K <= 7, (K-1)*dil <= 62");
+        return 1;
+    }
+    if (rows != sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planesq: rows must be sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
+    if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3_planesq: backward epilogue needs alpha2/beta2/partials"); return 1; }
+    SatConvBfLaunch a;
+    a.p = SatConvParams{nullptr, nullptr, bias, nullptr, nullptr, res, y, x2, alpha2, beta2, part_da, part_db,
+                        B, Cin, Cout, Tin, Tout, K, 1, dil, pad, tanh_out};
+    a.w_hi = w_hi;
+    a.w_lo = w_lo;
+    a.cout_v = Cout;
+    a.cout_pad = sat_cdiv(Cout, SAT_CO_T) * SAT_CO_T;
+    a.cin_v = Cin;
+    a.sin_log2 = 0;
+    a.sout_log2 = 0;
+    a.in_shift = 0;
+    a.out_shift = 0;
+    a.nq = Tout;
+    a.xp_hi = xp_hi;
+    a.xp_lo = xp_lo;
+    a.xp_rows = rows;
+    a.xp_c8 = sat_cdiv(Cin, 8);
+    a.wq = 1;
+    SatBfPlan pl{8, 1, K};
+    return sat_bf_launch("sat_conv1d_bf16x3_planesq", a, pl, stream);
 }
 
 // Same contract as sat_convtr1d (y[co][q*stride + k - pad] += W[ci][co][k] act(x)[ci][q], K == 2*stride, power-of-two

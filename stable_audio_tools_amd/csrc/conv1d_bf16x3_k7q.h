@@ -1,0 +1,365 @@
+// conv1d_bf16x3_k7q.h — the k = 5..7 stride-1 (dilated) convolutions of the ResidualUnits (autoencoders.py:58-83) and their
+// data-gradients from pre-split activation planes, third generation.  Included by conv1d_bf16x3.hip.
+//
+// conv1d_bf16x3_k7p.h runs its eight waves in lock-step (fragment reads and MFMAs of both waves of a SIMD at the same time: matrix
+// pipe 47 % busy at C = 128) and spends one k-slot in eight on a zero tap (8 tap groups for 7 taps).  Here:
+//   * a K-chunk is 16 input channels x the K taps: MFMA k-step tau = tap tau, k-slots 0-7 = channels 0-7 of the chunk (lanes 0-31),
+//     8-15 = channels 8-15 (lanes 32-63) — 7 k-steps for 7 taps, no padding.  Weights are packed for it by sat_pack_weights_k7q as
+//     [chunk][tap][8-channel group][co][8]: the A fragment of (tap, group) is 16 bytes per lane at consecutive co rows (conflict
+//     free, no swizzle), and a stage's weight slab is a lane-linear copy (56 one-KiB LDS-DMA pieces of the 128-row channel tile).
+//     Activations: the planes of conv1d_bf16x3_k7p.h ([B][Cin/8][rows][8]); a stage holds [plane][group][320 rows][8] (20 pieces).
+//   * the two wave rows (wr = wave >> 2: 64 of the 128 output channels each; wc = wave & 3: 64 of the 256 time steps) run ONE
+//     BARRIER APART, as in gemm.hip's 256 x 256 kernel: a chunk is two phases (taps 0-3: 48 MFMAs per wave, taps 4..K-1: 36), each
+//     [read section: the phase's fragment reads (8 ds_read_b128 per tap) + half of the NEXT chunk's LDS-DMA, lgkmcnt(0)] s_barrier
+//     [MFMAs at raised priority] s_barrier; in every interval one wave of each SIMD multiplies while its partner reads / issues DMA.
+//     Two stages of 76 KiB; the wait for chunk c+1 (vmcnt(0)) sits in front of the middle barrier of chunk c's second phase: the
+//     first read of chunk c+1 is two barriers later for the waiting wave and one barrier after the other wave row's wait; a stage
+//     is overwritten from the phase after the barrier that retired its last reads.
+//   * epilogue: as conv1d_bf16x3_k7.h (bias, dsnake + its per-channel sums, residual, tanh; 16-byte accesses through an LDS
+//     transposition that reuses the drained stage memory).
+#pragma once
+
+#define SAT_K7Q_TAPS 7
+#define SAT_K7Q_WBYTES (2 * SAT_K7Q_TAPS * 2 * 2048)        // [plane][tap][group][128 co][16 B]
+#define SAT_K7Q_ABYTES (2 * 2 * SAT_K7_AROWS * 16)           // [plane][group][320 rows][16 B]
+#define SAT_K7Q_STAGE (SAT_K7Q_WBYTES + SAT_K7Q_ABYTES)
+#define SAT_K7Q_WPIECES (2 * SAT_K7Q_TAPS * 2 * 2)           // 56
+#define SAT_K7Q_APIECES (2 * 2 * (SAT_K7_AROWS / 64))        // 20
+#define SAT_K7Q_PIECES (SAT_K7Q_WPIECES + SAT_K7Q_APIECES)   // 76
+
+// weight preparation for this kernel: torch weight w[D0][D1][K] (fp32) -> hi / lo bf16 planes [chunk c16][tap][group g][m (padded to
+// 128)][e] holding W'[m][v][tap], v = (c16 * 2 + g) * 8 + e (0 where m / v are out of range):
+//   mode 0 (conv, w = [out][in][K]): W' = w[m][v][tap];   mode 1 (data-gradient of a stride-1 conv): W'[m][v][tap] = w[v][m][K-1-tap]
+struct SatPackQParams {
+    const float* w;
+    short* hi;
+    short* lo;
+    int D0, D1, K, mode, m_v, v_v, out_pad;
+    long long total;
+};
+__global__ void __launch_bounds__(256) sat_pack_k7q_kernel(SatPackQParams p) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.total) return;
+    const int e = (int)(o & 7);
+    long long q = o >> 3;
+    const int m = (int)(q % p.out_pad);
+    q /= p.out_pad;
+    const int g = (int)(q & 1);
+    q >>= 1;
+    const int tap = (int)(q % p.K), chunk = (int)(q / p.K);
+    const int v = (chunk * 2 + g) * 8 + e;
+    float val = 0.0f;
+    if (m < p.m_v && v < p.v_v) {
+        if (p.mode == 0) val = p.w[((size_t)m * p.D1 + v) * p.K + tap];
+        else val = p.w[((size_t)v * p.D1 + m) * p.K + (p.K - 1 - tap)];
+    }
+    short h, l;
+    sat_split2(val, &h, &l);
+    p.hi[o] = h;
+    p.lo[o] = l;
+}
+static bool sat_pack_q_geometry(int D0, int D1, int K, int mode, SatPackQParams* p) {
+    if (mode < 0 || mode > 1 || D0 <= 0 || D1 <= 0 || K < 5 || K > SAT_K7Q_TAPS) return false;
+    p->D0 = D0; p->D1 = D1; p->K = K; p->mode = mode;
+    if (mode == 0) { p->m_v = D0; p->v_v = D1; } else { p->m_v = D1; p->v_v = D0; }
+    p->out_pad = sat_cdiv(p->m_v, SAT_K7_CO) * SAT_K7_CO;
+    p->total = (long long)sat_cdiv(p->v_v, 16) * K * 2 * p->out_pad * 8;
+    return true;
+}
+extern "C" long long sat_pack_weights_k7q_size(int D0, int D1, int K, int mode) {
+    SatPackQParams p{};
+    return sat_pack_q_geometry(D0, D1, K, mode, &p) ? p.total : -1;
+}
+extern "C" int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream) {
+    SatPackQParams p{};
+    if (!sat_pack_q_geometry(D0, D1, K, mode, &p)) { sat_set_error("sat_pack_weights_k7q: needs 5 <= K <= 7, mode 0|1"); return 1; }
+    p.w = w; p.hi = hi; p.lo = lo;
+    SAT_LAUNCH(sat_pack_k7q_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
+    return sat_check_launch("sat_pack_weights_k7q");
+}
+
+template <int DUMMY_UNUSED = 0>
+__global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatConvBfLaunch a) {
+    constexpr int CO_T = SAT_K7_CO, T_T = SAT_K7_T, NT = SAT_K7_NT, AROWS = SAT_K7_AROWS;
+    constexpr int TW = T_T / 64;                          // waves along time
+    const SatConvParams& p = a.p;
+    // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue in front of every fragment read: cdna_hip_programming.md §5)
+    constexpr int RED_OFF = 2 * SAT_K7Q_STAGE, EP_OFF = RED_OFF + 2 * TW * CO_T * 4;
+    __shared__ __attribute__((aligned(1024))) char lds[EP_OFF + 3 * CO_T * 4];
+    float (*red_lds)[TW][CO_T] = reinterpret_cast<float (*)[TW][CO_T]>(lds + RED_OFF);
+    float (*ep_lds)[CO_T] = reinterpret_cast<float (*)[CO_T]>(lds + EP_OFF);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SAT_UNIFORM(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave / TW;
+    const int co_w = wr * 64, t_w = (wave % TW) * 64;
+    const int K = p.K, dil = p.dil;
+    const int nchunks = (a.cin_v + 15) / 16;
+    const int co_tiles = a.cout_pad / CO_T, t_tiles = (a.nq + T_T - 1) / T_T;
+    int co_tile, win;
+    sat_xcd_tile((int)blockIdx.x, co_tiles, t_tiles * p.B, &co_tile, &win);
+    const int b = win / t_tiles, t_tile = win - b * t_tiles;
+    const int co0 = co_tile * CO_T, t0 = t_tile * T_T;
+    const int row_in0 = SAT_K7P_LEAD + t0 - p.pad;        // plane row of the window's first input step (>= 0: pad <= LEAD)
+
+    if (tid < CO_T) {
+        const int m = co0 + tid;
+        const bool ok = m < a.cout_v;
+        ep_lds[0][tid] = (ok && p.bias) ? p.bias[m] : 0.0f;
+        ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[m]) : 1.0f;
+        ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[m]) : 1.0f;
+    }
+
+    // ---- LDS-DMA of a chunk: 56 weight pieces (per tap: 8 = plane x group x 64-row half, ONE per wave) + 20 activation pieces
+    //      ((plane, group) x 5 x 64 rows: waves 0-7 twice, waves 0-3 a third).  Every source address is a WAVE-UNIFORM base
+    //      (scalar registers) + lane * 16 bytes: no per-piece address registers to keep alive (a spilled address would be reloaded
+    //      with a vmcnt(0) that drains the DMA queue) ----
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int w_pl = wave >> 2, w_g = (wave >> 1) & 1, w_half = wave & 1;
+    const char* w_src0 = (const char*)(w_pl ? a.w_lo : a.w_hi) + ((size_t)w_g * a.cout_pad + co0 + w_half * 64) * 16;
+    const size_t w_tap_stride = (size_t)a.cout_pad * 32;                      // bytes between taps: [tap][2 groups][cout_pad][16 B]
+    const int w_dst0 = w_pl * (SAT_K7Q_TAPS * 4096) + (w_g * 2 + w_half) * 1024;
+    auto issue_w = [&](int c, int st, int tap) {                             // this wave's piece of tap `tap`
+        if (tap < K) sat_glds16(w_src0 + ((size_t)c * K + tap) * w_tap_stride + lane16, lds + st * SAT_K7Q_STAGE + w_dst0 + tap * 4096);
+    };
+    auto issue_a = [&](int c, int st, int i) {                               // activation piece r = 8 i + wave (r < 20)
+        const int r = 8 * i + wave;
+        if (r < SAT_K7Q_APIECES) {
+            const int pl = r / 10, g = (r / 5) & 1, sub = r % 5;
+            int c8 = c * 2 + g;
+            c8 = c8 < a.xp_c8 ? c8 : a.xp_c8 - 1;         // past the end: any finite rows (their weights are zero)
+            const char* src = (const char*)(pl ? a.xp_lo : a.xp_hi) + (((size_t)b * a.xp_c8 + c8) * a.xp_rows + row_in0 + sub * 64) * 16;
+            sat_glds16(src + lane16, lds + st * SAT_K7Q_STAGE + SAT_K7Q_WBYTES + r * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct Frags { bf16x8 wa[2][2], xa[2][2]; };          // [mi | ni][plane]
+    Frags fr[4];
+    auto load_frags = [&](Frags& f, const char* sb, int tap) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const char* wb = sb + ((pl * SAT_K7Q_TAPS + tap) * 2 + hi) * 2048;
+            f.wa[0][pl] = *reinterpret_cast<const bf16x8*>(wb + (co_w + l31) * 16);
+            f.wa[1][pl] = *reinterpret_cast<const bf16x8*>(wb + (co_w + 32 + l31) * 16);
+            const char* ab = sb + SAT_K7Q_WBYTES + (pl * 2 + hi) * (AROWS * 16);
+            f.xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31 + tap * dil) * 16);
+            f.xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31 + tap * dil) * 16);
+        }
+    };
+    auto mfma_frags = [&](const Frags& f) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][0], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][1], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
+    };
+
+    // prologue: chunk 0 complete in stage 0
+#pragma unroll
+    for (int tap = 0; tap < SAT_K7Q_TAPS; ++tap) issue_w(0, 0, tap);
+    issue_a(0, 0, 0); issue_a(0, 0, 1); issue_a(0, 0, 2);
+    SAT_WAIT_VMCNT(0);
+    SAT_RAW_BARRIER();
+    if (wr == 1) SAT_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
+
+    for (int c = 0; c < nchunks; ++c) {
+        const char* sb = lds + (c & 1) * SAT_K7Q_STAGE;
+        const bool more = c + 1 < nchunks;
+        // ---- phase 0: taps 0..3 ----
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_frags(fr[u], sb, u);
+        if (more) {
+#pragma unroll
+            for (int tap = 0; tap < 5; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+        }
+        SAT_WAIT_LGKM0();
+        SAT_RAW_BARRIER();
+        SAT_SCHED_FENCE();
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mfma_frags(fr[u]);
+        SAT_SETPRIO(0);
+        SAT_SCHED_FENCE();
+        SAT_RAW_BARRIER();
+        // ---- phase 1: taps 4..K-1 ----
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (4 + u < K) load_frags(fr[u], sb, 4 + u);
+        if (more) {
+            issue_w(c + 1, (c + 1) & 1, 5); issue_w(c + 1, (c + 1) & 1, 6);
+            issue_a(c + 1, (c + 1) & 1, 0); issue_a(c + 1, (c + 1) & 1, 1); issue_a(c + 1, (c + 1) & 1, 2);
+            SAT_WAIT_VMCNT(0);                             // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
+        }
+        SAT_WAIT_LGKM0();
+        SAT_RAW_BARRIER();
+        SAT_SCHED_FENCE();
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (4 + u < K) mfma_frags(fr[u]);
+        SAT_SETPRIO(0);
+        SAT_SCHED_FENCE();
+        SAT_RAW_BARRIER();
+    }
+    if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
+    __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue
+
+    // ------------------------------------ epilogue (as the generic kernel) ------------------------------------
+    const bool bwd = (p.x2 != nullptr);
+    const bool wave_on = (co0 + co_w) < a.cout_v;
+    const bool mi1_on = (co0 + co_w + 32) < a.cout_v;
+    if (bwd) {
+        __syncthreads();
+        for (int i = tid; i < 2 * TW * CO_T; i += NT) (&red_lds[0][0][0])[i] = 0.0f;
+        __syncthreads();
+    }
+    const bool vec4 = (p.Tout & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.x2 | (uintptr_t)p.res) & 15) == 0;
+    if (vec4) {
+        // 16-byte epilogue: each wave transposes its accumulators through LDS (the stage memory is free now) so that
+        // a lane owns 4 consecutive time steps of a row; the x2 / res loads of a 32-row half are all issued before use.
+        if (!bwd) __syncthreads();                          // (bwd already synchronised above)
+        float (*tile)[68] = reinterpret_cast<float (*)[68]>(lds) + wave * 32;       // 32 x 68 floats per wave, in the (drained) stage memory
+        const int lr = lane >> 4, t4 = (lane & 15) * 4;    // this lane's row within a group of 4, its 4 time steps
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const bool half_on = wave_on && (mi == 0 || mi1_on);
+            if (mi == 1) __syncthreads();                   // every wave is done reading its first half
+            if (half_on) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile[(r & 3) + 8 * (r >> 2) + 4 * hi][ni * 32 + l31] = acc[mi][ni][r];
+            }
+            __syncthreads();                                // (a wave only reads its own tile: this orders its own lanes)
+            if (half_on) {
+                const int tg = t0 + t_w + t4;
+                f32x4 xv[8], rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = co_w + mi * 32 + j * 4 + lr;
+                    const int co = co0 + col;
+                    const bool ok = co < a.cout_v && tg < p.Tout;
+                    const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? tg : 0);
+                    xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(p.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    rv[j] = (p.res && ok) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = j * 4 + lr;
+                    const int col = co_w + mi * 32 + row;
+                    const int co = co0 + col;
+                    const bool ok = co < a.cout_v && tg < p.Tout;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
+                    const float bias = ep_lds[0][col];
+                    const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
+                    float pda = 0.f, pdb = 0.f;
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = av[e] + bias;
+                        if (bwd) {
+                            const SatSnakeGrad g = sat_snake_grad(xv[j][e], a2, b2);
+                            pda += v * g.dla;
+                            pdb += v * g.dlb;
+                            v *= g.dx;
+                        }
+                        v += rv[j][e];
+                        if (p.tanh_out) v = tanhf(v);
+                        ov[e] = v;
+                    }
+                    if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (bwd) {
+                        if (!ok) { pda = 0.f; pdb = 0.f; }
+#pragma unroll
+                        for (int m = 8; m >= 1; m >>= 1) {     // sum over the 16 lanes that share this row
+                            pda += __shfl_xor(pda, m);
+                            pdb += __shfl_xor(pdb, m);
+                        }
+                        if ((lane & 15) == 0) {
+                            red_lds[0][wave % TW][col] = pda;
+                            red_lds[1][wave % TW][col] = pdb;
+                        }
+                    }
+                }
+            }
+        }
+    } else
+    if (wave_on) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if (mi == 1 && !mi1_on) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int co = co0 + col;
+                const bool co_ok = co < a.cout_v;
+                const float bias = ep_lds[0][col];
+                const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
+                float pda = 0.f, pdb = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int t = t0 + t_w + ni * 32 + l31;
+                    if (co_ok && t < p.Tout) {
+                        const size_t o = ((size_t)b * p.Cout + co) * p.Tout + t;
+                        float v = acc[mi][ni][r] + bias;
+                        if (bwd) {
+                            const SatSnakeGrad g = sat_snake_grad(p.x2[o], a2, b2);
+                            pda += v * g.dla;
+                            pdb += v * g.dlb;
+                            v *= g.dx;
+                        }
+                        if (p.res) v += p.res[o];
+                        if (p.tanh_out) v = tanhf(v);
+                        p.y[o] = v;
+                    }
+                }
+                if (bwd) {
+                    pda = sat_half_sum(pda);
+                    pdb = sat_half_sum(pdb);
+                    if (l31 == 0) {
+                        red_lds[0][wave % TW][col] = pda;
+                        red_lds[1][wave % TW][col] = pdb;
+                    }
+                }
+            }
+        }
+    }
+    if (bwd) {
+        __syncthreads();
+        const int m = co0 + tid;
+        if (tid < CO_T && m < a.cout_v) {
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int w = 0; w < TW; ++w) {
+                sa += red_lds[0][w][tid];
+                sb += red_lds[1][w][tid];
+            }
+            const size_t row = (size_t)b * t_tiles + t_tile;
+            const size_t nrows_p = (size_t)p.B * t_tiles;
+            p.part_da[(size_t)m * nrows_p + row] = sa;
+            p.part_db[(size_t)m * nrows_p + row] = sb;
+        }
+    }
+}
+
+static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
+    const long long total = (long long)(a.cout_pad / SAT_K7_CO) * sat_cdiv(a.nq, SAT_K7_T) * a.p.B;
+    SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a);
+}

@@ -82,7 +82,8 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out
     the caller's tensor (it may alias `res`: accumulation in place)."""
     if stride == 1:
         if ops.bf16x3_ok(k, 1, dil):
-            return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
+            q = ops.k7q_applicable(w.shape[0], k, 1, dil, (k - 1) * dil - pad)       # the data-gradient's input channels = Cout
+            return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1, q=q), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
                                      dsnake=dsnake, res=res, out=out)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
         return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res, out=out)
@@ -110,7 +111,8 @@ def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh
     passes only) for the packed planes and the SnakeBeta constants."""
     cout, cin, k = w.shape
     if ops.bf16x3_ok(k, stride, dil):
-        planes = _cached(cache, "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride))
+        q = ops.k7q_applicable(cin, k, stride, dil, pad)
+        planes = _cached(cache, "pack_fwd_q" if q else "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride, q=q))
         sconsts = _cached(cache, "snake", snake, lambda: ops.snake_consts(snake[0], snake[1])) if snake is not None else None
         return ops.conv1d_bf16x3(x, planes, cout, k, stride, dil, pad, tout=tout, bias=bias,
                                  snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake, sconsts=sconsts)

@@ -127,11 +127,28 @@ class SatOps:
             return k == 2 * stride and stride & (stride - 1) == 0 and dil == 1
         return k == 1 or (2 <= k <= 4 and dil == 1) or (5 <= k <= 8 and (k - 1) * dil <= 62)
 
-    def pack_bf16x3(self, w, mode=0, stride=1):
+    # third-generation k7 kernel (csrc/conv1d_bf16x3_k7q.h): planes + 16-channel chunks + two wave rows one barrier apart
+    k7q = os.environ.get("SAT_K7Q", "1") != "0"
+    k7q_min_cin = int(os.environ.get("SAT_K7Q_MIN", "64"))
+
+    def k7q_applicable(self, cin, k, stride, dil, pad):
+        return (self.k7q and self.k7_planes and self.use_bf16x3 and stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32
+                and (k - 1) * dil <= 62 and cin >= self.k7q_min_cin)
+
+    def pack_bf16x3(self, w, mode=0, stride=1, q=False):
         """w: (D0, D1, K) fp32 -> (hi, lo) int16 planes.  mode 0: conv weight [out][in][K]; mode 1: data-gradient of a
-        stride-1 conv; mode 2: transposed-conv weight [in][out][K]."""
+        stride-1 conv; mode 2: transposed-conv weight [in][out][K].  q=True (stride 1, 5 <= K <= 7, modes 0 / 1): the layout of
+        the k7q kernel (sat_pack_weights_k7q) — returned as (hi, lo, "q") so that conv1d_bf16x3 routes to it."""
         self._f32(w)
         d0, d1, k = w.shape
+        if q:
+            n = self.lib.sat_pack_weights_k7q_size(d0, d1, k, mode)
+            if n <= 0 or stride != 1:
+                raise RuntimeError("sat_pack_weights_k7q: unsupported shape")
+            hi = torch.empty(n, dtype=torch.int16, device=w.device)
+            lo = torch.empty(n, dtype=torch.int16, device=w.device)
+            self._chk(self.lib.sat_pack_weights_k7q(_ptr(w), _ptr(hi), _ptr(lo), d0, d1, k, mode, self._stream(w)))
+            return hi, lo, "q"
         n = self.lib.sat_pack_weights_bf16x3_size(d0, d1, k, stride, mode)
         if n <= 0:
             raise RuntimeError("sat_pack_weights_bf16x3: unsupported shape")
@@ -184,6 +201,10 @@ class SatOps:
         if tout is None:
             tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
         rows = self.lib.sat_conv1d_bf16x3_partial_rows(b, tout, k, stride)
+        if len(w_planes) == 3:          # sat_pack_weights_k7q layout (pack_bf16x3(q=True) after k7q_applicable)
+            if not (stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32 and (k - 1) * dil <= 62):
+                raise ValueError("conv1d_bf16x3: q-packed weights need stride 1, 5 <= K <= 7, pad <= 32, (K-1)*dil <= 62")
+            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts, q=True)
         if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
             return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
@@ -195,7 +216,7 @@ class SatOps:
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
 
-    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None):
+    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None, q=False):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
@@ -218,9 +239,10 @@ class SatOps:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
             pda, pdb = torch.empty(2, cout, prows, dtype=torch.float32, device=x.device).unbind(0)
-        self._chk(self.lib.sat_conv1d_bf16x3_planes(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
-                                                    _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
-                                                    k, dil, pad, int(tanh_out), st))
+        fn = self.lib.sat_conv1d_bf16x3_planesq if q else self.lib.sat_conv1d_bf16x3_planes
+        self._chk(fn(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
+                     _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
+                     k, dil, pad, int(tanh_out), st))
         if dsnake is not None:
             return (y, *self._sum_pair(pda, pdb))
         return y

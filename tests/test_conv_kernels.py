@@ -119,15 +119,19 @@ def test_conv_up_sim(emu, case):
     _run_up(emu, "cpu", case, True)
 
 
-def _run_planes(ops, dev, cases):
+def _run_planes(ops, dev, cases, q_min=None):
     """The k = 7 convs fed from pre-split activation planes (conv1d_bf16x3_k7p.h: sat_conv1d_k7_planes + sat_conv1d_bf16x3_planes) —
     the path the C >= 512 levels take — forced on for every channel count: forward and all gradients vs torch, and bit-identical
     outputs to the direct kernel (same split, same MFMA order)."""
     keep = (ops.k7_planes, ops.k7_planes_min_cin)
+    keepq = (ops.k7q, ops.k7q_min_cin)
     try:
         for case in cases:
             ops.k7_planes, ops.k7_planes_min_cin = True, 1
-            _run_s1(ops, dev, case, True)
+            ops.k7q = False
+            _run_s1(ops, dev, case, True)               # autograd units through the planes kernel (k7p)
+            ops.k7q, ops.k7q_min_cin = True, 1
+            _run_s1(ops, dev, case, True)               # ... and through the third-generation kernel (k7q)
             B, Cin, Cout, T, K, dil = case
             gen = torch.Generator().manual_seed(7)
             x = torch.randn(B, Cin, T, generator=gen).to(dev)
@@ -144,8 +148,17 @@ def _run_planes(ops, dev, cases):
                              *ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2))))
             for a, b in zip(*outs):
                 assert torch.equal(a, b)
+            # third-generation kernel (conv1d_bf16x3_k7q.h): another accumulation order (16-channel chunks, one tap per k-step)
+            if 5 <= K <= 7:
+                ops.k7_planes = True
+                wq = ops.pack_bf16x3(w, 0, 1, q=True)
+                outq = (ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, snake=(la, lb)),
+                        *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
+                for a, b in zip(outq, outs[1]):
+                    assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), (case, (a - b).abs().max().item())
     finally:
         ops.k7_planes, ops.k7_planes_min_cin = keep
+        ops.k7q, ops.k7q_min_cin = keepq
 
 
 def test_conv_k7_planes_sim(emu):

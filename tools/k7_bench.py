@@ -26,9 +26,19 @@ for (c, t, dil) in shapes:
     pad = 3 * dil
     row = {"C": c, "T": t, "dil": dil}
     flops = 2.0 * c * c * 7 * t
-    for name, flag in (("direct", False), ("planes", True)):
+    wq = o.pack_bf16x3(w, 0, 1, q=True)
+    for name, flag, wts in (("direct", False, wp), ("planes", True, wp), ("q", True, wq)):
         o.k7_planes = flag
-        us = timeit(lambda: o.conv1d_bf16x3(x, wp, c, 7, 1, dil, pad, bias=bias, snake=(la, lb)))
-        usb = timeit(lambda: o.conv1d_bf16x3(x, wp, c, 7, 1, dil, pad, dsnake=(x2, la, lb)))
+        o.k7_planes_min_cin = 1
+        us = timeit(lambda: o.conv1d_bf16x3(x, wts, c, 7, 1, dil, pad, bias=bias, snake=(la, lb)))
+        usb = timeit(lambda: o.conv1d_bf16x3(x, wts, c, 7, 1, dil, pad, dsnake=(x2, la, lb)))
         row[name] = {"fwd_us": round(us, 1), "fwd_tf": round(flops / us * 1e-6, 1), "dgrad_us": round(usb, 1), "dgrad_tf": round(flops / usb * 1e-6, 1)}
+    # the planes pre-pass alone (SnakeBeta + split of the input), included in the "planes" and "q" rows above
+    import ctypes
+    rows = o.lib.sat_conv1d_k7_plane_rows(t, t, pad)
+    hi = torch.empty(((c + 7) // 8) * rows * 8, dtype=torch.int16, device='cuda'); lo = torch.empty_like(hi)
+    sa, sib = o.snake_consts(la, lb)
+    P = lambda z: ctypes.c_void_p(z.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    row["prepass_us"] = round(timeit(lambda: o.lib.sat_conv1d_k7_planes(P(x), P(sa), P(sib), P(hi), P(lo), 1, c, t, rows, st)), 1)
     print(json.dumps(row), flush=True)
