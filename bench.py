@@ -324,6 +324,9 @@ class ConvProfiler:
                               X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_conv1d_k7_planes": ("sat_k7_planes_kernel", X3, lambda a: 0.0),     # the planes kernel's pre-pass: time, no flops of its own
         "sat_conv1d_bf16x3_planes": ("sat_conv1d_bf16x3_k7p_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        "sat_conv1d_bf16x3_planesq": ("sat_conv1d_bf16x3_k7q_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        # the k1 / strided convs that also write their consumer's activation planes (generic kernel, plane emission)
+        "sat_conv1d_bf16x3_emit": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),
         "sat_convtr1d": ("sat_convtr1d_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[12] * a[13] * a[14] * 2 * a[16]),
         "sat_conv_wgrad": ("sat_conv_wgrad_kernel", PEAK_F32_MFMA_TFLOPS, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
@@ -379,7 +382,7 @@ def k7_family(allk):
     """The k = 7 convs of the ResidualUnits run on two kernels since round 2 (direct staging below C = 256, pre-split planes above):
     their combined algorithmic flops / combined HIP-event time (the planes pre-pass included), for continuity with the single-kernel
     figure of round 1."""
-    fam = [d for d in allk if d["kernel"].startswith("sat_conv1d_bf16x3_k7") or d["kernel"] == "sat_k7_planes_kernel"]
+    fam = [d for d in allk if d["kernel"].startswith("sat_conv1d_bf16x3_k7") or d["kernel"] == "sat_k7_planes_kernel"]     # k7, k7p, k7q + pre-pass
     if not fam:
         return None
     ms = sum(d["total_ms"] for d in fam)

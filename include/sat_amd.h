@@ -65,6 +65,15 @@ int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, cons
                       const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                       const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
                       int K, int stride, int dil, int pad, int tanh_out, void* stream);
+/* The same conv that ALSO writes act(y) as the activation planes its consumer reads (sat_conv1d_bf16x3_planes / _planesq): em_hi /
+ * em_lo [B][ceil(Cout/8)][em_rows][8] bf16, row 32 + t (the caller keeps the rows around the sequence zero); em_a / em_ib = the
+ * consumer's pre-exponentiated SnakeBeta constants (sat_snake_consts) or NULL for planes of y itself.  Replaces the consumer's
+ * sat_conv1d_k7_planes pre-pass (ResidualUnit chains: autoencoders.py:58-83, :233-283).  K <= 4 or strided plans, Tout % 4 == 0. */
+int sat_conv1d_bf16x3_emit(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
+                      const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
+                      const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
+                      int K, int stride, int dil, int pad, int tanh_out, void* em_hi, void* em_lo,
+                           const float* em_a, const float* em_ib, int em_rows, void* stream);
 int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
                         const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                         const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,

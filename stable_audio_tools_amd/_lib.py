@@ -23,6 +23,7 @@ SIGNATURES = {
     "sat_conv1d_partial_rows": (_I, [_I, _I]),
     # conv1d_bf16x3.hip
     "sat_conv1d_bf16x3": (_I, [_P] * 13 + [_I] * 10 + [_P]),
+    "sat_conv1d_bf16x3_emit": (_I, [_P] * 13 + [_I] * 10 + [_P] * 4 + [_I, _P]),
     "sat_convtr1d_bf16x3": (_I, [_P] * 13 + [_I] * 9 + [_P]),
     "sat_conv1d_bf16x3_partial_rows": (_I, [_I] * 4),
     "sat_rows_pack": (_I, [_P, _P] + [_I] * 10 + [_P]),

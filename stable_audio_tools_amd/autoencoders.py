@@ -163,10 +163,11 @@ class _WNConvBase(nn.Module):
 
 
 class WNConv1d(_WNConvBase):
-    def forward(self, x, snake=None, res=None, tanh_out=False):
+    def forward(self, x, snake=None, res=None, tanh_out=False, next_snake=None):
+        """next_snake: (log-alpha, log-beta, dilation) of the ResidualUnit that reads the output next — see ResidualUnit.forward."""
         a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
         return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias, res, self.stride, self.dilation,
-                                      self.padding, tanh_out, None, self.derived_cache(a, b))
+                                      self.padding, tanh_out, None, self.derived_cache(a, b), next_snake)
 
 
 class WNConvTranspose1d(_WNConvBase):
@@ -204,12 +205,20 @@ class ResidualUnit(nn.Module):
             WNConv1d(out_channels, out_channels, kernel_size=1),
         )
 
-    def forward(self, x):
+    def entry_snake(self):
+        """(log-alpha, log-beta, dilation) of this unit's first activation + k7 conv: what the PRODUCER of its input needs to write
+        the input as the k7 conv's activation planes in its own epilogue (csrc/conv1d_bf16x3.hip, plane emission)."""
+        s1 = self.layers[0]
+        return (s1.alpha, s1.beta, self.dilation)
+
+    def forward(self, x, next_snake=None):
+        """next_snake: entry_snake() of the ResidualUnit that reads this unit's output next (None: something else does)."""
         s1, c1, s2, c2 = self.layers
         ca, cb = c1.derived_cache(s1.alpha, s1.beta), c2.derived_cache(s2.alpha, s2.beta)
         return Fn.ResidualUnitFn.apply(x, s1.alpha, s1.beta, c1.folded_weight(), c1.bias,
                                        s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation, None,
-                                       self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None)
+                                       self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None,
+                                       next_snake)
 
 
 class EncoderBlock(nn.Module):
@@ -224,9 +233,12 @@ class EncoderBlock(nn.Module):
             WNConv1d(in_channels, out_channels, kernel_size=2 * stride, stride=stride, padding=math.ceil(stride / 2)),
         )
 
-    def forward(self, x):
+    def forward(self, x, next_snake=None):
+        """next_snake: entry_snake() of the first ResidualUnit of the NEXT block (it reads the down conv's output)."""
         r1, r2, r3, snake, down = self.layers
-        return down(r3(r2(r1(x))), snake=snake)
+        x = r1(x, next_snake=r2.entry_snake())
+        x = r2(x, next_snake=r3.entry_snake())
+        return down(r3(x), snake=snake, next_snake=next_snake)
 
 
 class DecoderBlock(nn.Module):
@@ -247,7 +259,8 @@ class DecoderBlock(nn.Module):
 
     def forward(self, x):
         snake, up, r1, r2, r3 = self.layers
-        return r3(r2(r1(up(x, snake=snake))))
+        x = r1(up(x, snake=snake), next_snake=r2.entry_snake())       # (the transposed conv's depth-to-space epilogue emits no planes)
+        return r3(r2(x, next_snake=r3.entry_snake()))
 
 
 class OobleckEncoder(nn.Module):
@@ -268,8 +281,10 @@ class OobleckEncoder(nn.Module):
     def forward(self, x):
         mods = list(self.layers)
         x = mods[0](x)
-        for blk in mods[1:-2]:
-            x = blk(x)
+        blocks = mods[1:-2]
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1].layers[0].entry_snake() if i + 1 < len(blocks) else None
+            x = blk(x, next_snake=nxt)
         return mods[-1](x, snake=mods[-2])
 
 

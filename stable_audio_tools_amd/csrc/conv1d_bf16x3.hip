@@ -20,6 +20,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
+#define SAT_K7P_LEAD_ROWS 32  // zero rows before t = 0 in an activation plane (= SAT_K7P_LEAD of conv1d_bf16x3_k7p.h)
 #define SAT_BF_AROWS1 192  // CS == 1: max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
 #define SAT_BF_AROWSN 136  // CS  > 1: 128 + (taps-1) rows, taps <= 4, dil = 1
 
@@ -39,6 +40,15 @@ struct SatConvBfLaunch {
     const short* xp_lo = nullptr;
     int xp_rows = 0, xp_c8 = 0;
     int wq = 0;            // conv1d_bf16x3_k7q.h: the weight planes are in sat_pack_weights_k7q layout ([chunk16][tap][group][co][8])
+    // plane EMISSION (generic kernel, 16-byte epilogue): besides y the kernel writes act(y) as the bf16 hi / lo planes the next k7
+    // conv reads ([B][em_c8][em_rows][8], row = 32 + t; the zero rows around the sequence belong to the caller) — the consumer's
+    // sat_k7_planes_kernel pre-pass (one read + one write of the tensor) disappears.  em_a / em_ib: pre-exponentiated SnakeBeta
+    // constants of the CONSUMER's activation (null: planes of y itself, for a data-gradient consumer).
+    short* em_hi = nullptr;
+    short* em_lo = nullptr;
+    const float* em_a = nullptr;
+    const float* em_ib = nullptr;
+    int em_rows = 0, em_c8 = 0;
 };
 
 SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
@@ -74,7 +84,7 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
     short (*w_lds)[SAT_CO_T][KROW] = reinterpret_cast<short (*)[SAT_CO_T][KROW]>(lds_pool);                 // [plane][co][g*8+e]
     short (*a_lds)[CS][AROWS][8] = reinterpret_cast<short (*)[CS][AROWS][8]>(lds_pool + W_BYTES);           // [plane][sub-block][time row][8 ci]
     __shared__ float red_lds[2][2][SAT_CO_T];
-    __shared__ float ep_lds[3][SAT_CO_T];
+    __shared__ float ep_lds[5][SAT_CO_T];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -111,6 +121,8 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
         ep_lds[0][tid] = (ok && p.bias) ? p.bias[co] : 0.0f;
         ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[co]) : 1.0f;
         ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[co]) : 1.0f;
+        ep_lds[3][tid] = (ok && a.em_a) ? a.em_a[co] : 0.0f;
+        ep_lds[4][tid] = (ok && a.em_a) ? a.em_ib[co] : 0.0f;
     }
 
     const int nchunks = (a.cin_v + 8 * CS - 1) / (8 * CS);
@@ -304,6 +316,18 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
                         ov[e] = v;
                     }
                     if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (a.em_hi) {
+                        // plane emission, step 1: the consumer's activation of the finished values goes back into this lane's own
+                        // cell of the transposition tile (rows past Cout hold act(0) = 0)
+                        f32x4 ev = ov;
+                        if (a.em_a) {
+                            const float ea = ep_lds[3][col], eib = ep_lds[4][col];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ev[e] = sat_snake(ov[e], ea, eib);
+                        }
+                        if (!ok) ev = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(&tile[row][t4]) = ev;
+                    }
                     if (bwd) {
                         if (!ok) { pda = 0.f; pdb = 0.f; }
 #pragma unroll
@@ -314,6 +338,28 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
                         if ((lane & 15) == 0) {
                             red_lds[0][wave & 1][col] = pda;
                             red_lds[1][wave & 1][col] = pdb;
+                        }
+                    }
+                }
+                if (a.em_hi) {
+                    // step 2: read the tile COLUMN-wise — an item is 8 consecutive channels of one time step = one 16-byte plane
+                    // row — split and store: 64 lanes write 1 KiB of each plane contiguously (the wave's LDS ops execute in order)
+                    sat_wave_sync();
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int tt = lane, g = it;
+                        const int c8i = ((co0 + co_w + mi * 32) >> 3) + g;
+                        const int tq = t0 + t_w + tt;
+                        float v8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v8[e] = tile[g * 8 + e][tt];
+                        uint32_t h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sat_split2_pk(v8[2 * e], v8[2 * e + 1], &h[e], &l[e]);
+                        if (c8i < a.em_c8 && tq < p.Tout) {
+                            const size_t o = (((size_t)b * a.em_c8 + c8i) * a.em_rows + SAT_K7P_LEAD_ROWS + tq) * 8;
+                            *reinterpret_cast<u32x4*>(a.em_hi + o) = u32x4{h[0], h[1], h[2], h[3]};
+                            *reinterpret_cast<u32x4*>(a.em_lo + o) = u32x4{l[0], l[1], l[2], l[3]};
                         }
                     }
                 }
@@ -504,11 +550,12 @@ static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& 
 // Same contract as sat_conv1d (y[co][t] = sum W[co][ci][k] act(x)[ci][t*stride + k*dil - pad]), with the weights given
 // as sat_pack_weights_bf16x3 planes (mode 0, or mode 1 for a stride-1 data-gradient) and the SnakeBeta constants given
 // pre-exponentiated (sat_snake_consts), or NULL for no activation.  stride 1: K <= 8; stride S: K == 2S, S a power of two.
-extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias,
-                                 const float* snake_a, const float* snake_ib, const float* res, float* y,
-                                 const float* x2, const float* alpha2, const float* beta2, float* part_da,
-                                 float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil,
-                                 int pad, int tanh_out, void* stream) {
+static int sat_conv1d_bf16x3_impl(const char* what, const float* x, const short* w_hi, const short* w_lo, const float* bias,
+                                  const float* snake_a, const float* snake_ib, const float* res, float* y,
+                                  const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                                  float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil,
+                                  int pad, int tanh_out, short* em_hi, short* em_lo, const float* em_a, const float* em_ib, int em_rows,
+                                  void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3: empty shape"); return 1; }
     SatBfPlan pl;
     if (!sat_bf_plan(K, stride, 0, &pl) || dil < 1 || (stride > 1 && dil != 1)) {
@@ -531,7 +578,40 @@ extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short*
     a.in_shift = stride == 1 ? 0 : pad;
     a.out_shift = 0;
     a.nq = Tout;
-    return sat_bf_launch("sat_conv1d_bf16x3", a, pl, stream);
+    if (em_hi) {
+        // plane emission lives in the generic kernel's 16-byte epilogue
+        const bool generic = !(pl.ng == 8 && pl.cs == 1);
+        const bool vec4 = (Tout & 3) == 0 && (((uintptr_t)y | (uintptr_t)x2 | (uintptr_t)res) & 15) == 0;
+        if (!generic || !vec4 || !em_lo || (em_a == nullptr) != (em_ib == nullptr) || em_rows < SAT_K7P_LEAD_ROWS + Tout ||
+            (((uintptr_t)em_hi | (uintptr_t)em_lo) & 15)) {
+            sat_set_error("sat_conv1d_bf16x3_emit: emission needs K <= 4 or a strided conv, Tout % 4 == 0, 16-byte aligned tensors, rows >= 32 + Tout");
+            return 1;
+        }
+        a.em_hi = em_hi; a.em_lo = em_lo; a.em_a = em_a; a.em_ib = em_ib; a.em_rows = em_rows; a.em_c8 = sat_cdiv(Cout, 8);
+    }
+    return sat_bf_launch(what, a, pl, stream);
+}
+extern "C" int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias,
+                                 const float* snake_a, const float* snake_ib, const float* res, float* y,
+                                 const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                                 float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil,
+                                 int pad, int tanh_out, void* stream) {
+    return sat_conv1d_bf16x3_impl("sat_conv1d_bf16x3", x, w_hi, w_lo, bias, snake_a, snake_ib, res, y, x2, alpha2, beta2, part_da, part_db,
+                                  B, Cin, Cout, Tin, Tout, K, stride, dil, pad, tanh_out, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+// sat_conv1d_bf16x3 that ALSO writes act(y) as the activation planes of the k7 conv that consumes y next (sat_conv1d_bf16x3_planes /
+// _planesq): em_hi / em_lo [B][ceil(Cout/8)][em_rows][8] bf16 (row 32 + t; the caller keeps the rows around the sequence zero),
+// em_a / em_ib the consumer's pre-exponentiated SnakeBeta constants (sat_snake_consts) or NULL for planes of y itself.  The k = 1 /
+// K <= 4 / strided plans only (the producers of a ResidualUnit's input), Tout % 4 == 0.
+extern "C" int sat_conv1d_bf16x3_emit(const float* x, const short* w_hi, const short* w_lo, const float* bias,
+                                      const float* snake_a, const float* snake_ib, const float* res, float* y,
+                                      const float* x2, const float* alpha2, const float* beta2, float* part_da,
+                                      float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil,
+                                      int pad, int tanh_out, void* em_hi, void* em_lo, const float* em_a, const float* em_ib, int em_rows,
+                                      void* stream) {
+    if (!em_hi) { sat_set_error("sat_conv1d_bf16x3_emit: planes missing"); return 1; }
+    return sat_conv1d_bf16x3_impl("sat_conv1d_bf16x3_emit", x, w_hi, w_lo, bias, snake_a, snake_ib, res, y, x2, alpha2, beta2, part_da, part_db,
+                                  B, Cin, Cout, Tin, Tout, K, stride, dil, pad, tanh_out, (short*)em_hi, (short*)em_lo, em_a, em_ib, em_rows, stream);
 }
 
 // ---- the k = 5..8 stride-1 convs from pre-split activation planes (conv1d_bf16x3_k7p.h) ----
@@ -562,7 +642,7 @@ extern "C" int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, 
         sat_set_error("sat_conv1d_bf16x3_planes: needs stride 1, 5 <= K <= 8, (K-1)*dil <= 62");
         return 1;
     }
-    if (rows != sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planes: rows must be sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
+    if (rows < sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planes: rows must be >= sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
     if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3_planes: backward epilogue needs alpha2/beta2/partials"); return 1; }
     SatConvBfLaunch a;
     a.p = SatConvParams{nullptr, nullptr, bias, nullptr, nullptr, res, y, x2, alpha2, beta2, part_da, part_db,
@@ -593,7 +673,7 @@ extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo,
         sat_set_error("sat_conv1d_bf16x3_planesq: needs stride 1, 5 <= K <= 7, (K-1)*dil <= 62");
         return 1;
     }
-    if (rows != sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planesq: rows must be sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
+    if (rows < sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planesq: rows must be >= sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
     if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3_planesq: backward epilogue needs alpha2/beta2/partials"); return 1; }
     SatConvBfLaunch a;
     a.p = SatConvParams{nullptr, nullptr, bias, nullptr, nullptr, res, y, x2, alpha2, beta2, part_da, part_db,

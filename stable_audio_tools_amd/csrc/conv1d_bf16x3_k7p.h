@@ -17,6 +17,7 @@
 #pragma once
 
 #define SAT_K7P_LEAD 32           // zero rows before t = 0 in a plane (>= pad)
+static_assert(SAT_K7P_LEAD == SAT_K7P_LEAD_ROWS, "plane emission (conv1d_bf16x3.hip) writes row 32 + t");
 #define SAT_K7P_WBYTES 32768      // weight slab of a stage
 #define SAT_K7P_ABYTES 10240      // activation slab of a stage
 #define SAT_K7P_STAGE (SAT_K7P_WBYTES + SAT_K7P_ABYTES)

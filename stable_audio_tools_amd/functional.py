@@ -77,14 +77,15 @@ class WeightNormFn(torch.autograd.Function):
         return dv, dg.view(ctx.g_shape), None
 
 
-def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out=None):
+def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out=None, emit=None):
     """dL/d(conv input pre-activation) of a Conv1d with torch weight w (Cout, Cin, K).  out= (stride-1 kernels only): write into
-    the caller's tensor (it may alias `res`: accumulation in place)."""
+    the caller's tensor (it may alias `res`: accumulation in place).  emit: {"snake": None | (la, lb)} — also write the result as
+    the activation planes of the k7 conv that consumes it next (ops.emit_ok decides)."""
     if stride == 1:
         if ops.bf16x3_ok(k, 1, dil):
             q = ops.k7q_applicable(w.shape[0], k, 1, dil, (k - 1) * dil - pad)       # the data-gradient's input channels = Cout
             return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1, q=q), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
-                                     dsnake=dsnake, res=res, out=out)
+                                     dsnake=dsnake, res=res, out=out, emit=emit)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
         return ops.conv1d(dy, wpb, cin, k, 1, dil, (k - 1) * dil - pad, tout=tin, dsnake=dsnake, res=res, out=out)
     if out is not None:
@@ -105,7 +106,7 @@ def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False):
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad)
 
 
-def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None, cache=None):
+def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None, cache=None, emit=None):
     """conv1d(snake(x), w) [+bias] [+res]: the bf16x3 split-MFMA kernel (fp32-accurate, csrc/conv1d_bf16x3.hip) where
     its shape rules allow, else the fp32-MFMA kernel (csrc/conv1d.hip).  cache: DerivedCache of the layer (no-grad / frozen
     passes only) for the packed planes and the SnakeBeta constants."""
@@ -115,7 +116,7 @@ def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh
         planes = _cached(cache, "pack_fwd_q" if q else "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride, q=q))
         sconsts = _cached(cache, "snake", snake, lambda: ops.snake_consts(snake[0], snake[1])) if snake is not None else None
         return ops.conv1d_bf16x3(x, planes, cout, k, stride, dil, pad, tout=tout, bias=bias,
-                                 snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake, sconsts=sconsts)
+                                 snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake, sconsts=sconsts, emit=emit)
     return ops.conv1d(x, _cached(cache, "pack_fwd32", (w,), lambda: ops.pack(w, PACK_CONV_FWD)), cout, k, stride, dil, pad, tout=tout,
                       bias=bias, snake=snake, res=res, tanh_out=tanh_out, dsnake=dsnake)
 
@@ -135,14 +136,21 @@ class SnakeConv1dFn(torch.autograd.Function):
     """y = tanh?( conv1d(snake(x; alpha, beta), w, bias, stride, dil, pad) + res )."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None, cache=None):
+    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None, cache=None, next_snake=None):
+        """next_snake = (log-alpha, log-beta, dilation) of the ResidualUnit that reads y next (its k7 conv): the conv also emits
+        snake(y) as that conv's activation planes (no autograd through them: the consumer's own backward recomputes from y)."""
         ops = _ops(ops)
         x = x.contiguous()
         w = w.contiguous()
         cout, cin, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
+        emit = None
+        if next_snake is not None and not tanh_out:
+            tout_ = (x.shape[2] + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            if ops.emit_ok(cout, k, stride, tout_, next_snake[2]) and ops.bf16x3_ok(k, stride, dil):
+                emit = {"snake": (next_snake[0].detach(), next_snake[1].detach())}
         y = _conv_fwd(ops, x, w, stride, dil, pad, bias=bias, snake=snake,
-                      res=res.contiguous() if res is not None else None, tanh_out=tanh_out, cache=cache)
+                      res=res.contiguous() if res is not None else None, tanh_out=tanh_out, cache=cache, emit=emit)
         ctx.ops = ops
         ctx.cfg = (stride, dil, pad, tanh_out, bias is not None, res is not None, alpha is not None)
         ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None)
@@ -171,7 +179,7 @@ class SnakeConv1dFn(torch.autograd.Function):
             dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
         elif ctx.needs_input_grad[0]:
             dx = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], None)
-        return dx, da, db, dw, dbias, dres, None, None, None, None, None, None
+        return dx, da, db, dw, dbias, dres, None, None, None, None, None, None, None
 
 
 class SnakeConvTr1dFn(torch.autograd.Function):
@@ -216,7 +224,9 @@ class ResidualUnitFn(torch.autograd.Function):
     +1/3 of its forward flops.  caches = (DerivedCache of the k7 conv, of the k1 conv) or None."""
 
     @staticmethod
-    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None):
+    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None, next_snake=None):
+        """next_snake = (log-alpha, log-beta, dilation) of the ResidualUnit that follows: the k1 conv's epilogue then also writes
+        snake(y) as that unit's k7 activation planes (its sat_conv1d_k7_planes pre-pass disappears)."""
         ops = _ops(ops)
         x = x.contiguous()
         w1 = w1.contiguous()
@@ -226,7 +236,10 @@ class ResidualUnitFn(torch.autograd.Function):
         pad = dil * (k1 - 1) // 2
         c1, c2 = caches if caches is not None else (None, None)
         h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1), cache=c1)
-        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2)
+        emit = None
+        if next_snake is not None and ops.emit_ok(c, w2.shape[2], 1, h.shape[2], next_snake[2]):
+            emit = {"snake": (next_snake[0].detach(), next_snake[1].detach())}
+        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2, emit=emit)
         ctx.ops = ops
         ctx.dil = dil
         ctx.recompute = bool(recompute)
@@ -246,10 +259,12 @@ class ResidualUnitFn(torch.autograd.Function):
         if ctx.recompute:
             h = _conv_fwd(ops, x, w1, 1, dil, pad1, bias=bias1, snake=(a1, b1))
         dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
-        dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2))
+        # the k1 data-gradient also writes dh as the planes its consumer — the k7 data-gradient two launches below — reads
+        emit = {"snake": None} if ops.emit_ok(w1.shape[0], k2, 1, t, dil) else None
+        dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit=emit)
         dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
-        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None
+        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None
 
 
 class VaeSampleFn(torch.autograd.Function):

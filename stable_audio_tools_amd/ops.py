@@ -174,7 +174,7 @@ class SatOps:
         self._f32(out)
         return out
 
-    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None):
+    def _bf16x3_call(self, fn, rows, x, w_planes, cout, tout, dims, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None, emit=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
@@ -186,6 +186,21 @@ class SatOps:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
             pda, pdb = torch.empty(2, cout, rows, dtype=torch.float32, device=x.device).unbind(0)
+        if emit is not None:
+            # plane emission (sat_conv1d_bf16x3_emit): the planes the k7 conv that consumes y next would otherwise build in a pre-pass
+            esnake = emit.get("snake")
+            ea = eib = None
+            if esnake is not None:
+                ea, eib = self.snake_consts(esnake[0], esnake[1])
+            ehi, elo, erows = self._emit_planes(b, cout, tout, x.device, self._stream(x))
+            self._chk(self.lib.sat_conv1d_bf16x3_emit(_ptr(x), _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(sa), _ptr(sib),
+                                                      _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
+                                                      b, cin, cout, tin, tout, *dims, int(tanh_out), _ptr(ehi), _ptr(elo), _ptr(ea), _ptr(eib),
+                                                      erows, self._stream(x)))
+            self._emitted = {"ptr": y.data_ptr(), "shape": tuple(y.shape), "snake": self._snake_key(esnake), "hi": ehi, "lo": elo, "rows": erows}
+            if dsnake is not None:
+                return (y, *self._sum_pair(pda, pdb))
+            return y
         self._chk(fn(_ptr(x), _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(sa), _ptr(sib),
                      _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                      b, cin, cout, tin, tout, *dims, int(tanh_out), self._stream(x)))
@@ -193,8 +208,45 @@ class SatOps:
             return (y, *self._sum_pair(pda, pdb))
         return y
 
+    # ---- plane emission bookkeeping: producer -> the ONE k7 conv that consumes its output next ----
+    k7_emit = os.environ.get("SAT_K7_EMIT", "1") != "0"
+
+    @staticmethod
+    def _snake_key(snake):
+        return None if snake is None else (snake[0].data_ptr(), snake[1].data_ptr(), snake[0]._version, snake[1]._version)
+
+    def emit_ok(self, cout, k, stride, tout, consumer_dil):
+        """May the conv (k, stride) producing (B, cout, tout) emit planes for a k7 conv of dilation consumer_dil that reads it next?"""
+        if not (self.k7_emit and self.use_bf16x3 and self.k7q_applicable(cout, 7, 1, consumer_dil, 3 * consumer_dil)):
+            return False
+        generic = (stride == 1 and k <= 4) or stride > 1          # the plans of csrc/conv1d_bf16x3.hip's generic kernel
+        return generic and tout % 4 == 0
+
+    def _emit_planes(self, b, c, t, device, st):
+        """Emission target for a (b, c, t) tensor: planes [b][ceil(c/8)][rows][8] with the rows around the sequence zero.  One pair
+        per (shape, device, stream), zero-filled ONCE: producers only ever write rows 32 .. 32 + t - 1 of existing channels."""
+        rows = self.lib.sat_conv1d_k7_plane_rows(t, t, 0)          # pad 0 needs the most rows: valid for every consumer padding
+        key = ("emit", b, c, t, device, st.value if st is not None else 0)
+        cache = self.__dict__.setdefault("_planes", {})
+        pl = cache.get(key)
+        if pl is None:
+            n = b * ((c + 7) // 8) * rows * 8
+            pl = (torch.zeros(n, dtype=torch.int16, device=device), torch.zeros(n, dtype=torch.int16, device=device), rows)
+            cache[key] = pl
+        return pl
+
+    def _take_emitted(self, x, snake):
+        """Planes a producer emitted for exactly this tensor and activation (consumed once), or None."""
+        e = self.__dict__.get("_emitted")
+        if e is None:
+            return None
+        self._emitted = None
+        if e["ptr"] == x.data_ptr() and e["shape"] == tuple(x.shape) and e["snake"] == self._snake_key(snake):
+            return e
+        return None
+
     def conv1d_bf16x3(self, x, w_planes, cout, k, stride=1, dil=1, pad=0, tout=None, bias=None, snake=None, res=None,
-                      tanh_out=False, dsnake=None, out=None, sconsts=None):
+                      tanh_out=False, dsnake=None, out=None, sconsts=None, emit=None):
         """Same contract as conv1d; `snake` = (log-alpha, log-beta) as everywhere else; sconsts = snake_consts(*snake) if the
         caller keeps them (frozen layers)."""
         b, cin, tin = x.shape
@@ -208,7 +260,7 @@ class SatOps:
         if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
             return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
-                                 bias, snake, res, tanh_out, dsnake, out, sconsts)
+                                 bias, snake, res, tanh_out, dsnake, out, sconsts, emit)
 
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
@@ -222,17 +274,21 @@ class SatOps:
         sa = sib = None
         if snake is not None:
             sa, sib = sconsts if sconsts is not None else self.snake_consts(snake[0], snake[1])
-        rows = self.lib.sat_conv1d_k7_plane_rows(tin, tout, pad)
-        c8 = (cin + 7) // 8
-        need = 2 * b * c8 * rows * 8
         st = self._stream(x)
-        wkey = ("k7p", x.device, st.value if st is not None else 0)       # one workspace per (device, stream)
-        ws = self.__dict__.setdefault("_planes", {}).get(wkey)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.int16, device=x.device)
-            self._planes[wkey] = ws
-        hi, lo = ws[:need // 2], ws[need // 2:need]
-        self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
+        em = self._take_emitted(x, snake)
+        if em is not None:
+            hi, lo, rows = em["hi"], em["lo"], em["rows"]          # the producer's epilogue already wrote act(x) as planes
+        else:
+            rows = self.lib.sat_conv1d_k7_plane_rows(tin, tout, pad)
+            c8 = (cin + 7) // 8
+            need = 2 * b * c8 * rows * 8
+            wkey = ("k7p", x.device, st.value if st is not None else 0)       # one workspace per (device, stream)
+            ws = self.__dict__.setdefault("_planes", {}).get(wkey)
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.int16, device=x.device)
+                self._planes[wkey] = ws
+            hi, lo = ws[:need // 2], ws[need // 2:need]
+            self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
         y = self._conv_out(out, b, cout, tout, x.device)
         x2 = a2 = b2 = pda = pdb = None
         if dsnake is not None:

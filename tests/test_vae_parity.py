@@ -62,6 +62,50 @@ def test_vae_matches_reference_golden_gpu(hip, name, batch, in_len, seed):
     _run_case(name, batch, in_len, seed, "cuda")
 
 
+def _emission_case(ops, device):
+    """The k7q kernel + plane emission forced on at the tiny / mid channel counts (they normally start at 64 channels): every k7 conv
+    reads planes — written by its producer's epilogue where the producer is a k1 / strided conv of the generic kernel (forward: the
+    previous unit's k1 conv or the block's down conv; backward: the unit's own k1 data-gradient), by the sat_conv1d_k7_planes pre-pass
+    otherwise — and the golden comparison (forward + every gradient) must still hold."""
+    keep = (ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit)
+    counts = {"emit": 0, "prepass": 0, "q": 0}
+    orig = {n: getattr(ops.lib, n) for n in ("sat_conv1d_bf16x3_emit", "sat_conv1d_k7_planes", "sat_conv1d_bf16x3_planesq")}
+
+    def wrap(name, key):
+        def f(*a):
+            counts[key] += 1
+            return orig[name](*a)
+        setattr(ops.lib, name, f)
+    wrap("sat_conv1d_bf16x3_emit", "emit")
+    wrap("sat_conv1d_k7_planes", "prepass")
+    wrap("sat_conv1d_bf16x3_planesq", "q")
+    try:
+        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit = True, 1, True, True
+        for name, batch, in_len, seed in CASES[:2]:
+            _run_case(name, batch, in_len, seed, device)
+        with_emit = dict(counts)
+        ops.k7_emit = False
+        for k in counts:
+            counts[k] = 0
+        _run_case(*CASES[0], device)
+        assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission: one pre-pass per k7 conv
+    finally:
+        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit = keep
+        for n, f in orig.items():
+            setattr(ops.lib, n, f)
+    assert with_emit["emit"] > 0 and with_emit["prepass"] < with_emit["q"], with_emit
+    return with_emit
+
+
+def test_vae_plane_emission_simulator(emu_modules):
+    print(_emission_case(emu_modules, "cpu"))
+
+
+@pytest.mark.gpu
+def test_vae_plane_emission_gpu(hip):
+    print(_emission_case(hip, "cuda"))
+
+
 def _chunked(device):
     g = load_golden("vae_chunked_tiny")
     model = build_native_ae("tiny", 400, device)
