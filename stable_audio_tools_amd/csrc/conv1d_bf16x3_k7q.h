@@ -78,8 +78,13 @@ extern "C" int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0
     return sat_check_launch("sat_pack_weights_k7q");
 }
 
-template <int DUMMY_UNUSED = 0>
+template <int VARIANT = 1>
 __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatConvBfLaunch a) {
+    // VARIANT 1 (shipped): the next chunk's LDS-DMA goes out longest latency first — phase 0 issues its activation pieces (HBM) and
+    // taps 0, 1, phase 1 taps 2..6 (L2-resident weights) — with COUNTED waits: phase 1 leaves taps 4-6 in flight (vmcnt(3)), they are
+    // retired by the next chunk's phase 0 (which leaves its own new pieces in flight: 5 for waves 0-3, 4 for waves 4-7) one phase
+    // before they are read.  VARIANT 0: weights first, vmcnt(0) once per chunk (3-4 % slower at C = 128 / 256, profiles/EXPERIMENTS.md).
+    constexpr bool REORDER = (VARIANT & 1) != 0;
     constexpr int CO_T = SAT_K7_CO, T_T = SAT_K7_T, NT = SAT_K7_NT, AROWS = SAT_K7_AROWS;
     constexpr int TW = T_T / 64;                          // waves along time
     const SatConvParams& p = a.p;
@@ -185,9 +190,21 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         // ---- phase 0: taps 0..3 ----
 #pragma unroll
         for (int u = 0; u < 4; ++u) load_frags(fr[u], sb, u);
-        if (more) {
+        if constexpr (REORDER) {
+            if (more) {
+                issue_a(c + 1, (c + 1) & 1, 0); issue_a(c + 1, (c + 1) & 1, 1); issue_a(c + 1, (c + 1) & 1, 2);
+                issue_w(c + 1, (c + 1) & 1, 0); issue_w(c + 1, (c + 1) & 1, 1);
+                if (K != SAT_K7Q_TAPS) { SAT_WAIT_VMCNT(0); }
+                else if (wave < 4) { SAT_WAIT_VMCNT(5); }
+                else { SAT_WAIT_VMCNT(4); }
+            } else {
+                SAT_WAIT_VMCNT(0);
+            }
+        } else {
+            if (more) {
 #pragma unroll
-            for (int tap = 0; tap < 5; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+                for (int tap = 0; tap < 5; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+            }
         }
         SAT_WAIT_LGKM0();
         SAT_RAW_BARRIER();
@@ -202,7 +219,13 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 #pragma unroll
         for (int u = 0; u < 3; ++u)
             if (4 + u < K) load_frags(fr[u], sb, 4 + u);
-        if (more) {
+        if constexpr (REORDER) {
+            if (more) {
+#pragma unroll
+                for (int tap = 2; tap < SAT_K7Q_TAPS; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+                if (K == SAT_K7Q_TAPS) { SAT_WAIT_VMCNT(3); } else { SAT_WAIT_VMCNT(0); }
+            }
+        } else if (more) {
             issue_w(c + 1, (c + 1) & 1, 5); issue_w(c + 1, (c + 1) & 1, 6);
             issue_a(c + 1, (c + 1) & 1, 0); issue_a(c + 1, (c + 1) & 1, 1); issue_a(c + 1, (c + 1) & 1, 2);
             SAT_WAIT_VMCNT(0);                             // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
@@ -361,5 +384,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     const long long total = (long long)(a.cout_pad / SAT_K7_CO) * sat_cdiv(a.nq, SAT_K7_T) * a.p.B;
-    SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a);
+    const char* ev = getenv("SAT_K7Q_VARIANT");            // A/B switch (tools/kq_ab.py)
+    if (ev && atoi(ev) == 0) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
+    else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
 }
