@@ -38,16 +38,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-step", action="store_true", help="skip the timing of the alternating discriminator / generator step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
+    ap.add_argument("--no-long-context", action="store_true", help="skip the N = 6145 fp8 sampling measurement (BASELINE.json configs[4])")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check of the bench item (about one CPU-minute)")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
-    ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train"], default="vae_train",
+    ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train", "long_context"], default="vae_train",
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
                          "dit_sample: configs[2] DiT sampling steps/s (the metric's second half)")
     ap.add_argument("--dit-dtype", choices=["bf16", "f32"], default="bf16")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.workload == "dit_train" else 1
-    dsteps, dwarm = {"vae_train": (3, 1), "dit_sample": (50, 5), "dit_train": (5, 2)}[args.workload]
+    dsteps, dwarm = {"vae_train": (3, 1), "dit_sample": (50, 5), "dit_train": (5, 2), "long_context": (6, 2)}[args.workload]
     if args.steps is None:
         args.steps = dsteps
     if args.warmup is None:
@@ -89,7 +90,13 @@ class AttnProfiler:
         self.gemm_budget = 2 * max_launches     # (about two model evaluations: events cost host time in the measured loop)
         self._gemm_orig = {}
         specs = {"sat_gemm_bf16": lambda a: 2.0 * a[15] * a[16] * a[17],
-                 "sat_gemm_qkv_bf16": lambda a: 2.0 * (a[10] * a[11]) * (a[16] * a[13] * 64) * a[14]}
+                 "sat_gemm_qkv_bf16": lambda a: 2.0 * (a[10] * a[11]) * (a[16] * a[13] * 64) * a[14],
+                 # fp8 (e4m3, MX MFMA) forward projections of the long-context configuration
+                 "sat_gemm_fp8": lambda a: 2.0 * a[16] * a[17] * a[18],
+                 "sat_gemm_qkv_fp8": lambda a: 2.0 * (a[11] * a[12]) * (a[17] * a[14] * 64) * a[15],
+                 # activation quantisation passes in front of the fp8 GEMMs: time only
+                 "sat_quant_fp8": lambda a: 0.0}
+        self.kinds = {}
         for name, fl in specs.items():
             self._wrap_gemm(ops.lib, name, fl)
 
@@ -106,7 +113,7 @@ class AttnProfiler:
             s.record()
             rc = orig(*a)
             e.record()
-            self.gemm.append((s, e, flops(a)))
+            self.gemm.append((s, e, flops(a), name))
             return rc
 
         setattr(lib, name, timed)
@@ -116,13 +123,21 @@ class AttnProfiler:
         for name, orig in self._gemm_orig.items():
             setattr(self._lib, name, orig)
 
-    def gemm_summary(self, peak):
+    def gemm_summary(self, peak, fp8=False):
+        """bf16 (or, fp8=True, fp8) projection launches: achieved TFLOP/s over HIP-event time; the fp8 summary also carries the
+        time of the sat_quant_fp8 passes that feed them."""
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.gemm)
-        fl = sum(f for _, _, f in self.gemm)
+        want = ("sat_gemm_fp8", "sat_gemm_qkv_fp8") if fp8 else ("sat_gemm_bf16", "sat_gemm_qkv_bf16")
+        recs = [r for r in self.gemm if r[3] in want]
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+        fl = sum(f for _, _, f, _ in recs)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"kernel": "sat_gemm_kernel", "launches": len(self.gemm), "total_ms": round(ms, 3), "achieved": round(ach, 1), "peak": peak,
-                "frac": round(ach / peak, 4),
+        out_extra = {}
+        if fp8:
+            q = [r for r in self.gemm if r[3] == "sat_quant_fp8"]
+            out_extra = {"quant_launches": len(q), "quant_total_ms": round(sum(s.elapsed_time(e) for s, e, _, _ in q), 3)}
+        return {"kernel": "sat_gemm_kernel" + ("<fp8>" if fp8 else ""), "launches": len(recs), "total_ms": round(ms, 3), "achieved": round(ach, 1),
+                "peak": peak, "frac": round(ach / peak, 4), **out_extra,
                 "note": "every projection launch (sat_gemm_bf16 / sat_gemm_qkv_bf16) of the first model evaluations of the timed region: "
                         "2*M*N*K over HIP-event time, epilogues (SwiGLU, residual, head split + rotary + plane layout) included"}
 
@@ -307,6 +322,111 @@ def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
         line["cpu_baseline"] = dit_cpu_baseline(dcfg, tlat, m)
     del model
     torch.cuda.empty_cache()
+    return line
+
+
+PEAK_FP8_MFMA_TFLOPS = 5000.0   # MI355X_MICROARCH.md: dense fp8 (MX) MFMA peak
+
+
+def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
+    """BASELINE.json configs[4] on ONE GPU: the Stable-Audio-2.0-length DiT (sample_size 12582912 -> 6144 latent frames, N = 6145
+    tokens; reference configs/model_configs/txt2audio/stable_audio_2_0.json:3, :79-86) sampled with CFG (model batch 2), every
+    projection with >= 256 features in fp8 e4m3 on the MX MFMA (linear.set_fp8: per-tensor dynamic scales, sat_quant_fp8 per GEMM
+    input), attention in bf16 with fp32 softmax.  Reports sampler steps/s (eager and HIP-graph), the self-attention kernel against the
+    2.5 PF bf16 peak, the fp8 projections against the 5 PF fp8 peak (with the quantisation passes' time beside them), and a CPU
+    baseline on ONE of the 24 layers (the oracle at N = 6145, scaled x24)."""
+    dev = torch.device("cuda", 0)
+    from stable_audio_tools_amd import ops as O
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    from stable_audio_tools_amd.linear import set_fp8
+    from stable_audio_tools_amd.sampling import GraphedDenoiser, sample_v_ddim
+    import math
+    cfg = json.load(open(os.path.join(ROOT, "stable_audio_tools_amd", "configs", "stable_audio_open_dit.json")))
+    dcfg = cfg["diffusion"]["config"]
+    tlat, m, b = 6144, cfg["context_length"], 1
+    torch.manual_seed(1234)
+    model = DiffusionTransformer(**dcfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("to_out.weight") or ".ff.ff.2." in n_ or "process_conv" in n_:
+                p_.normal_(0.0, 0.02)
+    model = model.to(device=dev, dtype=torch.bfloat16).train(False)
+    nfp8 = set_fp8(model, True)
+    ops = O.get_ops()
+    prof = AttnProfiler(ops, max_launches=96)
+    g = torch.Generator().manual_seed(0)
+    noise = torch.randn(b, dcfg["io_channels"], tlat, generator=g).to(dev, torch.bfloat16)
+    cross = torch.randn(b, m, dcfg["cond_token_dim"], generator=g).to(dev, torch.bfloat16)
+    glob = torch.randn(b, dcfg["global_cond_dim"], generator=g).to(dev, torch.bfloat16)
+    kw = dict(cross_attn_cond=cross, global_embed=glob, cfg_scale=6.0, scale_phi=0.75)
+    sample_v_ddim(model, noise, warmup, **kw)
+    torch.cuda.synchronize()
+    prof.enabled = True
+    t0 = time.perf_counter()
+    out = sample_v_ddim(model, noise, steps, **kw)
+    torch.cuda.synchronize()
+    el_eager = time.perf_counter() - t0
+    prof.enabled = False
+    prof.restore()
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    gd = GraphedDenoiser(model, noise, noise.new_ones([b]), **kw)
+    tt = torch.linspace(1.0, 0, steps + 1)[:-1]
+    al, sg = torch.cos(tt * math.pi / 2), torch.sin(tt * math.pi / 2)
+    an, sn = torch.cat([al[1:], al.new_ones(1)]), torch.cat([sg[1:], sg.new_zeros(1)])
+    table = torch.stack([an * al + sn * sg, -an * sg + sn * al, al, -sg], dim=1).float().to(dev)
+    tsteps = (noise.new_ones([b])[:, None] * tt.to(dev)[None, :]).t().contiguous()
+
+    def graph_loop(ns):
+        x = noise
+        for i in range(ns):
+            x, pred = gd(x, tsteps[i], fused_update=table[i])
+        return pred
+    graph_loop(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    graph_loop(steps)
+    torch.cuda.synchronize()
+    el_graph = time.perf_counter() - t0
+    elapsed = min(el_eager, el_graph)
+    n = tlat + 1
+    d, depth = dcfg["embed_dim"], dcfg["depth"]
+    fwd = depth * (2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 2 * n * d * d + 2 * m * 768 * 2 * 768
+                   + 4 * n * m * d + 2 * n * d * d + 2 * n * d * 8 * d + 2 * n * 4 * d * d)
+    nl, ms, fl = prof.summary("self")
+    attn_tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    line = {"workload": "stable_audio_2_0-length DiT sampling step (d=1536, 24 layers, N=6145 tokens = 285 s of audio, context 130), CFG scale 6 "
+                        "(model batch 2), fp8 e4m3 projections (MX MFMA, dynamic per-tensor scales), bf16 attention, random init; ONE GPU "
+                        "(BASELINE.json configs[4] names 8: sampling is replicas-only, no collective)",
+            "value": steps / elapsed, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "steps_per_s": {"eager": steps / el_eager, "hip_graph": steps / el_graph}, "fp8_linears": nfp8,
+            "finite": bool(torch.isfinite(out.float()).all()), "peak_hbm_gib": round(peak_mem, 2),
+            "model_tflop_per_step": 2 * fwd / 1e12, "achieved_model_tflops": 2 * fwd * steps / elapsed / 1e12,
+            "attention": {"kernel": "sat_attn_fwd_kernel", "launches": nl, "avg_launch_ms": ms / nl if nl else None, "achieved": round(attn_tf, 1),
+                          "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(attn_tf / PEAK_BF16_MFMA_TFLOPS, 4)},
+            "fp8_projections": prof.gemm_summary(PEAK_FP8_MFMA_TFLOPS, fp8=True),
+            "bf16_projections": prof.gemm_summary(PEAK_BF16_MFMA_TFLOPS)}
+    del model, gd
+    torch.cuda.empty_cache()
+    if with_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import dit_oracle
+        one = dict(dcfg, depth=1)
+        with torch.device("meta"):
+            shapes = {k: (tuple(v.shape), v.dtype) for k, v in DiffusionTransformer(**one).state_dict().items()}
+        sd = {k: (torch.randn(sh) * 0.02 if dt.is_floating_point else torch.zeros(sh, dtype=dt)) for k, (sh, dt) in shapes.items()}
+        sd["transformer.rotary_pos_emb.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+        xg = torch.randn(1, dcfg["io_channels"], tlat)
+        cg, gg = torch.randn(1, m, dcfg["cond_token_dim"]), torch.randn(1, dcfg["global_cond_dim"])
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+
+        def step():
+            with torch.no_grad():
+                dit_oracle.dit_forward(sd, one, xg, torch.tensor([0.5]), cg, gg, cfg_scale=6.0, scale_phi=0.75)
+        dt1 = _median_time(step, reps=2)
+        line["cpu_baseline"] = {"value": 1.0 / (dt1 * depth), "unit": "steps/s", "cores": cores, "kind": "port",
+                                "sample": f"ONE of the {depth} layers (oracle, fp32, CFG batch 2, N={n}): median of 2 after warm-up = {dt1:.2f} s at "
+                                          f"{cores} threads, scaled x{depth}"}
     return line
 
 
@@ -629,6 +749,15 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
         return run_dit_train(args)
+    if args.workload == "long_context":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
+        torch.cuda.set_device(0)
+        lc = long_context_line(args.steps, args.warmup, not args.no_cpu_baseline)
+        print(json.dumps({"metric": "DiT sampling steps/sec", "value": lc["value"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": lc["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "fp8(e4m3 projections) + bf16", "data": "synthetic", "config": {"workload": lc["workload"]}, "long_context": lc}), flush=True)
+        return
     if args.workload == "dit_sample":
         if int(os.environ.get("WORLD_SIZE", 1)) > 1:
             raise SystemExit("dit_sample is replicas-only (independent prompts per GPU, no collective): run it per GPU")
@@ -750,6 +879,8 @@ def main():
                                  if k in sec}
             if "cpu_baseline" in sec:
                 line["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
+            if not args.no_long_context:
+                line["long_context"] = long_context_line(with_cpu_baseline=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

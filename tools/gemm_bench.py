@@ -56,6 +56,20 @@ def main():
                     for sp in SPLITS:      # split-K slabs + fused bias / residual epilogue kernel
                         row[f"native_t{tile}_splitk{sp}_res_us"] = round(timeit(lambda: ops.gemm_bf16_splitk(a, b, sp, res=res)), 1)
             ops.gemm_tile = None
+            # fp8 e4m3 projections (BASELINE.json configs[4]): the MX-MFMA GEMM alone, the activation quantisation pass that feeds it
+            # (amax reduction + sat_quant_fp8), and their sum — what a fp8 nn.Linear costs per call (weights are quantised once)
+            if k % 16 == 0:
+                qa, sa_ = ops.quant_fp8(a)
+                qb, sb_ = ops.quant_fp8(b)
+                alpha = (sa_ * sb_)
+                t8 = timeit(lambda: ops.gemm_fp8(qa, qb, alpha))
+                tq = timeit(lambda: ops.quant_fp8(a))
+                row["fp8_gemm_us"] = round(t8, 1)
+                row["fp8_gemm_tf"] = round(fl / t8 / 1e6, 1)
+                row["fp8_quant_act_us"] = round(tq, 1)
+                row["fp8_total_us"] = round(t8 + tq, 1)
+                if name == "ff1":
+                    row["fp8_swiglu_us"] = round(timeit(lambda: ops.gemm_fp8(qa, qb, alpha, epilogue=ops.EPI_SWIGLU)), 1)
             print(json.dumps(row), flush=True)
 
 
