@@ -282,18 +282,20 @@ def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
     # (a serving process captures once per shape); `value` is the faster of the two modes on this box, both are reported.
     from stable_audio_tools_amd.sampling import GraphedDenoiser
     import math
-    gd = GraphedDenoiser(model, noise, noise.new_ones([b]), **kw)
+    with torch.no_grad():
+        gd = GraphedDenoiser(model, noise, noise.new_ones([b]), **kw)
     tt = torch.linspace(1.0, 0, steps + 1)[:-1]
     al, sg = torch.cos(tt * math.pi / 2), torch.sin(tt * math.pi / 2)
     an, sn = torch.cat([al[1:], al.new_ones(1)]), torch.cat([sg[1:], sg.new_zeros(1)])
     table = torch.stack([an * al + sn * sg, -an * sg + sn * al, al, -sg], dim=1).float().to(dev)
     tsteps = (noise.new_ones([b])[:, None] * tt.to(dev)[None, :]).t().contiguous()
 
+    @torch.no_grad()
     def graph_loop(nsteps):
         x = noise
         for i in range(nsteps):
             x, pred = gd(x, tsteps[i], fused_update=table[i])
-        return pred
+        return pred.clone()
     graph_loop(max(warmup, 1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -369,13 +371,15 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
     prof.enabled = False
     prof.restore()
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
-    gd = GraphedDenoiser(model, noise, noise.new_ones([b]), **kw)
+    with torch.no_grad():
+        gd = GraphedDenoiser(model, noise, noise.new_ones([b]), **kw)
     tt = torch.linspace(1.0, 0, steps + 1)[:-1]
     al, sg = torch.cos(tt * math.pi / 2), torch.sin(tt * math.pi / 2)
     an, sn = torch.cat([al[1:], al.new_ones(1)]), torch.cat([sg[1:], sg.new_zeros(1)])
     table = torch.stack([an * al + sn * sg, -an * sg + sn * al, al, -sg], dim=1).float().to(dev)
     tsteps = (noise.new_ones([b])[:, None] * tt.to(dev)[None, :]).t().contiguous()
 
+    @torch.no_grad()
     def graph_loop(ns):
         x = noise
         for i in range(ns):

@@ -340,6 +340,11 @@ int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb,
                      void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
                      int heads, int K, int sec0, int nsec, void* stream);
 /* dst (R, C) fp8 e4m3 = saturate_448(src * qscale[0]), round to nearest even; src fp32 | bf16; qscale a DEVICE scalar. */
+/* Dynamic per-tensor scale of the fp8 quantisation in one launch (last-arriving block reduces the per-block maxima): scales[0] =
+ * 448 / max|src| (what sat_quant_fp8 takes as qscale), scales[1] = max|src| / 448 (the GEMM's de-quantisation factor).  work: >= 1 +
+ * sat_absmax_scale_blocks(R, C) floats, work[0] == 0 on entry (left 0).  src (R, C) fp32 | bf16, C % 4 == 0. */
+int sat_absmax_scale_blocks(int R, int C);
+int sat_absmax_scale(const void* src, long long lds, float* work, float* scales, int R, int C, int src_f32, void* stream);
 int sat_quant_fp8(const void* src, long long lds, void* dst, long long ldd, const float* qscale, int R, int C, int src_f32,
                   void* stream);
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "sat_gemm_fp8": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P, _P] + [_I] * 5 + [_P]),
     "sat_gemm_qkv_fp8": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P, _P] + [_I] * 7 + [_P]),
     "sat_quant_fp8": (_I, [_P, _L, _P, _L, _P, _I, _I, _I, _P]),
+    "sat_absmax_scale": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),
+    "sat_absmax_scale_blocks": (_I, [_I, _I]),
     "sat_splitk_epilogue": (_I, [_P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _P]),
     "sat_cast_bf16": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     "sat_split_bf16x3": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),

@@ -913,6 +913,79 @@ extern "C" int sat_quant_fp8(const void* src, long long lds, void* dst, long lon
     return sat_check_launch("sat_quant_fp8");
 }
 
+
+// Per-tensor dynamic scale of the fp8 quantisation in ONE launch: every block reduces max|x| over its share, the LAST block to
+// arrive (device-scope ticket; agent-scope release / acquire around it, cdna_hip_programming.md §6 Guideline 16) reduces the partial
+// maxima and writes scales[0] = 448 / amax (the quantisation scale sat_quant_fp8 reads) and scales[1] = amax / 448 (the
+// de-quantisation scale for the GEMM's alpha), amax clamped at 1e-12.  work: caller-owned, >= 1 + gridDim floats; work[0] is the
+// ticket counter — zero before the first call, reset by the kernel.
+struct SatAbsmaxParams {
+    const void* src;
+    float* work;
+    float* scales;
+    long long lds_;
+    int R, Cc, src_f32;
+};
+__global__ void __launch_bounds__(256) sat_absmax_scale_kernel(SatAbsmaxParams p) {
+    __shared__ float red[4];
+    __shared__ int last;
+    const int cch = p.Cc >> 2;
+    const long long total = (long long)p.R * cch;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / cch), c = (int)(i % cch) * 4;
+        if (p.src_f32) {
+            const f32x4 v = *(const f32x4*)((const float*)p.src + (long long)r * p.lds_ + c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        } else {
+            const f32x4 v = sat_load4<false>(p.src, (long long)r * p.lds_ + c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        p.work[1 + blockIdx.x] = bm;
+#if !defined(SAT_HIPEMU)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned ticket = atomicAdd((unsigned*)p.work, 1u);
+        last = (ticket == gridDim.x - 1);
+#if !defined(SAT_HIPEMU)
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    }
+    __syncthreads();
+    if (!last) return;
+    float g = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) g = fmaxf(g, p.work[1 + i]);
+    for (int k = 32; k >= 1; k >>= 1) g = fmaxf(g, __shfl_xor(g, k));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float am = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-12f);
+        p.scales[0] = 448.0f / am;
+        p.scales[1] = am / 448.0f;
+        *(unsigned*)p.work = 0u;
+    }
+}
+extern "C" int sat_absmax_scale_blocks(int R, int C) {
+    const long long total = (long long)R * (C >> 2);
+    const long long b = sat_cdivll(total, 256 * 4);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+// src (R, C) fp32|bf16 (row stride lds elements, C % 4 == 0) -> scales[0] = 448 / max|src|, scales[1] = max|src| / 448.
+// work: >= 1 + sat_absmax_scale_blocks(R, C) floats, work[0] == 0 on entry (the kernel leaves it 0).
+extern "C" int sat_absmax_scale(const void* src, long long lds, float* work, float* scales, int R, int C, int src_f32, void* stream) {
+    if (R <= 0 || C <= 0 || (C & 3) || !work || !scales) { sat_set_error("sat_absmax_scale: bad arguments (C % 4 == 0)"); return 1; }
+    SatAbsmaxParams p{src, work, scales, lds, R, C, src_f32};
+    SAT_LAUNCH(sat_absmax_scale_kernel, dim3((unsigned)sat_absmax_scale_blocks(R, C)), dim3(256), stream, p);
+    return sat_check_launch("sat_absmax_scale");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Operand preparation: cast / transpose / bf16x3 split, 16-byte accesses on both sides.
 //   dst[c][r] (C, ldd) <- src[r][c] (R, lds)   (mode bit 0: transpose), source fp32 or bf16, destination bf16;

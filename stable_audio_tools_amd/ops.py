@@ -847,12 +847,18 @@ class SatOps:
         dt = self._dt(src)
         if src.dim() != 2 or src.stride(1) != 1 or src.shape[1] % 4:
             raise ValueError("quant_fp8 takes a 2-D tensor with a contiguous last dim, C % 4 == 0")
-        amax = src.detach().abs().amax().float().clamp_min(1e-12)
-        qs = (448.0 / amax).contiguous()
+        # two launches: max|src| -> (448 / amax, amax / 448) on the device (sat_absmax_scale), then the conversion itself
+        st = self._stream(src)
+        wkey = ("absmax", src.device, st.value if st is not None else 0)
+        work = self.__dict__.setdefault("_planes", {}).get(wkey)
+        if work is None:
+            work = torch.zeros(1 + 1024, dtype=torch.float32, device=src.device)
+            self._planes[wkey] = work
+        scales = torch.empty(2, dtype=torch.float32, device=src.device)
+        self._chk(self.lib.sat_absmax_scale(_ptr(src), src.stride(0), _ptr(work), _ptr(scales), src.shape[0], src.shape[1], int(dt == 0), st))
         q = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
-        self._chk(self.lib.sat_quant_fp8(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(qs), src.shape[0], src.shape[1], int(dt == 0),
-                                         self._stream(src)))
-        return q, (amax / 448.0)
+        self._chk(self.lib.sat_quant_fp8(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(scales), src.shape[0], src.shape[1], int(dt == 0), st))
+        return q, scales[1]
 
     def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
                  out=None):
