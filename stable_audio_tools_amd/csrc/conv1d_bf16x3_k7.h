@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
     const int q_in0 = t0 - p.pad;
     const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
     const bool mfma_first = wave < 4;
+    const bool wave_on_co = (co0 + co_w) < a.cout_v;      // a wave whose 64 output channels are all past Cout (Cout <= 64: the discriminator's
+                                                          // convs) skips its MFMAs — its accumulators stay zero and its epilogue is skipped
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -167,11 +169,11 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
     // halves of the workgroup take them in opposite order
     auto phase = [&](auto bc, auto bn) {
         if (mfma_first) {
-            mfma_phase(bc);
+            if (wave_on_co) mfma_phase(bc);
             write_lds(bn, bn);
         } else {
             write_lds(bn, bn);
-            mfma_phase(bc);
+            if (wave_on_co) mfma_phase(bc);
         }
     };
 
@@ -209,9 +211,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7_kernel(SatConv
     if (c + 1 < nchunks) {
         phase(I0{}, I1{});
         __syncthreads();
-        mfma_phase(I1{});
+        if (wave_on_co) mfma_phase(I1{});
     } else {
-        mfma_phase(I0{});
+        if (wave_on_co) mfma_phase(I0{});
     }
 
     // ------------------------------------ epilogue (as the generic kernel) ------------------------------------

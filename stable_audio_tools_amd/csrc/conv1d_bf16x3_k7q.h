@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
     };
 
+    const bool wave_on_co = (co0 + co_w) < a.cout_v;      // Cout <= 64 (one co half empty): that wave row multiplies nothing
     // prologue: chunk 0 complete in stage 0
 #pragma unroll
     for (int tap = 0; tap < SAT_K7Q_TAPS; ++tap) issue_w(0, 0, tap);
@@ -210,8 +211,10 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         SAT_RAW_BARRIER();
         SAT_SCHED_FENCE();
         SAT_SETPRIO(1);
+        if (wave_on_co) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) mfma_frags(fr[u]);
+            for (int u = 0; u < 4; ++u) mfma_frags(fr[u]);
+        }
         SAT_SETPRIO(0);
         SAT_SCHED_FENCE();
         SAT_RAW_BARRIER();
@@ -234,9 +237,11 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         SAT_RAW_BARRIER();
         SAT_SCHED_FENCE();
         SAT_SETPRIO(1);
+        if (wave_on_co) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (4 + u < K) mfma_frags(fr[u]);
+            for (int u = 0; u < 3; ++u)
+                if (4 + u < K) mfma_frags(fr[u]);
+        }
         SAT_SETPRIO(0);
         SAT_SCHED_FENCE();
         SAT_RAW_BARRIER();
