@@ -83,7 +83,7 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out
     the activation planes of the k7 conv that consumes it next (ops.emit_ok decides)."""
     if stride == 1:
         if ops.bf16x3_ok(k, 1, dil):
-            q = ops.k7q_applicable(w.shape[0], k, 1, dil, (k - 1) * dil - pad)       # the data-gradient's input channels = Cout
+            q = ops.k7q_applicable(w.shape[0], k, 1, dil, (k - 1) * dil - pad, cin)  # the data-gradient's input channels = Cout
             return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1, q=q), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
                                      dsnake=dsnake, res=res, out=out, emit=emit)
         wpb = ops.pack(w, PACK_CONV_DGRAD)
@@ -112,7 +112,7 @@ def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh
     passes only) for the packed planes and the SnakeBeta constants."""
     cout, cin, k = w.shape
     if ops.bf16x3_ok(k, stride, dil):
-        q = ops.k7q_applicable(cin, k, stride, dil, pad)
+        q = ops.k7q_applicable(cin, k, stride, dil, pad, cout)
         planes = _cached(cache, "pack_fwd_q" if q else "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride, q=q))
         sconsts = _cached(cache, "snake", snake, lambda: ops.snake_consts(snake[0], snake[1])) if snake is not None else None
         return ops.conv1d_bf16x3(x, planes, cout, k, stride, dil, pad, tout=tout, bias=bias,
@@ -260,7 +260,7 @@ class ResidualUnitFn(torch.autograd.Function):
             h = _conv_fwd(ops, x, w1, 1, dil, pad1, bias=bias1, snake=(a1, b1))
         dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
         # the k1 data-gradient also writes dh as the planes its consumer — the k7 data-gradient two launches below — reads
-        emit = {"snake": None} if ops.emit_ok(w1.shape[0], k2, 1, t, dil) else None
+        emit = {"snake": None} if (ops.emit_ok(w1.shape[0], k2, 1, t, dil) and ops.k7q_applicable(w1.shape[0], k1, 1, dil, pad1, c)) else None
         dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit=emit)
         dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)

@@ -131,9 +131,14 @@ class SatOps:
     k7q = os.environ.get("SAT_K7Q", "1") != "0"
     k7q_min_cin = int(os.environ.get("SAT_K7Q_MIN", "64"))
 
-    def k7q_applicable(self, cin, k, stride, dil, pad):
+    k7q_min_cout = int(os.environ.get("SAT_K7Q_MIN_COUT", "128"))
+
+    def k7q_applicable(self, cin, k, stride, dil, pad, cout=None):
+        """The ResidualUnit convs (C -> C, C >= 128) and their data-gradients.  Convs with fewer than k7q_min_cout output channels
+        stay on the direct kernel: the MS-STFT discriminator's (64 filters: half of the 128-row channel tile would be empty, and the
+        planes pre-pass is not paid back — measured, profiles/EXPERIMENTS.md) and the decoder's last conv (128 -> 2)."""
         return (self.k7q and self.k7_planes and self.use_bf16x3 and stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32
-                and (k - 1) * dil <= 62 and cin >= self.k7q_min_cin)
+                and (k - 1) * dil <= 62 and cin >= self.k7q_min_cin and (cout is None or cout >= self.k7q_min_cout))
 
     def pack_bf16x3(self, w, mode=0, stride=1, q=False):
         """w: (D0, D1, K) fp32 -> (hi, lo) int16 planes.  mode 0: conv weight [out][in][K]; mode 1: data-gradient of a
@@ -217,7 +222,7 @@ class SatOps:
 
     def emit_ok(self, cout, k, stride, tout, consumer_dil):
         """May the conv (k, stride) producing (B, cout, tout) emit planes for a k7 conv of dilation consumer_dil that reads it next?"""
-        if not (self.k7_emit and self.use_bf16x3 and self.k7q_applicable(cout, 7, 1, consumer_dil, 3 * consumer_dil)):
+        if not (self.k7_emit and self.use_bf16x3 and self.k7q_applicable(cout, 7, 1, consumer_dil, 3 * consumer_dil, cout)):
             return False
         generic = (stride == 1 and k <= 4) or stride > 1          # the plans of csrc/conv1d_bf16x3.hip's generic kernel
         return generic and tout % 4 == 0

@@ -124,13 +124,13 @@ def _run_planes(ops, dev, cases, q_min=None):
     the path the C >= 512 levels take — forced on for every channel count: forward and all gradients vs torch, and bit-identical
     outputs to the direct kernel (same split, same MFMA order)."""
     keep = (ops.k7_planes, ops.k7_planes_min_cin)
-    keepq = (ops.k7q, ops.k7q_min_cin)
+    keepq = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout)
     try:
         for case in cases:
             ops.k7_planes, ops.k7_planes_min_cin = True, 1
             ops.k7q = False
             _run_s1(ops, dev, case, True)               # autograd units through the planes kernel (k7p)
-            ops.k7q, ops.k7q_min_cin = True, 1
+            ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = True, 1, 1
             _run_s1(ops, dev, case, True)               # ... and through the third-generation kernel (k7q)
             B, Cin, Cout, T, K, dil = case
             gen = torch.Generator().manual_seed(7)
@@ -158,7 +158,7 @@ def _run_planes(ops, dev, cases, q_min=None):
                     assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), (case, (a - b).abs().max().item())
     finally:
         ops.k7_planes, ops.k7_planes_min_cin = keep
-        ops.k7q, ops.k7q_min_cin = keepq
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = keepq
 
 
 def test_conv_k7_planes_sim(emu):

@@ -67,7 +67,7 @@ def _emission_case(ops, device):
     reads planes — written by its producer's epilogue where the producer is a k1 / strided conv of the generic kernel (forward: the
     previous unit's k1 conv or the block's down conv; backward: the unit's own k1 data-gradient), by the sat_conv1d_k7_planes pre-pass
     otherwise — and the golden comparison (forward + every gradient) must still hold."""
-    keep = (ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit)
+    keep = (ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout)
     counts = {"emit": 0, "prepass": 0, "q": 0}
     orig = {n: getattr(ops.lib, n) for n in ("sat_conv1d_bf16x3_emit", "sat_conv1d_k7_planes", "sat_conv1d_bf16x3_planesq")}
 
@@ -80,7 +80,7 @@ def _emission_case(ops, device):
     wrap("sat_conv1d_k7_planes", "prepass")
     wrap("sat_conv1d_bf16x3_planesq", "q")
     try:
-        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit = True, 1, True, True
+        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = True, 1, True, True, 1
         for name, batch, in_len, seed in CASES[:2]:
             _run_case(name, batch, in_len, seed, device)
         with_emit = dict(counts)
@@ -90,7 +90,7 @@ def _emission_case(ops, device):
         _run_case(*CASES[0], device)
         assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission: one pre-pass per k7 conv
     finally:
-        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit = keep
+        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = keep
         for n, f in orig.items():
             setattr(ops.lib, n, f)
     assert with_emit["emit"] > 0 and with_emit["prepass"] < with_emit["q"], with_emit
