@@ -449,6 +449,8 @@ class ConvProfiler:
         "sat_conv1d_k7_planes": ("sat_k7_planes_kernel", X3, lambda a: 0.0),     # the planes kernel's pre-pass: time, no flops of its own
         "sat_conv1d_bf16x3_planes": ("sat_conv1d_bf16x3_k7p_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_conv1d_bf16x3_planesq": ("sat_conv1d_bf16x3_k7q_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        # the fused ResidualUnit forward (C <= 128): conv7 + conv1 in one launch of the k7q kernel
+        "sat_residual_unit_fwd": ("sat_conv1d_bf16x3_k7q_kernel", X3, lambda a: 2.0 * a[14] * a[15] * a[15] * (a[17] + 1) * a[16]),
         # the k1 / strided convs that also write their consumer's activation planes (generic kernel, plane emission)
         "sat_conv1d_bf16x3_emit": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_convtr1d_bf16x3": ("sat_conv1d_bf16x3_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[16]),

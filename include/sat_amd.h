@@ -74,6 +74,16 @@ int sat_conv1d_bf16x3_emit(const float* x, const short* w_hi, const short* w_lo,
                       const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
                       int K, int stride, int dil, int pad, int tanh_out, void* em_hi, void* em_lo,
                            const float* em_a, const float* em_ib, int em_rows, void* stream);
+/* The whole ResidualUnit forward in ONE launch (models/autoencoders.py:58-83), 1 <= C <= 128 (csrc/conv1d_bf16x3_k7q.h, FUSED):
+ *   h = conv7_dil(snake1(x)) + bias1   -> `h` (fp32 (B, C, T); NULL: not kept — the backward needs it)
+ *   y = x + conv1(snake2(h)) + bias2   -> `y`, and (em_hi != NULL) snake_next(y) as the next unit's activation planes.
+ * xp_hi / xp_lo [B][ceil(C/8)][rows][8]: planes of snake1(x) (sat_conv1d_k7_planes or a producer's emission); w7_*:
+ * sat_pack_weights_k7q(K, mode 0); w1_*: sat_pack_weights_k7q of the (C, C, 1) weight (K = 1); a2 / ib2: sat_snake_consts of snake2.
+ * 'same' padding (2 * pad == (K - 1) * dil), T % 4 == 0. */
+int sat_residual_unit_fwd(const short* xp_hi, const short* xp_lo, int rows, const short* w7_hi, const short* w7_lo,
+                          const float* bias1, const float* a2, const float* ib2, const short* w1_hi, const short* w1_lo,
+                          const float* bias2, const float* x, float* h, float* y, int B, int C, int T, int K, int dil, int pad,
+                          void* em_hi, void* em_lo, const float* em_a, const float* em_ib, int em_rows, void* stream);
 int sat_convtr1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, const float* bias, const float* snake_a,
                         const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                         const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,

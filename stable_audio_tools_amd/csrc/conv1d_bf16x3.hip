@@ -49,6 +49,14 @@ struct SatConvBfLaunch {
     const float* em_a = nullptr;
     const float* em_ib = nullptr;
     int em_rows = 0, em_c8 = 0;
+    // fused ResidualUnit forward (conv1d_bf16x3_k7q.h, FUSED): the 1x1 conv's weights in sat_pack_weights_k7q layout (K = 1), its bias,
+    // the second SnakeBeta's pre-exponentiated constants, and where the intermediate h goes (fp32 (B, C, T), or null: not kept)
+    const short* ru_w1_hi = nullptr;
+    const short* ru_w1_lo = nullptr;
+    const float* ru_bias2 = nullptr;
+    const float* ru_a2 = nullptr;
+    const float* ru_ib2 = nullptr;
+    float* ru_h = nullptr;
 };
 
 SAT_DEVICE void sat_split2(float x, short* hi, short* lo) {
@@ -695,6 +703,47 @@ extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo,
     a.wq = 1;
     SatBfPlan pl{8, 1, K};
     return sat_bf_launch("sat_conv1d_bf16x3_planesq", a, pl, stream);
+}
+
+// The whole ResidualUnit forward in one launch (autoencoders.py:58-83), C <= 128 channels:
+//   h = conv7(planes of snake1(x)) + bias1          (stored to `h` if given: the backward needs it)
+//   y = x + conv1(snake2(h)) + bias2                 (+ optionally written as the NEXT unit's activation planes: em_*)
+// xp_hi / xp_lo: activation planes of snake1(x) (sat_conv1d_k7_planes or a producer's emission); w7_*: sat_pack_weights_k7q(K, mode 0);
+// w1_*: sat_pack_weights_k7q of the (C, C, 1) weight (K = 1, mode 0); a2 / ib2: sat_snake_consts of the second activation.
+extern "C" int sat_residual_unit_fwd(const short* xp_hi, const short* xp_lo, int rows, const short* w7_hi, const short* w7_lo,
+                                     const float* bias1, const float* a2, const float* ib2, const short* w1_hi, const short* w1_lo,
+                                     const float* bias2, const float* x, float* h, float* y, int B, int C, int T, int K, int dil, int pad,
+                                     void* em_hi, void* em_lo, const float* em_a, const float* em_ib, int em_rows, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || C > SAT_K7_CO) { sat_set_error("sat_residual_unit_fwd: needs 1 <= C <= 128"); return 1; }
+    if (K < 5 || K > SAT_K7Q_TAPS || dil < 1 || (K - 1) * dil > 62 || 2 * pad != (K - 1) * dil) {
+        sat_set_error("sat_residual_unit_fwd: needs 5 <= K <= 7, (K-1)*dil <= 62, 'same' padding");
+        return 1;
+    }
+    if (rows < sat_conv1d_k7_plane_rows(T, T, pad)) { sat_set_error("sat_residual_unit_fwd: rows must be >= sat_conv1d_k7_plane_rows(T, T, pad)"); return 1; }
+    if (!xp_hi || !xp_lo || !w7_hi || !w7_lo || !w1_hi || !w1_lo || !a2 || !ib2 || !x || !y) { sat_set_error("sat_residual_unit_fwd: missing operand"); return 1; }
+    if ((T & 3) || (((uintptr_t)y | (uintptr_t)x) & 15)) { sat_set_error("sat_residual_unit_fwd: T % 4 == 0 and 16-byte aligned x / y"); return 1; }
+    SatConvBfLaunch a;
+    a.p = SatConvParams{nullptr, nullptr, bias1, nullptr, nullptr, x, y, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        B, C, C, T, T, K, 1, dil, pad, 0};
+    a.w_hi = w7_hi;
+    a.w_lo = w7_lo;
+    a.cout_v = C;
+    a.cout_pad = SAT_CO_T;
+    a.cin_v = C;
+    a.sin_log2 = 0; a.sout_log2 = 0; a.in_shift = 0; a.out_shift = 0;
+    a.nq = T;
+    a.xp_hi = xp_hi; a.xp_lo = xp_lo; a.xp_rows = rows; a.xp_c8 = sat_cdiv(C, 8);
+    a.wq = 1;
+    a.ru_w1_hi = w1_hi; a.ru_w1_lo = w1_lo; a.ru_bias2 = bias2; a.ru_a2 = a2; a.ru_ib2 = ib2; a.ru_h = h;
+    if (em_hi) {
+        if (!em_lo || (em_a == nullptr) != (em_ib == nullptr) || em_rows < SAT_K7P_LEAD_ROWS + T || (((uintptr_t)em_hi | (uintptr_t)em_lo) & 15)) {
+            sat_set_error("sat_residual_unit_fwd: bad emission planes");
+            return 1;
+        }
+        a.em_hi = (short*)em_hi; a.em_lo = (short*)em_lo; a.em_a = em_a; a.em_ib = em_ib; a.em_rows = em_rows; a.em_c8 = sat_cdiv(C, 8);
+    }
+    SatBfPlan pl{8, 1, K};
+    return sat_bf_launch("sat_residual_unit_fwd", a, pl, stream);
 }
 
 // Same contract as sat_convtr1d (y[co][q*stride + k - pad] += W[ci][co][k] act(x)[ci][q], K == 2*stride, power-of-two

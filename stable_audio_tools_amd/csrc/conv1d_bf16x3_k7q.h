@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) sat_pack_k7q_kernel(SatPackQParams p) {
     p.lo[o] = l;
 }
 static bool sat_pack_q_geometry(int D0, int D1, int K, int mode, SatPackQParams* p) {
-    if (mode < 0 || mode > 1 || D0 <= 0 || D1 <= 0 || K < 5 || K > SAT_K7Q_TAPS) return false;
+    if (mode < 0 || mode > 1 || D0 <= 0 || D1 <= 0 || !(K == 1 || (K >= 5 && K <= SAT_K7Q_TAPS))) return false;
     p->D0 = D0; p->D1 = D1; p->K = K; p->mode = mode;
     if (mode == 0) { p->m_v = D0; p->v_v = D1; } else { p->m_v = D1; p->v_v = D0; }
     p->out_pad = sat_cdiv(p->m_v, SAT_K7_CO) * SAT_K7_CO;
@@ -72,13 +72,21 @@ extern "C" long long sat_pack_weights_k7q_size(int D0, int D1, int K, int mode) 
 }
 extern "C" int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0, int D1, int K, int mode, void* stream) {
     SatPackQParams p{};
-    if (!sat_pack_q_geometry(D0, D1, K, mode, &p)) { sat_set_error("sat_pack_weights_k7q: needs 5 <= K <= 7, mode 0|1"); return 1; }
+    if (!sat_pack_q_geometry(D0, D1, K, mode, &p)) { sat_set_error("sat_pack_weights_k7q: needs 5 <= K <= 7 (or K == 1: the fused unit's 1x1 conv), mode 0|1"); return 1; }
     p.w = w; p.hi = hi; p.lo = lo;
     SAT_LAUNCH(sat_pack_k7q_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
     return sat_check_launch("sat_pack_weights_k7q");
 }
 
-template <int VARIANT = 1>
+// FUSED (template): the whole ResidualUnit forward, y = x + conv1(snake2(conv7(snake1(x)))) (autoencoders.py:58-83), for C <= 128
+// (one channel tile holds every channel of the intermediate h): after the k7 K loop the workgroup owns h[:, t0 .. t0 + 256) in its
+// accumulators — it stores h (fp32, kept for the backward), writes snake2(h + bias1) as bf16 hi / lo planes into the drained stage
+// memory ([plane][16 channel groups][256 rows][8]: straight from the accumulator layout, 8-byte ds_writes, no transposition), runs the
+// 1x1 conv as a second GEMM on them (K = 128: 8 MFMA k-steps of 16 channels, 96 MFMAs per wave; its weight fragments come from L2
+// straight into registers) and finishes with the ordinary epilogue on the second accumulators (bias2, residual x, plane emission for
+// the next unit).  The k1 launch, its read of h and its separate activation pass disappear.
+typedef uint32_t u32x2_q __attribute__((ext_vector_type(2)));
+template <int VARIANT = 1, bool FUSED = false>
 __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatConvBfLaunch a) {
     // VARIANT 1 (shipped): the next chunk's LDS-DMA goes out longest latency first — phase 0 issues its activation pieces (HBM) and
     // taps 0, 1, phase 1 taps 2..6 (L2-resident weights) — with COUNTED waits: phase 1 leaves taps 4-6 in flight (vmcnt(3)), they are
@@ -90,7 +98,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     const SatConvParams& p = a.p;
     // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue in front of every fragment read: cdna_hip_programming.md §5)
     constexpr int RED_OFF = 2 * SAT_K7Q_STAGE, EP_OFF = RED_OFF + 2 * TW * CO_T * 4;
-    __shared__ __attribute__((aligned(1024))) char lds[EP_OFF + 3 * CO_T * 4];
+    __shared__ __attribute__((aligned(1024))) char lds[EP_OFF + 6 * CO_T * 4];
     float (*red_lds)[TW][CO_T] = reinterpret_cast<float (*)[TW][CO_T]>(lds + RED_OFF);
     float (*ep_lds)[CO_T] = reinterpret_cast<float (*)[CO_T]>(lds + EP_OFF);
 
@@ -115,6 +123,13 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         ep_lds[0][tid] = (ok && p.bias) ? p.bias[m] : 0.0f;
         ep_lds[1][tid] = (ok && p.x2) ? expf(p.alpha2[m]) : 1.0f;
         ep_lds[2][tid] = (ok && p.x2) ? expf(p.beta2[m]) : 1.0f;
+        if constexpr (FUSED) {                            // (never a data-gradient: rows 1 / 2 carry the second SnakeBeta's constants)
+            ep_lds[1][tid] = ok ? a.ru_a2[m] : 0.0f;
+            ep_lds[2][tid] = ok ? a.ru_ib2[m] : 0.0f;
+            ep_lds[5][tid] = (ok && a.ru_bias2) ? a.ru_bias2[m] : 0.0f;
+        }
+        ep_lds[3][tid] = (ok && a.em_a) ? a.em_a[m] : 0.0f;
+        ep_lds[4][tid] = (ok && a.em_a) ? a.em_ib[m] : 0.0f;
     }
 
     // ---- LDS-DMA of a chunk: 56 weight pieces (per tap: 8 = plane x group x 64-row half, ONE per wave) + 20 activation pieces
@@ -249,6 +264,68 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
     __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue
 
+    if constexpr (FUSED) {
+        // ---- h = acc + bias1: stored (fp32) and activated into the B-operand planes of the 1x1 conv ----
+        // accumulator register r of lane (l31, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column l31: a quad of registers 4k .. 4k+3 is
+        // channels 8k + 4hi + (0..3) at one time step = 8 bytes of the plane row of channel group k
+        char* pb = lds;                                    // [plane][16 groups][256 rows][16 B] = 128 KiB
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int tl = t_w + ni * 32 + l31;         // row of the planes = time step within the tile
+                const int tg = t0 + tl;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cl = co_w + mi * 32 + 8 * k + 4 * hi;      // first of the quad's 4 channels
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = acc[mi][ni][4 * k + j] + ep_lds[0][cl + j];
+                        if (a.ru_h && cl + j < a.cout_v && tg < p.Tout) a.ru_h[((size_t)b * p.Cout + cl + j) * p.Tout + tg] = hv;
+                        v[j] = sat_snake(hv, ep_lds[1][cl + j], ep_lds[2][cl + j]);
+                    }
+                    uint32_t h0, l0, h1, l1;
+                    sat_split2_pk(v[0], v[1], &h0, &l0);
+                    sat_split2_pk(v[2], v[3], &h1, &l1);
+                    const int g = (co_w + mi * 32) / 8 + k;
+                    char* dst = pb + g * 4096 + tl * 16 + hi * 8;
+                    *reinterpret_cast<u32x2_q*>(dst) = u32x2_q{h0, h1};
+                    *reinterpret_cast<u32x2_q*>(dst + 65536) = u32x2_q{l0, l1};
+                }
+            }
+        __syncthreads();                                   // the planes are complete (a wave reads all 128 channels of its 64 time steps)
+        if (tid < CO_T) ep_lds[0][tid] = ep_lds[5][tid];   // the final epilogue adds the 1x1 conv's bias (row 0 was last read above)
+        // ---- y_acc = W1 (128 x 128) . planes: 8 k-steps of 16 channels; A fragments straight from L2 (sat_pack_weights_k7q, K = 1) ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = half * 4 + u;               // k-step: channels 16 ks .. 16 ks + 15 (group 2 ks + hi)
+                if (ks >= nchunks) continue;               // (C < 128: the packed 1x1 weight has ceil(C / 16) chunks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const short* wsrc = (pl ? a.ru_w1_lo : a.ru_w1_hi) + ((size_t)(ks * 2 + hi) * a.cout_pad + co_w + l31) * 8;
+                    fr[u].wa[0][pl] = *reinterpret_cast<const bf16x8*>(wsrc);
+                    fr[u].wa[1][pl] = *reinterpret_cast<const bf16x8*>(wsrc + 32 * 8);
+                    const char* ab = pb + pl * 65536 + (ks * 2 + hi) * 4096;
+                    fr[u].xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31) * 16);
+                    fr[u].xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31) * 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (half * 4 + u < nchunks) mfma_frags(fr[u]);
+        }
+        __syncthreads();                                   // the planes are dead: their memory serves the epilogue's transposition
+    }
+
     // ------------------------------------ epilogue (as the generic kernel) ------------------------------------
     const bool bwd = (p.x2 != nullptr);
     const bool wave_on = (co0 + co_w) < a.cout_v;
@@ -313,6 +390,18 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         ov[e] = v;
                     }
                     if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (a.em_hi) {
+                        // plane emission (as conv1d_bf16x3.hip's generic kernel), step 1: the consumer's activation of the finished
+                        // values goes back into this lane's own cell of the transposition tile (rows past Cout hold act(0) = 0)
+                        f32x4 ev = ov;
+                        if (a.em_a) {
+                            const float ea = ep_lds[3][col], eib = ep_lds[4][col];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ev[e] = sat_snake(ov[e], ea, eib);
+                        }
+                        if (!ok) ev = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(&tile[row][t4]) = ev;
+                    }
                     if (bwd) {
                         if (!ok) { pda = 0.f; pdb = 0.f; }
 #pragma unroll
@@ -323,6 +412,26 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         if ((lane & 15) == 0) {
                             red_lds[0][wave % TW][col] = pda;
                             red_lds[1][wave % TW][col] = pdb;
+                        }
+                    }
+                }
+                if (a.em_hi) {
+                    // step 2: the tile read COLUMN-wise — 8 consecutive channels of one time step = one 16-byte plane row
+                    sat_wave_sync();
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c8i = ((co0 + co_w + mi * 32) >> 3) + g;
+                        const int tq = t0 + t_w + lane;
+                        float v8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v8[e] = tile[g * 8 + e][lane];
+                        uint32_t eh[4], el[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sat_split2_pk(v8[2 * e], v8[2 * e + 1], &eh[e], &el[e]);
+                        if (c8i < a.em_c8 && tq < p.Tout) {
+                            const size_t o = (((size_t)b * a.em_c8 + c8i) * a.em_rows + SAT_K7P_LEAD + tq) * 8;
+                            *reinterpret_cast<u32x4*>(a.em_hi + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
+                            *reinterpret_cast<u32x4*>(a.em_lo + o) = u32x4{el[0], el[1], el[2], el[3]};
                         }
                     }
                 }
@@ -389,6 +498,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     const long long total = (long long)(a.cout_pad / SAT_K7_CO) * sat_cdiv(a.nq, SAT_K7_T) * a.p.B;
+    if (a.ru_w1_hi) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, true>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); return; }
     const char* ev = getenv("SAT_K7Q_VARIANT");            // A/B switch (tools/kq_ab.py)
     if (ev && atoi(ev) == 0) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
     else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }

@@ -235,11 +235,20 @@ class ResidualUnitFn(torch.autograd.Function):
         k1 = w1.shape[2]
         pad = dil * (k1 - 1) // 2
         c1, c2 = caches if caches is not None else (None, None)
-        h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1), cache=c1)
         emit = None
-        if next_snake is not None and ops.emit_ok(c, w2.shape[2], 1, h.shape[2], next_snake[2]):
+        if next_snake is not None and ops.emit_ok(c, w2.shape[2], 1, x.shape[2], next_snake[2]):
             emit = {"snake": (next_snake[0].detach(), next_snake[1].detach())}
-        y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2, emit=emit)
+        if w2.shape[2] == 1 and w1.shape[0] == c and ops.ru_fused_ok(c, k1, dil, x.shape[2]):
+            # C <= 128: the whole unit in ONE launch (csrc/conv1d_bf16x3_k7q.h, FUSED) — the k1 launch and its read of h disappear
+            w7q = _cached(c1, "pack_q7", (w1,), lambda: ops.pack_k7q(w1))
+            w1q = _cached(c2, "pack_q1", (w2,), lambda: ops.pack_k7q(w2))
+            sc = None
+            if c1 is not None and c2 is not None:
+                sc = (_cached(c1, "snake", (a1, b1), lambda: ops.snake_consts(a1, b1)), _cached(c2, "snake", (a2, b2), lambda: ops.snake_consts(a2, b2)))
+            h, y = ops.residual_unit_fwd(x, (a1, b1), w7q, bias1, (a2, b2), w1q, bias2, k1, dil, keep_h=not recompute, emit=emit, sconsts=sc)
+        else:
+            h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1), cache=c1)
+            y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2, emit=emit)
         ctx.ops = ops
         ctx.dil = dil
         ctx.recompute = bool(recompute)

@@ -213,6 +213,69 @@ class SatOps:
             return (y, *self._sum_pair(pda, pdb))
         return y
 
+    # ---- fused ResidualUnit forward (csrc/conv1d_bf16x3_k7q.h, FUSED): one launch for snake -> conv7 -> snake -> conv1 -> + x ----
+    ru_fused = os.environ.get("SAT_RU_FUSED", "1") != "0"
+
+    def ru_fused_ok(self, c, k, dil, t):
+        return (self.ru_fused and self.use_bf16x3 and self.k7q and self.k7_planes and self.k7q_min_cin <= c <= 128
+                and 5 <= k <= 7 and (k - 1) * dil <= 62 and (k - 1) * dil % 2 == 0 and (k - 1) * dil // 2 <= 32 and t % 4 == 0)
+
+    def pack_k7q(self, w, mode=0):
+        """(D0, D1, K) fp32 -> (hi, lo) planes in sat_pack_weights_k7q layout (K in 5..7, or K = 1 for the fused unit's 1x1 conv)."""
+        self._f32(w)
+        d0, d1, k = w.shape
+        n = self.lib.sat_pack_weights_k7q_size(d0, d1, k, mode)
+        if n <= 0:
+            raise RuntimeError("sat_pack_weights_k7q: unsupported shape")
+        hi = torch.empty(n, dtype=torch.int16, device=w.device)
+        lo = torch.empty(n, dtype=torch.int16, device=w.device)
+        self._chk(self.lib.sat_pack_weights_k7q(_ptr(w), _ptr(hi), _ptr(lo), d0, d1, k, mode, self._stream(w)))
+        return hi, lo
+
+    def residual_unit_fwd(self, x, snake1, w7q, bias1, snake2, w1q, bias2, k, dil, keep_h=True, emit=None, sconsts=None):
+        """y = x + conv1(snake2(conv7_dil(snake1(x)) + bias1)) + bias2 in one launch; returns (h or None, y).  w7q / w1q: pack_k7q of the
+        (C, C, K) and (C, C, 1) weights; snake1 / snake2: (log-alpha, log-beta); emit: {"snake": (la, lb) | None} -> also write the
+        next unit's activation planes (as conv1d_bf16x3(emit=...))."""
+        b, c, t = x.shape
+        self._f32(x, bias1, bias2)
+        pad = (k - 1) * dil // 2
+        st = self._stream(x)
+        sa1, sib1 = sconsts[0] if sconsts is not None else self.snake_consts(snake1[0], snake1[1])
+        sa2, sib2 = sconsts[1] if sconsts is not None else self.snake_consts(snake2[0], snake2[1])
+        em = self._take_emitted(x, snake1)
+        if em is not None:
+            hi, lo, rows = em["hi"], em["lo"], em["rows"]
+        else:
+            rows = self.lib.sat_conv1d_k7_plane_rows(t, t, pad)
+            c8 = (c + 7) // 8
+            need = 2 * b * c8 * rows * 8
+            wkey = ("k7p", x.device, st.value if st is not None else 0)
+            ws = self.__dict__.setdefault("_planes", {}).get(wkey)
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.int16, device=x.device)
+                self._planes[wkey] = ws
+            hi, lo = ws[:need // 2], ws[need // 2:need]
+            self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa1), _ptr(sib1), _ptr(hi), _ptr(lo), b, c, t, rows, st))
+        h = torch.empty_like(x) if keep_h else None
+        y = torch.empty_like(x)
+        ehi = elo = ea = eib = None
+        erows = 0
+        if emit is not None:
+            esnake = emit.get("snake")
+            if esnake is not None:
+                ea, eib = self.snake_consts(esnake[0], esnake[1])
+            ehi, elo, erows = self._emit_planes(b, c, t, x.device, st)
+            if ehi.data_ptr() == hi.data_ptr():
+                # the input planes ARE this shape's emission target (written by the previous unit): a workgroup reads halo rows its
+                # neighbours' tiles would overwrite -> emit into a second buffer and alternate
+                ehi, elo, erows = self._emit_planes(b, c, t, x.device, st, alt=True)
+        self._chk(self.lib.sat_residual_unit_fwd(_ptr(hi), _ptr(lo), rows, _ptr(w7q[0]), _ptr(w7q[1]), _ptr(bias1), _ptr(sa2), _ptr(sib2),
+                                                 _ptr(w1q[0]), _ptr(w1q[1]), _ptr(bias2), _ptr(x), _ptr(h), _ptr(y), b, c, t, k, dil, pad,
+                                                 _ptr(ehi), _ptr(elo), _ptr(ea), _ptr(eib), erows, st))
+        if emit is not None:
+            self._emitted = {"ptr": y.data_ptr(), "shape": tuple(y.shape), "snake": self._snake_key(emit.get("snake")), "hi": ehi, "lo": elo, "rows": erows}
+        return h, y
+
     # ---- plane emission bookkeeping: producer -> the ONE k7 conv that consumes its output next ----
     k7_emit = os.environ.get("SAT_K7_EMIT", "1") != "0"
 
@@ -227,11 +290,12 @@ class SatOps:
         generic = (stride == 1 and k <= 4) or stride > 1          # the plans of csrc/conv1d_bf16x3.hip's generic kernel
         return generic and tout % 4 == 0
 
-    def _emit_planes(self, b, c, t, device, st):
+    def _emit_planes(self, b, c, t, device, st, alt=False):
         """Emission target for a (b, c, t) tensor: planes [b][ceil(c/8)][rows][8] with the rows around the sequence zero.  One pair
-        per (shape, device, stream), zero-filled ONCE: producers only ever write rows 32 .. 32 + t - 1 of existing channels."""
+        per (shape, device, stream) (+ an alternate for the fused unit, which reads one while writing the other), zero-filled ONCE:
+        producers only ever write rows 32 .. 32 + t - 1 of existing channels."""
         rows = self.lib.sat_conv1d_k7_plane_rows(t, t, 0)          # pad 0 needs the most rows: valid for every consumer padding
-        key = ("emit", b, c, t, device, st.value if st is not None else 0)
+        key = ("emit", b, c, t, device, st.value if st is not None else 0, alt)
         cache = self.__dict__.setdefault("_planes", {})
         pl = cache.get(key)
         if pl is None:

@@ -187,6 +187,49 @@ def test_conv_k7_planes_gpu(hip):
     _run_planes(hip, "cuda", [c for c in S1_CASES if c[4] == 7] + [(1, 128, 128, 8192, 7, 9), (1, 1024, 1024, 512, 7, 3), (2, 512, 512, 1000, 7, 1)])
 
 
+def _run_ru(ops, dev, cases):
+    """The fused ResidualUnit forward (csrc/conv1d_bf16x3_k7q.h, FUSED: one launch) vs torch's conv1d chain: y, the kept intermediate
+    through every gradient, with and without the plane emission for a following unit (whose k7 conv then consumes those planes)."""
+    keep = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit)
+    calls = {"n": 0}
+    orig = ops.lib.sat_residual_unit_fwd
+
+    def counted(*a):
+        calls["n"] += 1
+        return orig(*a)
+    ops.lib.sat_residual_unit_fwd = counted
+    try:
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit = True, 1, 1, True, True, True
+        for (B, C, T, dil) in cases:
+            gen = torch.Generator().manual_seed(C * 1000 + T + dil)
+            x = _leaf(gen, dev, B, C, T)
+            ps = [_leaf(gen, dev, C, s=.3) for _ in range(4)]                  # a1, b1, a2, b2
+            w1, bias1 = _leaf(gen, dev, C, C, 7, s=.2 / math.sqrt(C / 8)), _leaf(gen, dev, C)
+            w2, bias2 = _leaf(gen, dev, C, C, 1, s=.5 / math.sqrt(C / 8)), _leaf(gen, dev, C)
+            na, nb = _leaf(gen, dev, C, s=.3), _leaf(gen, dev, C, s=.3)        # the next unit's first activation
+            w3 = _leaf(gen, dev, C, C, 7, s=.2 / math.sqrt(C / 8))
+            n0 = calls["n"]
+            y1 = Fn.ResidualUnitFn.apply(x, ps[0], ps[1], w1, bias1, ps[2], ps[3], w2, bias2, dil, ops, False, None, (na, nb, 1))
+            z1 = Fn.SnakeConv1dFn.apply(y1, na, nb, w3, None, None, 1, 1, 3, False, ops)     # consumes the emitted planes
+            assert calls["n"] == n0 + 1
+            h = F.conv1d(snake(x, ps[0], ps[1]), w1, bias1, padding=3 * dil, dilation=dil)
+            y2 = x + F.conv1d(snake(h, ps[2], ps[3]), w2, bias2)
+            z2 = F.conv1d(snake(y2, na, nb), w3, None, padding=3)
+            _compare([y1, z1], [y2, z2], [x, *ps, w1, bias1, w2, bias2, na, nb, w3], gen)
+    finally:
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit = keep
+        ops.lib.sat_residual_unit_fwd = orig
+
+
+def test_residual_unit_fused_sim(emu):
+    _run_ru(emu, "cpu", [(1, 16, 300, 1), (2, 24, 520, 3), (1, 72, 260, 9), (1, 128, 256, 3)])
+
+
+@pytest.mark.gpu
+def test_residual_unit_fused_gpu(hip):
+    _run_ru(hip, "cuda", [(1, 16, 300, 1), (2, 24, 520, 3), (1, 72, 260, 9), (1, 128, 8192, 3), (2, 128, 70000, 9), (1, 128, 4096, 1)])
+
+
 def test_conv_fp32_kernels_sim(emu):
     _run_s1(emu, "cpu", S1_CASES[1], False)
     _run_s1(emu, "cpu", S1_CASES[7], False)

@@ -68,8 +68,8 @@ def _emission_case(ops, device):
     previous unit's k1 conv or the block's down conv; backward: the unit's own k1 data-gradient), by the sat_conv1d_k7_planes pre-pass
     otherwise — and the golden comparison (forward + every gradient) must still hold."""
     keep = (ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout)
-    counts = {"emit": 0, "prepass": 0, "q": 0}
-    orig = {n: getattr(ops.lib, n) for n in ("sat_conv1d_bf16x3_emit", "sat_conv1d_k7_planes", "sat_conv1d_bf16x3_planesq")}
+    counts = {"emit": 0, "prepass": 0, "q": 0, "fused": 0}
+    orig = {n: getattr(ops.lib, n) for n in ("sat_conv1d_bf16x3_emit", "sat_conv1d_k7_planes", "sat_conv1d_bf16x3_planesq", "sat_residual_unit_fwd")}
 
     def wrap(name, key):
         def f(*a):
@@ -79,21 +79,30 @@ def _emission_case(ops, device):
     wrap("sat_conv1d_bf16x3_emit", "emit")
     wrap("sat_conv1d_k7_planes", "prepass")
     wrap("sat_conv1d_bf16x3_planesq", "q")
+    wrap("sat_residual_unit_fwd", "fused")
+    keep_f = ops.ru_fused
     try:
         ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = True, 1, True, True, 1
         for name, batch, in_len, seed in CASES[:2]:
             _run_case(name, batch, in_len, seed, device)
         with_emit = dict(counts)
+        assert counts["fused"] > 0                           # every ResidualUnit forward of these models (C <= 128) ran as one launch
+        ops.ru_fused = False                                 # ... and the same comparison with the two-launch units
+        for k in counts:
+            counts[k] = 0
+        _run_case(*CASES[1], device)
+        assert counts["fused"] == 0 and counts["emit"] > 0
         ops.k7_emit = False
         for k in counts:
             counts[k] = 0
         _run_case(*CASES[0], device)
-        assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission: one pre-pass per k7 conv
+        assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission / fusion: one pre-pass per k7 conv
     finally:
         ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = keep
+        ops.ru_fused = keep_f
         for n, f in orig.items():
             setattr(ops.lib, n, f)
-    assert with_emit["emit"] > 0 and with_emit["prepass"] < with_emit["q"], with_emit
+    assert with_emit["emit"] > 0 and with_emit["prepass"] < with_emit["q"] + with_emit["fused"], with_emit
     return with_emit
 
 
