@@ -264,68 +264,10 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
     __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue
 
-    if constexpr (FUSED) {
-        // ---- h = acc + bias1: stored (fp32) and activated into the B-operand planes of the 1x1 conv ----
-        // accumulator register r of lane (l31, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column l31: a quad of registers 4k .. 4k+3 is
-        // channels 8k + 4hi + (0..3) at one time step = 8 bytes of the plane row of channel group k
-        char* pb = lds;                                    // [plane][16 groups][256 rows][16 B] = 128 KiB
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int tl = t_w + ni * 32 + l31;         // row of the planes = time step within the tile
-                const int tg = t0 + tl;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int cl = co_w + mi * 32 + 8 * k + 4 * hi;      // first of the quad's 4 channels
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float hv = acc[mi][ni][4 * k + j] + ep_lds[0][cl + j];
-                        if (a.ru_h && cl + j < a.cout_v && tg < p.Tout) a.ru_h[((size_t)b * p.Cout + cl + j) * p.Tout + tg] = hv;
-                        v[j] = sat_snake(hv, ep_lds[1][cl + j], ep_lds[2][cl + j]);
-                    }
-                    uint32_t h0, l0, h1, l1;
-                    sat_split2_pk(v[0], v[1], &h0, &l0);
-                    sat_split2_pk(v[2], v[3], &h1, &l1);
-                    const int g = (co_w + mi * 32) / 8 + k;
-                    char* dst = pb + g * 4096 + tl * 16 + hi * 8;
-                    *reinterpret_cast<u32x2_q*>(dst) = u32x2_q{h0, h1};
-                    *reinterpret_cast<u32x2_q*>(dst + 65536) = u32x2_q{l0, l1};
-                }
-            }
-        __syncthreads();                                   // the planes are complete (a wave reads all 128 channels of its 64 time steps)
-        if (tid < CO_T) ep_lds[0][tid] = ep_lds[5][tid];   // the final epilogue adds the 1x1 conv's bias (row 0 was last read above)
-        // ---- y_acc = W1 (128 x 128) . planes: 8 k-steps of 16 channels; A fragments straight from L2 (sat_pack_weights_k7q, K = 1) ----
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ks = half * 4 + u;               // k-step: channels 16 ks .. 16 ks + 15 (group 2 ks + hi)
-                if (ks >= nchunks) continue;               // (C < 128: the packed 1x1 weight has ceil(C / 16) chunks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    const short* wsrc = (pl ? a.ru_w1_lo : a.ru_w1_hi) + ((size_t)(ks * 2 + hi) * a.cout_pad + co_w + l31) * 8;
-                    fr[u].wa[0][pl] = *reinterpret_cast<const bf16x8*>(wsrc);
-                    fr[u].wa[1][pl] = *reinterpret_cast<const bf16x8*>(wsrc + 32 * 8);
-                    const char* ab = pb + pl * 65536 + (ks * 2 + hi) * 4096;
-                    fr[u].xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31) * 16);
-                    fr[u].xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31) * 16);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (half * 4 + u < nchunks) mfma_frags(fr[u]);
-        }
-        __syncthreads();                                   // the planes are dead: their memory serves the epilogue's transposition
-    }
-
+    // the epilogue of one accumulator set: bias (ep_lds row 0), dsnake + its sums (data-gradients), residual, tanh, stores, plane emission
+    auto epilogue = [&](float* y_out, const float* res_in, bool emit_on) __attribute__((always_inline)) {
+    short* em_hi_ = emit_on ? a.em_hi : nullptr;
+    short* em_lo_ = emit_on ? a.em_lo : nullptr;
     // ------------------------------------ epilogue (as the generic kernel) ------------------------------------
     const bool bwd = (p.x2 != nullptr);
     const bool wave_on = (co0 + co_w) < a.cout_v;
@@ -335,7 +277,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         for (int i = tid; i < 2 * TW * CO_T; i += NT) (&red_lds[0][0][0])[i] = 0.0f;
         __syncthreads();
     }
-    const bool vec4 = (p.Tout & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.x2 | (uintptr_t)p.res) & 15) == 0;
+    const bool vec4 = (p.Tout & 3) == 0 && (((uintptr_t)y_out | (uintptr_t)p.x2 | (uintptr_t)res_in) & 15) == 0;
     if (vec4) {
         // 16-byte epilogue: each wave transposes its accumulators through LDS (the stage memory is free now) so that
         // a lane owns 4 consecutive time steps of a row; the x2 / res loads of a 32-row half are all issued before use.
@@ -363,7 +305,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                     const bool ok = co < a.cout_v && tg < p.Tout;
                     const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? tg : 0);
                     xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(p.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    rv[j] = (p.res && ok) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    rv[j] = (res_in && ok) ? *reinterpret_cast<const f32x4*>(res_in + o) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -389,8 +331,8 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         if (p.tanh_out) v = tanhf(v);
                         ov[e] = v;
                     }
-                    if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
-                    if (a.em_hi) {
+                    if (ok) *reinterpret_cast<f32x4*>(y_out + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (em_hi_) {
                         // plane emission (as conv1d_bf16x3.hip's generic kernel), step 1: the consumer's activation of the finished
                         // values goes back into this lane's own cell of the transposition tile (rows past Cout hold act(0) = 0)
                         f32x4 ev = ov;
@@ -415,7 +357,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         }
                     }
                 }
-                if (a.em_hi) {
+                if (em_hi_) {
                     // step 2: the tile read COLUMN-wise — 8 consecutive channels of one time step = one 16-byte plane row
                     sat_wave_sync();
 #pragma unroll
@@ -430,8 +372,8 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         for (int e = 0; e < 4; ++e) sat_split2_pk(v8[2 * e], v8[2 * e + 1], &eh[e], &el[e]);
                         if (c8i < a.em_c8 && tq < p.Tout) {
                             const size_t o = (((size_t)b * a.em_c8 + c8i) * a.em_rows + SAT_K7P_LEAD + tq) * 8;
-                            *reinterpret_cast<u32x4*>(a.em_hi + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
-                            *reinterpret_cast<u32x4*>(a.em_lo + o) = u32x4{el[0], el[1], el[2], el[3]};
+                            *reinterpret_cast<u32x4*>(em_hi_ + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
+                            *reinterpret_cast<u32x4*>(em_lo_ + o) = u32x4{el[0], el[1], el[2], el[3]};
                         }
                     }
                 }
@@ -462,9 +404,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                             pdb += v * g.dlb;
                             v *= g.dx;
                         }
-                        if (p.res) v += p.res[o];
+                        if (res_in) v += res_in[o];
                         if (p.tanh_out) v = tanhf(v);
-                        p.y[o] = v;
+                        y_out[o] = v;
                     }
                 }
                 if (bwd) {
@@ -494,6 +436,79 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
             p.part_db[(size_t)m * nrows_p + row] = sb;
         }
     }
+    };
+
+    if constexpr (FUSED) {
+        // ---- h = acc + bias1 -> `h` (fp32) through the ordinary 16-byte epilogue (no residual, no emission) ----
+        if (a.ru_h) {
+            epilogue(a.ru_h, nullptr, false);
+            __syncthreads();                               // the transposition windows are free again
+        }
+        // the 1x1 conv's A fragments (sat_pack_weights_k7q, K = 1) come from L2 straight into registers
+        auto load_w1 = [&](int u, int ks) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const short* wsrc = (pl ? a.ru_w1_lo : a.ru_w1_hi) + ((size_t)(ks * 2 + hi) * a.cout_pad + co_w + l31) * 8;
+                fr[u].wa[0][pl] = *reinterpret_cast<const bf16x8*>(wsrc);
+                fr[u].wa[1][pl] = *reinterpret_cast<const bf16x8*>(wsrc + 32 * 8);
+            }
+        };
+        // ---- snake2(h) as the B-operand planes of the 1x1 conv, straight from the accumulator layout ----
+        // accumulator register r of lane (l31, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column l31: a quad of registers 4k .. 4k+3 is
+        // channels 8k + 4hi + (0..3) at one time step = 8 bytes of the plane row of channel group k
+        char* pb = lds;                                    // [plane][16 groups][256 rows][16 B] = 128 KiB
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int tl = t_w + ni * 32 + l31;         // row of the planes = time step within the tile
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cl = co_w + mi * 32 + 8 * k + 4 * hi;      // first of the quad's 4 channels
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = sat_snake(acc[mi][ni][4 * k + j] + ep_lds[0][cl + j], ep_lds[1][cl + j], ep_lds[2][cl + j]);
+                    uint32_t h0, l0, h1, l1;
+                    sat_split2_pk(v[0], v[1], &h0, &l0);
+                    sat_split2_pk(v[2], v[3], &h1, &l1);
+                    const int g = (co_w + mi * 32) / 8 + k;
+                    char* dst = pb + g * 4096 + tl * 16 + hi * 8;
+                    *reinterpret_cast<u32x2_q*>(dst) = u32x2_q{h0, h1};
+                    *reinterpret_cast<u32x2_q*>(dst + 65536) = u32x2_q{l0, l1};
+                }
+            }
+        __syncthreads();                                   // the planes are complete (a wave reads all 128 channels of its 64 time steps)
+        if (tid < CO_T) ep_lds[0][tid] = ep_lds[5][tid];   // the final epilogue adds the 1x1 conv's bias (row 0 was last read above)
+        // ---- y_acc = W1 (128 x 128) . planes: 8 k-steps of 16 channels ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = half * 4 + u;               // k-step: channels 16 ks .. 16 ks + 15 (group 2 ks + hi)
+                if (ks >= nchunks) continue;               // (C < 128: the packed 1x1 weight has ceil(C / 16) chunks)
+                load_w1(u, ks);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const char* ab = pb + pl * 65536 + (ks * 2 + hi) * 4096;
+                    fr[u].xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31) * 16);
+                    fr[u].xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31) * 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (half * 4 + u < nchunks) mfma_frags(fr[u]);
+        }
+        __syncthreads();                                   // the planes are dead: their memory serves the epilogue's transposition
+    }
+
+    epilogue(p.y, p.res, true);
 }
 
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
