@@ -192,6 +192,9 @@ class ResidualUnit(nn.Module):
     # 47.55 s stereo item per GPU needs 31 GB here and 288 GB are available — switch on (class-wide or per instance) to halve the
     # unit's saved activations when the per-GPU batch does not fit; results are identical (tests/test_vae_parity.py)
     checkpointing = False
+    # the unit as ONE launch (C <= 128: csrc/conv1d_bf16x3_k7q.h, FUSED).  None = automatic: fused without keeping the intermediate
+    # under no_grad (inference), two launches when a backward will need it; True forces the fused launch (tests, measurements)
+    fuse = None
 
     def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
         super().__init__()
@@ -218,7 +221,7 @@ class ResidualUnit(nn.Module):
         return Fn.ResidualUnitFn.apply(x, s1.alpha, s1.beta, c1.folded_weight(), c1.bias,
                                        s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation, None,
                                        self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None,
-                                       next_snake)
+                                       next_snake, self.fuse if self.fuse is not None else ("nokeep" if not torch.is_grad_enabled() else False))
 
 
 class EncoderBlock(nn.Module):

@@ -224,9 +224,12 @@ class ResidualUnitFn(torch.autograd.Function):
     +1/3 of its forward flops.  caches = (DerivedCache of the k7 conv, of the k1 conv) or None."""
 
     @staticmethod
-    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None, next_snake=None):
+    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None, next_snake=None, fuse=False):
         """next_snake = (log-alpha, log-beta, dilation) of the ResidualUnit that follows: the k1 conv's epilogue then also writes
-        snake(y) as that unit's k7 activation planes (its sat_conv1d_k7_planes pre-pass disappears)."""
+        snake(y) as that unit's k7 activation planes (its sat_conv1d_k7_planes pre-pass disappears).
+        fuse: run the unit as ONE launch where the kernel allows (C <= 128).  The caller asks for it when no backward will follow
+        (inference: h is not kept and never touches HBM — 2.30 vs 2.65 ms at C = 128, T = 2 097 152); with h kept the fused launch
+        is slower than the two launches (3.06 ms: its extra 1-GB store burst is not overlapped, profiles/EXPERIMENTS.md)."""
         ops = _ops(ops)
         x = x.contiguous()
         w1 = w1.contiguous()
@@ -238,14 +241,15 @@ class ResidualUnitFn(torch.autograd.Function):
         emit = None
         if next_snake is not None and ops.emit_ok(c, w2.shape[2], 1, x.shape[2], next_snake[2]):
             emit = {"snake": (next_snake[0].detach(), next_snake[1].detach())}
-        if w2.shape[2] == 1 and w1.shape[0] == c and ops.ru_fused_ok(c, k1, dil, x.shape[2]):
+        if fuse and w2.shape[2] == 1 and w1.shape[0] == c and ops.ru_fused_ok(c, k1, dil, x.shape[2]):
             # C <= 128: the whole unit in ONE launch (csrc/conv1d_bf16x3_k7q.h, FUSED) — the k1 launch and its read of h disappear
             w7q = _cached(c1, "pack_q7", (w1,), lambda: ops.pack_k7q(w1))
             w1q = _cached(c2, "pack_q1", (w2,), lambda: ops.pack_k7q(w2))
             sc = None
             if c1 is not None and c2 is not None:
                 sc = (_cached(c1, "snake", (a1, b1), lambda: ops.snake_consts(a1, b1)), _cached(c2, "snake", (a2, b2), lambda: ops.snake_consts(a2, b2)))
-            h, y = ops.residual_unit_fwd(x, (a1, b1), w7q, bias1, (a2, b2), w1q, bias2, k1, dil, keep_h=not recompute, emit=emit, sconsts=sc)
+            h, y = ops.residual_unit_fwd(x, (a1, b1), w7q, bias1, (a2, b2), w1q, bias2, k1, dil, keep_h=ctx is not None and not recompute and fuse != "nokeep",
+                                         emit=emit, sconsts=sc)
         else:
             h = _conv_fwd(ops, x, w1, 1, dil, pad, bias=bias1, snake=(a1, b1), cache=c1)
             y = _conv_fwd(ops, h, w2, 1, 1, 0, bias=bias2, snake=(a2, b2), res=x, cache=c2, emit=emit)
@@ -273,7 +277,7 @@ class ResidualUnitFn(torch.autograd.Function):
         dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit=emit)
         dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
-        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None
+        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None, None
 
 
 class VaeSampleFn(torch.autograd.Function):

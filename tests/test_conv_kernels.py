@@ -209,13 +209,16 @@ def _run_ru(ops, dev, cases):
             na, nb = _leaf(gen, dev, C, s=.3), _leaf(gen, dev, C, s=.3)        # the next unit's first activation
             w3 = _leaf(gen, dev, C, C, 7, s=.2 / math.sqrt(C / 8))
             n0 = calls["n"]
-            y1 = Fn.ResidualUnitFn.apply(x, ps[0], ps[1], w1, bias1, ps[2], ps[3], w2, bias2, dil, ops, False, None, (na, nb, 1))
+            y1 = Fn.ResidualUnitFn.apply(x, ps[0], ps[1], w1, bias1, ps[2], ps[3], w2, bias2, dil, ops, False, None, (na, nb, 1), True)
             z1 = Fn.SnakeConv1dFn.apply(y1, na, nb, w3, None, None, 1, 1, 3, False, ops)     # consumes the emitted planes
             assert calls["n"] == n0 + 1
             h = F.conv1d(snake(x, ps[0], ps[1]), w1, bias1, padding=3 * dil, dilation=dil)
             y2 = x + F.conv1d(snake(h, ps[2], ps[3]), w2, bias2)
             z2 = F.conv1d(snake(y2, na, nb), w3, None, padding=3)
             _compare([y1, z1], [y2, z2], [x, *ps, w1, bias1, w2, bias2, na, nb, w3], gen)
+            with torch.no_grad():                                               # inference form: the intermediate is never stored
+                y3 = Fn.ResidualUnitFn.apply(x, ps[0], ps[1], w1, bias1, ps[2], ps[3], w2, bias2, dil, ops, False, None, None, "nokeep")
+            assert calls["n"] == n0 + 2 and torch.equal(y3, y1.detach())
     finally:
         ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit = keep
         ops.lib.sat_residual_unit_fwd = orig

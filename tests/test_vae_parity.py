@@ -80,7 +80,9 @@ def _emission_case(ops, device):
     wrap("sat_conv1d_k7_planes", "prepass")
     wrap("sat_conv1d_bf16x3_planesq", "q")
     wrap("sat_residual_unit_fwd", "fused")
-    keep_f = ops.ru_fused
+    from stable_audio_tools_amd.autoencoders import ResidualUnit
+    keep_f = (ops.ru_fused, ResidualUnit.fuse)
+    ResidualUnit.fuse = True                                # (default: fused only under no_grad)
     try:
         ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = True, 1, True, True, 1
         for name, batch, in_len, seed in CASES[:2]:
@@ -99,7 +101,7 @@ def _emission_case(ops, device):
         assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission / fusion: one pre-pass per k7 conv
     finally:
         ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = keep
-        ops.ru_fused = keep_f
+        ops.ru_fused, ResidualUnit.fuse = keep_f
         for n, f in orig.items():
             setattr(ops.lib, n, f)
     assert with_emit["emit"] > 0 and with_emit["prepass"] < with_emit["q"] + with_emit["fused"], with_emit
