@@ -40,6 +40,7 @@ struct SatConvBfLaunch {
     const short* xp_lo = nullptr;
     int xp_rows = 0, xp_c8 = 0;
     int wq = 0;            // conv1d_bf16x3_k7q.h: the weight planes are in sat_pack_weights_k7q layout ([chunk16][tap][group][co][8])
+    int stagger = 0;       // conv1d_bf16x3_k7q.h: start delay units (x ~4 us x (0..7)) that de-phase the CUs' epilogue bursts
     // plane EMISSION (generic kernel, 16-byte epilogue): besides y the kernel writes act(y) as the bf16 hi / lo planes the next k7
     // conv reads ([B][em_c8][em_rows][8], row = 32 + t; the zero rows around the sequence belong to the caller) — the consumer's
     // sat_k7_planes_kernel pre-pass (one read + one write of the tensor) disappears.  em_a / em_ib: pre-exponentiated SnakeBeta

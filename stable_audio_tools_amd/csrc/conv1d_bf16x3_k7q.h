@@ -192,6 +192,16 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     };
 
     const bool wave_on_co = (co0 + co_w) < a.cout_v;      // Cout <= 64 (one co half empty): that wave row multiplies nothing
+#if !defined(SAT_HIPEMU)
+    // De-phase the CUs: the first wave of workgroups starts everywhere at once and every tile takes the same time, so all 256 CUs
+    // would reach their epilogues — 128 KiB of stores (+ two loads of the same size in a data-gradient) each — in the same few
+    // microseconds, and the HBM burst is not overlapped with anybody's K loop.  A one-off start delay of 0 .. 7 x ~4 us keeps the
+    // CUs' epilogues apart for the rest of the launch.
+    if (a.stagger && blockIdx.x < 256) {
+        const int steps = (int)((blockIdx.x >> 3) & 7) * a.stagger;
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     // prologue: chunk 0 complete in stage 0
 #pragma unroll
     for (int tap = 0; tap < SAT_K7Q_TAPS; ++tap) issue_w(0, 0, tap);
@@ -513,6 +523,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     const long long total = (long long)(a.cout_pad / SAT_K7_CO) * sat_cdiv(a.nq, SAT_K7_T) * a.p.B;
+    a.stagger = 1;                                         // measured: -1 % forward, -2.5 % data-gradient (tools/kq_ab.py); 2 and 4 lose
+    if (const char* es = getenv("SAT_K7Q_STAGGER")) a.stagger = atoi(es);
+    if (total < 1024) a.stagger = 0;                       // few tiles per CU: the delay would not be paid back
     if (a.ru_w1_hi) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, true>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); return; }
     const char* ev = getenv("SAT_K7Q_VARIANT");            // A/B switch (tools/kq_ab.py)
     if (ev && atoi(ev) == 0) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }

@@ -14,4 +14,7 @@ for (c, t, dil) in [(128, 2097152, 1), (256, 262144, 3), (1024, 8192, 1)]:
     x = torch.randn(1, c, t, device='cuda'); w = torch.randn(c, c, 7, device='cuda') / (7 * c) ** 0.5
     bias = torch.randn(c, device='cuda'); la = torch.randn(c, device='cuda') * 0.3; lb = torch.randn(c, device='cuda') * 0.3
     wq = o.pack_bf16x3(w, 0, 1, q=True)
-    print(c, t, os.environ.get("SAT_K7Q_VARIANT"), round(timeit(lambda: o.conv1d_bf16x3(x, wq, c, 7, 1, dil, 3 * dil, bias=bias, snake=(la, lb))), 1), flush=True)
+    x2 = torch.randn(1, c, t, device='cuda')
+    print(c, t, "variant", os.environ.get("SAT_K7Q_VARIANT"), "stagger", os.environ.get("SAT_K7Q_STAGGER"),
+          "fwd", round(timeit(lambda: o.conv1d_bf16x3(x, wq, c, 7, 1, dil, 3 * dil, bias=bias, snake=(la, lb))), 1),
+          "dgrad", round(timeit(lambda: o.conv1d_bf16x3(x, wq, c, 7, 1, dil, 3 * dil, dsnake=(x2, la, lb), res=x2)), 1), flush=True)
