@@ -524,7 +524,7 @@ def pmc_traffic(kernel, args):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     try:
-        for name in ("r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 doc = json.load(open(path))
@@ -533,6 +533,33 @@ def pmc_traffic(kernel, args):
         return None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def hbm_roofline(args, ms_per_step):
+    """The north-star's HBM view of the whole step (BASELINE.json: >= 60 % of the HBM roofline on the conv stack): HBM bytes per step
+    summed over every kernel of the committed rocprofv3 --pmc passes of this same command (profiles/r03_pmc_traffic.json: 2 x
+    FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction; the passes profile `--steps 1 --warmup 1` = 2 steps) against the
+    algorithmic bytes of SURVEY.md 8(d)'s fusion-unit convention (16.4 GB per direction per sample forward; x3 for forward +
+    backward) and the 8 TB/s peak, at this run's step time."""
+    if args.sample_size != 2097152 or args.batch != 1:
+        return None
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        doc = json.load(open(path))
+        steps = float(doc.get("steps_profiled", 2))
+        counter = sum(v["hbm_bytes_per_launch"] * v.get("launches", 0) for v in doc["kernels"].values()) / steps
+    except (OSError, KeyError, ValueError):
+        return None
+    algorithmic = 3 * 2 * 16.4e9
+    t = ms_per_step * 1e-3
+    return {"counter_bytes_per_step": counter, "algorithmic_bytes_per_step": algorithmic, "peak_bytes_per_s": 8.0e12,
+            "counter_rate_frac_of_8TBs": counter / t / 8.0e12, "frac_of_8TBs": algorithmic / t / 8.0e12,
+            "traffic_over_algorithmic": counter / algorithmic,
+            "note": "counter bytes: every sat_* kernel of the committed --pmc passes (profiles/r03_pmc_traffic.json); algorithmic: 3 x (16.4 + 16.4) GB "
+                    "(fusion-unit convention, forward + backward); frac_of_8TBs = algorithmic bytes / this run's step time / 8 TB/s — the "
+                    "step is matrix-pipe-bound (roofline.bound), this is the north-star's second view of it"}
 
 
 def _reference_importable():
@@ -847,8 +874,9 @@ def main():
                                  "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
                                  "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
                                  "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
-                                 "same command (profiles/r02_pmc_traffic.json; null for a non-default workload size)",
+                                 "same command (profiles/r03_pmc_traffic.json; null for a non-default workload size)",
                          "k7_family": k7_family(allk),
+                         "hbm": hbm_roofline(args, 1e3 * elapsed / args.steps),
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
         if world == 1 and not args.no_cpu_baseline:

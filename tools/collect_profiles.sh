@@ -10,9 +10,9 @@ R=$(pwd)
 OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-GEN="--no-cpu-baseline --no-real-step --no-secondary"
+GEN="--no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context"
 rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 $GEN > $OUT/vae_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/real_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-long-context > $OUT/real_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_sample -- python $R/bench.py --workload dit_sample --steps 10 --warmup 2 --no-cpu-baseline > $OUT/dit_sample_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_train -- python $R/bench.py --workload dit_train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/dit_train_prof.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -25,7 +25,10 @@ python tools/pmc_traffic_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pm
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/real $OUT/dit_sample $OUT/dit_train
+cp $OUT/pmc_traffic.json $R/profiles/r03_pmc_traffic.json      # bench.py reads it for roofline.traffic / roofline.hbm
 python bench.py > $OUT/bench_vae_train.json 2> $OUT/bench_vae_train.err
-python bench.py --workload dit_sample > $OUT/bench_dit_sample.json 2> /dev/null
-python bench.py --workload dit_train > $OUT/bench_dit_train.json 2> /dev/null
+python bench.py --workload dit_train --no-cpu-baseline > $OUT/bench_dit_train.json 2> /dev/null
+SAT_TILES=0,4 SAT_SPLITS=2,3 python tools/gemm_bench.py 2050 4100 12290 > $OUT/gemm_bench.jsonl 2> /dev/null
+python tools/k7_bench.py > $OUT/k7_bench.jsonl 2> /dev/null
+python tools/ru_bench.py > $OUT/ru_bench.jsonl 2> /dev/null
 tail -c 3000 $OUT/bench_vae_train.json

@@ -23,7 +23,7 @@ def per_kernel(root):
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 unit = float(os.environ.get("PMC_UNIT_BYTES", "1024"))     # counter unit in bytes (rocprofv3 derived FETCH_SIZE / WRITE_SIZE: KiB)
-doc = {"source": sys.argv[4] if len(sys.argv) > 4 else "", "unit_bytes": unit,
+doc = {"source": sys.argv[4] if len(sys.argv) > 4 else "", "unit_bytes": unit, "steps_profiled": int(os.environ.get("PMC_STEPS", "2")),
        "correction": "gfx950: FETCH_SIZE x2 (128-byte fabric reads tallied at 64 bytes); WRITE_SIZE as reported", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("sat_"):
