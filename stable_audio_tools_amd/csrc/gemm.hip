@@ -485,12 +485,17 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 //     K-step (one VALU add per instruction); the K tail (K % 64 != 0) takes the general path.
 // Rows of an M-tail tile beyond M are neither read nor multiplied (a 2050-row activation costs its ninth row tile the DMA
 // stream only).
-template <int EPI, bool F32OUT>
+template <int EPI, bool F32OUT, int TOUCH = 0>
 __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
     constexpr int WIN = 2 * STAGE / 8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    // TOUCH > 0: L2 prefetch TOUCH K-steps ahead of the LDS-DMA front.  The two 64-KB stages bound the DMA lookahead at ~1.5 K-steps
+    // (~1.5 us), which covers an L2 hit but not an HBM miss — and inside the sampler every layer's weights come from HBM (2 GB of
+    // weights against a 256-MB Infinity Cache: the in-situ launches run 10-60 % slower than the warm micro-benchmark).  Each wave
+    // therefore also issues, per K-step, its 8 pieces' addresses of K-step t + 2 + TOUCH as 4-byte LDS-DMAs into a 256-byte dummy
+    // window (no VGPR destination, counted in vmcnt like the real ones): the lines are in L2 when the real DMA asks for them.
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH > 0 ? 8 * 256 : 0)];
     const int lane = threadIdx.x & 63;
     const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
@@ -596,6 +601,19 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         if constexpr (P == 1) {
             if (t + 2 < nk) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
             else { SAT_WAIT_VMCNT(0); }
+            if constexpr (TOUCH > 0) {
+                // (issued AFTER the counted wait: they are older than the next K-step's DMAs and retired by its wait, ~2 K-steps later)
+                const int kt = t + 2 + TOUCH;
+                if (kt < nk && kbeg + kt * 64 + 64 <= kend) {
+                    char* dummy = smem + 2 * STAGE + wave * 256;
+                    const long long ko = (long long)(kbeg + kt * 64) * 2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sat_glds4((const char*)p.A + aoff[q] + ko, dummy);
+                        sat_glds4((const char*)p.B + boff[q] + ko, dummy);
+                    }
+                }
+            }
         }
         SAT_WAIT_LGKM0();
         SAT_RAW_BARRIER();
@@ -657,13 +675,14 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     }
 }
 
-static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
+static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 2) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
 #define SAT_GEMM256_CASE(E, F)                                                                       \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        SAT_LAUNCH((sat_gemm256_kernel<E, F>), grid, block, stream, p);                              \
+        if (touch > 0) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 2>), grid, block, stream, p); }       \
+        else { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0>), grid, block, stream, p); }                  \
         return sat_check_launch("sat_gemm_bf16 (256x256)");                                          \
     }
     SAT_GEMM256_CASE(SAT_EPI_STORE, false)
@@ -711,10 +730,11 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 // 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel)
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
+    if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 0);      // (A/B: without the L2 touch prefetch)
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile < 0 || tile > 4) { sat_set_error("sat_gemm: tile must be 0..4"); return 1; }
+    if (tile < 0 || tile > 5) { sat_set_error("sat_gemm: tile must be 0..5"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
 }
 

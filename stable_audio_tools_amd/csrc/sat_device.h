@@ -276,6 +276,7 @@ SAT_DEVICE float sat_snake(float x, float a, float ib) {
 // ---- LDS-DMA staging, counted waits, scheduling hints (gemm.hip, attention_fwd64.h) ----
 #if defined(SAT_HIPEMU)
 static inline void sat_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::lane_id(), g, 16); }
+static inline void sat_glds4(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu::lane_id(), g, 4); }
 #define SAT_WAIT_VMCNT(n)
 #define SAT_RAW_BARRIER() hipemu::block_barrier()
 #define SAT_WAIT_LGKM0()
@@ -293,6 +294,11 @@ static inline bool sat_wave_any(bool v) {
 SAT_DEVICE void sat_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// 4 bytes per lane (LDS destination = wave-uniform base + lane * 4): the L2 "touch" prefetch of gemm.hip
+SAT_DEVICE void sat_glds4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 // counted wait on this wave's LDS-DMA queue + a bare s_barrier: tiles further down the ring stay in flight across the barrier
 // (__syncthreads() would drain them: an LDS-DMA is a pending LDS write on the VM counter)
