@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
     constexpr int WIN = 2 * STAGE / 8;
-    // TOUCH > 0: L2 prefetch TOUCH K-steps ahead of the LDS-DMA front.  The two 64-KB stages bound the DMA lookahead at ~1.5 K-steps
+    // TOUCH > 0 (experiment, NOT shipped: the sampler ran 103.7 vs 110.8 steps/s with it): L2 prefetch TOUCH K-steps ahead of the LDS-DMA front.  The two 64-KB stages bound the DMA lookahead at ~1.5 K-steps
     // (~1.5 us), which covers an L2 hit but not an HBM miss — and inside the sampler every layer's weights come from HBM (2 GB of
     // weights against a 256-MB Infinity Cache: the in-situ launches run 10-60 % slower than the warm micro-benchmark).  Each wave
     // therefore also issues, per K-step, its 8 pieces' addresses of K-step t + 2 + TOUCH as 4-byte LDS-DMAs into a 256-byte dummy
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     }
 }
 
-static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 2) {
+static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 0) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
@@ -730,7 +730,7 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 // 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel)
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
-    if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 0);      // (A/B: without the L2 touch prefetch)
+    if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 2);      // (A/B: WITH the L2 touch prefetch: measured -6 % in the sampler)
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);

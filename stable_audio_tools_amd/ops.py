@@ -791,7 +791,7 @@ class SatOps:
         if self.gemm_tile is not None:
             return self.gemm_tile
         if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
-            return 5 if os.environ.get("SAT_GEMM_NO_TOUCH") == "1" else 4       # 5 = 4 without the L2 touch prefetch (A/B)
+            return 5 if os.environ.get("SAT_GEMM_TOUCH") == "1" else 4          # 5 = 4 + the L2 touch prefetch experiment (slower)
         return 0
 
     def gemm_bf16(self, a, b, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
