@@ -103,6 +103,30 @@ int sat_rows_unpack(const float* y, float* out, int B, int C, int T, int W, int 
 int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, int C, int T, int W, int pad_w, int pitch, float slope,
                         void* stream);
 
+/* The Conv2d layers of the MS-STFT discriminator (models/encodec.py:19-28 NormConv2d, :37-106 DiscriminatorSTFT: kernel (3, 9) /
+ * dilated (3, 9) / (3, 3), stride (1, 1), 'same' padding, LeakyReLU 0.2) on the "pitched rows" layout — csrc/disc_conv.hip:
+ * a (B, C, frames, W) activation is kept as (B, C, L), frame r = [4 zeros | W samples | >= 4 zeros] of pitch P; sat_disc_geom gives
+ * P, L = frames * P and the geometry of the bf16 hi / lo planes [B][ceil(C/8)][rows][8] (`lead` zero rows before position 0) that the
+ * matrix kernels read.  The frame taps are virtual channels read from the same buffer dil_t * P positions away: nothing is copied.
+ *   sat_disc_planes   src ((B, C, frames, W), or pitched (B, C, L) when pitched != 0), optionally times LeakyReLU'(out) (out pitched,
+ *                     slope), pad positions zeroed -> dst (pitched fp32, or NULL) and hi / lo planes (or NULL)
+ *   sat_disc_pack_weights  w (Cout, Cin, kh, kw) -> hi / lo weight planes (sat_disc_pack_size bf16 each); mode 0: the conv,
+ *                     mode 1: its data-gradient (a conv of Cout channels -> Cin channels)
+ *   sat_disc_conv     y = LeakyReLU_slope(conv2d + bias) (slope 1: none), pitched fp32 (B, Cout, L), pads zero; em_hi / em_lo (or
+ *                     NULL): y's planes for the next layer.  Cin / Cout are the channels of the conv RUN (swapped for mode 1 weights).
+ *   sat_disc_wgrad    dW slabs [nsplit][kw][ceil64(M)][ceil64(kh * Cin)] (virtual channel tap_t * Cin + c) from dy = dL/d(pre-
+ *                     activation) (B, M, L) and the layer input x (B, Cin, L), both pitched; sum with sat_reduce_splits.  kw 9 or 3. */
+int sat_disc_geom(int frames, int W, int* P, int* L, int* lead, int* rows);
+int sat_disc_planes(const float* src, const float* out, float* dst, void* hi, void* lo, int B, int C, int frames, int W, int pitched,
+                    float slope, void* stream);
+long long sat_disc_pack_size(int Cout, int Cin, int kh, int kw, int mode);
+int sat_disc_pack_weights(const float* w, short* hi, short* lo, int Cout, int Cin, int kh, int kw, int mode, void* stream);
+int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w_hi, const void* w_lo, const float* bias, float* y, void* em_hi,
+                  void* em_lo, int B, int Cin, int Cout, int frames, int W, int kh, int kw, int dil_t, float slope, void* stream);
+int sat_disc_wgrad_nsplit(int B, int M, int Cin, int kh, int frames, int W);
+int sat_disc_wgrad(const float* dy, const float* x, float* partial, int B, int M, int Cin, int frames, int W, int kh, int kw, int dil_t,
+                   void* stream);
+
 /* The stride-1, 5 <= K <= 8 convolutions (the k = 7 convs of the ResidualUnits, autoencoders.py:58-83, and their data-gradients) with
  * the activated input converted ONCE into bf16 hi / lo planes [B][ceil(Cin/8)][rows][8 channels] (row = 32 + t, zero rows around the
  * sequence) instead of per workgroup while staging: sat_conv1d_k7_planes writes the planes (SnakeBeta with pre-exponentiated constants

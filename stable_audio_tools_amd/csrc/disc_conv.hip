@@ -1,0 +1,684 @@
+// disc_conv.hip — the Conv2d layers of the MS-STFT discriminator (stable_audio_tools/models/encodec.py:37-106: NormConv2d 3 x 9 /
+// dilated 3 x 9 / 3 x 3, stride (1, 1), 'same' padding, LeakyReLU 0.2) on the bf16 matrix cores at fp32 accuracy (hi / lo split,
+// three MFMAs per product: conv1d_bf16x3.hip), forward, data-gradient and weight-gradient.
+//
+// Layout ("pitched rows").  A (B, C, frames, freq) activation lives as (B, C, L): frame r occupies [r P, (r + 1) P) as
+// [4 zeros | W samples | >= 4 zeros], P = ceil4(W + 8), L = frames * P.  A 'same' 1-D conv along that sequence never mixes two
+// frames, so the frequency taps are a 1-D conv; the kh frame taps are "virtual channels": virtual channel (tap_t, c) is channel c
+// read (tap_t - (kh-1)/2) * dil_t * P positions further along the SAME buffer — no shifted copies (round 2 materialised them:
+// sat_rows_pack, 3 x the activation, and un-pitched every output again).  The kernels' matrix operands are the bf16 hi / lo PLANES of
+// that sequence, [B][ceil(C/8)][rows][8 channels] with `lead` zero rows before position 0 and zero rows after L (they are the frame
+// padding), written by the producing layer's epilogue (activation + pad mask applied) or by sat_disc_planes.
+//
+//   sat_disc_conv_kernel   64(co) x 512(positions) per workgroup, 8 waves of 64 x 64 (2 x 2 accumulators of 32 x 32), K-chunk = 16
+//       virtual channels x kw taps: MFMA k-step tau = frequency tap tau, k-slots 0-7 / 8-15 = the chunk's two 8-channel groups —
+//       the structure of conv1d_bf16x3_k7q.h (LDS-DMA of lane-linear 1-KiB pieces, two 72-KiB stages, the two wave rows ONE BARRIER
+//       APART, fragment reads + next chunk's DMA in one wave row under the other's MFMAs), three phases of three taps per chunk.
+//       The data-gradient is the same kernel on the planes of dL/d(pre-activation) with the weights packed transposed / flipped.
+//   sat_disc_wgrad_kernel  dW = sum over positions of dy (x) shifted x: conv_wgrad7_bf16x3_pipe.h's register-staged pipeline
+//       (global loads of stage c+2 | MFMAs of stage c | hi/lo split of stage c+1 into LDS) re-tiled for 64 output channels:
+//       64(co) x 64(virtual ci) x kw taps per workgroup, the two halves of a 128-position stage on different waves.
+#include "sat_device.h"
+#include <stdlib.h>
+
+#define SAT_DC_CO 64
+#define SAT_DC_T 512
+#define SAT_DC_NT 512
+#define SAT_DC_TAPS 9
+#define SAT_DC_AROWS 576                                   // 512 positions + 8 taps of halo, in 64-row pieces
+#define SAT_DC_WBYTES (2 * SAT_DC_TAPS * 2 * 1024)         // [plane][tap][group][64 co][16 B]
+#define SAT_DC_ABYTES (2 * 2 * SAT_DC_AROWS * 16)          // [plane][group][576 rows][16 B]
+#define SAT_DC_STAGE (SAT_DC_WBYTES + SAT_DC_ABYTES)       // 73728
+#define SAT_DC_APIECES (2 * 2 * (SAT_DC_AROWS / 64))       // 36
+#define SAT_DC_MAXSHIFT 4                                  // max |frame shift| = dil_t * (kh - 1) / 2 frames
+
+SAT_DEVICE void sat_dc_split2(float x, short* hi, short* lo) {
+    const short h = sat_f32_to_bf16(x);
+    *hi = h;
+    *lo = sat_f32_to_bf16(x - sat_bf16_to_f32(h));
+}
+
+// ---- geometry of the pitched sequence and of its planes ----
+extern "C" int sat_disc_geom(int frames, int W, int* P, int* L, int* lead, int* rows) {
+    if (frames <= 0 || W <= 0) { sat_set_error("sat_disc_geom: empty shape"); return 1; }
+    const int p = (W + 8 + 3) / 4 * 4;
+    const long long l = (long long)frames * p;
+    const int ld = sat_cdiv(SAT_DC_MAXSHIFT * p + 8, 64) * 64;
+    const long long r = ld + sat_cdivll(l, SAT_DC_T) * SAT_DC_T + ld + 64;
+    if (r * 16 >= (1ll << 40) || l >= (1ll << 31) - 1024) { sat_set_error("sat_disc_geom: sequence too long"); return 1; }
+    *P = p; *L = (int)l; *lead = ld; *rows = (int)r;
+    return 0;
+}
+
+// ---- weights: w (Cout, Cin, kh, kw) fp32 -> hi / lo planes [co tile][chunk][tap][group g][64 m][e], element = W'[m][v][tap] with
+//      virtual channel v: group gv = chunk * 2 + g = tap_t * c8 + cg, channel c = cg * 8 + e (c8 = groups of the conv INPUT):
+//   mode 0 (conv):          m = co, c = ci:  W' = w[m][c][tap_t][tap]
+//   mode 1 (data-gradient): m = ci, c = co:  W' = w[c][m][kh-1-tap_t][kw-1-tap]
+struct SatDiscPackParams {
+    const float* w;
+    short* hi;
+    short* lo;
+    int Cout, Cin, kh, kw, mode, c8, nchunks, m_v, c_v;
+    long long total;
+};
+__global__ void __launch_bounds__(256) sat_disc_pack_kernel(SatDiscPackParams p) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.total) return;
+    const int e = (int)(o & 7), ml = (int)((o >> 3) & 63), g = (int)((o >> 9) & 1);
+    long long q = o >> 10;
+    const int tap = (int)(q % p.kw);
+    q /= p.kw;
+    const int chunk = (int)(q % p.nchunks), tile = (int)(q / p.nchunks);
+    const int m = tile * SAT_DC_CO + ml;
+    const int gv = chunk * 2 + g;
+    float val = 0.0f;
+    if (gv < p.kh * p.c8 && m < p.m_v) {
+        const int tap_t = gv / p.c8, c = (gv - tap_t * p.c8) * 8 + e;
+        if (c < p.c_v) {
+            if (p.mode == 0) val = p.w[(((size_t)m * p.Cin + c) * p.kh + tap_t) * p.kw + tap];
+            else val = p.w[(((size_t)c * p.Cin + m) * p.kh + (p.kh - 1 - tap_t)) * p.kw + (p.kw - 1 - tap)];
+        }
+    }
+    short h, l;
+    sat_dc_split2(val, &h, &l);
+    p.hi[o] = h;
+    p.lo[o] = l;
+}
+static bool sat_disc_pack_geometry(int Cout, int Cin, int kh, int kw, int mode, SatDiscPackParams* p) {
+    if (mode < 0 || mode > 1 || Cout <= 0 || Cin <= 0 || kh < 1 || !(kh & 1) || kw < 1 || kw > SAT_DC_TAPS || !(kw & 1)) return false;
+    p->Cout = Cout; p->Cin = Cin; p->kh = kh; p->kw = kw; p->mode = mode;
+    p->m_v = mode == 0 ? Cout : Cin;
+    p->c_v = mode == 0 ? Cin : Cout;
+    p->c8 = sat_cdiv(p->c_v, 8);
+    p->nchunks = sat_cdiv(kh * p->c8, 2);
+    p->total = (long long)sat_cdiv(p->m_v, SAT_DC_CO) * p->nchunks * kw * 2 * SAT_DC_CO * 8;
+    return true;
+}
+extern "C" long long sat_disc_pack_size(int Cout, int Cin, int kh, int kw, int mode) {
+    SatDiscPackParams p{};
+    return sat_disc_pack_geometry(Cout, Cin, kh, kw, mode, &p) ? p.total : -1;
+}
+extern "C" int sat_disc_pack_weights(const float* w, short* hi, short* lo, int Cout, int Cin, int kh, int kw, int mode, void* stream) {
+    SatDiscPackParams p{};
+    if (!sat_disc_pack_geometry(Cout, Cin, kh, kw, mode, &p)) { sat_set_error("sat_disc_pack_weights: odd kh, odd kw <= 9, mode 0|1"); return 1; }
+    p.w = w; p.hi = hi; p.lo = lo;
+    SAT_LAUNCH(sat_disc_pack_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
+    return sat_check_launch("sat_disc_pack_weights");
+}
+
+// ---- planes / pitched fp32 from a tensor: one thread = one position of one 8-channel group ----
+//   src: (B, C, frames, W) (pitched == 0) or the pitched (B, C, L); `out` (pitched, or null): the values are multiplied by
+//   LeakyReLU'(out) = out > 0 ? 1 : slope (the gradient w.r.t. a layer's pre-activation from the gradient w.r.t. its output);
+//   pad positions are written as zeros.  dst (pitched fp32, or null) and hi / lo (planes, or null) receive the result.
+struct SatDiscPlanesParams {
+    const float* src;
+    const float* out;
+    float* dst;
+    short* hi;
+    short* lo;
+    int B, C, c8, frames, W, P, L, lead, rows, pitched;
+    float slope;
+};
+__global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, b = blockIdx.z;
+    if (t >= p.L) return;
+    const int r = t / p.P, f = t - r * p.P - 4;
+    const bool valid = (unsigned)f < (unsigned)p.W;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = g * 8 + e;
+        float o = 0.0f;
+        if (valid && ch < p.C) {
+            const size_t ip = ((size_t)b * p.C + ch) * p.L + t;
+            o = p.pitched ? p.src[ip] : p.src[(((size_t)b * p.C + ch) * p.frames + r) * p.W + f];
+            if (p.out) o *= (p.out[ip] > 0.0f ? 1.0f : p.slope);
+        }
+        if (p.dst && ch < p.C) p.dst[((size_t)b * p.C + ch) * p.L + t] = o;
+        v[e] = o;
+    }
+    if (p.hi) {
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sat_split2_pk(v[2 * j], v[2 * j + 1], &h[j], &l[j]);
+        const size_t o = (((size_t)b * p.c8 + g) * p.rows + p.lead + t) * 8;
+        *reinterpret_cast<u32x4*>(p.hi + o) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(p.lo + o) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+extern "C" int sat_disc_planes(const float* src, const float* out, float* dst, void* hi, void* lo, int B, int C, int frames, int W,
+                               int pitched, float slope, void* stream) {
+    int P, L, lead, rows;
+    if (B <= 0 || C <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_planes: bad shape"); return 1; }
+    if (!src || (!dst && !hi) || ((hi == nullptr) != (lo == nullptr))) { sat_set_error("sat_disc_planes: missing operand"); return 1; }
+    SatDiscPlanesParams p{src, out, dst, (short*)hi, (short*)lo, B, C, sat_cdiv(C, 8), frames, W, P, L, lead, rows, pitched, slope};
+    SAT_LAUNCH(sat_disc_planes_kernel, dim3(sat_cdiv(L, 256), p.c8, B), dim3(256), stream, p);
+    return sat_check_launch("sat_disc_planes");
+}
+
+// =====================================================================================================================
+struct SatDiscConvParams {
+    const short* xp_hi;   // input planes [B][c8][rows][8]
+    const short* xp_lo;
+    const short* w_hi;    // sat_disc_pack_weights
+    const short* w_lo;
+    const float* bias;    // (Cout) or null
+    float* y;             // (B, Cout, L) pitched
+    short* em_hi;         // planes of y [B][em_c8][rows][8] for the next layer, or null
+    short* em_lo;
+    int B, c8, Cout, em_c8;
+    int rows, lead, P, W, L;
+    int kh, kw, shift;    // shift = dil_t * P: positions between frame taps
+    int nchunks, t_tiles, co_tiles;
+    float slope;          // LeakyReLU slope of the epilogue (1: none)
+};
+
+template <int KW>
+__global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvParams p) {
+    constexpr int CO_T = SAT_DC_CO, T_T = SAT_DC_T, AROWS = SAT_DC_AROWS, STAGE = SAT_DC_STAGE, WB = SAT_DC_WBYTES;
+    // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue in front of every fragment read)
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE + CO_T * 4];
+    float* bias_lds = reinterpret_cast<float*>(lds + 2 * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = SAT_UNIFORM(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 2;                              // wave row: the one-barrier-apart halves of the workgroup
+    const int t_w = wave * 64;
+    constexpr int kw = KW;
+    const int kh = p.kh;
+    const int pad_w = (kw - 1) >> 1, pad_t = (kh - 1) >> 1;
+    constexpr int nph = (kw + 2) / 3;                      // phases of three taps
+    constexpr int ipp = (9 + nph - 1) / nph;               // DMA issue slots (of 9) per phase
+    // tile order: the tiles are dealt round-robin to the 8 XCDs; give every XCD a CONTIGUOUS range of the sequence so that the frame
+    // taps (the same plane rows, read again by the tiles dil_t * P positions earlier / later) and the halos hit in its L2
+    int L = (int)blockIdx.x;
+    {
+        const int n = (int)gridDim.x, per = n >> 3;
+        if (L < per * 8) L = (L & 7) * per + (L >> 3);
+    }
+    const int co_tile = L % p.co_tiles;
+    const int win = L / p.co_tiles;
+    const int b = win / p.t_tiles, t_tile = win - b * p.t_tiles;
+    const int co0 = co_tile * CO_T, t0 = t_tile * T_T;
+    const int row_in0 = p.lead + t0 - pad_w;
+
+    if (tid < CO_T) bias_lds[tid] = (co0 + tid < p.Cout && p.bias) ? p.bias[co0 + tid] : 0.0f;
+
+    // ---- LDS-DMA of a chunk: 36 activation pieces ((plane, group) x 9 x 64 rows) + 4 kw weight pieces ((plane, tap, group): 64 co x
+    //      16 B), piece q = 8 i + wave; every source address is a wave-uniform base + lane * 16 bytes ----
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int nvg = kh * p.c8;
+    const int npieces = SAT_DC_APIECES + 4 * kw;
+    const char* w_tile_hi = (const char*)p.w_hi + (size_t)co_tile * p.nchunks * kw * 2048;
+    const char* w_tile_lo = (const char*)p.w_lo + (size_t)co_tile * p.nchunks * kw * 2048;
+    auto issue = [&](int c, int st, int i) __attribute__((always_inline)) {
+        const int q = 8 * i + wave;
+        if (q < SAT_DC_APIECES) {
+            const int pl = q / 18, g = (q / 9) & 1, sub = q % 9;
+            int gv = c * 2 + g;
+            gv = gv < nvg ? gv : nvg - 1;                  // past the end: any finite rows (their weights are zero)
+            const int tap_t = gv / p.c8, cg = gv - tap_t * p.c8;
+            const long long row = (long long)row_in0 + (long long)(tap_t - pad_t) * p.shift + sub * 64;
+            const char* src = (const char*)(pl ? p.xp_lo : p.xp_hi) + (((size_t)b * p.c8 + cg) * p.rows + row) * 16;
+            sat_glds16(src + lane16, lds + st * STAGE + WB + ((pl * 2 + g) * AROWS + sub * 64) * 16);
+        } else if (q < npieces) {
+            const int r = q - SAT_DC_APIECES;
+            const int pl = r / (2 * kw), tg = r - pl * 2 * kw;      // tg = tap * 2 + group
+            const char* src = (pl ? w_tile_lo : w_tile_hi) + ((size_t)c * kw * 2 + tg) * 1024;
+            sat_glds16(src + lane16, lds + st * STAGE + (pl * SAT_DC_TAPS * 2 + tg) * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct Frags { bf16x8 wa[2][2], xa[2][2]; };          // [mi | ni][plane]
+    Frags fr[3];
+    auto load_frags = [&](Frags& f, const char* sb, int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const char* wb = sb + ((pl * SAT_DC_TAPS + tap) * 2 + hi) * 1024;
+            f.wa[0][pl] = *reinterpret_cast<const bf16x8*>(wb + l31 * 16);
+            f.wa[1][pl] = *reinterpret_cast<const bf16x8*>(wb + (32 + l31) * 16);
+            const char* ab = sb + WB + (pl * 2 + hi) * (AROWS * 16);
+            f.xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31 + tap) * 16);
+            f.xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31 + tap) * 16);
+        }
+    };
+    auto mfma_frags = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][0], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][0], f.xa[ni][1], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
+    };
+    const bool mi1_on = co0 + 32 < p.Cout;                // Cout <= 32 in this tile: the second row of accumulators multiplies nothing
+
+    // prologue: chunk 0 complete in stage 0
+#pragma unroll
+    for (int i = 0; i < 9; ++i) issue(0, 0, i);
+    SAT_WAIT_VMCNT(0);
+    SAT_RAW_BARRIER();
+    if (wr == 1) SAT_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        const char* sb = lds + (c & 1) * STAGE;
+        const bool more = c + 1 < p.nchunks;
+#pragma unroll
+        for (int ph = 0; ph < nph; ++ph) {
+            // read section: this phase's fragments + this phase's share of the next chunk's DMA
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (3 * ph + u < kw) load_frags(fr[u], sb, 3 * ph + u);
+            if (more) {
+#pragma unroll
+                for (int i = ph * ipp; i < (ph + 1) * ipp && i < 9; ++i) issue(c + 1, (c + 1) & 1, i);
+            }
+            if (ph == nph - 1) { SAT_WAIT_VMCNT(0); }      // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
+            SAT_WAIT_LGKM0();
+            SAT_RAW_BARRIER();
+            SAT_SCHED_FENCE();
+            SAT_SETPRIO(1);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (3 * ph + u < kw) {
+                    if (mi1_on) mfma_frags(fr[u]);
+                    else {
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][0], fr[u].xa[ni][0], acc[0][ni]);
+                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][0], fr[u].xa[ni][1], acc[0][ni]);
+                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][1], fr[u].xa[ni][0], acc[0][ni]);
+                        }
+                    }
+                }
+            SAT_SETPRIO(0);
+            SAT_SCHED_FENCE();
+            SAT_RAW_BARRIER();
+        }
+    }
+    if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
+    __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue
+
+    // ---- epilogue: bias, LeakyReLU, pad mask; 16-byte stores through a per-wave LDS transposition (32 rows x 68 floats in the drained
+    //      stage memory); plane emission = the same tile read column-wise (8 consecutive channels of a position = one plane row) ----
+    float (*tile)[68] = reinterpret_cast<float (*)[68]>(lds) + wave * 32;
+    const int lr = lane >> 4, t4 = (lane & 15) * 4;
+    const int tg = t0 + t_w + t4;                          // this lane's four positions (L % 4 == 0, P % 4 == 0: same frame, all in / out)
+    const int rem = tg % p.P;
+    bool valid[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) valid[e] = tg < p.L && (unsigned)(rem + e - 4) < (unsigned)p.W;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        if (mi == 1) __syncthreads();                      // every wave is done reading its first half
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(r & 3) + 8 * (r >> 2) + 4 * hi][ni * 32 + l31] = acc[mi][ni][r];
+        __syncthreads();                                    // (a wave only reads its own tile: this orders its own lanes)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = j * 4 + lr;
+            const int co = co0 + mi * 32 + row;
+            const bool ok = co < p.Cout && tg < p.L;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
+            const float bias = bias_lds[mi * 32 + row];
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = av[e] + bias;
+                v = v > 0.0f ? v : v * p.slope;
+                ov[e] = valid[e] ? v : 0.0f;
+            }
+            if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.L + tg) = ov;
+            if (p.em_hi) {
+                if (!ok) ov = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&tile[row][t4]) = ov;
+            }
+        }
+        if (p.em_hi) {
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c8i = ((co0 + mi * 32) >> 3) + g;
+                const int tq = t0 + t_w + lane;
+                float v8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = tile[g * 8 + e][lane];
+                uint32_t eh[4], el[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sat_split2_pk(v8[2 * e], v8[2 * e + 1], &eh[e], &el[e]);
+                if (c8i < p.em_c8 && tq < p.L) {
+                    const size_t o = (((size_t)b * p.em_c8 + c8i) * p.rows + p.lead + tq) * 8;
+                    *reinterpret_cast<u32x4*>(p.em_hi + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
+                    *reinterpret_cast<u32x4*>(p.em_lo + o) = u32x4{el[0], el[1], el[2], el[3]};
+                }
+            }
+        }
+    }
+}
+
+// y = LeakyReLU_slope(conv2d(x, w) + bias) on the pitched layout (slope 1: no activation), pad positions written as zeros:
+//   xp_hi / xp_lo: planes of x (Cin channels; sat_disc_planes or a previous layer's emission); w_hi / w_lo: sat_disc_pack_weights
+//   (mode 0; mode 1 with Cin / Cout swapped: the data-gradient, xp = planes of dL/d(pre-activation)); y (B, Cout, L) fp32;
+//   em_hi / em_lo (or null): the planes of y for the layer that consumes it.  kh frame taps dil_t frames apart, kw <= 9 frequency taps.
+extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                             void* em_hi, void* em_lo, int B, int Cin, int Cout, int frames, int W, int kh, int kw, int dil_t,
+                             float slope, void* stream) {
+    int P, L, lead, rows;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_conv: bad shape"); return 1; }
+    if (kh < 1 || !(kh & 1) || kw < 1 || kw > SAT_DC_TAPS || !(kw & 1) || dil_t < 1 || dil_t * ((kh - 1) / 2) > SAT_DC_MAXSHIFT) {
+        sat_set_error("sat_disc_conv: odd kh, odd kw <= 9, dil_t * (kh - 1) / 2 <= 4");
+        return 1;
+    }
+    if (!xp_hi || !xp_lo || !w_hi || !w_lo || !y || ((em_hi == nullptr) != (em_lo == nullptr)) || (((uintptr_t)y) & 15)) {
+        sat_set_error("sat_disc_conv: missing / misaligned operand");
+        return 1;
+    }
+    SatDiscConvParams p{};
+    p.xp_hi = (const short*)xp_hi; p.xp_lo = (const short*)xp_lo; p.w_hi = (const short*)w_hi; p.w_lo = (const short*)w_lo;
+    p.bias = bias; p.y = y; p.em_hi = (short*)em_hi; p.em_lo = (short*)em_lo;
+    p.B = B; p.c8 = sat_cdiv(Cin, 8); p.Cout = Cout; p.em_c8 = sat_cdiv(Cout, 8);
+    p.rows = rows; p.lead = lead; p.P = P; p.W = W; p.L = L;
+    p.kh = kh; p.kw = kw; p.shift = dil_t * P;
+    p.nchunks = sat_cdiv(kh * p.c8, 2);
+    p.t_tiles = sat_cdiv(L, SAT_DC_T);
+    p.co_tiles = sat_cdiv(Cout, SAT_DC_CO);
+    p.slope = slope;
+    const long long total = (long long)p.t_tiles * B * p.co_tiles;
+    const dim3 grid((unsigned)total), block(SAT_DC_NT);
+    switch (kw) {
+        case 1: SAT_LAUNCH((sat_disc_conv_kernel<1>), grid, block, stream, p); break;
+        case 3: SAT_LAUNCH((sat_disc_conv_kernel<3>), grid, block, stream, p); break;
+        case 5: SAT_LAUNCH((sat_disc_conv_kernel<5>), grid, block, stream, p); break;
+        case 7: SAT_LAUNCH((sat_disc_conv_kernel<7>), grid, block, stream, p); break;
+        default: SAT_LAUNCH((sat_disc_conv_kernel<9>), grid, block, stream, p); break;
+    }
+    return sat_check_launch("sat_disc_conv");
+}
+
+// =====================================================================================================================
+// weight gradient.  dW[m][(tap_t, c)][tap] = sum_b sum_t dy[b][m][t] * x[b][c][t + (tap_t - pad_t) * shift + tap - pad_w]
+//
+// One workgroup = 8 waves = 64(co) x 64(virtual ci) x kw taps over a range of 128-position stages: wave w owns the 32 x 32 tile
+// (co half w & 1, ci half (w >> 1) & 1) of taps 0..4 (w < 4) or 5..8 (w >= 4) — five / four accumulators, 120 / 96 MFMAs per stage;
+// waves w and w + 4 share a SIMD: the first multiplies while the second converts the next stage, then they swap.
+#define SAT_DW_NT 512
+#define SAT_DW_TT 128                // positions per stage (8 MFMA k-steps)
+#define SAT_DW_ROW 136               // 128 + 8 taps of halo / pad: 272-byte rows (68 dwords = 4 x odd: conflict-free b128)
+#define SAT_DW_NI 64                 // virtual input channels per workgroup
+
+struct SatDiscWgParams {
+    const float* dy;     // (B, M, L)
+    const float* x;      // (B, Cr, L)
+    float* out;          // [nsplit][kw][m_pad][n_pad]
+    int B, M, Cr, N, L, kh, shift, pad_w;
+    int m_pad, n_pad;
+    int chunks_per_split, nchunks, nT;
+};
+
+#if defined(SAT_HIPEMU)
+static inline unsigned sat_dw_alignbit(unsigned hi, unsigned lo, unsigned s) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> s); }
+#else
+SAT_DEVICE unsigned sat_dw_alignbit(unsigned hi, unsigned lo, unsigned s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+#endif
+
+template <int KW>
+__global__ void __launch_bounds__(SAT_DW_NT) sat_disc_wgrad_kernel(SatDiscWgParams p) {
+    constexpr int NXU = 5;                                           // x staging: 16 threads per row walk its 68 pairs 16 at a time
+    constexpr bool PAIR = (((KW - 1) / 2) & 1) == 0;                 // pad_w even: the pairs are 8-byte aligned
+    constexpr int K0 = (KW + 1) / 2;                                 // taps of the first wave group; the second takes K0 .. KW-1
+    __shared__ __attribute__((aligned(16))) short y_lds0[2][SAT_DC_CO][SAT_DW_ROW], y_lds1[2][SAT_DC_CO][SAT_DW_ROW];   // dy [plane][co][t]
+    __shared__ __attribute__((aligned(16))) short x_lds0[2][SAT_DW_NI][SAT_DW_ROW], x_lds1[2][SAT_DW_NI][SAT_DW_ROW];   // x  [plane][n][t]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m_w = (wave & 1) * 32, n_w = ((wave >> 1) & 1) * 32;
+    const bool first = wave < 4;                                     // tap group 0: MFMAs first; tap group 1: conversion first
+    const int m0 = blockIdx.x * SAT_DC_CO, n0 = blockIdx.y * SAT_DW_NI, split = blockIdx.z;
+    const int pad_t = (p.kh - 1) >> 1;
+
+    f32x16 acc[K0];
+#pragma unroll
+    for (int k = 0; k < K0; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    // this thread's two x rows: n = n0 + (tid >> 4) + 32 v -> (tap_t, c)
+    long long xoff[2];
+    int xshift[2];
+    bool xon[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int n = n0 + (tid >> 4) + 32 * v;
+        xon[v] = n < p.N;
+        const int tap_t = xon[v] ? n / p.Cr : 0, c = xon[v] ? n - tap_t * p.Cr : 0;
+        xoff[v] = (long long)c * p.L;
+        xshift[v] = (tap_t - pad_t) * p.shift - p.pad_w;
+    }
+
+    const int c_begin = split * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > p.nchunks) c_end = p.nchunks;
+    const int nst = c_end - c_begin;                                 // stages of this workgroup (>= 1)
+    auto clampc = [&](int c) { return c < nst - 1 ? c : nst - 1; };  // (redundant reloads past the end keep phases branch-free)
+
+    f32x4 dyv[4];
+    float xv[2][NXU][2];
+    auto issue_loads = [&](int c) __attribute__((always_inline)) {
+        const int ch = c_begin + c;
+        const int b = ch / p.nT;
+        const int tt0 = (ch - b * p.nT) * SAT_DW_TT;
+        // dy: 64 rows x 128 positions = 2048 float4, four per thread: 32 threads per row (L % 4 == 0: a float4 is all in or all out)
+        const float* sdy = p.dy + (size_t)b * p.M * p.L;
+        const int c4 = (tid & 31) * 4;
+        const bool t_ok = tt0 + c4 < p.L;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + (tid >> 5) + u * 16;
+            const bool ok = t_ok && m < p.M;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(sdy + (size_t)(ok ? m : 0) * p.L + (ok ? tt0 + c4 : 0));
+            dyv[u] = ok ? q : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* sx = p.x + (size_t)b * p.Cr * p.L;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const float* s = sx + xoff[v];
+            const int th0 = tt0 + xshift[v];
+#pragma unroll
+            for (int u = 0; u < NXU; ++u) {
+                const int pi = (tid & 15) + 16 * u;
+                const int t = th0 + 2 * pi;
+                const bool ok = pi < SAT_DW_ROW / 2 && xon[v];
+                if constexpr (PAIR) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const bool in = ok && t >= 0 && t + 1 < p.L;    // t even, L even: a pair is all in or all out
+                    const f2 q = *reinterpret_cast<const f2*>(s + (in ? t : 0));
+                    xv[v][u][0] = in ? q[0] : 0.0f;
+                    xv[v][u][1] = in ? q[1] : 0.0f;
+                } else {
+                    const bool in0 = ok && t >= 0 && t < p.L, in1 = ok && t + 1 >= 0 && t + 1 < p.L;
+                    xv[v][u][0] = in0 ? s[in0 ? t : 0] : 0.0f;
+                    xv[v][u][1] = in1 ? s[in1 ? t + 1 : 0] : 0.0f;
+                }
+            }
+        }
+    };
+    auto write_lds = [&](auto buf_c) __attribute__((always_inline)) {
+        auto& y_lds = sat_pick<decltype(buf_c)::value>(y_lds0, y_lds1);
+        auto& x_lds = sat_pick<decltype(buf_c)::value>(x_lds0, x_lds1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (tid >> 5) + u * 16, col = (tid & 31) * 4;
+            uint32_t h0, h1, l0, l1;
+            sat_split2_pk(dyv[u][0], dyv[u][1], &h0, &l0);
+            sat_split2_pk(dyv[u][2], dyv[u][3], &h1, &l1);
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u2*>(&y_lds[0][row][col]) = u2{h0, h1};
+            *reinterpret_cast<u2*>(&y_lds[1][row][col]) = u2{l0, l1};
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int row = (tid >> 4) + 32 * v;
+#pragma unroll
+            for (int u = 0; u < NXU; ++u) {
+                const int pi = (tid & 15) + 16 * u;
+                if (pi < SAT_DW_ROW / 2) {
+                    uint32_t h, l;
+                    sat_split2_pk(xv[v][u][0], xv[v][u][1], &h, &l);
+                    *reinterpret_cast<uint32_t*>(&x_lds[0][row][2 * pi]) = h;
+                    *reinterpret_cast<uint32_t*>(&x_lds[1][row][2 * pi]) = l;
+                }
+            }
+        }
+    };
+    const bool wave_on = (m0 + m_w < p.M) && (n0 + n_w < p.N);
+    // the MFMAs of one stage for taps KB .. KB + NK - 1 (compile-time: each tap's fragment is a register selection + v_alignbit of the
+    // two aligned 16-byte chunks covering positions [t, t + 16))
+    auto mfma_taps = [&](auto buf_c, auto kb_c, auto nk_c) __attribute__((always_inline)) {
+        constexpr int KB = decltype(kb_c)::value, NK = decltype(nk_c)::value;
+        auto& y_lds = sat_pick<decltype(buf_c)::value>(y_lds0, y_lds1);
+        auto& x_lds = sat_pick<decltype(buf_c)::value>(x_lds0, x_lds1);
+#pragma unroll 2
+        for (int ks = 0; ks < SAT_DW_TT / 16; ++ks) {
+            const int tb = 16 * ks + 8 * hi;
+            bf16x8 af[2];
+            af[0] = *reinterpret_cast<const bf16x8*>(&y_lds[0][m_w + l31][tb]);
+            af[1] = *reinterpret_cast<const bf16x8*>(&y_lds[1][m_w + l31][tb]);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                u32x4 cw[2];
+#if !defined(SAT_HIPEMU)
+                asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cw[j] = *reinterpret_cast<const u32x4*>(&x_lds[pl][n_w + l31][tb + 8 * j]);
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int k = KB + kk;
+                    const int wbase = (k >> 3) * 4 + ((k & 7) >> 1);
+                    const bool odd = (k & 1) != 0;
+                    u32x4 r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int w0 = wbase + i, w1 = wbase + i + 1;
+                        const unsigned a0 = cw[w0 >> 2][w0 & 3];
+                        if (odd) r[i] = sat_dw_alignbit(cw[(w1 >> 2) & 1][w1 & 3], a0, 16);
+                        else r[i] = a0;
+                    }
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, r);
+                    acc[kk] = sat_mfma_32x32x16_bf16(af[0], bf, acc[kk]);
+                    if (pl == 0) acc[kk] = sat_mfma_32x32x16_bf16(af[1], bf, acc[kk]);
+                }
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto mfma_phase = [&](auto buf_c) __attribute__((always_inline)) {
+        if (!wave_on) return;
+        if (first) mfma_taps(buf_c, std::integral_constant<int, 0>{}, std::integral_constant<int, K0>{});
+        else if constexpr (KW > K0) mfma_taps(buf_c, std::integral_constant<int, K0>{}, std::integral_constant<int, KW - K0>{});
+    };
+    auto phase = [&](auto bc, auto bn, int next) __attribute__((always_inline)) {
+        if (!first) {
+            write_lds(bn);
+            issue_loads(next);
+        }
+        mfma_phase(bc);
+        if (first) {
+            write_lds(bn);
+            issue_loads(next);
+        }
+    };
+
+    // prologue: stage 0 into buffer 0, stage 1's data in flight in the registers
+    issue_loads(0);
+    write_lds(I0{});
+    issue_loads(clampc(1));
+    __syncthreads();
+    int c = 0;
+    for (; c + 2 < nst; c += 2) {
+        phase(I0{}, I1{}, c + 2);                          // stage c out of buffer 0; stage c+1 -> buffer 1
+        __syncthreads();
+        phase(I1{}, I0{}, clampc(c + 3));                  // stage c+1 out of buffer 1; stage c+2 -> buffer 0
+        __syncthreads();
+    }
+    if (c + 1 < nst) {                                     // stage c in buffer 0, stage c+1 in the registers
+        if (!first) write_lds(I1{});
+        mfma_phase(I0{});
+        if (first) write_lds(I1{});
+        __syncthreads();
+        mfma_phase(I1{});
+    } else {
+        mfma_phase(I0{});
+    }
+
+    // partial slab of this split: [kw][m_pad][n_pad], n contiguous (an accumulator row stores 128 contiguous bytes)
+    float* ob = p.out + (size_t)split * KW * p.m_pad * p.n_pad;
+    const int n = n0 + n_w + l31;
+    const int kb = first ? 0 : K0, nk = first ? K0 : KW - K0;
+#pragma unroll
+    for (int kk = 0; kk < K0; ++kk)
+        if (kk < nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + m_w + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                ob[((size_t)(kb + kk) * p.m_pad + m) * p.n_pad + n] = acc[kk][r];
+            }
+        }
+}
+
+struct SatDiscWgPlan { int nsplit, cps, nchunks, nT; };
+static void sat_disc_wg_plan(int B, int M, int N, int L, SatDiscWgPlan* pl) {
+    pl->nT = sat_cdiv(L, SAT_DW_TT);
+    pl->nchunks = B * pl->nT;
+    const int tiles = sat_cdiv(M, SAT_DC_CO) * sat_cdiv(N, SAT_DW_NI);
+    int want = sat_cdiv(512, tiles);               // one workgroup per CU (LDS), two rounds
+    if (want > pl->nchunks) want = pl->nchunks;
+    if (want < 1) want = 1;
+    pl->cps = sat_cdiv(pl->nchunks, want);
+    pl->nsplit = sat_cdiv(pl->nchunks, pl->cps);
+}
+extern "C" int sat_disc_wgrad_nsplit(int B, int M, int Cin, int kh, int frames, int W) {
+    int P, L, lead, rows;
+    if (B <= 0 || M <= 0 || Cin <= 0 || kh < 1 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) return -1;
+    SatDiscWgPlan pl;
+    sat_disc_wg_plan(B, M, kh * Cin, L, &pl);
+    return pl.nsplit;
+}
+// dW of sat_disc_conv: dy (B, M, L) = dL/d(pre-activation) (pitched, zeros at pad positions), x (B, Cin, L) the layer's input (pitched).
+// Writes nsplit slabs [kw][ceil64(M)][ceil64(kh * Cin)] (virtual channel n = tap_t * Cin + c); sum them with sat_reduce_splits.
+extern "C" int sat_disc_wgrad(const float* dy, const float* x, float* partial, int B, int M, int Cin, int frames, int W, int kh, int kw,
+                              int dil_t, void* stream) {
+    int P, L, lead, rows;
+    if (B <= 0 || M <= 0 || Cin <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_wgrad: bad shape"); return 1; }
+    if (kh < 1 || !(kh & 1) || !(kw == 9 || kw == 3) || dil_t < 1) { sat_set_error("sat_disc_wgrad: odd kh, kw 9 or 3"); return 1; }
+    if ((((uintptr_t)dy | (uintptr_t)x) & 15) || !partial) { sat_set_error("sat_disc_wgrad: missing / misaligned operand"); return 1; }
+    SatDiscWgPlan pl;
+    const int N = kh * Cin;
+    sat_disc_wg_plan(B, M, N, L, &pl);
+    SatDiscWgParams p{dy, x, partial, B, M, Cin, N, L, kh, dil_t * P, (kw - 1) / 2,
+                      sat_cdiv(M, SAT_DC_CO) * SAT_DC_CO, sat_cdiv(N, SAT_DW_NI) * SAT_DW_NI, pl.cps, pl.nchunks, pl.nT};
+    dim3 grid(sat_cdiv(M, SAT_DC_CO), sat_cdiv(N, SAT_DW_NI), pl.nsplit);
+    if (kw == 9) SAT_LAUNCH(sat_disc_wgrad_kernel<9>, grid, dim3(SAT_DW_NT), stream, p);
+    else SAT_LAUNCH(sat_disc_wgrad_kernel<3>, grid, dim3(SAT_DW_NT), stream, p);
+    return sat_check_launch("sat_disc_wgrad");
+}

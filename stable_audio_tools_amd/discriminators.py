@@ -10,7 +10,13 @@ Execution
     by ||w||, real/imag planes written directly in the (B, 2C, frames, freq) layout the convs read; backward without atomics.
     (torchaudio's Spectrogram is not in the reference tree: restated from its published algorithm, torch.stft(center=False)/||w||.)
   * Conv2d (3 x 9 / 3 x 3 kernels, dilation along frames, stride 1 — DiscriminatorSTFT's default, the only one the reference
-    configures): run as stride-1 Conv1d over "virtual channels" on the conv stack's bf16x3 MFMA kernels (csrc/conv1d_bf16x3*.hip,
+    configures), round 3: csrc/disc_conv.hip on the "pitched rows" layout — every activation of a scale stays (B, C, frames * P)
+    (frame = [4 zeros | freq bins | zeros]) from the spectrogram to the logits, the frame taps are virtual channels read from the
+    same buffer (no shifted copies, no un-pitching between layers), each layer's epilogue applies bias + LeakyReLU + the pad mask and
+    writes the next layer's bf16 hi / lo operand planes; data-gradient = the same kernel on transposed weights, weight-gradient =
+    sat_disc_wgrad (_DiscConvFn).  The public forward returns strided (B, C, frames, freq) views of those buffers.
+    Fallback (fp32-MFMA mode, other kernel shapes; round 2's path):
+    run as stride-1 Conv1d over "virtual channels" on the conv stack's bf16x3 MFMA kernels (csrc/conv1d_bf16x3*.hip,
     conv_wgrad*): the kh frame taps become channels (time-shifted copies), and the (frames x freq) plane is laid out as one long
     sequence of zero-separated rows, so the 1-D kernels see the same regime as the VAE convs (C' = 192 channels, millions of
     steps) instead of thousands of short rows; a 9-tap kernel is taps 0..7 in one launch of the k7 kernels + tap 8 as a 1-tap conv on
@@ -131,6 +137,72 @@ class _Conv9Fn(torch.autograd.Function):
         return dbuf, dw, dbias, None, None, None
 
 
+class _PitchFn(torch.autograd.Function):
+    """(B, C, frames, W) -> the pitched sequence (B, C, frames * P) (csrc/disc_conv.hip layout) + its operand planes for the first
+    conv; backward = un-pitching."""
+
+    @staticmethod
+    def forward(ctx, z):
+        ops = _fn._ops(None)
+        z = z.contiguous()
+        frames, wd = z.shape[2], z.shape[3]
+        h, pl = ops.disc_planes(z, frames, wd, want_dst=True, slot=0)
+        ops.disc_register(h, pl, z.shape[1], frames, wd, 0)
+        ctx.meta = (ops, frames, wd)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        ops, frames, wd = ctx.meta
+        return ops.rows_unpack(g.contiguous(), frames, wd, 4, ops.disc_geom(frames, wd)[0], 1.0)
+
+
+class _DiscConvFn(torch.autograd.Function):
+    """One NormConv2d + LeakyReLU of DiscriminatorSTFT on the pitched layout: h (B, Cin, L) -> LeakyReLU_slope(conv2d(h, w) + bias)
+    (B, Cout, L), pad positions zero.  Forward: sat_disc_conv on the planes the producer emitted for h (or sat_disc_planes), emitting
+    the planes of its own output unless `last`.  Backward: dpre = g * LeakyReLU'(y) as pitched fp32 + planes in one pass
+    (sat_disc_planes), dW = sat_disc_wgrad(dpre, h), dbias = row sums, dh = sat_disc_conv(planes of dpre, transposed weights)."""
+
+    @staticmethod
+    def forward(ctx, h, w4, bias, frames, wd, dil_t, slope, last):
+        ops = _fn._ops(None)
+        h = h.contiguous()
+        w4 = w4.contiguous()
+        b, cin, _ = h.shape
+        cout, _, kh, kw = w4.shape
+        pl, slot = ops.disc_take(h, cin, frames, wd)
+        y, em = ops.disc_conv(pl, ops.disc_pack(w4, 0), bias, b, cin, cout, frames, wd, kh, kw, dil_t, slope,
+                              emit_slot=None if last else 1 - slot)
+        if em is not None:
+            ops.disc_register(y, em, cout, frames, wd, 1 - slot)
+        ctx.meta = (ops, frames, wd, dil_t, slope, bias is not None)
+        ctx.save_for_backward(h, w4, y if slope != 1.0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        ops, frames, wd, dil_t, slope, has_bias = ctx.meta
+        h, w4, y = ctx.saved_tensors
+        cout, cin, kh, kw = w4.shape
+        b = h.shape[0]
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dpre, dpl = ops.disc_planes(g.contiguous(), frames, wd, out=y, slope=slope, want_dst=True, want_planes=need_h, slot=0)
+        dw = ops.disc_wgrad(dpre, h, frames, wd, kh, kw, dil_t) if need_w else None
+        dbias = ops.rowsum(dpre) if (has_bias and ctx.needs_input_grad[2]) else None
+        dh = None
+        if need_h:
+            dh, _ = ops.disc_conv(dpl, ops.disc_pack(w4, 1), None, b, cout, cin, frames, wd, kh, kw, dil_t, 1.0)
+        return dh, dw, dbias, None, None, None, None, None
+
+
+def _pitched_ok(ops, kernel_size, dilation):
+    """May this Conv2d run on csrc/disc_conv.hip?  (bf16x3 mode; kw 9 or 3 — the weight-gradient kernel's tap counts; frame taps within
+    the planes' lead rows)"""
+    kh, kw = kernel_size
+    return bool(ops.use_bf16x3 and getattr(ops, "disc_pitched", True) and kw in (3, 9) and kh % 2 == 1 and dilation[1] == 1
+                and dilation[0] * (kh - 1) // 2 <= 4)
+
+
 def conv2d_virtual(x, w, bias, dil_t=1, pad_t=0, split_wide=True, slope=1.0):
     """leaky_relu(F.conv2d(x, w, bias, stride=1, dilation=(dil_t, 1), padding=(pad_t, (kw-1)//2)), slope) on the 1-D conv kernels
     ("same" along the frequency axis, as get_2d_padding gives; slope 1 = no activation).  x (B, Cin, T, W); w (Cout, Cin, kh, kw), kw odd.
@@ -192,6 +264,14 @@ class _WNConv2d(nn.Module):
         w = WeightNormFn.apply(self.weight_v, self.weight_g)
         return conv2d_virtual(x, w, self.bias, dil_t=self.dilation[0], pad_t=self.padding[0], slope=slope)
 
+    def pitched_ok(self):
+        return _pitched_ok(_fn._ops(None), self.kernel_size, self.dilation)
+
+    def forward_pitched(self, h, frames, wd, slope=1.0, last=False):
+        """The same layer on the pitched sequence (B, Cin, frames * P) -> (B, Cout, frames * P) (_DiscConvFn)."""
+        w = WeightNormFn.apply(self.weight_v, self.weight_g)
+        return _DiscConvFn.apply(h, w, self.bias, frames, wd, self.dilation[0], float(slope), last)
+
 
 class NormConv2d(nn.Module):
     def __init__(self, *args, **kwargs):
@@ -226,7 +306,25 @@ class DiscriminatorSTFT(nn.Module):
         self.convs.append(NormConv2d(in_chs, out_chs, kernel_size=k0, padding=get_2d_padding(k0)))
         self.conv_post = NormConv2d(out_chs, out_channels, kernel_size=k0, padding=get_2d_padding(k0))
 
+    def pitched_ok(self):
+        return isinstance(self.activation, torch.nn.LeakyReLU) and all(l.conv.pitched_ok() for l in list(self.convs) + [self.conv_post])
+
+    def forward_pitched(self, x):
+        """(logits, feature maps, (frames, freq bins)) with every tensor in the pitched layout (B, C, frames * P), pad positions zero."""
+        z = _SpecFn.apply(x, self.n_fft, self.hop_length)
+        frames, wd = z.shape[2], z.shape[3]
+        h = _PitchFn.apply(z)
+        fmap = []
+        for layer in self.convs:
+            h = layer.conv.forward_pitched(h, frames, wd, self.activation.negative_slope)
+            fmap.append(h)
+        return self.conv_post.conv.forward_pitched(h, frames, wd, 1.0, last=True), fmap, (frames, wd)
+
     def forward(self, x):
+        if self.pitched_ok():
+            logit, fmap, (frames, wd) = self.forward_pitched(x)
+            unp = lambda t: _unpitch_view(t, frames, wd)           # noqa: E731
+            return unp(logit), [unp(f) for f in fmap]
         fmap = []
         z = _SpecFn.apply(x, self.n_fft, self.hop_length)          # (B, 2C, frames, freq) = cat(real, imag) + 'b c w t -> b c t w'
         leaky = isinstance(self.activation, torch.nn.LeakyReLU)
@@ -235,6 +333,12 @@ class DiscriminatorSTFT(nn.Module):
             z = layer(z, self.activation.negative_slope) if leaky else self.activation(layer(z))
             fmap.append(z)
         return self.conv_post(z), fmap
+
+
+def _unpitch_view(t, frames, wd):
+    """pitched (B, C, frames * P) -> the (B, C, frames, wd) strided view of its sample positions (no copy)."""
+    b, c, L = t.shape
+    return t.view(b, c, frames, L // frames)[..., 4:4 + wd]
 
 
 class MultiScaleSTFTDiscriminator(nn.Module):
@@ -275,20 +379,37 @@ class EncodecDiscriminator(nn.Module):
     def forward(self, x):
         return self.discriminators(x)
 
-    def scale_losses(self, i, reals, fakes):
-        """The terms scale i contributes to loss(): (dis_i, adv_i, fm_i), each already divided by the number of scales.  The training
+    def scale_losses(self, i, reals, fakes, need_fm=True):
+        """The terms scale i contributes to loss(): (dis_i, adv_i, fm_i), each already divided by the number of scales (need_fm=False:
+        fm_i = 0 without computing it — the discriminator update only uses dis_i).  The training
         step back-propagates scale by scale (one scale's activations alive at a time: a 47 s stereo item makes ~23 GB of them per
         scale and branch) instead of holding all five graphs."""
         d = self.discriminators.discriminators[i]
         n = self.discriminators.num_discriminators
+        if d.pitched_ok():
+            # feature matching on the pitched buffers themselves (pad positions are zero in both: sums over the whole buffer / the
+            # number of samples = the reference's means); only the one-channel logits are viewed un-pitched
+            logit_t, feat_t, (frames, wd) = d.forward_pitched(reals)
+            logit_f, feat_f, _ = d.forward_pitched(fakes)
+            fm = sum(self._fm_pitched(a, b, frames, wd) for a, b in zip(feat_t, feat_f)) / len(feat_t) if need_fm else 0.0
+            dis, adv = get_hinge_losses(_unpitch_view(logit_t, frames, wd), _unpitch_view(logit_f, frames, wd))
+            return dis / n, adv / n, fm / n
         logit_t, feat_t = d(reals)
         logit_f, feat_f = d(fakes)
-        fm = sum(map(self.fm_reduction, feat_t, feat_f)) / len(feat_t)
+        fm = sum(map(self.fm_reduction, feat_t, feat_f)) / len(feat_t) if need_fm else 0.0
         dis, adv = get_hinge_losses(logit_t, logit_f)
         return dis / n, adv / n, fm / n
 
+    def _fm_pitched(self, x, y, frames, wd):
+        count = x.shape[0] * x.shape[1] * frames * wd
+        d = (x - y).abs().sum() / count
+        return d / (x.abs().sum() / count + 1e-3) if self.normalize_losses else d
+
     def loss(self, reals, fakes):
         """(dis_loss, adv_loss, feature_matching_distance) / num_scales — models/discriminators.py:31-63."""
+        if all(d.pitched_ok() for d in self.discriminators.discriminators):
+            terms = [self.scale_losses(i, reals, fakes) for i in range(self.discriminators.num_discriminators)]
+            return tuple(sum(t[k] for t in terms) for k in range(3))
         feature_matching_distance = torch.tensor(0., device=reals.device)
         dis_loss = torch.tensor(0., device=reals.device)
         adv_loss = torch.tensor(0., device=reals.device)

@@ -552,6 +552,99 @@ class SatOps:
         self._chk(self.lib.sat_rows_pack_bwd(_ptr(dbuf), _ptr(dx), b, c, t, w, kh, dil_t, pad_t, pad_w, pitch, lead, self._stream(dbuf)))
         return dx
 
+    # ---- the discriminator's Conv2d layers on the pitched-rows layout (csrc/disc_conv.hip; discriminators._DiscConvFn) ----
+    def disc_geom(self, frames, w):
+        """(P, L, lead, rows) of the pitched sequence / planes of a (.., frames, w) activation (sat_disc_geom)."""
+        key = ("disc_geom", frames, w)
+        cache = self.__dict__.setdefault("_disc_geoms", {})
+        g = cache.get(key)
+        if g is None:
+            out = [ctypes.c_int() for _ in range(4)]
+            self._chk(self.lib.sat_disc_geom(frames, w, *[ctypes.byref(o) for o in out]))
+            g = cache[key] = tuple(o.value for o in out)
+        return g
+
+    def _disc_plane_buf(self, b, c, frames, w, device, slot):
+        """bf16 hi / lo plane pair [b][ceil(c/8)][rows][8] for a (b, c, frames, w) activation; `slot` 0 / 1: the two alternating
+        targets of a layer chain (a layer reads one and emits into the other).  Zero-filled ONCE: writers only touch rows
+        lead .. lead + L - 1 of existing channel groups, the rows around them are the frame padding."""
+        rows = self.disc_geom(frames, w)[3]
+        key = ("disc", b, (c + 7) // 8, frames, w, device, slot)
+        gen = self.__dict__.setdefault("_disc_gen", {})
+        gen[key] = gen.get(key, 0) + 1                              # every request is a write: invalidates earlier registrations
+        cache = self.__dict__.setdefault("_planes", {})
+        pl = cache.get(key)
+        if pl is None:
+            n = b * ((c + 7) // 8) * rows * 8
+            pl = cache[key] = (torch.zeros(n, dtype=torch.int16, device=device), torch.zeros(n, dtype=torch.int16, device=device))
+        return pl
+
+    def disc_register(self, t, planes, c, frames, w, slot):
+        """Remember that `planes` (slot `slot` of the (c, frames, w) plane buffers) hold tensor t's operand planes."""
+        key = ("disc", t.shape[0], (c + 7) // 8, frames, w, t.device, slot)
+        self._disc_emitted = {"ptr": t.data_ptr(), "ver": t._version, "key": key, "gen": self.__dict__.setdefault("_disc_gen", {}).get(key, 0),
+                              "planes": planes, "slot": slot}
+
+    def disc_take(self, h, c, frames, w):
+        """((hi, lo) planes of the pitched tensor h, their slot): the producer's emission if it is still intact, else a planes pass."""
+        e = self.__dict__.get("_disc_emitted")
+        self._disc_emitted = None
+        if (e is not None and e["ptr"] == h.data_ptr() and e["ver"] == h._version and e["key"][:5] == ("disc", h.shape[0], (c + 7) // 8, frames, w)
+                and self.__dict__.get("_disc_gen", {}).get(e["key"], 0) == e["gen"]):
+            return e["planes"], e["slot"]
+        return self.disc_planes(h, frames, w, slot=0)[1], 0
+
+    def disc_planes(self, src, frames, w, out=None, slope=1.0, want_dst=False, want_planes=True, slot=0):
+        """src: (B, C, frames, w) or pitched (B, C, L) -> (dst pitched fp32 or None, (hi, lo) planes or None); with `out` (pitched):
+        src * LeakyReLU'(out)."""
+        self._f32(src, out)
+        b, c = src.shape[0], src.shape[1]
+        P, L, lead, rows = self.disc_geom(frames, w)
+        pitched = src.dim() == 3
+        if pitched and src.shape[2] != L or not pitched and tuple(src.shape[2:]) != (frames, w):
+            raise ValueError("disc_planes: shape does not match (frames, w)")
+        dst = torch.empty(b, c, L, dtype=torch.float32, device=src.device) if want_dst else None
+        pl = self._disc_plane_buf(b, c, frames, w, src.device, slot) if want_planes else None
+        self._chk(self.lib.sat_disc_planes(_ptr(src), _ptr(out), _ptr(dst), _ptr(pl[0]) if pl else None, _ptr(pl[1]) if pl else None,
+                                           b, c, frames, w, 1 if pitched else 0, float(slope), self._stream(src)))
+        return dst, pl
+
+    def disc_pack(self, w4, mode):
+        """w (Cout, Cin, kh, kw) -> (hi, lo) bf16 planes for sat_disc_conv (mode 0) / its data-gradient (mode 1)."""
+        self._f32(w4)
+        cout, cin, kh, kw = w4.shape
+        n = self.lib.sat_disc_pack_size(cout, cin, kh, kw, mode)
+        if n < 0:
+            raise ValueError("disc_pack: unsupported kernel shape")
+        hi = torch.empty(n, dtype=torch.int16, device=w4.device)
+        lo = torch.empty(n, dtype=torch.int16, device=w4.device)
+        self._chk(self.lib.sat_disc_pack_weights(_ptr(w4), _ptr(hi), _ptr(lo), cout, cin, kh, kw, mode, self._stream(w4)))
+        return hi, lo
+
+    def disc_conv(self, planes, wq, bias, b, cin, cout, frames, w, kh, kw, dil_t, slope, emit_slot=None):
+        """LeakyReLU_slope(conv2d + bias) on the pitched layout: planes (hi, lo) of the (b, cin) input, wq = disc_pack(...).
+        Returns (y (b, cout, L), emitted planes of y or None)."""
+        self._f32(bias)
+        L = self.disc_geom(frames, w)[1]
+        y = torch.empty(b, cout, L, dtype=torch.float32, device=planes[0].device)
+        em = self._disc_plane_buf(b, cout, frames, w, y.device, emit_slot) if emit_slot is not None else None
+        self._chk(self.lib.sat_disc_conv(_ptr(planes[0]), _ptr(planes[1]), _ptr(wq[0]), _ptr(wq[1]), _ptr(bias), _ptr(y),
+                                         _ptr(em[0]) if em else None, _ptr(em[1]) if em else None, b, cin, cout, frames, w, kh, kw, dil_t,
+                                         float(slope), self._stream(y)))
+        return y, em
+
+    def disc_wgrad(self, dy, x, frames, w, kh, kw, dil_t):
+        """dW (M, Cin, kh, kw) from dy = dL/d(pre-activation) (B, M, L) and the layer input x (B, Cin, L), both pitched."""
+        self._f32(dy, x)
+        b, m, _ = dy.shape
+        cin = x.shape[1]
+        nsplit = self.lib.sat_disc_wgrad_nsplit(b, m, cin, kh, frames, w)
+        mp, npad = (m + 63) // 64 * 64, (kh * cin + 63) // 64 * 64
+        partial = torch.empty(nsplit, kw * mp * npad, dtype=torch.float32, device=dy.device)
+        self._chk(self.lib.sat_disc_wgrad(_ptr(dy), _ptr(x), _ptr(partial), b, m, cin, frames, w, kh, kw, dil_t, self._stream(dy)))
+        dw = self._reduce_rows(partial, nsplit, kw * mp * npad).view(kw, mp, npad)[:, :m, :kh * cin]
+        return dw.reshape(kw, m, kh, cin).permute(1, 3, 2, 0).contiguous()
+
     def rows_unpack(self, y, t, w, pad_w, pitch, slope):
         """y (B, C, T*pitch) -> leaky_relu(y[..., t*pitch + pad_w + w], slope) as (B, C, T, W)."""
         self._f32(y)

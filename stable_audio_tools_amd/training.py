@@ -356,7 +356,7 @@ class AutoencoderTrainStep:
             decoded = decoded.contiguous()
             loss_dis = torch.zeros((), device=reals.device)
             for i in range(self.discriminator.discriminators.num_discriminators):
-                dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded)
+                dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded, need_fm=False)
                 dis_i.backward()
                 loss_dis = loss_dis + dis_i.detach()
             self.flat_d.gather_grads()
