@@ -110,9 +110,13 @@ extern "C" int sat_disc_pack_weights(const float* w, short* hi, short* lo, int C
 //   src: (B, C, frames, W) (pitched == 0) or the pitched (B, C, L); `out` (pitched, or null): the values are multiplied by
 //   LeakyReLU'(out) = out > 0 ? 1 : slope (the gradient w.r.t. a layer's pre-activation from the gradient w.r.t. its output);
 //   pad positions are written as zeros.  dst (pitched fp32, or null) and hi / lo (planes, or null) receive the result.
+//   fm_ref / fm_coef (with `out`): the L1 feature-matching term of this layer's output rides along — the gradient w.r.t. the output
+//   is src + fm_coef[0] * sign(out - fm_ref) (fm_coef: a device scalar, dL/d(sum |out - fm_ref|)) before the LeakyReLU' factor.
 struct SatDiscPlanesParams {
     const float* src;
     const float* out;
+    const float* fm_ref;
+    const float* fm_coef;
     float* dst;
     short* hi;
     short* lo;
@@ -125,6 +129,7 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
     if (t >= p.L) return;
     const int r = t / p.P, f = t - r * p.P - 4;
     const bool valid = (unsigned)f < (unsigned)p.W;
+    const float fmc = p.fm_ref ? p.fm_coef[0] : 0.0f;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -133,7 +138,14 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
         if (valid && ch < p.C) {
             const size_t ip = ((size_t)b * p.C + ch) * p.L + t;
             o = p.pitched ? p.src[ip] : p.src[(((size_t)b * p.C + ch) * p.frames + r) * p.W + f];
-            if (p.out) o *= (p.out[ip] > 0.0f ? 1.0f : p.slope);
+            if (p.out) {
+                const float ov = p.out[ip];
+                if (p.fm_ref) {
+                    const float d = ov - p.fm_ref[ip];
+                    o += d > 0.0f ? fmc : (d < 0.0f ? -fmc : 0.0f);
+                }
+                o *= (ov > 0.0f ? 1.0f : p.slope);
+            }
         }
         if (p.dst && ch < p.C) p.dst[((size_t)b * p.C + ch) * p.L + t] = o;
         v[e] = o;
@@ -147,14 +159,38 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
         *reinterpret_cast<u32x4*>(p.lo + o) = u32x4{l[0], l[1], l[2], l[3]};
     }
 }
-extern "C" int sat_disc_planes(const float* src, const float* out, float* dst, void* hi, void* lo, int B, int C, int frames, int W,
-                               int pitched, float slope, void* stream) {
+extern "C" int sat_disc_planes(const float* src, const float* out, const float* fm_ref, const float* fm_coef, float* dst, void* hi, void* lo,
+                               int B, int C, int frames, int W, int pitched, float slope, void* stream) {
     int P, L, lead, rows;
     if (B <= 0 || C <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_planes: bad shape"); return 1; }
     if (!src || (!dst && !hi) || ((hi == nullptr) != (lo == nullptr))) { sat_set_error("sat_disc_planes: missing operand"); return 1; }
-    SatDiscPlanesParams p{src, out, dst, (short*)hi, (short*)lo, B, C, sat_cdiv(C, 8), frames, W, P, L, lead, rows, pitched, slope};
+    if (fm_ref && (!out || !fm_coef || !pitched)) { sat_set_error("sat_disc_planes: the feature-matching term needs out, fm_coef and a pitched src"); return 1; }
+    SatDiscPlanesParams p{src, out, fm_ref, fm_coef, dst, (short*)hi, (short*)lo, B, C, sat_cdiv(C, 8), frames, W, P, L, lead, rows, pitched, slope};
     SAT_LAUNCH(sat_disc_planes_kernel, dim3(sat_cdiv(L, 256), p.c8, B), dim3(256), stream, p);
     return sat_check_launch("sat_disc_planes");
+}
+
+// sum |a - b| over n floats (n % 4 == 0, 16-byte aligned): partial[block], 1024 blocks of grid-stride float4 loads — the L1 feature-
+// matching distance of two feature maps in the pitched layout (pad positions are zero in both)
+struct SatDiscL1Params { const float* a; const float* b; float* partial; long long n4; };
+__global__ void __launch_bounds__(256) sat_disc_l1_kernel(SatDiscL1Params p) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (long long)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(p.a)[i], y = reinterpret_cast<const f32x4*>(p.b)[i];
+        s += (fabsf(x[0] - y[0]) + fabsf(x[1] - y[1])) + (fabsf(x[2] - y[2]) + fabsf(x[3] - y[3]));
+    }
+    s = sat_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int sat_disc_l1_blocks(void) { return 1024; }
+extern "C" int sat_disc_l1_sum(const float* a, const float* b, float* partial, long long n, void* stream) {
+    if (!a || !b || !partial || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b) & 15)) { sat_set_error("sat_disc_l1_sum: n % 4 == 0, 16-byte aligned operands"); return 1; }
+    SatDiscL1Params p{a, b, partial, n >> 2};
+    SAT_LAUNCH(sat_disc_l1_kernel, dim3(1024), dim3(256), stream, p);
+    return sat_check_launch("sat_disc_l1_sum");
 }
 
 // =====================================================================================================================
@@ -172,6 +208,8 @@ struct SatDiscConvParams {
     int kh, kw, shift;    // shift = dil_t * P: positions between frame taps
     int nchunks, t_tiles, co_tiles;
     float slope;          // LeakyReLU slope of the epilogue (1: none)
+    const float* lk_src;  // (B, Cout, L) or null: the result is multiplied by LeakyReLU'(lk_src) = lk_src > 0 ? 1 : lk_slope — a
+    float lk_slope;       // data-gradient that leaves as dL/d(pre-activation) of the layer that produced lk_src (its activated output)
 };
 
 template <int KW>
@@ -339,11 +377,14 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             const bool ok = co < p.Cout && tg < p.L;
             const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
             const float bias = bias_lds[mi * 32 + row];
+            f32x4 lk = {1.f, 1.f, 1.f, 1.f};
+            if (p.lk_src && ok) lk = *reinterpret_cast<const f32x4*>(p.lk_src + ((size_t)b * p.Cout + co) * p.L + tg);
             f32x4 ov;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = av[e] + bias;
                 v = v > 0.0f ? v : v * p.slope;
+                if (p.lk_src) v *= (lk[e] > 0.0f ? 1.0f : p.lk_slope);
                 ov[e] = valid[e] ? v : 0.0f;
             }
             if (ok) *reinterpret_cast<f32x4*>(p.y + ((size_t)b * p.Cout + co) * p.L + tg) = ov;
@@ -378,16 +419,18 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
 //   xp_hi / xp_lo: planes of x (Cin channels; sat_disc_planes or a previous layer's emission); w_hi / w_lo: sat_disc_pack_weights
 //   (mode 0; mode 1 with Cin / Cout swapped: the data-gradient, xp = planes of dL/d(pre-activation)); y (B, Cout, L) fp32;
 //   em_hi / em_lo (or null): the planes of y for the layer that consumes it.  kh frame taps dil_t frames apart, kw <= 9 frequency taps.
+//   lk_src (or null): y *= LeakyReLU'(lk_src) with slope lk_slope — the data-gradient of a layer whose input was the activated output
+//   lk_src of the previous layer, leaving directly as that layer's dL/d(pre-activation) (fp32 + planes), when nothing else consumes lk_src.
 extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w_hi, const void* w_lo, const float* bias, float* y,
                              void* em_hi, void* em_lo, int B, int Cin, int Cout, int frames, int W, int kh, int kw, int dil_t,
-                             float slope, void* stream) {
+                             float slope, const float* lk_src, float lk_slope, void* stream) {
     int P, L, lead, rows;
     if (B <= 0 || Cin <= 0 || Cout <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_conv: bad shape"); return 1; }
     if (kh < 1 || !(kh & 1) || kw < 1 || kw > SAT_DC_TAPS || !(kw & 1) || dil_t < 1 || dil_t * ((kh - 1) / 2) > SAT_DC_MAXSHIFT) {
         sat_set_error("sat_disc_conv: odd kh, odd kw <= 9, dil_t * (kh - 1) / 2 <= 4");
         return 1;
     }
-    if (!xp_hi || !xp_lo || !w_hi || !w_lo || !y || ((em_hi == nullptr) != (em_lo == nullptr)) || (((uintptr_t)y) & 15)) {
+    if (!xp_hi || !xp_lo || !w_hi || !w_lo || !y || ((em_hi == nullptr) != (em_lo == nullptr)) || (((uintptr_t)y | (uintptr_t)lk_src) & 15)) {
         sat_set_error("sat_disc_conv: missing / misaligned operand");
         return 1;
     }
@@ -401,6 +444,7 @@ extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w
     p.t_tiles = sat_cdiv(L, SAT_DC_T);
     p.co_tiles = sat_cdiv(Cout, SAT_DC_CO);
     p.slope = slope;
+    p.lk_src = lk_src; p.lk_slope = lk_slope;
     const long long total = (long long)p.t_tiles * B * p.co_tiles;
     const dim3 grid((unsigned)total), block(SAT_DC_NT);
     switch (kw) {

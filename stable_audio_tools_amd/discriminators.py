@@ -158,13 +158,20 @@ class _PitchFn(torch.autograd.Function):
 
 
 class _DiscConvFn(torch.autograd.Function):
-    """One NormConv2d + LeakyReLU of DiscriminatorSTFT on the pitched layout: h (B, Cin, L) -> LeakyReLU_slope(conv2d(h, w) + bias)
+    """One NormConv2d + LeakyReLU of DiscriminatorSTFT on the pitched layout: h (B, Cin, L) -> y = LeakyReLU_slope(conv2d(h, w) + bias)
     (B, Cout, L), pad positions zero.  Forward: sat_disc_conv on the planes the producer emitted for h (or sat_disc_planes), emitting
     the planes of its own output unless `last`.  Backward: dpre = g * LeakyReLU'(y) as pitched fp32 + planes in one pass
-    (sat_disc_planes), dW = sat_disc_wgrad(dpre, h), dbias = row sums, dh = sat_disc_conv(planes of dpre, transposed weights)."""
+    (sat_disc_planes), dW = sat_disc_wgrad(dpre, h), dbias = row sums, dh = sat_disc_conv(planes of dpre, transposed weights).
+
+    fm_ref (pitched, no gradient): the layer also returns sum |y - fm_ref| (the L1 feature-matching distance to the other signal's
+    feature map, models/discriminators.py:52-56); its gradient enters the same dpre pass (+ g_fm * sign(y - fm_ref) before the
+    LeakyReLU' factor) — no elementwise autograd graph over the feature maps.
+    Chained gradients (a chain of layers whose feature maps nothing else consumes — the discriminator update): fold_slope = the slope of
+    the layer that produced h: the data-gradient leaves as THAT layer's dL/d(pre-activation) (fp32 + planes, sat_disc_conv's lk_src);
+    dpre_in = the gradient this layer receives is already w.r.t. its pre-activation.  One pass over each gradient less per layer."""
 
     @staticmethod
-    def forward(ctx, h, w4, bias, frames, wd, dil_t, slope, last):
+    def forward(ctx, h, w4, bias, frames, wd, dil_t, slope, last, fm_ref, fold_slope, dpre_in):
         ops = _fn._ops(None)
         h = h.contiguous()
         w4 = w4.contiguous()
@@ -175,24 +182,42 @@ class _DiscConvFn(torch.autograd.Function):
                               emit_slot=None if last else 1 - slot)
         if em is not None:
             ops.disc_register(y, em, cout, frames, wd, 1 - slot)
-        ctx.meta = (ops, frames, wd, dil_t, slope, bias is not None)
-        ctx.save_for_backward(h, w4, y if slope != 1.0 else None)
-        return y
+        if fm_ref is not None and (dpre_in or slope == 1.0):
+            raise ValueError("_DiscConvFn: the feature-matching term needs an activated layer with the ordinary gradient contract")
+        ctx.meta = (ops, frames, wd, dil_t, slope, bias is not None, fold_slope, dpre_in)
+        ctx.save_for_backward(h, w4, y if (slope != 1.0 and not dpre_in) else None, fm_ref)
+        if fm_ref is None:
+            return y
+        return y, ops.disc_l1_sum(y, fm_ref.contiguous())
 
     @staticmethod
-    def backward(ctx, g):
-        ops, frames, wd, dil_t, slope, has_bias = ctx.meta
-        h, w4, y = ctx.saved_tensors
+    def backward(ctx, g, g_fm=None):
+        ops, frames, wd, dil_t, slope, has_bias, fold_slope, dpre_in = ctx.meta
+        h, w4, y, fm_ref = ctx.saved_tensors
         cout, cin, kh, kw = w4.shape
         b = h.shape[0]
         need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dpre, dpl = ops.disc_planes(g.contiguous(), frames, wd, out=y, slope=slope, want_dst=True, want_planes=need_h, slot=0)
+        if g is None:
+            g = torch.zeros(b, cout, h.shape[2], dtype=torch.float32, device=h.device)
+        g = g.contiguous()
+        if dpre_in:
+            dpre = g
+            dpl, slot = ops.disc_take(dpre, cout, frames, wd) if need_h else (None, 0)
+        else:
+            fm = fm_ref is not None and g_fm is not None
+            dpre, dpl = ops.disc_planes(g, frames, wd, out=y, slope=slope, want_dst=True, want_planes=need_h, slot=0,
+                                        fm_ref=fm_ref if fm else None, fm_coef=g_fm.contiguous() if fm else None)
+            slot = 0
         dw = ops.disc_wgrad(dpre, h, frames, wd, kh, kw, dil_t) if need_w else None
         dbias = ops.rowsum(dpre) if (has_bias and ctx.needs_input_grad[2]) else None
         dh = None
         if need_h:
-            dh, _ = ops.disc_conv(dpl, ops.disc_pack(w4, 1), None, b, cout, cin, frames, wd, kh, kw, dil_t, 1.0)
-        return dh, dw, dbias, None, None, None, None, None
+            fold = fold_slope is not None
+            dh, em = ops.disc_conv(dpl, ops.disc_pack(w4, 1), None, b, cout, cin, frames, wd, kh, kw, dil_t, 1.0,
+                                   emit_slot=(1 - slot) if fold else None, lk_src=h if fold else None, lk_slope=fold_slope if fold else 1.0)
+            if fold:
+                ops.disc_register(dh, em, cin, frames, wd, 1 - slot)
+        return (dh, dw, dbias) + (None,) * 8
 
 
 def _pitched_ok(ops, kernel_size, dilation):
@@ -267,10 +292,10 @@ class _WNConv2d(nn.Module):
     def pitched_ok(self):
         return _pitched_ok(_fn._ops(None), self.kernel_size, self.dilation)
 
-    def forward_pitched(self, h, frames, wd, slope=1.0, last=False):
-        """The same layer on the pitched sequence (B, Cin, frames * P) -> (B, Cout, frames * P) (_DiscConvFn)."""
+    def forward_pitched(self, h, frames, wd, slope=1.0, last=False, fm_ref=None, fold_slope=None, dpre_in=False):
+        """The same layer on the pitched sequence (B, Cin, frames * P) -> (B, Cout, frames * P) (_DiscConvFn; with fm_ref: (y, sum |y - fm_ref|))."""
         w = WeightNormFn.apply(self.weight_v, self.weight_g)
-        return _DiscConvFn.apply(h, w, self.bias, frames, wd, self.dilation[0], float(slope), last)
+        return _DiscConvFn.apply(h, w, self.bias, frames, wd, self.dilation[0], float(slope), last, fm_ref, fold_slope, dpre_in)
 
 
 class NormConv2d(nn.Module):
@@ -309,20 +334,33 @@ class DiscriminatorSTFT(nn.Module):
     def pitched_ok(self):
         return isinstance(self.activation, torch.nn.LeakyReLU) and all(l.conv.pitched_ok() for l in list(self.convs) + [self.conv_post])
 
-    def forward_pitched(self, x):
-        """(logits, feature maps, (frames, freq bins)) with every tensor in the pitched layout (B, C, frames * P), pad positions zero."""
+    def forward_pitched(self, x, fm_refs=None, exclusive=False):
+        """(logits, feature maps, (frames, freq bins), fm sums) with every tensor in the pitched layout (B, C, frames * P), pad positions
+        zero.  fm_refs: the other signal's feature maps (no gradient) -> fm sums[i] = sum |fmap[i] - fm_refs[i]|, differentiable w.r.t.
+        this signal's path (else None).  exclusive: the caller consumes ONLY the logits — the layers chain their gradients
+        (_DiscConvFn fold_slope / dpre_in); gradients w.r.t. the returned feature maps would be wrong, so they are detached."""
+        if fm_refs is not None and exclusive:
+            raise ValueError("forward_pitched: feature-matching terms need the feature maps' ordinary gradients")
         z = _SpecFn.apply(x, self.n_fft, self.hop_length)
         frames, wd = z.shape[2], z.shape[3]
         h = _PitchFn.apply(z)
-        fmap = []
-        for layer in self.convs:
-            h = layer.conv.forward_pitched(h, frames, wd, self.activation.negative_slope)
-            fmap.append(h)
-        return self.conv_post.conv.forward_pitched(h, frames, wd, 1.0, last=True), fmap, (frames, wd)
+        slope = self.activation.negative_slope
+        fmap, sums = [], []
+        for i, layer in enumerate(self.convs):
+            out = layer.conv.forward_pitched(h, frames, wd, slope, fm_ref=None if fm_refs is None else fm_refs[i],
+                                             fold_slope=slope if (exclusive and i > 0) else None, dpre_in=exclusive)
+            if fm_refs is not None:
+                h, s_i = out
+                sums.append(s_i)
+            else:
+                h = out
+            fmap.append(h.detach() if exclusive else h)
+        logit = self.conv_post.conv.forward_pitched(h, frames, wd, 1.0, last=True, fold_slope=slope if exclusive else None)
+        return logit, fmap, (frames, wd), (sums if fm_refs is not None else None)
 
     def forward(self, x):
         if self.pitched_ok():
-            logit, fmap, (frames, wd) = self.forward_pitched(x)
+            logit, fmap, (frames, wd), _ = self.forward_pitched(x)
             unp = lambda t: _unpitch_view(t, frames, wd)           # noqa: E731
             return unp(logit), [unp(f) for f in fmap]
         fmap = []
@@ -389,9 +427,18 @@ class EncodecDiscriminator(nn.Module):
         if d.pitched_ok():
             # feature matching on the pitched buffers themselves (pad positions are zero in both: sums over the whole buffer / the
             # number of samples = the reference's means); only the one-channel logits are viewed un-pitched
-            logit_t, feat_t, (frames, wd) = d.forward_pitched(reals)
-            logit_f, feat_f, _ = d.forward_pitched(fakes)
-            fm = sum(self._fm_pitched(a, b, frames, wd) for a, b in zip(feat_t, feat_f)) / len(feat_t) if need_fm else 0.0
+            #   need_fm=False: only the logits are consumed -> the layers chain their gradients (exclusive);
+            #   real feature maps without gradient (the generator update: frozen discriminator, real signal): the distances and their
+            #   gradients ride in the fake path's layers (fm_refs); otherwise the distances are torch ops on the pitched buffers.
+            logit_t, feat_t, (frames, wd), _ = d.forward_pitched(reals, exclusive=not need_fm)
+            fused = need_fm and not any(f.requires_grad for f in feat_t)
+            logit_f, feat_f, _, sums = d.forward_pitched(fakes, fm_refs=feat_t if fused else None, exclusive=not need_fm)
+            if not need_fm:
+                fm = 0.0
+            elif fused:
+                fm = sum(self._fm_from_sum(s_i, a, frames, wd) for s_i, a in zip(sums, feat_t)) / len(feat_t)
+            else:
+                fm = sum(self._fm_pitched(a, b, frames, wd) for a, b in zip(feat_t, feat_f)) / len(feat_t)
             dis, adv = get_hinge_losses(_unpitch_view(logit_t, frames, wd), _unpitch_view(logit_f, frames, wd))
             return dis / n, adv / n, fm / n
         logit_t, feat_t = d(reals)
@@ -399,6 +446,11 @@ class EncodecDiscriminator(nn.Module):
         fm = sum(map(self.fm_reduction, feat_t, feat_f)) / len(feat_t) if need_fm else 0.0
         dis, adv = get_hinge_losses(logit_t, logit_f)
         return dis / n, adv / n, fm / n
+
+    def _fm_from_sum(self, s_i, x, frames, wd):
+        count = x.shape[0] * x.shape[1] * frames * wd
+        d = s_i / count
+        return d / (x.abs().sum() / count + 1e-3) if self.normalize_losses else d
 
     def _fm_pitched(self, x, y, frames, wd):
         count = x.shape[0] * x.shape[1] * frames * wd

@@ -566,38 +566,47 @@ class SatOps:
 
     def _disc_plane_buf(self, b, c, frames, w, device, slot):
         """bf16 hi / lo plane pair [b][ceil(c/8)][rows][8] for a (b, c, frames, w) activation; `slot` 0 / 1: the two alternating
-        targets of a layer chain (a layer reads one and emits into the other).  Zero-filled ONCE: writers only touch rows
-        lead .. lead + L - 1 of existing channel groups, the rows around them are the frame padding."""
-        rows = self.disc_geom(frames, w)[3]
-        key = ("disc", b, (c + 7) // 8, frames, w, device, slot)
+        targets of a layer chain (a layer reads one and emits into the other).  ONE pool entry per (device, narrow | wide, slot) serves
+        every scale of the discriminator (the scales run one after the other): writers only touch rows lead .. lead + L - 1 of the
+        existing channel groups, so when an entry changes geometry the rows around them — the frame padding — are zeroed again."""
+        P, L, lead, rows = self.disc_geom(frames, w)
+        c8 = (c + 7) // 8
+        n = b * c8 * rows * 8
+        key = (device, 0 if c8 == 1 else 1, slot)
         gen = self.__dict__.setdefault("_disc_gen", {})
         gen[key] = gen.get(key, 0) + 1                              # every request is a write: invalidates earlier registrations
-        cache = self.__dict__.setdefault("_planes", {})
-        pl = cache.get(key)
-        if pl is None:
-            n = b * ((c + 7) // 8) * rows * 8
-            pl = cache[key] = (torch.zeros(n, dtype=torch.int16, device=device), torch.zeros(n, dtype=torch.int16, device=device))
-        return pl
+        pool = self.__dict__.setdefault("_disc_pool", {})
+        e = pool.get(key)
+        if e is None or e["cap"] < n:
+            e = pool[key] = {"hi": torch.zeros(n, dtype=torch.int16, device=device), "lo": torch.zeros(n, dtype=torch.int16, device=device),
+                             "cap": n, "geom": (b, c8, frames, w)}
+        elif e["geom"] != (b, c8, frames, w):
+            for t in (e["hi"], e["lo"]):
+                v = t[:n].view(b * c8, rows, 8)
+                v[:, :lead].zero_()
+                v[:, lead + L:].zero_()
+            e["geom"] = (b, c8, frames, w)
+        return e["hi"][:n], e["lo"][:n]
 
     def disc_register(self, t, planes, c, frames, w, slot):
-        """Remember that `planes` (slot `slot` of the (c, frames, w) plane buffers) hold tensor t's operand planes."""
-        key = ("disc", t.shape[0], (c + 7) // 8, frames, w, t.device, slot)
-        self._disc_emitted = {"ptr": t.data_ptr(), "ver": t._version, "key": key, "gen": self.__dict__.setdefault("_disc_gen", {}).get(key, 0),
-                              "planes": planes, "slot": slot}
+        """Remember that `planes` (slot `slot`) hold tensor t's operand planes (consumed by disc_take if nothing wrote the slot since)."""
+        key = (t.device, 0 if (c + 7) // 8 == 1 else 1, slot)
+        self._disc_emitted = {"ptr": t.data_ptr(), "ver": t._version, "key": key, "gen": self.__dict__.get("_disc_gen", {}).get(key, 0),
+                              "geom": (t.shape[0], (c + 7) // 8, frames, w), "planes": planes, "slot": slot}
 
     def disc_take(self, h, c, frames, w):
         """((hi, lo) planes of the pitched tensor h, their slot): the producer's emission if it is still intact, else a planes pass."""
         e = self.__dict__.get("_disc_emitted")
         self._disc_emitted = None
-        if (e is not None and e["ptr"] == h.data_ptr() and e["ver"] == h._version and e["key"][:5] == ("disc", h.shape[0], (c + 7) // 8, frames, w)
+        if (e is not None and e["ptr"] == h.data_ptr() and e["ver"] == h._version and e["geom"] == (h.shape[0], (c + 7) // 8, frames, w)
                 and self.__dict__.get("_disc_gen", {}).get(e["key"], 0) == e["gen"]):
             return e["planes"], e["slot"]
         return self.disc_planes(h, frames, w, slot=0)[1], 0
 
-    def disc_planes(self, src, frames, w, out=None, slope=1.0, want_dst=False, want_planes=True, slot=0):
+    def disc_planes(self, src, frames, w, out=None, slope=1.0, want_dst=False, want_planes=True, slot=0, fm_ref=None, fm_coef=None):
         """src: (B, C, frames, w) or pitched (B, C, L) -> (dst pitched fp32 or None, (hi, lo) planes or None); with `out` (pitched):
-        src * LeakyReLU'(out)."""
-        self._f32(src, out)
+        (src + fm_coef * sign(out - fm_ref)) * LeakyReLU'(out) — fm_ref / fm_coef (a device scalar) optional."""
+        self._f32(src, out, fm_ref, fm_coef)
         b, c = src.shape[0], src.shape[1]
         P, L, lead, rows = self.disc_geom(frames, w)
         pitched = src.dim() == 3
@@ -605,9 +614,16 @@ class SatOps:
             raise ValueError("disc_planes: shape does not match (frames, w)")
         dst = torch.empty(b, c, L, dtype=torch.float32, device=src.device) if want_dst else None
         pl = self._disc_plane_buf(b, c, frames, w, src.device, slot) if want_planes else None
-        self._chk(self.lib.sat_disc_planes(_ptr(src), _ptr(out), _ptr(dst), _ptr(pl[0]) if pl else None, _ptr(pl[1]) if pl else None,
-                                           b, c, frames, w, 1 if pitched else 0, float(slope), self._stream(src)))
+        self._chk(self.lib.sat_disc_planes(_ptr(src), _ptr(out), _ptr(fm_ref), _ptr(fm_coef), _ptr(dst), _ptr(pl[0]) if pl else None,
+                                           _ptr(pl[1]) if pl else None, b, c, frames, w, 1 if pitched else 0, float(slope), self._stream(src)))
         return dst, pl
+
+    def disc_l1_sum(self, a, b):
+        """sum |a - b| of two equal-shape contiguous tensors (numel % 4 == 0) as a 0-d tensor."""
+        self._f32(a, b)
+        partial = torch.empty(self.lib.sat_disc_l1_blocks(), dtype=torch.float32, device=a.device)
+        self._chk(self.lib.sat_disc_l1_sum(_ptr(a), _ptr(b), _ptr(partial), a.numel(), self._stream(a)))
+        return partial.sum()
 
     def disc_pack(self, w4, mode):
         """w (Cout, Cin, kh, kw) -> (hi, lo) bf16 planes for sat_disc_conv (mode 0) / its data-gradient (mode 1)."""
@@ -621,16 +637,16 @@ class SatOps:
         self._chk(self.lib.sat_disc_pack_weights(_ptr(w4), _ptr(hi), _ptr(lo), cout, cin, kh, kw, mode, self._stream(w4)))
         return hi, lo
 
-    def disc_conv(self, planes, wq, bias, b, cin, cout, frames, w, kh, kw, dil_t, slope, emit_slot=None):
+    def disc_conv(self, planes, wq, bias, b, cin, cout, frames, w, kh, kw, dil_t, slope, emit_slot=None, lk_src=None, lk_slope=1.0):
         """LeakyReLU_slope(conv2d + bias) on the pitched layout: planes (hi, lo) of the (b, cin) input, wq = disc_pack(...).
-        Returns (y (b, cout, L), emitted planes of y or None)."""
-        self._f32(bias)
+        Returns (y (b, cout, L), emitted planes of y or None).  lk_src (b, cout, L): y *= LeakyReLU'(lk_src) (slope lk_slope)."""
+        self._f32(bias, lk_src)
         L = self.disc_geom(frames, w)[1]
         y = torch.empty(b, cout, L, dtype=torch.float32, device=planes[0].device)
         em = self._disc_plane_buf(b, cout, frames, w, y.device, emit_slot) if emit_slot is not None else None
         self._chk(self.lib.sat_disc_conv(_ptr(planes[0]), _ptr(planes[1]), _ptr(wq[0]), _ptr(wq[1]), _ptr(bias), _ptr(y),
                                          _ptr(em[0]) if em else None, _ptr(em[1]) if em else None, b, cin, cout, frames, w, kh, kw, dil_t,
-                                         float(slope), self._stream(y)))
+                                         float(slope), _ptr(lk_src), float(lk_slope), self._stream(y)))
         return y, em
 
     def disc_wgrad(self, dy, x, frames, w, kh, kw, dil_t):

@@ -138,3 +138,44 @@ def test_discriminator_full_width_properties_gpu(hip):
         sd = {("d." + k): v.detach().cpu() for k, v in d.state_dict().items()}
         ref, _ = disc_oracle.discriminator_stft(sd, "d.", x.cpu(), 512, 128, 512)
     assert rel_err(logit, ref) < TOL
+
+
+def _modes_case(device):
+    """The three ways EncodecDiscriminator.scale_losses runs the pitched path give the same numbers and gradients:
+    generic (feature-matching as torch ops on the feature maps), fused (frozen discriminator: the distances and their gradients ride
+    in the fake path's layers) and chained (need_fm=False: the layers hand each other dL/d(pre-activation))."""
+    name, seed = "tiny", 800
+    cfg = seeded.DISC_CONFIGS[name]
+    disc = _build(name, seed, device)
+    assert all(d.pitched_ok() for d in disc.discriminators.discriminators)
+    reals, fakes = _signals(cfg, seed)
+    reals, fakes = reals.to(device), fakes.to(device).requires_grad_(True)
+    params = list(disc.parameters())
+    for i in range(disc.discriminators.num_discriminators):
+        dis, adv, fm = disc.scale_losses(i, reals, fakes)                       # generic
+        g_f = torch.autograd.grad(0.1 * adv + 5.0 * fm, fakes, retain_graph=True)[0]
+        g_p = torch.autograd.grad(dis, params, allow_unused=True)
+        for p in params:
+            p.requires_grad_(False)
+        _, adv2, fm2 = disc.scale_losses(i, reals, fakes)                       # fused feature matching
+        g_f2 = torch.autograd.grad(0.1 * adv2 + 5.0 * fm2, fakes)[0]
+        for p in params:
+            p.requires_grad_(True)
+        assert abs(float(fm2) - float(fm)) <= 1e-5 * abs(float(fm)) and abs(float(adv2) - float(adv)) <= 1e-6
+        assert rel_err(g_f2, g_f) < 1e-5
+        dis3, _, fm3 = disc.scale_losses(i, reals, fakes.detach(), need_fm=False)   # chained gradients
+        assert fm3 == 0.0 and abs(float(dis3) - float(dis)) <= 1e-6
+        g_p3 = torch.autograd.grad(dis3, params, allow_unused=True)
+        for a, r in zip(g_p3, g_p):
+            assert (a is None) == (r is None)
+            if a is not None:
+                assert rel_err(a, r) < 1e-5
+
+
+def test_discriminator_loss_modes_simulator(emu_modules):
+    _modes_case("cpu")
+
+
+@pytest.mark.gpu
+def test_discriminator_loss_modes_gpu(hip):
+    _modes_case("cuda")
