@@ -113,7 +113,7 @@ int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, i
  *                     NULL): + fm_coef[0] * sign(out - fm_ref) before the LeakyReLU' factor (the L1 feature-matching term of `out`,
  *                     models/discriminators.py:52-56; fm_coef a DEVICE scalar).  sat_disc_l1_sum: sat_disc_l1_blocks() partial
  *                     sums of |a - b| (the feature-matching distance on pitched buffers).
- *   sat_disc_pack_weights  w (Cout, Cin, kh, kw) -> hi / lo weight planes (sat_disc_pack_size bf16 each); mode 0: the conv,
+ *   sat_disc_pack_weights  w (Cout, Cin, kh, kw) -> wq, the packed bf16 hi + lo weights (sat_disc_pack_size elements); mode 0: the conv,
  *                     mode 1: its data-gradient (a conv of Cout channels -> Cin channels)
  *   sat_disc_conv     y = LeakyReLU_slope(conv2d + bias) (slope 1: none), pitched fp32 (B, Cout, L), pads zero; em_hi / em_lo (or
  *                     NULL): y's planes for the next layer.  Cin / Cout are the channels of the conv RUN (swapped for mode 1 weights).
@@ -127,8 +127,8 @@ int sat_disc_planes(const float* src, const float* out, const float* fm_ref, con
 int sat_disc_l1_blocks(void);
 int sat_disc_l1_sum(const float* a, const float* b, float* partial, long long n, void* stream);
 long long sat_disc_pack_size(int Cout, int Cin, int kh, int kw, int mode);
-int sat_disc_pack_weights(const float* w, short* hi, short* lo, int Cout, int Cin, int kh, int kw, int mode, void* stream);
-int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w_hi, const void* w_lo, const float* bias, float* y, void* em_hi,
+int sat_disc_pack_weights(const float* w, short* wq, int Cout, int Cin, int kh, int kw, int mode, void* stream);
+int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* wq, const float* bias, float* y, void* em_hi,
                   void* em_lo, int B, int Cin, int Cout, int frames, int W, int kh, int kw, int dil_t, float slope, const float* lk_src,
                   float lk_slope, void* stream);
 int sat_disc_wgrad_nsplit(int B, int M, int Cin, int kh, int frames, int W);

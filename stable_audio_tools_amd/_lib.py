@@ -36,8 +36,8 @@ SIGNATURES = {
     "sat_disc_l1_blocks": (_I, []),
     "sat_disc_l1_sum": (_I, [_P, _P, _P, _L, _P]),
     "sat_disc_pack_size": (_L, [_I] * 5),
-    "sat_disc_pack_weights": (_I, [_P] * 3 + [_I] * 5 + [_P]),
-    "sat_disc_conv": (_I, [_P] * 8 + [_I] * 8 + [_F, _P, _F, _P]),
+    "sat_disc_pack_weights": (_I, [_P] * 2 + [_I] * 5 + [_P]),
+    "sat_disc_conv": (_I, [_P] * 7 + [_I] * 8 + [_F, _P, _F, _P]),
     "sat_disc_wgrad_nsplit": (_I, [_I] * 6),
     "sat_disc_wgrad": (_I, [_P] * 3 + [_I] * 8 + [_P]),
     "sat_conv1d_k7_plane_rows": (_I, [_I] * 3),

@@ -26,7 +26,7 @@
 #define SAT_DC_NT 512
 #define SAT_DC_TAPS 9
 #define SAT_DC_AROWS 576                                   // 512 positions + 8 taps of halo, in 64-row pieces
-#define SAT_DC_WBYTES (2 * SAT_DC_TAPS * 2 * 1024)         // [plane][tap][group][64 co][16 B]
+#define SAT_DC_WBYTES (SAT_DC_TAPS * 2 * 2 * 1024)         // [tap][plane][group][64 co][16 B]
 #define SAT_DC_ABYTES (2 * 2 * SAT_DC_AROWS * 16)          // [plane][group][576 rows][16 B]
 #define SAT_DC_STAGE (SAT_DC_WBYTES + SAT_DC_ABYTES)       // 73728
 #define SAT_DC_APIECES (2 * 2 * (SAT_DC_AROWS / 64))       // 36
@@ -50,14 +50,14 @@ extern "C" int sat_disc_geom(int frames, int W, int* P, int* L, int* lead, int* 
     return 0;
 }
 
-// ---- weights: w (Cout, Cin, kh, kw) fp32 -> hi / lo planes [co tile][chunk][tap][group g][64 m][e], element = W'[m][v][tap] with
+// ---- weights: w (Cout, Cin, kh, kw) fp32 -> ONE bf16 buffer [co tile][chunk][tap][plane hi | lo][group g][64 m][e] (a K-chunk's
+//      4 kw one-KiB pieces are contiguous, taps in the order the kernel's phases consume them), element = W'[m][v][tap] with
 //      virtual channel v: group gv = chunk * 2 + g = tap_t * c8 + cg, channel c = cg * 8 + e (c8 = groups of the conv INPUT):
 //   mode 0 (conv):          m = co, c = ci:  W' = w[m][c][tap_t][tap]
 //   mode 1 (data-gradient): m = ci, c = co:  W' = w[c][m][kh-1-tap_t][kw-1-tap]
 struct SatDiscPackParams {
     const float* w;
-    short* hi;
-    short* lo;
+    short* wq;
     int Cout, Cin, kh, kw, mode, c8, nchunks, m_v, c_v;
     long long total;
 };
@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(256) sat_disc_pack_kernel(SatDiscPackParams p)
     }
     short h, l;
     sat_dc_split2(val, &h, &l);
-    p.hi[o] = h;
-    p.lo[o] = l;
+    const long long oq = (o >> 10) * 2048 + (o & 1023);    // (tile, chunk, tap) block of [plane][group][64][8]
+    p.wq[oq] = h;
+    p.wq[oq + 1024] = l;
 }
 static bool sat_disc_pack_geometry(int Cout, int Cin, int kh, int kw, int mode, SatDiscPackParams* p) {
     if (mode < 0 || mode > 1 || Cout <= 0 || Cin <= 0 || kh < 1 || !(kh & 1) || kw < 1 || kw > SAT_DC_TAPS || !(kw & 1)) return false;
@@ -96,12 +97,12 @@ static bool sat_disc_pack_geometry(int Cout, int Cin, int kh, int kw, int mode, 
 }
 extern "C" long long sat_disc_pack_size(int Cout, int Cin, int kh, int kw, int mode) {
     SatDiscPackParams p{};
-    return sat_disc_pack_geometry(Cout, Cin, kh, kw, mode, &p) ? p.total : -1;
+    return sat_disc_pack_geometry(Cout, Cin, kh, kw, mode, &p) ? 2 * p.total : -1;
 }
-extern "C" int sat_disc_pack_weights(const float* w, short* hi, short* lo, int Cout, int Cin, int kh, int kw, int mode, void* stream) {
+extern "C" int sat_disc_pack_weights(const float* w, short* wq, int Cout, int Cin, int kh, int kw, int mode, void* stream) {
     SatDiscPackParams p{};
     if (!sat_disc_pack_geometry(Cout, Cin, kh, kw, mode, &p)) { sat_set_error("sat_disc_pack_weights: odd kh, odd kw <= 9, mode 0|1"); return 1; }
-    p.w = w; p.hi = hi; p.lo = lo;
+    p.w = w; p.wq = wq;
     SAT_LAUNCH(sat_disc_pack_kernel, dim3((unsigned)sat_cdivll(p.total, 256)), dim3(256), stream, p);
     return sat_check_launch("sat_disc_pack_weights");
 }
@@ -197,8 +198,7 @@ extern "C" int sat_disc_l1_sum(const float* a, const float* b, float* partial, l
 struct SatDiscConvParams {
     const short* xp_hi;   // input planes [B][c8][rows][8]
     const short* xp_lo;
-    const short* w_hi;    // sat_disc_pack_weights
-    const short* w_lo;
+    const short* wq;      // sat_disc_pack_weights
     const float* bias;    // (Cout) or null
     float* y;             // (B, Cout, L) pitched
     short* em_hi;         // planes of y [B][em_c8][rows][8] for the next layer, or null
@@ -245,28 +245,56 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
 
     if (tid < CO_T) bias_lds[tid] = (co0 + tid < p.Cout && p.bias) ? p.bias[co0 + tid] : 0.0f;
 
-    // ---- LDS-DMA of a chunk: 36 activation pieces ((plane, group) x 9 x 64 rows) + 4 kw weight pieces ((plane, tap, group): 64 co x
-    //      16 B), piece q = 8 i + wave; every source address is a wave-uniform base + lane * 16 bytes ----
+    // ---- LDS-DMA of a chunk: 36 activation pieces ((plane, group) x 9 x 64 rows) + 4 kw weight pieces (tap, plane, group: 64 co x 16 B)
+    //      in nine issue slots per wave: slots 0-3 = (plane, group) s, rows 64 wave ..; slot 4 = the ninth row piece of (plane, group)
+    //      `wave` (waves 0-3) | weight pieces 0-3 (waves 4-7); slots 5-8 = weight pieces 8 (s - 5) + wave + 4.  Every source address is
+    //      a wave-uniform base + lane * 16 bytes, and the bases are a handful of scalar adds per piece: the per-chunk part (which
+    //      virtual groups, i.e. which frame tap / channel group / row shift) is computed once per chunk (set_chunk) ----
     const unsigned lane16 = (unsigned)lane * 16u;
     const int nvg = kh * p.c8;
-    const int npieces = SAT_DC_APIECES + 4 * kw;
-    const char* w_tile_hi = (const char*)p.w_hi + (size_t)co_tile * p.nchunks * kw * 2048;
-    const char* w_tile_lo = (const char*)p.w_lo + (size_t)co_tile * p.nchunks * kw * 2048;
-    auto issue = [&](int c, int st, int i) __attribute__((always_inline)) {
-        const int q = 8 * i + wave;
-        if (q < SAT_DC_APIECES) {
-            const int pl = q / 18, g = (q / 9) & 1, sub = q % 9;
+    const char* wq_tile = (const char*)p.wq + (size_t)co_tile * p.nchunks * (kw * 4096);
+    long long aoff[2];                                     // byte offset (within a plane) of row row_in0 of the chunk's two groups
+    auto set_chunk = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
             int gv = c * 2 + g;
             gv = gv < nvg ? gv : nvg - 1;                  // past the end: any finite rows (their weights are zero)
             const int tap_t = gv / p.c8, cg = gv - tap_t * p.c8;
-            const long long row = (long long)row_in0 + (long long)(tap_t - pad_t) * p.shift + sub * 64;
-            const char* src = (const char*)(pl ? p.xp_lo : p.xp_hi) + (((size_t)b * p.c8 + cg) * p.rows + row) * 16;
-            sat_glds16(src + lane16, lds + st * STAGE + WB + ((pl * 2 + g) * AROWS + sub * 64) * 16);
-        } else if (q < npieces) {
-            const int r = q - SAT_DC_APIECES;
-            const int pl = r / (2 * kw), tg = r - pl * 2 * kw;      // tg = tap * 2 + group
-            const char* src = (pl ? w_tile_lo : w_tile_hi) + ((size_t)c * kw * 2 + tg) * 1024;
-            sat_glds16(src + lane16, lds + st * STAGE + (pl * SAT_DC_TAPS * 2 + tg) * 1024);
+            aoff[g] = (((long long)b * p.c8 + cg) * p.rows + row_in0 + (long long)(tap_t - pad_t) * p.shift) * 16;
+        }
+    };
+    auto issue_w = [&](int c, char* stage, int r) __attribute__((always_inline)) {
+        if (r < 4 * kw) sat_glds16(wq_tile + ((size_t)c * (4 * kw) + r) * 1024 + lane16, stage + r * 1024);
+    };
+    auto issue = [&](int c, int st, auto slot_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(slot_c)::value;
+        char* stage = lds + st * STAGE;
+        if constexpr (s < 4) {
+            const char* src = (const char*)((s >> 1) ? p.xp_lo : p.xp_hi) + aoff[s & 1] + wave * 1024;
+            sat_glds16(src + lane16, stage + WB + (s * AROWS + wave * 64) * 16);
+        } else if constexpr (s == 4) {
+            if (wave < 4) {
+                const char* src = (const char*)((wave >> 1) ? p.xp_lo : p.xp_hi) + aoff[wave & 1] + 8 * 1024;
+                sat_glds16(src + lane16, stage + WB + (wave * AROWS + 512) * 16);
+            } else {
+                issue_w(c, stage, wave - 4);
+            }
+        } else {
+            issue_w(c, stage, (s - 5) * 8 + wave + 4);
+        }
+    };
+    auto issue_range = [&](int c, int st, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_c)::value, hi_ = decltype(hi_c)::value;
+        if constexpr (lo < hi_ && lo < 9) {
+            issue(c, st, std::integral_constant<int, lo>{});
+            if constexpr (lo + 1 < hi_ && lo + 1 < 9) issue(c, st, std::integral_constant<int, lo + 1>{});
+            if constexpr (lo + 2 < hi_ && lo + 2 < 9) issue(c, st, std::integral_constant<int, lo + 2>{});
+            if constexpr (lo + 3 < hi_ && lo + 3 < 9) issue(c, st, std::integral_constant<int, lo + 3>{});
+            if constexpr (lo + 4 < hi_ && lo + 4 < 9) issue(c, st, std::integral_constant<int, lo + 4>{});
+            if constexpr (lo + 5 < hi_ && lo + 5 < 9) issue(c, st, std::integral_constant<int, lo + 5>{});
+            if constexpr (lo + 6 < hi_ && lo + 6 < 9) issue(c, st, std::integral_constant<int, lo + 6>{});
+            if constexpr (lo + 7 < hi_ && lo + 7 < 9) issue(c, st, std::integral_constant<int, lo + 7>{});
+            if constexpr (lo + 8 < hi_ && lo + 8 < 9) issue(c, st, std::integral_constant<int, lo + 8>{});
         }
     };
 
@@ -283,7 +311,7 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
     auto load_frags = [&](Frags& f, const char* sb, int tap) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            const char* wb = sb + ((pl * SAT_DC_TAPS + tap) * 2 + hi) * 1024;
+            const char* wb = sb + ((tap * 2 + pl) * 2 + hi) * 1024;
             f.wa[0][pl] = *reinterpret_cast<const bf16x8*>(wb + l31 * 16);
             f.wa[1][pl] = *reinterpret_cast<const bf16x8*>(wb + (32 + l31) * 16);
             const char* ab = sb + WB + (pl * 2 + hi) * (AROWS * 16);
@@ -308,15 +336,19 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
     const bool mi1_on = co0 + 32 < p.Cout;                // Cout <= 32 in this tile: the second row of accumulators multiplies nothing
 
     // prologue: chunk 0 complete in stage 0
-#pragma unroll
-    for (int i = 0; i < 9; ++i) issue(0, 0, i);
+    set_chunk(0);
+    issue_range(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
     SAT_WAIT_VMCNT(0);
     SAT_RAW_BARRIER();
     if (wr == 1) SAT_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
 
+    // kw == 9: COUNTED waits — the last phase's three pieces per wave (weights of taps 3-8, L2-resident) stay in flight across the
+    // chunk boundary and are retired by the next chunk's phase 0, one phase before they are read (as conv1d_bf16x3_k7q.h, VARIANT 1)
+    constexpr bool COUNTED = (KW == 9);
     for (int c = 0; c < p.nchunks; ++c) {
         const char* sb = lds + (c & 1) * STAGE;
         const bool more = c + 1 < p.nchunks;
+        if (more) set_chunk(c + 1);
 #pragma unroll
         for (int ph = 0; ph < nph; ++ph) {
             // read section: this phase's fragments + this phase's share of the next chunk's DMA
@@ -324,10 +356,16 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             for (int u = 0; u < 3; ++u)
                 if (3 * ph + u < kw) load_frags(fr[u], sb, 3 * ph + u);
             if (more) {
-#pragma unroll
-                for (int i = ph * ipp; i < (ph + 1) * ipp && i < 9; ++i) issue(c + 1, (c + 1) & 1, i);
+                if (ph == 0) issue_range(c + 1, (c + 1) & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, ipp>{});
+                if (ph == 1) issue_range(c + 1, (c + 1) & 1, std::integral_constant<int, ipp>{}, std::integral_constant<int, 2 * ipp>{});
+                if (ph == 2) issue_range(c + 1, (c + 1) & 1, std::integral_constant<int, 2 * ipp>{}, std::integral_constant<int, 3 * ipp>{});
             }
-            if (ph == nph - 1) { SAT_WAIT_VMCNT(0); }      // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
+            if constexpr (COUNTED) {
+                if (ph == 0) { if (more) { SAT_WAIT_VMCNT(3); } else { SAT_WAIT_VMCNT(0); } }
+                if (ph == 2 && more) { SAT_WAIT_VMCNT(3); }
+            } else {
+                if (ph == nph - 1) { SAT_WAIT_VMCNT(0); }  // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
+            }
             SAT_WAIT_LGKM0();
             SAT_RAW_BARRIER();
             SAT_SCHED_FENCE();
@@ -416,12 +454,12 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
 }
 
 // y = LeakyReLU_slope(conv2d(x, w) + bias) on the pitched layout (slope 1: no activation), pad positions written as zeros:
-//   xp_hi / xp_lo: planes of x (Cin channels; sat_disc_planes or a previous layer's emission); w_hi / w_lo: sat_disc_pack_weights
+//   xp_hi / xp_lo: planes of x (Cin channels; sat_disc_planes or a previous layer's emission); wq: sat_disc_pack_weights
 //   (mode 0; mode 1 with Cin / Cout swapped: the data-gradient, xp = planes of dL/d(pre-activation)); y (B, Cout, L) fp32;
 //   em_hi / em_lo (or null): the planes of y for the layer that consumes it.  kh frame taps dil_t frames apart, kw <= 9 frequency taps.
 //   lk_src (or null): y *= LeakyReLU'(lk_src) with slope lk_slope — the data-gradient of a layer whose input was the activated output
 //   lk_src of the previous layer, leaving directly as that layer's dL/d(pre-activation) (fp32 + planes), when nothing else consumes lk_src.
-extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w_hi, const void* w_lo, const float* bias, float* y,
+extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* wq, const float* bias, float* y,
                              void* em_hi, void* em_lo, int B, int Cin, int Cout, int frames, int W, int kh, int kw, int dil_t,
                              float slope, const float* lk_src, float lk_slope, void* stream) {
     int P, L, lead, rows;
@@ -430,12 +468,12 @@ extern "C" int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* w
         sat_set_error("sat_disc_conv: odd kh, odd kw <= 9, dil_t * (kh - 1) / 2 <= 4");
         return 1;
     }
-    if (!xp_hi || !xp_lo || !w_hi || !w_lo || !y || ((em_hi == nullptr) != (em_lo == nullptr)) || (((uintptr_t)y | (uintptr_t)lk_src) & 15)) {
+    if (!xp_hi || !xp_lo || !wq || !y || ((em_hi == nullptr) != (em_lo == nullptr)) || (((uintptr_t)y | (uintptr_t)lk_src) & 15)) {
         sat_set_error("sat_disc_conv: missing / misaligned operand");
         return 1;
     }
     SatDiscConvParams p{};
-    p.xp_hi = (const short*)xp_hi; p.xp_lo = (const short*)xp_lo; p.w_hi = (const short*)w_hi; p.w_lo = (const short*)w_lo;
+    p.xp_hi = (const short*)xp_hi; p.xp_lo = (const short*)xp_lo; p.wq = (const short*)wq;
     p.bias = bias; p.y = y; p.em_hi = (short*)em_hi; p.em_lo = (short*)em_lo;
     p.B = B; p.c8 = sat_cdiv(Cin, 8); p.Cout = Cout; p.em_c8 = sat_cdiv(Cout, 8);
     p.rows = rows; p.lead = lead; p.P = P; p.W = W; p.L = L;

@@ -626,16 +626,15 @@ class SatOps:
         return partial.sum()
 
     def disc_pack(self, w4, mode):
-        """w (Cout, Cin, kh, kw) -> (hi, lo) bf16 planes for sat_disc_conv (mode 0) / its data-gradient (mode 1)."""
+        """w (Cout, Cin, kh, kw) -> the packed bf16 hi + lo weights for sat_disc_conv (mode 0) / its data-gradient (mode 1)."""
         self._f32(w4)
         cout, cin, kh, kw = w4.shape
         n = self.lib.sat_disc_pack_size(cout, cin, kh, kw, mode)
         if n < 0:
             raise ValueError("disc_pack: unsupported kernel shape")
-        hi = torch.empty(n, dtype=torch.int16, device=w4.device)
-        lo = torch.empty(n, dtype=torch.int16, device=w4.device)
-        self._chk(self.lib.sat_disc_pack_weights(_ptr(w4), _ptr(hi), _ptr(lo), cout, cin, kh, kw, mode, self._stream(w4)))
-        return hi, lo
+        wq = torch.empty(n, dtype=torch.int16, device=w4.device)
+        self._chk(self.lib.sat_disc_pack_weights(_ptr(w4), _ptr(wq), cout, cin, kh, kw, mode, self._stream(w4)))
+        return wq
 
     def disc_conv(self, planes, wq, bias, b, cin, cout, frames, w, kh, kw, dil_t, slope, emit_slot=None, lk_src=None, lk_slope=1.0):
         """LeakyReLU_slope(conv2d + bias) on the pitched layout: planes (hi, lo) of the (b, cin) input, wq = disc_pack(...).
@@ -644,7 +643,7 @@ class SatOps:
         L = self.disc_geom(frames, w)[1]
         y = torch.empty(b, cout, L, dtype=torch.float32, device=planes[0].device)
         em = self._disc_plane_buf(b, cout, frames, w, y.device, emit_slot) if emit_slot is not None else None
-        self._chk(self.lib.sat_disc_conv(_ptr(planes[0]), _ptr(planes[1]), _ptr(wq[0]), _ptr(wq[1]), _ptr(bias), _ptr(y),
+        self._chk(self.lib.sat_disc_conv(_ptr(planes[0]), _ptr(planes[1]), _ptr(wq), _ptr(bias), _ptr(y),
                                          _ptr(em[0]) if em else None, _ptr(em[1]) if em else None, b, cin, cout, frames, w, kh, kw, dil_t,
                                          float(slope), _ptr(lk_src), float(lk_slope), self._stream(y)))
         return y, em

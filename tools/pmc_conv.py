@@ -1,5 +1,5 @@
 """Run ONE conv configuration a few times (for rocprofv3 --pmc runs).  usage: pmc_conv.py <kind> [C] [T]
-kind: conv7 | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | calib"""
+kind: conv7 | conv7q | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | disc9 | calib"""
 import os
 import sys
 
@@ -24,6 +24,20 @@ w1 = torch.randn(C, C, 1, device=dev) / C ** 0.5
 if kind == "conv7":
     pl = ops.pack_bf16x3(w7)
     fn = lambda: ops.conv1d_bf16x3(x, pl, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
+elif kind == "conv7q":      # conv1d_bf16x3_k7q.h (the shipped kernel: planes pre-pass + q-packed weights)
+    ops.k7_planes = True
+    ops.k7_planes_min_cin = 1
+    pl = ops.pack_bf16x3(w7, 0, 1, q=True)
+    fn = lambda: ops.conv1d_bf16x3(x, pl, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
+elif kind == "disc9":       # csrc/disc_conv.hip: the discriminator's 64 -> 64 (3 x 9) layer at the n_fft = 1024 scale of a 2 097 152-sample item
+    frames, wd = 8189, 513
+    L = ops.disc_geom(frames, wd)[1]
+    xd = torch.randn(1, 64, L, device=dev) * 0.5
+    w4 = torch.randn(64, 64, 3, 9, device=dev) * 0.05
+    _, xp = ops.disc_planes(xd, frames, wd, slot=0)
+    wq = ops.disc_pack(w4, 0)
+    b64 = torch.randn(64, device=dev)
+    fn = lambda: ops.disc_conv(xp, wq, b64, 1, 64, 64, frames, wd, 3, 9, 2, 0.2, emit_slot=1)
 elif kind == "conv7ns":
     pl = ops.pack_bf16x3(w7)
     fn = lambda: ops.conv1d_bf16x3(x, pl, C, 7, 1, 9, 27, bias=bias)

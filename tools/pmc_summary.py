@@ -7,12 +7,12 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else ""
+pats = sys.argv[2:] or [""]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if pat in k:
+        if any(p in k for p in pats):
             acc[k[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for f in glob.glob(os.path.join(root, "**", "*.db"), recursive=True):
     db = sqlite3.connect(f)
@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(root, "**", "*.db"), recursive=True):
     cols = [r[1] for r in db.execute(f"pragma table_info({view[0]})")]
     kcol = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c][0]
     for k, cn, v in db.execute(f"select {kcol}, counter_name, value from {view[0]}"):
-        if pat in k:
+        if any(p in k for p in pats):
             acc[k[:60]][cn].append(float(v))
 for k, d in acc.items():
     print(k)
