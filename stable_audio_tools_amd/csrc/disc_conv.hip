@@ -333,7 +333,6 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
     };
-    const bool mi1_on = co0 + 32 < p.Cout;                // Cout <= 32 in this tile: the second row of accumulators multiplies nothing
 
     // prologue: chunk 0 complete in stage 0
     set_chunk(0);
@@ -372,17 +371,7 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             SAT_SETPRIO(1);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                if (3 * ph + u < kw) {
-                    if (mi1_on) mfma_frags(fr[u]);
-                    else {
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][0], fr[u].xa[ni][0], acc[0][ni]);
-                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][0], fr[u].xa[ni][1], acc[0][ni]);
-                            acc[0][ni] = sat_mfma_32x32x16_bf16(fr[u].wa[0][1], fr[u].xa[ni][0], acc[0][ni]);
-                        }
-                    }
-                }
+                if (3 * ph + u < kw) mfma_frags(fr[u]);
             SAT_SETPRIO(0);
             SAT_SCHED_FENCE();
             SAT_RAW_BARRIER();
@@ -533,7 +522,10 @@ __global__ void __launch_bounds__(SAT_DW_NT) sat_disc_wgrad_kernel(SatDiscWgPara
     const int l31 = lane & 31, hi = lane >> 5;
     const int m_w = (wave & 1) * 32, n_w = ((wave >> 1) & 1) * 32;
     const bool first = wave < 4;                                     // tap group 0: MFMAs first; tap group 1: conversion first
-    const int m0 = blockIdx.x * SAT_DC_CO, n0 = blockIdx.y * SAT_DW_NI, split = blockIdx.z;
+    // grid = (m tiles, n tiles, splits): the (m, n) tiles of one split read the same dy / x positions -> same XCD (sat_xcd_tile)
+    int mn_tile, split;
+    sat_xcd_tile(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y, gridDim.z, &mn_tile, &split);
+    const int m0 = (mn_tile % (int)gridDim.x) * SAT_DC_CO, n0 = (mn_tile / (int)gridDim.x) * SAT_DW_NI;
     const int pad_t = (p.kh - 1) >> 1;
 
     f32x16 acc[K0];
@@ -733,8 +725,8 @@ static void sat_disc_wg_plan(int B, int M, int N, int L, SatDiscWgPlan* pl) {
     pl->nT = sat_cdiv(L, SAT_DW_TT);
     pl->nchunks = B * pl->nT;
     const int tiles = sat_cdiv(M, SAT_DC_CO) * sat_cdiv(N, SAT_DW_NI);
-    int want = sat_cdiv(512, tiles);               // one workgroup per CU (LDS), two rounds
-    if (want > pl->nchunks) want = pl->nchunks;
+    int want = 512 / tiles;                        // one workgroup per CU (LDS): at most two FULL rounds of the 256 CUs (a 513th
+    if (want > pl->nchunks) want = pl->nchunks;    // workgroup would be a third round on its own)
     if (want < 1) want = 1;
     pl->cps = sat_cdiv(pl->nchunks, want);
     pl->nsplit = sat_cdiv(pl->nchunks, pl->cps);
