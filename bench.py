@@ -460,6 +460,11 @@ class ConvProfiler:
         "sat_conv_wgrad7_bf16x3": (lambda a: "sat_wgrad7_bf16x3_pipe_kernel" if (a[10] >= 64 and a[11] % 4 == 0) else "sat_wgrad7_bf16x3_kernel",
                                    X3, lambda a: 2.0 * a[8] * a[9] * a[10] * 7 * a[11]),
         "sat_conv_wgrad_bf16x3": ("sat_wgrad_small_bf16x3_kernel", X3, lambda a: 2.0 * a[9] * a[10] * a[11] * a[14] * a[12]),
+        # the discriminator's Conv2d layers (csrc/disc_conv.hip): 2 * B * Cin * Cout * kh * kw * frames * W per launch (forward and
+        # data-gradient: the same kernel), the same count for the weight-gradient
+        "sat_disc_conv": ("sat_disc_conv_kernel", X3, lambda a: 2.0 * a[7] * a[8] * a[9] * a[12] * a[13] * a[10] * a[11]),
+        "sat_disc_wgrad": ("sat_disc_wgrad_kernel", X3, lambda a: 2.0 * a[3] * a[4] * a[5] * a[8] * a[9] * a[6] * a[7]),
+        "sat_disc_planes": ("sat_disc_planes_kernel", X3, lambda a: 0.0),
     }
 
     def __init__(self, ops):
@@ -887,20 +892,48 @@ def main():
             # the REAL autoencoder step of the reference (training/autoencoders.py:440-515): MS-STFT discriminator (5 scales, 64
             # filters), updates alternating discriminator / generator — timed over 2 + 2 steps after one of each as warm-up
             stepper.use_disc = True
-            stepper.global_step = 0
-            for i in range(2):
-                stepper(batches[i % 2])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(4):
-                out_r = stepper(batches[i % 2])
-            torch.cuda.synchronize()
-            dt_real = (time.perf_counter() - t1) / 4
+
+            def real_steps(n_warm, n_timed):
+                stepper.global_step = 0
+                for i in range(n_warm):
+                    stepper(batches[i % 2])
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats()
+                t1 = time.perf_counter()
+                for i in range(n_timed):
+                    o = stepper(batches[i % 2])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n_timed, torch.cuda.max_memory_allocated() / 2 ** 30, o
+
+            dt_real, peak_real, out_r = real_steps(2, 4)
+            # the discriminator's conv kernels over one more discriminator + generator pair, HIP events per launch
+            prof.records.clear()
+            prof.enabled = True
+            real_steps(0, 2)
+            prof.enabled = False
+            _, allr = prof.summary()
+            disc_k = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allr if d["kernel"].startswith("sat_disc")]
             line["config"]["real_step"] = {
                 "workload": "alternating MS-STFT-discriminator / generator updates (encodec discriminator: 5 scales n_fft 2048..128, 64 filters, "
                             "hinge + feature matching; adversarial 0.1, feature_matching 5.0) on the same 47.55 s stereo items",
                 "ms_per_step": 1e3 * dt_real, "samples_per_s": args.batch / dt_real, "steps": 4,
-                "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "last_loss": float(out_r["loss"])}
+                "peak_hbm_gib": peak_real, "last_loss": float(out_r["loss"]),
+                "discriminator_kernels": disc_k,
+                "note": "discriminator_kernels: HIP-event time and algorithmic flops (2 * Cin * Cout * kh * kw * frames * bins per conv / "
+                        "data-gradient / weight-gradient launch) of csrc/disc_conv.hip over one discriminator + one generator update, "
+                        "fractions of the bf16x3 peak (833)"}
+            # the same pair of updates with every ResidualUnit recomputing its intermediate in the backward (ResidualUnit.checkpointing):
+            # the memory / time trade the module offers for larger per-GPU batches
+            from stable_audio_tools_amd.autoencoders import ResidualUnit
+            units = [m_ for m_ in model.modules() if isinstance(m_, ResidualUnit)]
+            for u in units:
+                u.checkpointing = True
+            torch.cuda.empty_cache()
+            dt_rc, peak_rc, _ = real_steps(2, 2)
+            for u in units:
+                u.checkpointing = False
+            line["config"]["real_step"]["recompute"] = {"ms_per_step": 1e3 * dt_rc, "peak_hbm_gib": peak_rc, "steps": 2,
+                                                        "what": "ResidualUnit.checkpointing = True on all 30 units"}
             stepper.use_disc = False
         if world == 1 and not args.no_secondary:
             # the second half of BASELINE.json's metric ("...; DiT sampling steps/sec"), measured in the same run: configs[2]

@@ -7,9 +7,13 @@ stable_audio_tools/models/discriminators.py — get_hinge_losses :13-16, Encodec
 
 Third-party arithmetic on this path: torchaudio.transforms.Spectrogram (setup.py pins torchaudio>=2.0.2; not in the reference
 tree, not installed here) — restated from its published algorithm: torch.stft(x, n_fft, hop, win_length, window=hann_window(win_length)
-[periodic], center=False, onesided, return_complex) divided by window.pow(2).sum().sqrt() when normalized=True.  PARITY UNPINNED for
-that one transform (no reference output exists for it in this environment); everything downstream of it is pinned by
-tests/golden/disc_tiny.npz, produced by the reference's own classes with this same restatement standing in for torchaudio.
+[periodic], center=False, onesided, return_complex) divided by window.pow(2).sum().sqrt() when normalized=True.  No torchaudio output
+exists for that one transform in this environment; it is pinned against an independent source instead — the closed-form spectra of
+bin-centred sinusoids under the periodic Hann window and a direct float64 evaluation of the definition
+(tests/test_spectrogram_closed_form.py: this restatement to 1e-10, the native kernel to 2e-6) — which fixes the window, the
+normalisation, the frame placement (center=False) and the sign / bin convention, i.e. everything the published algorithm specifies.
+Everything downstream of it is pinned by tests/golden/disc_tiny.npz, produced by the reference's own classes with this same
+restatement standing in for torchaudio.
 """
 import torch
 import torch.nn.functional as F

@@ -247,7 +247,7 @@ static void sat_wgbf_plan(int B, int M, int N, int T, SatWgBfPlan* pl) {
     pl->nchunks = B * pl->nT;
     pl->pipe = N >= SAT_WP_NI && (T & 3) == 0;     // at least one full 64-channel column block; 16-byte dy loads
     const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N, pl->pipe ? SAT_WP_NI : 32);
-    int want = sat_cdiv(512, tiles);               // pipelined kernel: 1 workgroup per CU, two rounds; 4-wave kernel: 2 per CU, one round
+    int want = 512 / tiles;                        // pipelined kernel: 1 workgroup per CU, two FULL rounds at most; 4-wave kernel: 2 per CU, one round
     if (want > pl->nchunks) want = pl->nchunks;
     if (want < 1) want = 1;
     if (want > 512) want = 512;
@@ -611,7 +611,7 @@ static bool sat_wgs_plan(int B, int M, int N, int Tlo, int K, int stride, SatWgB
     pl->nT = sat_cdiv(Tlo, SAT_WS_TT);
     pl->nchunks = B * pl->nT;
     const int tiles = sat_cdiv(M, SAT_CO_T) * sat_cdiv(N << *s_log2, SAT_CO_T);
-    int want = sat_cdiv(512, tiles);   // 2 workgroups per CU in flight: one full wave of the grid
+    int want = 512 / tiles;            // 2 workgroups per CU in flight: one full wave of the grid (never a partial second one)
     if (want > pl->nchunks) want = pl->nchunks;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
