@@ -327,6 +327,10 @@ int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int
                  float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream);
 /* The same with (c0x, c0v, c1x, c1v) read from device memory (coef[4], fp32): the launch can be frozen in a HIP graph and replayed
  * with new sampler coefficients (inference/sampling.py:254-307 changes them every step). */
+/* Cache prefetch: reads n <= 16 read-only device buffers (ptrs / bytes: host arrays; 16-byte aligned) and discards them — launched on a
+ * side stream one transformer layer ahead, it puts the next layer's weights into the memory-side cache before the projection GEMMs ask
+ * for them (transformer.ContinuousTransformer, inference).  No reference counterpart: a scheduling hint, results are unaffected. */
+int sat_prefetch(const void* const* ptrs, const long long* bytes, int n, void* stream);
 int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
                      float phi, const float* coef, int dtype, void* stream);
 

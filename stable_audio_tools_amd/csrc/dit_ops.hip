@@ -598,3 +598,56 @@ extern "C" int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void*
     else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_cfg_step_dev");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Cache prefetch of read-only buffers (the NEXT transformer layer's weights).  A sampler step streams ~2 GB of bf16 weights through a
+// 256-MB memory-side cache and 8 x 4 MB of L2: inside the sampler every projection GEMM finds its B operand in HBM, and with
+// ~1.5 K-steps of LDS-DMA lookahead the HBM latency sits in its K loop (QKV at M = 2050: 77 us in the sampler, 46 us with warm
+// weights — profiles/).  This kernel just READS up to 16 buffers (16 bytes per lane, 8 loads in flight per lane, 64 workgroups — a
+// few CUs' worth of waves next to the GEMMs' one LDS-bound workgroup per CU) on a side stream one layer ahead, so that the lines are in
+// the memory-side cache when the GEMM asks for them.  Nothing is written (a never-true store keeps the loads alive).
+// MEASURED (round 3): the sampler got SLOWER with it (105.6 vs 110.9 steps/s) — like the in-kernel L2 touch of gemm.hip — so
+// transformer.ContinuousTransformer leaves it off (SAT_WEIGHT_PREFETCH=1 switches it on for A/B runs): the in-situ slowdown of the
+// projections is not their weights' HBM latency.
+#define SAT_PF_MAX 16
+struct SatPrefetchParams {
+    const void* ptr[SAT_PF_MAX];
+    long long n16[SAT_PF_MAX];       // 16-byte units
+    int n;
+    unsigned* sink;                  // any device word (only written if the xor of everything read equals an impossible pattern)
+};
+__global__ void __launch_bounds__(256) sat_prefetch_kernel(SatPrefetchParams p) {
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    const long long stride = (long long)gridDim.x * 256;
+    for (int i = 0; i < p.n; ++i) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.ptr[i]);
+        const long long n = p.n16[i];
+        long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+        for (; j + 7 * stride < n; j += 8 * stride) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[j + u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+        for (; j < n; j += stride) acc ^= src[j];
+    }
+    const unsigned x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (x == 0x9e3779b9u && p.sink && threadIdx.x == 257) p.sink[0] = x;      // (never true: threadIdx.x < 256)
+}
+// ptrs / bytes: HOST arrays of n <= 16 device buffers (16-byte aligned; the tail bytes % 16 are skipped)
+extern "C" int sat_prefetch(const void* const* ptrs, const long long* bytes, int n, void* stream) {
+    if (n < 0 || n > SAT_PF_MAX || (n > 0 && (!ptrs || !bytes))) { sat_set_error("sat_prefetch: 0 <= n <= 16 buffers"); return 1; }
+    if (n == 0) return 0;
+    SatPrefetchParams p{};
+    for (int i = 0; i < n; ++i) {
+        if (!ptrs[i] || bytes[i] < 0 || ((uintptr_t)ptrs[i] & 15)) { sat_set_error("sat_prefetch: null / misaligned buffer"); return 1; }
+        p.ptr[i] = ptrs[i];
+        p.n16[i] = bytes[i] >> 4;
+    }
+    p.n = n;
+    p.sink = nullptr;
+    SAT_LAUNCH(sat_prefetch_kernel, dim3(64), dim3(256), stream, p);
+    return sat_check_launch("sat_prefetch");
+}

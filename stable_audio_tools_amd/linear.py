@@ -240,6 +240,16 @@ class Linear(nn.Module):
         w = self.weight
         return self._cache.get(w, "bf16", lambda: _pad_rows8(w.detach() if w.dtype == torch.bfloat16 else _ops().cast_bf16(w.detach())))
 
+    def prefetch_tensor(self):
+        """The tensor the forward GEMM reads as its B operand right now (cached low-precision copy or the bf16 parameter itself), or
+        None before the first call created it — what ContinuousTransformer's weight prefetch touches one layer ahead."""
+        items = self._cache.items
+        if self.fp8 and "fp8" in items:
+            return items["fp8"][1][0]
+        if "bf16" in items:
+            return items["bf16"][1]
+        return self.weight.detach() if self.weight.dtype == torch.bfloat16 else None
+
     def forward(self, x, res=None, mode=None):
         """mode None: x W^T + b [+ res];  'swiglu': value * silu(gate) over W rows = [value | gate]."""
         if mode is None:

@@ -552,6 +552,16 @@ class SatOps:
         self._chk(self.lib.sat_rows_pack_bwd(_ptr(dbuf), _ptr(dx), b, c, t, w, kh, dil_t, pad_t, pad_w, pitch, lead, self._stream(dbuf)))
         return dx
 
+    def prefetch(self, tensors, stream):
+        """Read (and discard) up to 16 device tensors on `stream` (a torch.cuda.Stream): cache prefetch of the next layer's weights."""
+        ts = [t for t in tensors if t is not None and t.numel() > 0][:16]
+        if not ts:
+            return
+        n = len(ts)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        sizes = (ctypes.c_longlong * n)(*[t.numel() * t.element_size() for t in ts])
+        self._chk(self.lib.sat_prefetch(ptrs, sizes, n, ctypes.c_void_p(stream.cuda_stream) if stream is not None else None))
+
     # ---- the discriminator's Conv2d layers on the pitched-rows layout (csrc/disc_conv.hip; discriminators._DiscConvFn) ----
     def disc_geom(self, frames, w):
         """(P, L, lead, rows) of the pitched sequence / planes of a (.., frames, w) activation (sat_disc_geom)."""
