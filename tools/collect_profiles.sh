@@ -5,6 +5,7 @@
 #   gpurun_out/final/dit_{sample,train}_stats.csv
 #   gpurun_out/final/pmc_{FETCH,WRITE}_SIZE.txt + pmc_traffic.json   per-kernel HBM counters of the same bench command (separate passes)
 #   gpurun_out/final/bench_*.json         the bench lines themselves (with cpu_baseline)
+#   gpurun_out/final/{gemm,k7,ru,disc,qkv}_bench.jsonl, pmc_k7_summary.txt   the kernel micro-benchmarks and SQ counters
 set -u
 R=$(pwd)
 OUT=$R/gpurun_out/final
@@ -31,4 +32,7 @@ python bench.py --workload dit_train --no-cpu-baseline > $OUT/bench_dit_train.js
 SAT_TILES=0,4 SAT_SPLITS=2,3 python tools/gemm_bench.py 2050 4100 12290 > $OUT/gemm_bench.jsonl 2> /dev/null
 python tools/k7_bench.py > $OUT/k7_bench.jsonl 2> /dev/null
 python tools/ru_bench.py > $OUT/ru_bench.jsonl 2> /dev/null
+python tools/disc_bench.py > $OUT/disc_bench.jsonl 2> /dev/null
+python tools/qkv_bench.py > $OUT/qkv_bench.jsonl 2> /dev/null
+bash tools/pmc_k7.sh > /dev/null 2>&1; cp gpurun_out/pmc_k7/summary.txt $OUT/pmc_k7_summary.txt
 tail -c 3000 $OUT/bench_vae_train.json
