@@ -70,6 +70,13 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     // MFMA phase (~1 us) to arrive before it is converted, and 32 registers fewer are live (7 accumulator tiles = 112)
     float4 dyv[1][NDY];
     float xv[1][NXP][2];
+    // bias gradient (sum over (b, t) of the dy rows) by the workgroups of the first column block: dy streams through them anyway —
+    // every stage is converted exactly once (write_lds), so each thread adds its four columns there and the 16 lanes of a row are
+    // reduced once at the end (no separate sat_rowsum pass over dy: 1 GB per C = 128 unit)
+    const bool want_rs = p.rowsum != nullptr && n0 == 0;            // block-uniform
+    float rs[NDY];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) rs[u] = 0.0f;
     auto issue_loads = [&](int c) {
         constexpr int st = 0;
         const int ch = c_begin + c;
@@ -110,6 +117,7 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
             const int row = (tid >> 4) + u * 32, c4 = (tid & 15) * 4;
+            if (want_rs) rs[u] += (dyv[st][u].x + dyv[st][u].y) + (dyv[st][u].z + dyv[st][u].w);
             uint32_t h0, h1, l0, l1;
             sat_split2_pk(dyv[st][u].x, dyv[st][u].y, &h0, &l0);
             sat_split2_pk(dyv[st][u].z, dyv[st][u].w, &h1, &l1);
@@ -217,6 +225,16 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
         mfma_phase(I0{});
     }
 
+    if (want_rs) {
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            float v = rs[u];
+#pragma unroll
+            for (int m = 1; m <= 8; m <<= 1) v += __shfl_xor(v, m);
+            const int row = m0 + (tid >> 4) + u * 32;
+            if ((tid & 15) == 0 && row < p.M) p.rowsum[(size_t)row * p.nsplit + split] = v;
+        }
+    }
     if (m0 + m_w < p.M) {
         float* ob = p.out + (size_t)split * p.so_split;
         const int n = n0 + n_w + l31;

@@ -13,6 +13,7 @@
 // register selection + v_alignbit (dil is a template parameter: 1, 3, 9).
 #include "conv_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define SAT_WB_TT 64                 // time steps per LDS stage (4 MFMA k-steps)
 #define SAT_WB_LOROW (SAT_WB_TT + 8) // 144 B rows: conflict-free b128
@@ -262,7 +263,9 @@ extern "C" int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T) {
 extern "C" int sat_conv_wgrad7_bf16x3_fuses_rowsum(int B, int M, int N, int T) {
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
-    return pl.pipe ? 0 : 1;
+    // both kernels produce dy_rowsum (round 3: the pipelined one too; SAT_WG_ROWSUM=0: A/B switch back to a separate sat_rowsum pass)
+    if (pl.pipe) { const char* e = getenv("SAT_WG_ROWSUM"); if (e && atoi(e) == 0) return 0; }
+    return 1;
 }
 // dW[m][n][k] for a K = 7, stride-1 conv with dilation in {1, 3, 9}: dy (B, M, T), x (B, N, T) pre-activation,
 // alpha/beta = SnakeBeta log-params of the conv input (or NULL).  Writes nsplit slabs (element (m,n,k) at
@@ -275,7 +278,6 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
     if ((alpha == nullptr) != (beta == nullptr)) { sat_set_error("sat_conv_wgrad7_bf16x3: alpha/beta must both be given"); return 1; }
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
-    if (dy_rowsum && pl.pipe) { sat_set_error("sat_conv_wgrad7_bf16x3: dy_rowsum is only produced by the 4-wave kernel (N < 64 or T % 4 != 0); use sat_rowsum"); return 1; }
     SatWgBfParams p{dy, x, alpha, beta, partial, (long long)M * N * 7, so_m, so_n, so_k, B, M, N, T, pad, pl.cps, pl.nchunks, pl.nT,
                     dy_rowsum, pl.nsplit};
     if (pl.pipe) {

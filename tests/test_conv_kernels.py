@@ -40,7 +40,8 @@ def _compare(outs, refs, inputs, gen, tol=TOL):
 S1_CASES = [(1, 8, 8, 300, 7, 1), (1, 16, 70, 280, 7, 3), (2, 24, 8, 200, 7, 9), (1, 32, 130, 150, 7, 9), (1, 40, 6, 520, 7, 3),
             (1, 6, 40, 150, 7, 9), (1, 32, 8, 140, 1, 1), (1, 64, 130, 200, 1, 1), (1, 96, 8, 130, 1, 1), (2, 160, 20, 100, 1, 1),
             (1, 70, 20, 150, 1, 1), (1, 12, 4, 100, 3, 1), (1, 9, 5, 77, 2, 1), (1, 20, 5, 90, 5, 2),
-            (1, 64, 40, 200, 7, 3), (1, 72, 130, 150, 7, 9), (2, 128, 8, 140, 7, 1)]   # >= 64 in-channels: the pipelined wgrad kernel
+            (1, 64, 40, 200, 7, 3), (1, 72, 130, 150, 7, 9), (2, 128, 8, 140, 7, 1),
+            (1, 64, 130, 152, 7, 1)]   # >= 64 in-channels: the pipelined wgrad kernel (incl. its fused bias-gradient row sums over two co tiles)
 DOWN_CASES = [(1, 8, 16, 256, 2), (2, 12, 20, 333, 4), (1, 6, 130, 1100, 8), (1, 40, 6, 300, 2), (1, 8, 8, 520, 4)]
 UP_CASES = [(1, 16, 8, 40, 2), (2, 12, 20, 33, 4), (1, 6, 130, 70, 8), (1, 70, 6, 150, 2), (1, 48, 8, 131, 4)]
 
