@@ -122,16 +122,18 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                 const int d = pass * 8 + (lane >> 3), tq = (lane & 7) * 4;
                 const int m = mrow0 + tq;                 // 4 consecutive rows m .. m+3 (may straddle a batch item)
                 short o[4];
+                float of[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = sat_f32_to_bf16(ep[d * 33 + tq + e]);
+                for (int e = 0; e < 4; ++e) of[e] = ep[d * 33 + tq + e];
+                const uint32_t q01 = sat_cvt2_pk(of[0], of[1]), q23 = sat_cvt2_pk(of[2], of[3]);     // packed RNE converts
+                o[0] = (short)(q01 & 0xffffu); o[1] = (short)(q01 >> 16); o[2] = (short)(q23 & 0xffffu); o[3] = (short)(q23 >> 16);
                 const int b = m / p.ntok, t = m - b * p.ntok;
                 short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
                 if (m + 3 < p.M && t + 3 < p.ntok) {
                     // 4 tokens of one batch item: the widest aligned stores their phase allows (ntok is odd for the DiT —
                     // 1 + 1024 — so every batch item but the first starts its rows off the 8-byte grid)
-                    const uint32_t p01 = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
-                    const uint32_t p12 = (uint32_t)(uint16_t)o[1] | ((uint32_t)(uint16_t)o[2] << 16);
-                    const uint32_t p23 = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+                    const uint32_t p01 = q01, p23 = q23;
+                    const uint32_t p12 = (q01 >> 16) | (q23 << 16);
                     if ((t & 3) == 0) {
                         *(u32x2*)dst = u32x2{p01, p23};
                     } else if ((t & 1) == 0) {
