@@ -109,10 +109,11 @@ int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, i
  * P, L = frames * P and the geometry of the bf16 hi / lo planes [B][ceil(C/8)][rows][8] (`lead` zero rows before position 0) that the
  * matrix kernels read.  The frame taps are virtual channels read from the same buffer dil_t * P positions away: nothing is copied.
  *   sat_disc_planes   src ((B, C, frames, W), or pitched (B, C, L) when pitched != 0), optionally times LeakyReLU'(out) (out pitched,
- *                     slope), pad positions zeroed -> dst (pitched fp32, or NULL) and hi / lo planes (or NULL); fm_ref / fm_coef (or
- *                     NULL): + fm_coef[0] * sign(out - fm_ref) before the LeakyReLU' factor (the L1 feature-matching term of `out`,
- *                     models/discriminators.py:52-56; fm_coef a DEVICE scalar).  sat_disc_l1_sum: sat_disc_l1_blocks() partial
- *                     sums of |a - b| (the feature-matching distance on pitched buffers).
+ *                     slope), pad positions zeroed -> dst (pitched fp32, or NULL) and hi / lo planes (or NULL); fm_sign / fm_coef (or
+ *                     NULL): + fm_coef[0] * fm_sign before the LeakyReLU' factor (the L1 feature-matching term of `out`,
+ *                     models/discriminators.py:52-56; fm_sign = sign(out - other signal's feature map) as int8, fm_coef a DEVICE
+ *                     scalar).  sat_disc_l1_sum: sat_disc_l1_blocks() partial sums of |a - b| (the feature-matching distance on
+ *                     pitched buffers) and, optionally, sign(a - b) as int8.
  *   sat_disc_pack_weights  w (Cout, Cin, kh, kw) -> wq, the packed bf16 hi + lo weights (sat_disc_pack_size elements); mode 0: the conv,
  *                     mode 1: its data-gradient (a conv of Cout channels -> Cin channels)
  *   sat_disc_conv     y = LeakyReLU_slope(conv2d + bias) (slope 1: none), pitched fp32 (B, Cout, L), pads zero; em_hi / em_lo (or
@@ -122,10 +123,10 @@ int sat_rows_unpack_bwd(const float* dout, const float* out, float* dy, int B, i
  *   sat_disc_wgrad    dW slabs [nsplit][kw][ceil64(M)][ceil64(kh * Cin)] (virtual channel tap_t * Cin + c) from dy = dL/d(pre-
  *                     activation) (B, M, L) and the layer input x (B, Cin, L), both pitched; sum with sat_reduce_splits.  kw 9 or 3. */
 int sat_disc_geom(int frames, int W, int* P, int* L, int* lead, int* rows);
-int sat_disc_planes(const float* src, const float* out, const float* fm_ref, const float* fm_coef, float* dst, void* hi, void* lo, int B,
+int sat_disc_planes(const float* src, const float* out, const signed char* fm_sign, const float* fm_coef, float* dst, void* hi, void* lo, int B,
                     int C, int frames, int W, int pitched, float slope, void* stream);
 int sat_disc_l1_blocks(void);
-int sat_disc_l1_sum(const float* a, const float* b, float* partial, long long n, void* stream);
+int sat_disc_l1_sum(const float* a, const float* b, float* partial, signed char* sign, long long n, void* stream);
 long long sat_disc_pack_size(int Cout, int Cin, int kh, int kw, int mode);
 int sat_disc_pack_weights(const float* w, short* wq, int Cout, int Cin, int kh, int kw, int mode, void* stream);
 int sat_disc_conv(const void* xp_hi, const void* xp_lo, const void* wq, const float* bias, float* y, void* em_hi,

@@ -34,7 +34,7 @@ SIGNATURES = {
     "sat_disc_geom": (_I, [_I, _I, _P, _P, _P, _P]),
     "sat_disc_planes": (_I, [_P] * 7 + [_I] * 5 + [_F, _P]),
     "sat_disc_l1_blocks": (_I, []),
-    "sat_disc_l1_sum": (_I, [_P, _P, _P, _L, _P]),
+    "sat_disc_l1_sum": (_I, [_P, _P, _P, _P, _L, _P]),
     "sat_disc_pack_size": (_L, [_I] * 5),
     "sat_disc_pack_weights": (_I, [_P] * 2 + [_I] * 5 + [_P]),
     "sat_disc_conv": (_I, [_P] * 7 + [_I] * 8 + [_F, _P, _F, _P]),

@@ -111,12 +111,13 @@ extern "C" int sat_disc_pack_weights(const float* w, short* wq, int Cout, int Ci
 //   src: (B, C, frames, W) (pitched == 0) or the pitched (B, C, L); `out` (pitched, or null): the values are multiplied by
 //   LeakyReLU'(out) = out > 0 ? 1 : slope (the gradient w.r.t. a layer's pre-activation from the gradient w.r.t. its output);
 //   pad positions are written as zeros.  dst (pitched fp32, or null) and hi / lo (planes, or null) receive the result.
-//   fm_ref / fm_coef (with `out`): the L1 feature-matching term of this layer's output rides along — the gradient w.r.t. the output
-//   is src + fm_coef[0] * sign(out - fm_ref) (fm_coef: a device scalar, dL/d(sum |out - fm_ref|)) before the LeakyReLU' factor.
+//   fm_sign / fm_coef (with `out`): the L1 feature-matching term of this layer's output rides along — the gradient w.r.t. the output
+//   is src + fm_coef[0] * fm_sign (fm_sign = sign(out - ref) as int8, written by sat_disc_l1_sum in the forward pass — the other
+//   signal's feature map itself need not stay alive; fm_coef: a device scalar, dL/d(sum |out - ref|)) before the LeakyReLU' factor.
 struct SatDiscPlanesParams {
     const float* src;
     const float* out;
-    const float* fm_ref;
+    const signed char* fm_sign;
     const float* fm_coef;
     float* dst;
     short* hi;
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
     if (t >= p.L) return;
     const int r = t / p.P, f = t - r * p.P - 4;
     const bool valid = (unsigned)f < (unsigned)p.W;
-    const float fmc = p.fm_ref ? p.fm_coef[0] : 0.0f;
+    const float fmc = p.fm_sign ? p.fm_coef[0] : 0.0f;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -141,10 +142,7 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
             o = p.pitched ? p.src[ip] : p.src[(((size_t)b * p.C + ch) * p.frames + r) * p.W + f];
             if (p.out) {
                 const float ov = p.out[ip];
-                if (p.fm_ref) {
-                    const float d = ov - p.fm_ref[ip];
-                    o += d > 0.0f ? fmc : (d < 0.0f ? -fmc : 0.0f);
-                }
+                if (p.fm_sign) o += fmc * (float)p.fm_sign[ip];
                 o *= (ov > 0.0f ? 1.0f : p.slope);
             }
         }
@@ -160,26 +158,37 @@ __global__ void __launch_bounds__(256) sat_disc_planes_kernel(SatDiscPlanesParam
         *reinterpret_cast<u32x4*>(p.lo + o) = u32x4{l[0], l[1], l[2], l[3]};
     }
 }
-extern "C" int sat_disc_planes(const float* src, const float* out, const float* fm_ref, const float* fm_coef, float* dst, void* hi, void* lo,
+extern "C" int sat_disc_planes(const float* src, const float* out, const signed char* fm_sign, const float* fm_coef, float* dst, void* hi, void* lo,
                                int B, int C, int frames, int W, int pitched, float slope, void* stream) {
     int P, L, lead, rows;
     if (B <= 0 || C <= 0 || sat_disc_geom(frames, W, &P, &L, &lead, &rows)) { sat_set_error("sat_disc_planes: bad shape"); return 1; }
     if (!src || (!dst && !hi) || ((hi == nullptr) != (lo == nullptr))) { sat_set_error("sat_disc_planes: missing operand"); return 1; }
-    if (fm_ref && (!out || !fm_coef || !pitched)) { sat_set_error("sat_disc_planes: the feature-matching term needs out, fm_coef and a pitched src"); return 1; }
-    SatDiscPlanesParams p{src, out, fm_ref, fm_coef, dst, (short*)hi, (short*)lo, B, C, sat_cdiv(C, 8), frames, W, P, L, lead, rows, pitched, slope};
+    if (fm_sign && (!out || !fm_coef || !pitched)) { sat_set_error("sat_disc_planes: the feature-matching term needs out, fm_coef and a pitched src"); return 1; }
+    SatDiscPlanesParams p{src, out, fm_sign, fm_coef, dst, (short*)hi, (short*)lo, B, C, sat_cdiv(C, 8), frames, W, P, L, lead, rows, pitched, slope};
     SAT_LAUNCH(sat_disc_planes_kernel, dim3(sat_cdiv(L, 256), p.c8, B), dim3(256), stream, p);
     return sat_check_launch("sat_disc_planes");
 }
 
 // sum |a - b| over n floats (n % 4 == 0, 16-byte aligned): partial[block], 1024 blocks of grid-stride float4 loads — the L1 feature-
-// matching distance of two feature maps in the pitched layout (pad positions are zero in both)
-struct SatDiscL1Params { const float* a; const float* b; float* partial; long long n4; };
+// matching distance of two feature maps in the pitched layout (pad positions are zero in both); sign (or null): sign(a - b) as int8,
+// all the backward needs of b (sat_disc_planes fm_sign)
+struct SatDiscL1Params { const float* a; const float* b; float* partial; signed char* sign; long long n4; };
 __global__ void __launch_bounds__(256) sat_disc_l1_kernel(SatDiscL1Params p) {
     __shared__ float red[4];
     float s = 0.0f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (long long)gridDim.x * 256) {
         const f32x4 x = reinterpret_cast<const f32x4*>(p.a)[i], y = reinterpret_cast<const f32x4*>(p.b)[i];
         s += (fabsf(x[0] - y[0]) + fabsf(x[1] - y[1])) + (fabsf(x[2] - y[2]) + fabsf(x[3] - y[3]));
+        if (p.sign) {                                      // sign(a - b) per element, four int8 per store
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = x[e] - y[e];
+                const uint32_t sg = d > 0.0f ? 0x01u : (d < 0.0f ? 0xffu : 0x00u);
+                w |= sg << (8 * e);
+            }
+            reinterpret_cast<uint32_t*>(p.sign)[i] = w;
+        }
     }
     s = sat_wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -187,9 +196,9 @@ __global__ void __launch_bounds__(256) sat_disc_l1_kernel(SatDiscL1Params p) {
     if (threadIdx.x == 0) p.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 extern "C" int sat_disc_l1_blocks(void) { return 1024; }
-extern "C" int sat_disc_l1_sum(const float* a, const float* b, float* partial, long long n, void* stream) {
-    if (!a || !b || !partial || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b) & 15)) { sat_set_error("sat_disc_l1_sum: n % 4 == 0, 16-byte aligned operands"); return 1; }
-    SatDiscL1Params p{a, b, partial, n >> 2};
+extern "C" int sat_disc_l1_sum(const float* a, const float* b, float* partial, signed char* sign, long long n, void* stream) {
+    if (!a || !b || !partial || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b) & 15) || ((uintptr_t)sign & 3)) { sat_set_error("sat_disc_l1_sum: n % 4 == 0, 16-byte aligned operands"); return 1; }
+    SatDiscL1Params p{a, b, partial, sign, n >> 2};
     SAT_LAUNCH(sat_disc_l1_kernel, dim3(1024), dim3(256), stream, p);
     return sat_check_launch("sat_disc_l1_sum");
 }

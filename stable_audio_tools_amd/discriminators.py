@@ -185,15 +185,19 @@ class _DiscConvFn(torch.autograd.Function):
         if fm_ref is not None and (dpre_in or slope == 1.0):
             raise ValueError("_DiscConvFn: the feature-matching term needs an activated layer with the ordinary gradient contract")
         ctx.meta = (ops, frames, wd, dil_t, slope, bias is not None, fold_slope, dpre_in)
-        ctx.save_for_backward(h, w4, y if (slope != 1.0 and not dpre_in) else None, fm_ref)
+        fm_sum = fm_sign = None
+        if fm_ref is not None:
+            # the distance now, and sign(y - ref) as int8 for the backward: the other signal's feature map need not stay alive
+            fm_sum, fm_sign = ops.disc_l1_sum(y, fm_ref.contiguous(), want_sign=True)
+        ctx.save_for_backward(h, w4, y if (slope != 1.0 and not dpre_in) else None, fm_sign)
         if fm_ref is None:
             return y
-        return y, ops.disc_l1_sum(y, fm_ref.contiguous())
+        return y, fm_sum
 
     @staticmethod
     def backward(ctx, g, g_fm=None):
         ops, frames, wd, dil_t, slope, has_bias, fold_slope, dpre_in = ctx.meta
-        h, w4, y, fm_ref = ctx.saved_tensors
+        h, w4, y, fm_sign = ctx.saved_tensors
         cout, cin, kh, kw = w4.shape
         b = h.shape[0]
         need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -204,9 +208,9 @@ class _DiscConvFn(torch.autograd.Function):
             dpre = g
             dpl, slot = ops.disc_take(dpre, cout, frames, wd) if need_h else (None, 0)
         else:
-            fm = fm_ref is not None and g_fm is not None
+            fm = fm_sign is not None and g_fm is not None
             dpre, dpl = ops.disc_planes(g, frames, wd, out=y, slope=slope, want_dst=True, want_planes=need_h, slot=0,
-                                        fm_ref=fm_ref if fm else None, fm_coef=g_fm.contiguous() if fm else None)
+                                        fm_sign=fm_sign if fm else None, fm_coef=g_fm.contiguous() if fm else None)
             slot = 0
         dw = ops.disc_wgrad(dpre, h, frames, wd, kh, kw, dil_t) if need_w else None
         dbias = ops.rowsum(dpre) if (has_bias and ctx.needs_input_grad[2]) else None
@@ -334,10 +338,11 @@ class DiscriminatorSTFT(nn.Module):
     def pitched_ok(self):
         return isinstance(self.activation, torch.nn.LeakyReLU) and all(l.conv.pitched_ok() for l in list(self.convs) + [self.conv_post])
 
-    def forward_pitched(self, x, fm_refs=None, exclusive=False):
+    def forward_pitched(self, x, fm_refs=None, exclusive=False, release_refs=False):
         """(logits, feature maps, (frames, freq bins), fm sums) with every tensor in the pitched layout (B, C, frames * P), pad positions
         zero.  fm_refs: the other signal's feature maps (no gradient) -> fm sums[i] = sum |fmap[i] - fm_refs[i]|, differentiable w.r.t.
-        this signal's path (else None).  exclusive: the caller consumes ONLY the logits — the layers chain their gradients
+        this signal's path (else None); release_refs: set fm_refs[i] = None as layer i has consumed it (the layers keep sign(y - ref) as
+        int8 for the backward, not the reference map).  exclusive: the caller consumes ONLY the logits — the layers chain their gradients
         (_DiscConvFn fold_slope / dpre_in); gradients w.r.t. the returned feature maps would be wrong, so they are detached."""
         if fm_refs is not None and exclusive:
             raise ValueError("forward_pitched: feature-matching terms need the feature maps' ordinary gradients")
@@ -349,6 +354,8 @@ class DiscriminatorSTFT(nn.Module):
         for i, layer in enumerate(self.convs):
             out = layer.conv.forward_pitched(h, frames, wd, slope, fm_ref=None if fm_refs is None else fm_refs[i],
                                              fold_slope=slope if (exclusive and i > 0) else None, dpre_in=exclusive)
+            if fm_refs is not None and release_refs:
+                fm_refs[i] = None                 # consumed (the layer kept sign(y - ref) only): the caller's list drops its reference
             if fm_refs is not None:
                 h, s_i = out
                 sums.append(s_i)
@@ -432,11 +439,16 @@ class EncodecDiscriminator(nn.Module):
             #   gradients ride in the fake path's layers (fm_refs); otherwise the distances are torch ops on the pitched buffers.
             logit_t, feat_t, (frames, wd), _ = d.forward_pitched(reals, exclusive=not need_fm)
             fused = need_fm and not any(f.requires_grad for f in feat_t)
-            logit_f, feat_f, _, sums = d.forward_pitched(fakes, fm_refs=feat_t if fused else None, exclusive=not need_fm)
+            if fused:
+                # what the distances need of the real maps besides the maps themselves: element counts (and mean |x| when normalising);
+                # the maps are released one by one as the fake path's layers consume them (they keep sign(y - x) as int8)
+                counts = [f.shape[0] * f.shape[1] * frames * wd for f in feat_t]
+                norms = [f.abs().sum() / c + 1e-3 for f, c in zip(feat_t, counts)] if self.normalize_losses else None
+            logit_f, feat_f, _, sums = d.forward_pitched(fakes, fm_refs=feat_t if fused else None, exclusive=not need_fm, release_refs=fused)
             if not need_fm:
                 fm = 0.0
             elif fused:
-                fm = sum(self._fm_from_sum(s_i, a, frames, wd) for s_i, a in zip(sums, feat_t)) / len(feat_t)
+                fm = sum((s_i / c) / (norms[j] if norms is not None else 1.0) for j, (s_i, c) in enumerate(zip(sums, counts))) / len(counts)
             else:
                 fm = sum(self._fm_pitched(a, b, frames, wd) for a, b in zip(feat_t, feat_f)) / len(feat_t)
             dis, adv = get_hinge_losses(_unpitch_view(logit_t, frames, wd), _unpitch_view(logit_f, frames, wd))
@@ -446,11 +458,6 @@ class EncodecDiscriminator(nn.Module):
         fm = sum(map(self.fm_reduction, feat_t, feat_f)) / len(feat_t) if need_fm else 0.0
         dis, adv = get_hinge_losses(logit_t, logit_f)
         return dis / n, adv / n, fm / n
-
-    def _fm_from_sum(self, s_i, x, frames, wd):
-        count = x.shape[0] * x.shape[1] * frames * wd
-        d = s_i / count
-        return d / (x.abs().sum() / count + 1e-3) if self.normalize_losses else d
 
     def _fm_pitched(self, x, y, frames, wd):
         count = x.shape[0] * x.shape[1] * frames * wd

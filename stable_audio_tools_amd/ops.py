@@ -613,10 +613,12 @@ class SatOps:
             return e["planes"], e["slot"]
         return self.disc_planes(h, frames, w, slot=0)[1], 0
 
-    def disc_planes(self, src, frames, w, out=None, slope=1.0, want_dst=False, want_planes=True, slot=0, fm_ref=None, fm_coef=None):
+    def disc_planes(self, src, frames, w, out=None, slope=1.0, want_dst=False, want_planes=True, slot=0, fm_sign=None, fm_coef=None):
         """src: (B, C, frames, w) or pitched (B, C, L) -> (dst pitched fp32 or None, (hi, lo) planes or None); with `out` (pitched):
-        (src + fm_coef * sign(out - fm_ref)) * LeakyReLU'(out) — fm_ref / fm_coef (a device scalar) optional."""
-        self._f32(src, out, fm_ref, fm_coef)
+        (src + fm_coef * fm_sign) * LeakyReLU'(out) — fm_sign (int8, disc_l1_sum) / fm_coef (a device scalar) optional."""
+        self._f32(src, out, fm_coef)
+        if fm_sign is not None and (fm_sign.dtype != torch.int8 or not fm_sign.is_contiguous() or fm_sign.numel() != src.numel()):
+            raise ValueError("disc_planes: fm_sign must be a contiguous int8 tensor of src's size")
         b, c = src.shape[0], src.shape[1]
         P, L, lead, rows = self.disc_geom(frames, w)
         pitched = src.dim() == 3
@@ -624,16 +626,17 @@ class SatOps:
             raise ValueError("disc_planes: shape does not match (frames, w)")
         dst = torch.empty(b, c, L, dtype=torch.float32, device=src.device) if want_dst else None
         pl = self._disc_plane_buf(b, c, frames, w, src.device, slot) if want_planes else None
-        self._chk(self.lib.sat_disc_planes(_ptr(src), _ptr(out), _ptr(fm_ref), _ptr(fm_coef), _ptr(dst), _ptr(pl[0]) if pl else None,
+        self._chk(self.lib.sat_disc_planes(_ptr(src), _ptr(out), _ptr(fm_sign), _ptr(fm_coef), _ptr(dst), _ptr(pl[0]) if pl else None,
                                            _ptr(pl[1]) if pl else None, b, c, frames, w, 1 if pitched else 0, float(slope), self._stream(src)))
         return dst, pl
 
-    def disc_l1_sum(self, a, b):
-        """sum |a - b| of two equal-shape contiguous tensors (numel % 4 == 0) as a 0-d tensor."""
+    def disc_l1_sum(self, a, b, want_sign=False):
+        """sum |a - b| of two equal-shape contiguous tensors (numel % 4 == 0) as a 0-d tensor (+ sign(a - b) as int8 if asked)."""
         self._f32(a, b)
         partial = torch.empty(self.lib.sat_disc_l1_blocks(), dtype=torch.float32, device=a.device)
-        self._chk(self.lib.sat_disc_l1_sum(_ptr(a), _ptr(b), _ptr(partial), a.numel(), self._stream(a)))
-        return partial.sum()
+        sign = torch.empty(a.shape, dtype=torch.int8, device=a.device) if want_sign else None
+        self._chk(self.lib.sat_disc_l1_sum(_ptr(a), _ptr(b), _ptr(partial), _ptr(sign), a.numel(), self._stream(a)))
+        return (partial.sum(), sign) if want_sign else partial.sum()
 
     def disc_pack(self, w4, mode):
         """w (Cout, Cin, kh, kw) -> the packed bf16 hi + lo weights for sat_disc_conv (mode 0) / its data-gradient (mode 1)."""
