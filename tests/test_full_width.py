@@ -194,8 +194,9 @@ def test_dit_block_full_width_fp32_gpu(hip):
 
 # bf16 bounds (stated here, as the 1e-3 bar of BASELINE.json is a float32 bar): every tensor is stored with an 8-bit
 # mantissa (unit round-off 2^-9 = 2e-3) and a token passes ~25 such roundings through two layers; relative L2 distance
-# to the float32 reference: forward <= 2e-2, gradients <= 4e-2 (dominated by the bf16 rounding of dy in the wgrad GEMMs).
-BF16_FWD, BF16_GRAD = 2e-2, 4e-2
+# to the float32 reference is dominated by the bf16 rounding of dy in the wgrad GEMMs.  Bars = 2 x the measured distances on MI355X
+# (forward 7.7e-3, gradients 1.8e-2).
+BF16_FWD, BF16_GRAD = 1.6e-2, 3.6e-2
 
 
 @pytest.mark.gpu
@@ -244,11 +245,11 @@ def test_dit_block_full_width_oracle_matches_reference():
     _check_grads(g, "", names, grads[1:], lambda n: TOL)
 
 
-# depth 24: the float32 model is held to 1e-3; the bf16 model to a relative L2 distance of 4e-2 from the float32 reference
+# depth 24: the float32 model is held to 1e-3; the bf16 model to a relative L2 distance of 2.8e-2 (2 x measured) from the float32 reference
 # (24 layers x ~12 bf16 roundings of the residual stream each, unit round-off 2e-3, accumulating like a random walk:
 # 2e-3 * sqrt(288) = 3.4e-2 is the expectation if every rounding hit the full stream; measured 1.4e-2).  CFG at scale 6 amplifies the difference of two such outputs,
 # so the guided output is compared in float32 only.
-BF16_DEPTH24 = 4e-2
+BF16_DEPTH24 = 2.8e-2
 
 
 @pytest.mark.gpu
