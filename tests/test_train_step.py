@@ -308,6 +308,65 @@ def test_alternating_discriminator_generator_steps_gpu(hip):
     _alternating("cuda")
 
 
+def _ddp_disc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from emu_util import emu_ops
+    from stable_audio_tools_amd import functional
+    functional._TEST_OPS = emu_ops()
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)                    # the discriminator's initialisation: the same on every rank
+        batches = [_batch(2, 900), _batch(2, 910)]
+        _, stepper, _ = _native_steps(_disc_config(), [(a[rank:rank + 1], n[rank:rank + 1]) for a, n in batches], "cpu",
+                                      ddp_mode="reduce_scatter", bucket_bytes=4096)
+        assert stepper.gen_steps == 1 and stepper.disc_steps == 1 and len(stepper.comm_d.buckets) >= 1
+        both = torch.cat([stepper.flat.data.reshape(-1), stepper.flat_d.data.reshape(-1)])
+        gathered = [torch.empty_like(both) for _ in range(world)]
+        dist.all_gather(gathered, both)
+        q.put((rank, ([g.numpy() for g in gathered], stepper.flat.data.numel()) if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_alternating_steps_data_parallel_gloo_world2(emu_modules):
+    """The REAL step (generator update with adversarial + feature-matching terms, then discriminator update) on two ranks, one item each,
+    gradients of both parameter sets exchanged from the backward hooks (the discriminator's scale-by-scale backward included): the
+    ranks stay identical and the updates equal the single-process full-batch ones."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 23
+    procs = [ctx.Process(target=_ddp_disc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, r1), n_g = results[0]
+    r0, r1 = torch.from_numpy(r0), torch.from_numpy(r1)
+    assert torch.equal(r0, r1), "ranks diverged after the exchanged generator + discriminator updates"
+    from stable_audio_tools_amd.training import AutoencoderTrainStep
+    torch.manual_seed(7)
+    model = build_native_ae(NAME, SEED, "cpu")
+    stepper = AutoencoderTrainStep(model, _disc_config())
+    g0, d0 = stepper.flat.data.clone(), stepper.flat_d.data.clone()
+    for a, n in [_batch(2, 900), _batch(2, 910)]:
+        stepper(a, noise=n)
+    ng, nd = g0.numel(), d0.numel()
+    for name, got, ref, init in (("generator", r0[:ng], stepper.flat.data.reshape(-1), g0.reshape(-1)),
+                                 ("discriminator", r0[n_g:n_g + nd], stepper.flat_d.data.reshape(-1), d0.reshape(-1))):
+        up, ur = got - init, ref - init
+        cos = float(torch.nn.functional.cosine_similarity(up, ur, dim=0))
+        assert cos >= 0.98, (name, cos)
+
+
 def _adamw_case(ops, dev):
     """sat_adamw_step (16-byte vector body + scalar tail) against torch.optim.AdamW over three steps, sizes around the vector width,
     with the gradient scale (1 / world) and the EMA shadow (updated from the parameters BEFORE the step, training/autoencoders.py:504-515)."""
