@@ -125,7 +125,7 @@ def _check_body(device, bf16x3, inverse_lr):
     assert bool(torch.isfinite(stepper.opt.ema).all())
 
 
-@pytest.mark.parametrize("bf16x3", [False, True])
+@pytest.mark.parametrize("bf16x3", [True])        # (the fp32-MFMA fallback mode runs on the GPU: test_generator_step_matches_oracle_gpu)
 def test_generator_step_matches_oracle_simulator(emu_modules, bf16x3):
     _check_against_oracle("cpu", emu_modules, bf16x3)
 
