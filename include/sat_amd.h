@@ -186,8 +186,9 @@ int sat_conv_wgrad_nsplit(int B, int M, int N, int Tlo, int K, int stride, int d
  * fp32 accuracy (hi/lo split).  dy: (B, M, T), x: (B, N, T) pre-activation, alpha/beta: SnakeBeta log-params of x or
  * NULL.  Slab stride M*N*7; nsplit from sat_conv_wgrad7_bf16x3_nsplit.  dy_rowsum (or NULL): [M][nsplit] per-split sums over
  * (b, t) of the dy rows — the conv's bias gradient, produced by the workgroups that stream dy anyway (sum the nsplit
- * columns with sat_rowsum) when sat_conv_wgrad7_bf16x3_fuses_rowsum says so (round 3: both kernels; the pipelined one adds each
- * thread's four columns while it converts a stage and reduces the 16 lanes of a row once at the end). */
+ * columns with sat_rowsum) when sat_conv_wgrad7_bf16x3_fuses_rowsum says so: the 4-wave kernel (N < 64 or T % 4 != 0) always, the
+ * pipelined kernel only in its A/B variant (SAT_WG_ROWSUM=1: per-thread partial sums while a stage is converted; it saves 13 GB of
+ * HBM reads per train step but costs the kernel ~13 % in situ, so the default is a separate sat_rowsum pass). */
 int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const float* alpha, const float* beta, float* partial,
                            long long so_m, long long so_n, long long so_k, int B, int M, int N, int T, int dil, int pad,
                            float* dy_rowsum, void* stream);

@@ -16,7 +16,7 @@
 #define SAT_WP_NT 512
 #define SAT_WP_NI 64                 // input channels per workgroup
 
-template <int DIL>
+template <int DIL, bool RS = false>
 __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWgBfParams p) {
     constexpr int NCH = (6 * DIL + 7) / 8 + 1;                       // aligned 8-element chunks covering all 7 taps
     constexpr int HSPAN = SAT_WB_TT + 6 * DIL;                       // activation samples needed per stage
@@ -70,10 +70,11 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     // MFMA phase (~1 us) to arrive before it is converted, and 32 registers fewer are live (7 accumulator tiles = 112)
     float4 dyv[1][NDY];
     float xv[1][NXP][2];
-    // bias gradient (sum over (b, t) of the dy rows) by the workgroups of the first column block: dy streams through them anyway —
-    // every stage is converted exactly once (write_lds), so each thread adds its four columns there and the 16 lanes of a row are
-    // reduced once at the end (no separate sat_rowsum pass over dy: 1 GB per C = 128 unit)
-    const bool want_rs = p.rowsum != nullptr && n0 == 0;            // block-uniform
+    // RS (A/B variant, SAT_WG_ROWSUM=1; NOT the default): bias gradient (sum over (b, t) of the dy rows) by the workgroups of the first
+    // column block — every stage is converted exactly once (write_lds), so each thread adds its four columns there and the 16 lanes of a
+    // row are reduced once at the end.  Saves the separate sat_rowsum pass over dy (13 GB of HBM reads per train step) but the four extra
+    // live registers cost the whole kernel ~13 % in situ (profiles/EXPERIMENTS.md): compiled out unless asked for.
+    const bool want_rs = RS && p.rowsum != nullptr && n0 == 0;      // block-uniform
     float rs[NDY];
 #pragma unroll
     for (int u = 0; u < NDY; ++u) rs[u] = 0.0f;

@@ -263,8 +263,8 @@ extern "C" int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T) {
 extern "C" int sat_conv_wgrad7_bf16x3_fuses_rowsum(int B, int M, int N, int T) {
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
-    // both kernels produce dy_rowsum (round 3: the pipelined one too; SAT_WG_ROWSUM=0: A/B switch back to a separate sat_rowsum pass)
-    if (pl.pipe) { const char* e = getenv("SAT_WG_ROWSUM"); if (e && atoi(e) == 0) return 0; }
+    // the 4-wave kernel produces dy_rowsum; the pipelined one only in its A/B variant (SAT_WG_ROWSUM=1: measured slower in the step)
+    if (pl.pipe) { const char* e = getenv("SAT_WG_ROWSUM"); return (e && atoi(e) == 1) ? 1 : 0; }
     return 1;
 }
 // dW[m][n][k] for a K = 7, stride-1 conv with dilation in {1, 3, 9}: dy (B, M, T), x (B, N, T) pre-activation,
@@ -282,9 +282,15 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
                     dy_rowsum, pl.nsplit};
     if (pl.pipe) {
         dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, SAT_WP_NI), pl.nsplit);
-        if (dil == 1) SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<1>, grid, dim3(SAT_WP_NT), stream, p);
-        else if (dil == 3) SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<3>, grid, dim3(SAT_WP_NT), stream, p);
-        else SAT_LAUNCH(sat_wgrad7_bf16x3_pipe_kernel<9>, grid, dim3(SAT_WP_NT), stream, p);
+        if (dy_rowsum) {
+            if (dil == 1) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<1, true>), grid, dim3(SAT_WP_NT), stream, p);
+            else if (dil == 3) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<3, true>), grid, dim3(SAT_WP_NT), stream, p);
+            else SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<9, true>), grid, dim3(SAT_WP_NT), stream, p);
+        } else {
+            if (dil == 1) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<1, false>), grid, dim3(SAT_WP_NT), stream, p);
+            else if (dil == 3) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<3, false>), grid, dim3(SAT_WP_NT), stream, p);
+            else SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<9, false>), grid, dim3(SAT_WP_NT), stream, p);
+        }
         return sat_check_launch("sat_conv_wgrad7_bf16x3");
     }
     dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, 32), pl.nsplit);

@@ -94,7 +94,7 @@ def test_argument_validation_never_launches():
     assert lib.sat_conv_wgrad_bf16x3_nsplit(1, 128, 128, 2097152, 1, 1) == 512
     assert lib.sat_conv_wgrad_bf16x3_nsplit(1, 128, 128, 65536, 3, 1) == -1
     assert lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(1, 128, 2, 2097152) == 1             # narrow input: 4-wave kernel
-    assert lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(1, 128, 128, 2097152) == 1           # pipelined kernel: fused too (round 3)
+    assert lib.sat_conv_wgrad7_bf16x3_fuses_rowsum(1, 128, 128, 2097152) == 0           # pipelined kernel: separate sat_rowsum (default)
     assert lib.sat_conv_wgrad7_bf16x3(*([null] * 5), 7, 1, 0, 1, 8, 8, 64, 2, 6, null, null) != 0
     assert b"dilation" in lib.sat_last_error()
 

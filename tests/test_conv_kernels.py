@@ -41,7 +41,7 @@ S1_CASES = [(1, 8, 8, 300, 7, 1), (1, 16, 70, 280, 7, 3), (2, 24, 8, 200, 7, 9),
             (1, 6, 40, 150, 7, 9), (1, 32, 8, 140, 1, 1), (1, 64, 130, 200, 1, 1), (1, 96, 8, 130, 1, 1), (2, 160, 20, 100, 1, 1),
             (1, 70, 20, 150, 1, 1), (1, 12, 4, 100, 3, 1), (1, 9, 5, 77, 2, 1), (1, 20, 5, 90, 5, 2),
             (1, 64, 40, 200, 7, 3), (1, 72, 130, 150, 7, 9), (2, 128, 8, 140, 7, 1),
-            (1, 64, 130, 152, 7, 1)]   # >= 64 in-channels: the pipelined wgrad kernel (incl. its fused bias-gradient row sums over two co tiles)
+            (1, 64, 130, 152, 7, 1)]   # >= 64 in-channels: the pipelined wgrad kernel (two co tiles)
 DOWN_CASES = [(1, 8, 16, 256, 2), (2, 12, 20, 333, 4), (1, 6, 130, 1100, 8), (1, 40, 6, 300, 2), (1, 8, 8, 520, 4)]
 UP_CASES = [(1, 16, 8, 40, 2), (2, 12, 20, 33, 4), (1, 6, 130, 70, 8), (1, 70, 6, 150, 2), (1, 48, 8, 131, 4)]
 
@@ -296,3 +296,28 @@ def test_conv_random_shapes_sim(emu, kind, case):
         {"s1": _run_s1, "down": _run_down, "up": _run_up}[kind](emu, "cpu", case, True)
     finally:
         FLOOR[0] = 1e-3
+
+
+def _fused_rowsum_case(ops, dev):
+    """The A/B variant of the pipelined k7 weight-gradient kernel that also sums the dy rows (SAT_WG_ROWSUM=1): same dW and bias gradient."""
+    import os
+    gen = torch.Generator().manual_seed(5)
+    dy = torch.randn(2, 130, 152, generator=gen).to(dev)
+    x = torch.randn(2, 64, 152, generator=gen).to(dev)
+    ref_w = ops.conv_wgrad7_bf16x3(dy, x, 1, 3)
+    os.environ["SAT_WG_ROWSUM"] = "1"
+    try:
+        dw, db = ops.conv_wgrad7_bf16x3(dy, x, 1, 3, dy_rowsum=True)
+    finally:
+        os.environ.pop("SAT_WG_ROWSUM")
+    assert torch.equal(dw, ref_w)
+    assert (db.cpu() - dy.sum(dim=(0, 2)).cpu()).abs().max().item() <= 1e-4 * dy.abs().sum(dim=(0, 2)).max().item()
+
+
+def test_wgrad7_pipe_fused_rowsum_sim(emu):
+    _fused_rowsum_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_wgrad7_pipe_fused_rowsum_gpu(hip):
+    _fused_rowsum_case(hip, "cuda")
