@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-real-step", action="store_true", help="skip the timing of the alternating discriminator / generator step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
     ap.add_argument("--no-long-context", action="store_true", help="skip the N = 6145 fp8 sampling measurement (BASELINE.json configs[4])")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the generator step at per-GPU batch 2 and 4 (config.batch_sweep)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check of the bench item (about one CPU-minute)")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
     ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train", "long_context"], default="vae_train",
@@ -884,6 +885,27 @@ def main():
                          "hbm": hbm_roofline(args, 1e3 * elapsed / args.steps),
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},
         }
+        if world == 1 and args.batch == 1 and not args.no_batch_sweep:
+            # the same generator step at larger per-GPU batches (1 warm-up + 2 timed steps each): the headline stays at batch 1 per GPU
+            # (continuity with rounds 1-2 and with the per-step targets), this is what the 288 GB buy on top of it
+            sweep = {}
+            for bsz in (2, 4):
+                try:
+                    bb = [(0.1 * torch.randn(bsz, 2, args.sample_size, generator=g)).to(dev) for _ in range(2)]
+                    stepper(bb[0])
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(2):
+                        stepper(bb[i % 2])
+                    torch.cuda.synchronize()
+                    dt_b = (time.perf_counter() - t1) / 2
+                    sweep[str(bsz)] = {"samples_per_s": bsz / dt_b, "ms_per_step": 1e3 * dt_b}
+                    del bb
+                except torch.cuda.OutOfMemoryError:
+                    sweep[str(bsz)] = None
+                ops.release_workspaces()          # the per-shape plane buffers of this batch size
+                torch.cuda.empty_cache()
+            line["config"]["batch_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)
         if world == 1 and not args.no_parity:

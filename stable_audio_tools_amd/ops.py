@@ -552,6 +552,16 @@ class SatOps:
         self._chk(self.lib.sat_rows_pack_bwd(_ptr(dbuf), _ptr(dx), b, c, t, w, kh, dil_t, pad_t, pad_w, pitch, lead, self._stream(dbuf)))
         return dx
 
+    def release_workspaces(self):
+        """Drop the cached plane / emission buffers (they are per activation shape and re-created, zero-filled, on demand): call after a
+        run at a batch size or length that will not come back, before torch.cuda.empty_cache()."""
+        for name in ("_planes", "_disc_pool", "_disc_gen", "_disc_geoms"):
+            d = self.__dict__.get(name)
+            if d is not None:
+                d.clear()
+        self._emitted = None
+        self._disc_emitted = None
+
     def prefetch(self, tensors, stream):
         """Read (and discard) up to 16 device tensors on `stream` (a torch.cuda.Stream): cache prefetch of the next layer's weights."""
         ts = [t for t in tensors if t is not None and t.numel() > 0][:16]

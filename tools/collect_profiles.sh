@@ -11,9 +11,9 @@ R=$(pwd)
 OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-GEN="--no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context"
+GEN="--no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context --no-batch-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 $GEN > $OUT/vae_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-long-context > $OUT/real_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-long-context --no-batch-sweep > $OUT/real_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_sample -- python $R/bench.py --workload dit_sample --steps 10 --warmup 2 --no-cpu-baseline > $OUT/dit_sample_prof.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dit_train -- python $R/bench.py --workload dit_train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/dit_train_prof.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
