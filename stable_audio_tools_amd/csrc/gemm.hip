@@ -677,6 +677,189 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     }
 }
 
+// ---- 128 x 256 tiles, same eight waves (2 x 4, 64 x 64 per wave) --------------------------------------------------------------------
+// For shapes whose 256 x 256 tile count falls just over a multiple of the 256 CUs: the DiT's FF1 at M = 2050 is 8 x 48 = 384 full tiles =
+// TWO rounds of the chip for 1.5 rounds of work; as 16 x 48 = 768 half-size tiles it is three rounds of half the length.  One phase per
+// K-step (16 MFMAs per wave and interval, as each phase of the 256-row kernel), the two wave rows one barrier apart, and — the stage being
+// 48 KB instead of 64 — a THREE-slot ring: K-step t's read section requests all of tile t + 2 (six LDS-DMAs per wave) and waits only for
+// tile t + 1 (vmcnt(6)), two K-steps of lookahead instead of one and a half.
+template <int EPI, bool F32OUT>
+__global__ void __launch_bounds__(512) sat_gemm128_kernel(SatGemmParams p) {
+    constexpr int BM = 128, BN = 256, NST = 3;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+    constexpr int WIN = NST * STAGE / 8;
+    static_assert(WIN >= 64 * 33 * 4, "epilogue window must fit");
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
+    const int wr = wave >> 2, wc = wave & 3;
+    int tm, tn;
+    sat_xcd_tile((int)blockIdx.x, p.ntm, p.ntn, &tm, &tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.klen;
+    const int kend = (kbeg + p.klen < p.K) ? kbeg + p.klen : p.K;
+    const int nk = (kend - kbeg + 63) >> 6;
+    constexpr bool GLU = (EPI == SAT_EPI_SWIGLU);
+    const int glu_f = p.N >> 1, glu_tile0 = tn * (BN / 2);
+    const int mv = p.M - m0 - wr * 64;           // valid rows of this wave's 64 (<= 0: none)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this wave's pieces of a tile: A pieces wave, wave + 8 (of 16), B pieces wave + 8 q (of 32); per-lane source offsets as in the 256-row kernel
+    long long aoff[2], boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave + 8 * q;
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        if (q < 2) {
+            int ga = m0 + r;
+            ga = ga < p.M ? ga : p.M - 1;
+            aoff[q] = ((long long)ga * p.lda + c * 8) * 2;
+        }
+        int gb;
+        if constexpr (GLU) gb = ((r >> 5) & 1) * glu_f + glu_tile0 + (r >> 6) * 32 + (r & 31);
+        else gb = n0 + r;
+        gb = gb < p.N ? gb : p.N - 1;
+        boff[q] = ((long long)gb * p.ldb + c * 8) * 2;
+    }
+    auto stage = [&](int kt) __attribute__((always_inline)) {
+        char* s = smem + (kt % NST) * STAGE;
+        const int k0 = kbeg + kt * 64;
+        if (k0 + 64 <= kend) {
+            const char* ab = (const char*)p.A + (long long)k0 * 2;
+            const char* bb = (const char*)p.B + (long long)k0 * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sat_glds16(bb + boff[q], s + ABYTES + (wave + 8 * q) * 1024);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) sat_glds16(ab + aoff[q], s + (wave + 8 * q) * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, wave + 8 * q, lane, glu_f, glu_tile0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, wave + 8 * q, lane, 0, 0);
+        }
+    };
+
+    // prologue: tile 0 complete, tile 1 in flight
+    stage(0);
+    if (nk > 1) {
+        stage(1);
+        SAT_WAIT_VMCNT(6);
+    } else {
+        SAT_WAIT_VMCNT(0);
+    }
+    SAT_RAW_BARRIER();
+    if (wr == 1) SAT_RAW_BARRIER();              // the second wave row runs one barrier behind the first
+
+    bf16x8 bfr[2][4], afr[2][4];
+    const int frow = lane & 31, fkc = lane >> 5;
+    const bool on0 = 0 < mv, on1 = 32 < mv;
+    for (int t = 0; t < nk; ++t) {
+        const char* As = smem + (t % NST) * STAGE;
+        const char* Bs = As + ABYTES;
+        // ---- read section: this K-step's fragments, the request for tile t + 2, the wait for tile t + 1 ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, ks * 2 + fkc);
+        if (on0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) afr[0][ks] = sat_gemm_frag(As, wr * 64 + frow, ks * 2 + fkc);
+        }
+        if (on1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) afr[1][ks] = sat_gemm_frag(As, wr * 64 + 32 + frow, ks * 2 + fkc);
+        }
+        if (t + 2 < nk) { stage(t + 2); SAT_WAIT_VMCNT(6); }
+        else { SAT_WAIT_VMCNT(0); }
+        SAT_WAIT_LGKM0();
+        SAT_RAW_BARRIER();
+        // ---- MFMA section ----
+        SAT_SCHED_FENCE();
+        if (on0) {
+            SAT_SETPRIO(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][j] = sat_mfma_32x32x16_bf16(afr[0][ks], bfr[j][ks], acc[0][j]);
+                if (on1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[1][j] = sat_mfma_32x32x16_bf16(afr[1][ks], bfr[j][ks], acc[1][j]);
+                }
+            }
+            SAT_SETPRIO(0);
+        }
+        SAT_SCHED_FENCE();
+        SAT_RAW_BARRIER();
+    }
+    if (wr == 0) SAT_RAW_BARRIER();              // pairs with the second wave row's last barrier: every LDS read is done
+    SAT_RAW_BARRIER();
+
+    if (p.alpha) {
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= al;
+    }
+    float* ep = (float*)(smem + wave * WIN);
+    const int hi = lane >> 5, col = lane & 31;
+    const int nwin = n0 + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i * 32 >= mv) break;                 // (wave-uniform)
+        sat_wave_sync();
+        const int mrow0 = m0 + wr * 64 + i * 32;
+        if (sat_gemm_window_is_v<EPI>(p, nwin)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ep[(j * 32 + col) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[i][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + col] = acc[i][j][r];
+        }
+        sat_wave_sync();
+        sat_gemm_epilogue_window<EPI, F32OUT>(p, ep, mrow0, nwin, glu_tile0 + wc * 32, glu_f, lane);
+    }
+}
+
+static int sat_gemm128_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
+    p.ntm = sat_cdiv(p.M, 128);
+    p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
+    dim3 grid(p.ntm * p.ntn, splits), block(512);
+#define SAT_GEMM128_CASE(E, F)                                                                       \
+    if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
+        SAT_LAUNCH((sat_gemm128_kernel<E, F>), grid, block, stream, p);                              \
+        return sat_check_launch("sat_gemm_bf16 (128x256)");                                          \
+    }
+    SAT_GEMM128_CASE(SAT_EPI_STORE, false)
+    SAT_GEMM128_CASE(SAT_EPI_STORE, true)
+    SAT_GEMM128_CASE(SAT_EPI_RES, false)
+    SAT_GEMM128_CASE(SAT_EPI_RES, true)
+    SAT_GEMM128_CASE(SAT_EPI_GATE_RES, false)
+    SAT_GEMM128_CASE(SAT_EPI_GATE_RES, true)
+    SAT_GEMM128_CASE(SAT_EPI_SWIGLU, false)
+    SAT_GEMM128_CASE(SAT_EPI_SWIGLU, true)
+    SAT_GEMM128_CASE(SAT_EPI_QKV, false)
+#undef SAT_GEMM128_CASE
+    sat_set_error("sat_gemm_bf16: unsupported epilogue / output type");
+    return 1;
+}
+
 static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 0) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
@@ -729,14 +912,16 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 
 // tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
 // 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure);
-// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel)
+// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel); 6 = 128x256 / 8 waves / 3-slot ring,
+// 2 intervals per K-step (sat_gemm128_kernel: shapes whose 256x256 tile count is just over a multiple of the CU count)
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
     if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 2);      // (A/B: WITH the L2 touch prefetch: measured -6 % in the sampler)
+    if (tile == 6) return sat_gemm128_launch(p, epi, f32out, splits, stream);
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile < 0 || tile > 5) { sat_set_error("sat_gemm: tile must be 0..5"); return 1; }
+    if (tile < 0 || tile > 6) { sat_set_error("sat_gemm: tile must be 0..6"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
 }
 

@@ -334,6 +334,7 @@ class SatOps:
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
     # per (device, stream): the pre-pass and its conv are enqueued back to back on the caller's current stream.
+    gemm_tile128 = os.environ.get("SAT_GEMM_TILE128", "0") == "1"   # A/B switch, OFF: 128 x 256 GEMM tiles where they save a round of the chip (measured slower)
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
 
@@ -922,6 +923,15 @@ class SatOps:
         if self.gemm_tile is not None:
             return self.gemm_tile
         if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
+            # wave quantisation: FULL 256-row tiles run in rounds of 256 (one workgroup per CU; the row tile of the M tail only streams its
+            # B panel); when the count lands just over a multiple — FF1 at M = 2050: 8 x 48 = 384 = two rounds for 1.5 of work — the same
+            # structure on 128-row tiles (tile 6: 768 half-size tiles = three rounds) SHOULD be shorter; measured it is not (FF1 97.5 vs 89.0 us:
+            # a half-size tile takes 0.6 of the time, profiles/EXPERIMENTS.md), so this branch is an A/B switch (SAT_GEMM_TILE128=1)
+            nt = (n + 255) // 256
+            r256 = -(-((m // 256) * nt) // 256)
+            r128 = -(-((m // 128) * nt) // 256) * 0.5
+            if self.gemm_tile128 and m >= 256 and r128 + 0.2 < r256:
+                return 6
             return 5 if os.environ.get("SAT_GEMM_TOUCH") == "1" else 4          # 5 = 4 + the L2 touch prefetch experiment (slower)
         return 0
 

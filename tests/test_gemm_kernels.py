@@ -12,7 +12,7 @@ from golden_util import rel_err
 SHAPES = [(130, 136, 72), (257, 128, 64), (70, 264, 200), (33, 64, 8), (290, 520, 328)]
 
 
-def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3, 4, 5)):
+def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3, 4, 5, 6)):
     torch.manual_seed(0)
     for (m, n, k) in shapes:
         a = torch.randn(m, k).bfloat16().to(dev)
@@ -57,7 +57,7 @@ def _heads_case(ops, dev, nb, ntok, heads, k):
     q, kk, v = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
     freqs = dit_oracle.rotary_freqs(inv, ntok + 3)[-ntok:]
     qr, kr = dit_oracle.apply_rotary(q, freqs), dit_oracle.apply_rotary(kk, freqs)
-    for tile in (0, 1, 2, 3, 4, 5):
+    for tile in (0, 1, 2, 3, 4, 5, 6):
         ops.gemm_tile = tile
         try:
             pl = ops.gemm_heads_bf16(x, w, cs, heads, nb, ntok, 0, 3)
@@ -118,7 +118,7 @@ def test_gemm_epilogues_gpu(hip):
 @pytest.mark.gpu
 def test_gemm_ff_shapes_gpu(hip):
     """The feed-forward pair at full size: SwiGLU projection 1536 -> 2 x 6144 and the 6144 -> 1536 output projection."""
-    _gemm_cases(hip, "cuda", [(2050, 12288, 1536), (2050, 1536, 6144)], tiles=(0, 1, 2, 3, 4, 5))
+    _gemm_cases(hip, "cuda", [(2050, 12288, 1536), (2050, 1536, 6144)], tiles=(0, 1, 2, 3, 4, 5, 6))
 
 
 @pytest.mark.gpu
