@@ -67,6 +67,7 @@ SIM_CASES = [
     (1, 16, 12, 9, 33, 3, 9, 2, 0.2),      # dilated frame taps, two 8-channel groups, ragged Cout
     (1, 8, 1, 6, 21, 3, 3, 1, 1.0),        # conv_post: one output channel, 3 x 3, no activation
     (1, 24, 70, 4, 150, 3, 9, 4, 0.2),     # two co tiles, three position tiles (L = 632), dilation 4
+    (1, 2, 8, 6, 17, 3, 9, 1, 0.2),        # mono input: two spectrogram channels
 ]
 
 
