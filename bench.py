@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--no-long-context", action="store_true", help="skip the N = 6145 fp8 sampling measurement (BASELINE.json configs[4])")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the generator step at per-GPU batch 2 and 4 (config.batch_sweep)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check of the bench item (about one CPU-minute)")
-    ap.add_argument("--cpu-baseline-samples", type=int, default=32768)
+    ap.add_argument("--cpu-baseline-samples", type=int, default=32768, help="length of the probe crop that picks the thread count")
+    ap.add_argument("--cpu-baseline-budget-s", type=float, default=100.0,
+                    help="time budget of the ONE un-scaled CPU reference step (the full item when it fits, else the largest 1/2^k of it)")
     ap.add_argument("--workload", choices=["vae_train", "dit_sample", "dit_train", "long_context"], default="vae_train",
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
                          "dit_sample: configs[2] DiT sampling steps/s (the metric's second half)")
@@ -569,7 +571,8 @@ def hbm_roofline(args, ms_per_step):
 
 
 def _reference_importable():
-    """The reference checkout exists only in the build container; on the GPU box the baseline is the oracle port."""
+    """/root/reference in the build container; on the GPU box the tree oracle/stage_ref.py staged into oracle/_ref/ (git-ignored,
+    shipped with the working tree)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import refimport
     return refimport.available()
@@ -585,19 +588,54 @@ def _median_time(fn, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def cpu_baseline(cfg, nsamples):
-    """CPU baseline of the SAME workload on this box's host cores, on a bounded sample: ONE generator step (forward +
-    autograd backward + torch AdamW) on a `nsamples`-long stereo crop (the model is fully convolutional: cost is linear in
-    length), 1 warm-up + median of 3, at the thread count that measured fastest.  kind "reference": the reference's own
-    modules (stable_audio_tools.models.autoencoders + training/losses/auraloss.py) when /root/reference is importable;
-    "port": the oracle restatement (oracle/vae_oracle.py, oracle/stft_oracle.py) otherwise (the GPU box)."""
+class _PeakRSS:
+    """Peak resident set of this process while a CPU step runs (20 ms sampling thread): sizes the un-scaled baseline step so that
+    it cannot drive the box out of host memory."""
+
+    def __enter__(self):
+        import threading
+        import psutil
+        self._proc = psutil.Process()
+        self.base = self.peak = self._proc.memory_info().rss
+        self._stop = threading.Event()
+
+        def watch():
+            while not self._stop.wait(0.02):
+                self.peak = max(self.peak, self._proc.memory_info().rss)
+        self._thr = threading.Thread(target=watch, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thr.join()
+        self.peak = max(self.peak, self._proc.memory_info().rss)
+
+    @property
+    def delta(self):
+        return max(self.peak - self.base, 0)
+
+
+def cpu_baseline(cfg, probe_samples, budget_s=100.0, full_samples=SAMPLE_SIZE):
+    """CPU baseline of the SAME workload on this box's host cores: ONE generator step (forward + autograd backward
+    + torch AdamW) of the REFERENCE's own modules (stable_audio_tools.models.autoencoders + training/losses/auraloss.py, staged
+    for the GPU box by oracle/stage_ref.py; kind "reference") — or of the oracle restatement (kind "port") if no reference tree is
+    importable.  Protocol: (1) probe on a `probe_samples` crop — 1 warm-up + 1 timed step at 8 / 16 / 32 threads, peak RSS sampled —
+    picks the thread count and predicts time and memory (the model is fully convolutional: both are linear in length);
+    (2) ONE timed step at the LARGEST of {1, 1/2, 1/4, 1/8, ...} x the full 2 097 152-sample item whose prediction fits `budget_s`
+    seconds and half of the free host memory — un-scaled when that is the full item, which is what a default run does on the GPU
+    box; `sample` says what ran."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import psutil
     import stft_oracle
     import vae_oracle
-    g = torch.Generator().manual_seed(0)
-    audio = 0.1 * torch.randn(1, 2, nsamples, generator=g)
-    noise = torch.randn(1, cfg["model"]["latent_dim"], nsamples // cfg["model"]["downsampling_ratio"], generator=g)
     sc = cfg["training"]["loss_configs"]["spectral"]["config"]
+    lat, ratio = cfg["model"]["latent_dim"], cfg["model"]["downsampling_ratio"]
+
+    def make_inputs(n):
+        g = torch.Generator().manual_seed(0)
+        return 0.1 * torch.randn(1, 2, n, generator=g), torch.randn(1, lat, n // ratio, generator=g)
+
     kind = "port"
     if _reference_importable():
         import contextlib
@@ -613,7 +651,8 @@ def cpu_baseline(cfg, nsamples):
         lr_loss = al.MultiResolutionSTFTLoss(sample_rate=cfg["sample_rate"], **sc)
         kind = "reference"
 
-        def step():
+        def step(audio, noise):
+            # AutoencoderTrainingWrapper.training_step, generator branch (training/autoencoders.py:398-515), on the reference's modules
             opt.zero_grad(set_to_none=True)
             pre = model.encoder(audio)
             mean, scale = pre.chunk(2, dim=1)
@@ -630,27 +669,53 @@ def cpu_baseline(cfg, nsamples):
         sd = {k: v.detach().clone().requires_grad_(True) for k, v in create_autoencoder_from_config(cfg).state_dict().items()}
         opt = torch.optim.AdamW(list(sd.values()), lr=1.5e-4, betas=(0.8, 0.99), weight_decay=1e-3)
 
-        def step():
+        def step(audio, noise):
             opt.zero_grad(set_to_none=True)
             z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
             dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
             loss = stft_oracle.autoencoder_spectral_loss(audio, dec, sc, cfg["sample_rate"]) + 1e-4 * kl
             loss.backward()
             opt.step()
-    # torch's CPU conv path degrades when oversubscribed (256 hardware threads on the GPU box's host took 700 s for what 8
+    # (1) probe.  torch's CPU conv path degrades when oversubscribed (256 hardware threads on the GPU box's host took 700 s for what 8
     # do in ~25 s): try a few pool sizes, keep the fastest, report the threads actually used
     ncpu = os.cpu_count() or 1
-    best = None
+    pa, pn = make_inputs(probe_samples)
+    probes = {}
     for cores in sorted({min(ncpu, c) for c in (8, 16, 32)}):
         torch.set_num_threads(cores)
-        dt = _median_time(step)
-        if best is None or dt < best[0]:
-            best = (dt, cores)
-    dt, cores = best
-    scale = SAMPLE_SIZE / nsamples
-    return {"value": 1.0 / (dt * scale), "unit": "samples/s", "cores": cores, "kind": kind,
-            "sample": f"generator step (fwd + autograd bwd + AdamW) on a {nsamples}-sample stereo crop: median of 3 after 1 warm-up = "
-                      f"{dt:.2f} s at {cores} threads (fastest of 8/16/32), scaled x{scale:.0f} to {SAMPLE_SIZE} samples"}
+        step(pa, pn)
+        with _PeakRSS() as rss:
+            t0 = time.perf_counter()
+            step(pa, pn)
+            probes[cores] = (time.perf_counter() - t0, rss.delta)
+    cores = min(probes, key=lambda c: probes[c][0])
+    torch.set_num_threads(cores)
+    dt_probe, rss_probe = probes[cores]
+    rss_probe = max(rss_probe, 64 << 20)
+    free = psutil.virtual_memory().available
+    # (2) the largest fraction of the full item that fits the time and memory budget
+    n = full_samples
+    while n > probe_samples and (dt_probe * n / probe_samples > budget_s or 1.5 * rss_probe * n / probe_samples > 0.5 * free):
+        n //= 2
+    if n <= probe_samples:
+        n, dt, peak = probe_samples, dt_probe, rss_probe
+    else:
+        fa, fn = make_inputs(n)
+        with _PeakRSS() as rss:
+            t0 = time.perf_counter()
+            step(fa, fn)
+            dt = time.perf_counter() - t0
+        peak = rss.delta
+        del fa, fn
+    scale = full_samples / n
+    what = (f"ONE generator step (fwd + autograd bwd + AdamW) of the {'reference modules' if kind == 'reference' else 'oracle port'} on "
+            f"{'the full ' if n == full_samples else 'a '}{n}-sample stereo item: {dt:.1f} s at {cores} threads, peak host memory +{peak / 2 ** 30:.1f} GiB"
+            + ("" if n == full_samples else f", scaled x{scale:.0f} to {full_samples} samples (time / memory budget: {budget_s:.0f} s, "
+                                             f"{free / 2 ** 30:.0f} GiB free)")
+            + f"; thread count from a {probe_samples}-sample probe ("
+            + ", ".join(f"{c}: {v[0]:.2f} s" for c, v in probes.items()) + ")")
+    return {"value": 1.0 / (dt * scale), "unit": "samples/s", "cores": cores, "kind": kind, "sample": what,
+            "sample_samples": n, "seconds": dt, "scaled": n != full_samples}
 
 
 def headline_parity(model, cfg, stepper, audio):
@@ -907,7 +972,7 @@ def main():
                 torch.cuda.empty_cache()
             line["config"]["batch_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_samples, args.cpu_baseline_budget_s)
         if world == 1 and not args.no_parity:
             line["parity"] = headline_parity(model, cfg, stepper, batches[0])
         if stepper.discriminator is not None:

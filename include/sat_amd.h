@@ -327,14 +327,22 @@ int sat_gate_residual_bwd(const void* dy, const void* x, const void* gate, long 
  * y0 = c0x*x + c0v*v (x NULL: y0 = v); y1 = c1x*x + c1v*v (optional).  dtype 0 fp32 / 1 bf16. */
 int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
                  float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream);
-/* The same with (c0x, c0v, c1x, c1v) read from device memory (coef[4], fp32): the launch can be frozen in a HIP graph and replayed
- * with new sampler coefficients (inference/sampling.py:254-307 changes them every step). */
+/* The general sampler step: every update rule of inference/sampling.py is linear in (x, v, one more tensor `prev`, the
+ * unconditioned output u) — v-DDIM with eta > 0 (:296-300: prev = fresh noise) and cfg_pp (:270-284: eps from u), RK4 stages
+ * (:160-170: prev = the running k-sum), DPM-Solver++ (:203-217: prev = the previous step's denoised), ping-pong (:240-247: prev =
+ * fresh noise).  coef[8] (HOST, fp32) = c0x c0v c0p c0u c1x c1v c1p c1u:
+ *   y0 = c0x*x + c0v*v + c0p*prev + c0u*u,  y1 = c1x*x + c1v*v + c1p*prev + c1u*u   (prev NULL: its terms drop; y1 optional;
+ *   u = the unconditioned half of out2 when ncond == 2, else v). */
+int sat_sampler_step(const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T, int ncond,
+                     float scale, float phi, const float* coef, int dtype, void* stream);
+/* The same with coef[8] read from DEVICE memory: the launch can be frozen in a HIP graph and replayed with new sampler
+ * coefficients (inference/sampling.py changes them every step). */
+int sat_sampler_step_dev(const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T, int ncond,
+                         float scale, float phi, const float* coef, int dtype, void* stream);
 /* Cache prefetch: reads n <= 16 read-only device buffers (ptrs / bytes: host arrays; 16-byte aligned) and discards them — launched on a
  * side stream one transformer layer ahead, it puts the next layer's weights into the memory-side cache before the projection GEMMs ask
  * for them (transformer.ContinuousTransformer, inference).  No reference counterpart: a scheduling hint, results are unaffected. */
 int sat_prefetch(const void* const* ptrs, const long long* bytes, int n, void* stream);
-int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
-                     float phi, const float* coef, int dtype, void* stream);
 
 /* Complex spectrogram of the MS-STFT discriminator — models/encodec.py:73-76, :97-102 (torchaudio Spectrogram: periodic Hann,
  * normalized by ||w||_2, center = False, onesided, power = None; real / imaginary parts concatenated on the channel axis, axes

@@ -1,8 +1,9 @@
-"""TEST INFRASTRUCTURE ONLY — imports the *reference* (read-only checkout at /root/reference).
+"""TEST INFRASTRUCTURE ONLY — imports the *reference* itself.
 
-Only `oracle/gen_golden.py` (run in the build container, where /root/reference exists) uses this
-file.  Nothing in the product package, `bench.py`, `smoke()` or the `-m gpu` tests may import it:
-/root/reference does not exist on the GPU box.
+Where it comes from, in this order: $SAT_REFERENCE_ROOT, the read-only checkout /root/reference (build container), or
+the copy `oracle/stage_ref.py` stages into the git-ignored `oracle/_ref/` (what the GPU box sees: /root/reference does
+not exist there, the staged tree travels with the working tree like the built .so).  Users: `oracle/gen_golden*.py`,
+the drop-in / pinning tests, and bench.py's `cpu_baseline` leg.  Nothing in the product package imports it.
 
 The reference's hot-path modules import four off-path third-party packages at module scope
 (SURVEY.md §8c).  They are stubbed in ``sys.modules`` so that the in-scope code imports unchanged:
@@ -16,7 +17,17 @@ import os
 import sys
 import types
 
-REF_ROOT = os.environ.get("SAT_REFERENCE_ROOT", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _find_root():
+    for cand in (os.environ.get("SAT_REFERENCE_ROOT"), "/root/reference", _STAGED):
+        if cand and os.path.isdir(os.path.join(cand, "stable_audio_tools")):
+            return cand
+    return "/root/reference"
+
+
+REF_ROOT = _find_root()
 
 
 def _stub(name, **attrs):

@@ -1,4 +1,4 @@
-"""One invalidation epoch for every DERIVED copy of a parameter this package keeps: bf16 / bf16x3 / fp8 / transposed weight
+"""Invalidation epochs for every DERIVED copy of a parameter this package keeps: bf16 / bf16x3 / fp8 / transposed weight
 copies (linear._WeightCache), folded + packed conv weights (autoencoders._WNConvBase), fp32 LayerNorm parameters, and the
 no-grad inference caches of the DiT (embedded conditioning, CFG batch, cross-attention K / V planes).
 
@@ -7,14 +7,17 @@ in-place op on the parameter itself; it does NOT see
   * the fused optimizer kernel writing the flat parameter buffer (training.FusedAdamW.step),
   * updates made through `.data` — ema_pytorch's `ma_params.data.lerp_()` / `.copy_()`, which the reference's training
     wrappers use for the EMA models they demo / validate with (training/diffusion.py:58, :240-247; training/autoencoders.py:262-270).
-Both are covered by the epoch: it is bumped by FusedAdamW.step, by EVERY torch.optim optimizer step (a global
-`register_optimizer_step_post_hook`: an EMA update always follows an optimizer step, with no forward of the EMA model in
-between), by `ema_pytorch.EMA.update` itself when that package is importable (patch.patch_reference wraps it), and by
-`invalidate_weight_caches()` for any other out-of-band edit of `.data`.
+Both are covered by epochs, kept PER PARAMETER STORAGE (keyed on data_ptr): an optimizer step bumps the epochs of the
+parameters THAT optimizer owns — a frozen pretransform next to a training DiT keeps its folded / packed weights, the DiT's own
+copies are rebuilt — via FusedAdamW.step (its flat buffer's parameters), a global `register_optimizer_step_post_hook` (every
+torch.optim optimizer: its param_groups), and `ema_pytorch.EMA.update` (the EMA model's parameters; wrapped at import time
+when that package is importable, and again by patch.patch_reference).  `invalidate_weight_caches()` bumps a global epoch
+for any other out-of-band edit of `.data`.  `epoch_of(*tensors)` is the key component caches use.
 """
 import torch
 
 _EPOCH = 0
+_PARAM_EPOCH = {}        # data_ptr -> epoch of the storage that starts there (only ever grows: a recycled address costs one rebuild)
 _HOOKED = False
 
 
@@ -22,13 +25,31 @@ def weight_epoch():
     return _EPOCH
 
 
+def epoch_of(*tensors):
+    """Cache-key component for copies derived from `tensors`: (global epoch, per-storage epochs)."""
+    return (_EPOCH,) + tuple(_PARAM_EPOCH.get(t.data_ptr(), 0) for t in tensors if t is not None)
+
+
 def bump_weight_epoch(*_args, **_kwargs):
-    """Drop every derived weight copy and inference cache (they are rebuilt on next use)."""
+    """Drop EVERY derived weight copy and inference cache (they are rebuilt on next use)."""
     global _EPOCH
     _EPOCH += 1
 
 
 invalidate_weight_caches = bump_weight_epoch
+
+
+def bump_params(params):
+    """The storages of `params` were rewritten behind torch's version counters: drop what was derived from them (and only that)."""
+    for p in params:
+        if p is not None:
+            k = p.data_ptr()
+            _PARAM_EPOCH[k] = _PARAM_EPOCH.get(k, 0) + 1
+
+
+def _optimizer_post_hook(optimizer, *_args, **_kwargs):
+    for group in optimizer.param_groups:
+        bump_params(group["params"])
 
 
 def version_of(t):
@@ -52,7 +73,7 @@ def install_optimizer_hook():
     if _HOOKED:
         return
     from torch.optim.optimizer import register_optimizer_step_post_hook
-    register_optimizer_step_post_hook(bump_weight_epoch)
+    register_optimizer_step_post_hook(_optimizer_post_hook)
     _HOOKED = True
 
 
@@ -64,7 +85,12 @@ def wrap_ema_update(ema_cls):
 
     def update(self, *a, **kw):
         out = orig(self, *a, **kw)
-        bump_weight_epoch()
+        model = getattr(self, "ema_model", None)
+        if model is not None:
+            bump_params(model.parameters())
+            bump_params(model.buffers())
+        else:
+            bump_weight_epoch()
         return out
 
     update._sat_wrapped = True
@@ -72,3 +98,8 @@ def wrap_ema_update(ema_cls):
 
 
 install_optimizer_hook()
+try:        # outside patch_reference too: an EMA-model forward between optimizer.step and the `.data` EMA update must not see stale copies
+    from ema_pytorch import EMA as _EMA
+    wrap_ema_update(_EMA)
+except ImportError:
+    pass

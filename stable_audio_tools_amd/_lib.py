@@ -109,7 +109,8 @@ SIGNATURES = {
     "sat_gate_residual_bwd_nchunks": (_I, [_I]),
     "sat_cfg_step": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
     "sat_prefetch": (_I, [_P, _P, _I, _P]),
-    "sat_cfg_step_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
+    "sat_sampler_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
+    "sat_sampler_step_dev": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "sat_gate_residual_bwd": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
 }
 

@@ -44,7 +44,8 @@ class SnakeBeta(nn.Module):
         # identity 1x1 "conv" with the snake prologue: keeps the standalone call on the HIP path
         c = x.shape[1]
         eye = torch.eye(c, device=x.device, dtype=x.dtype).unsqueeze(-1)
-        return Fn.SnakeConv1dFn.apply(x, self.alpha, self.beta, eye, None, None, 1, 1, 0, False)
+        a, b = (self.alpha, self.beta) if self.alpha.dtype == torch.float32 else (self.alpha.detach().float(), self.beta.detach().float())
+        return Fn.SnakeConv1dFn.apply(x, a, b, eye, None, None, 1, 1, 0, False)
 
 
 class _NativeWeightNorm(_TorchWeightNorm):
@@ -61,7 +62,11 @@ class _NativeWeightNorm(_TorchWeightNorm):
         return module._fold_host()
 
     def remove(self, module):
-        module._to_folded(module._fold_host().detach())
+        # a module that already became folded by LOADING a weight-norm-removed checkpoint still carries this hook object: a later
+        # remove_weight_norm / remove_weight_norm_from_model (train.py `--remove-pretransform-weight-norm post_load`) then has nothing
+        # to fold — torch deletes the hook right after this call
+        if not module.is_folded:
+            module._to_folded(module._fold_host().detach())
 
     def __call__(self, module, inputs):
         return None
@@ -146,12 +151,26 @@ class _WNConvBase(nn.Module):
             state_dict[kw] = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
+    def p32(self, name, t):
+        """fp32 view of a parameter for the kernels.  After `.half()` / `.bfloat16()` on the module (AutoencoderPretransform's
+        `model_half`, models/pretransforms.py:48-49) the parameters are STORED in 16 bits — state_dict, memory and rounding as the
+        reference — while the HIP conv stack keeps computing at fp32 accuracy on those rounded values: the widened copy is made once
+        per parameter version (DerivedCache).  16-bit parameters cannot be trained through this path."""
+        if t is None or t.dtype == torch.float32:
+            return t
+        if t.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("16-bit parameters are inference-only on the HIP conv stack (freeze the model: AutoencoderPretransform does)")
+        return self._derived.get("f32/" + name, (t,), lambda: t.detach().float())
+
+    def bias32(self):
+        return self.p32("bias", self.bias)
+
     def folded_weight(self):
         """The conv weight for this pass: the `weight` parameter (folded layout), or g * v / ||v|| by sat_wn_fold — inside autograd
         when something is trained, from the layer's DerivedCache when nothing can ask for a gradient (no_grad, or a frozen layer)."""
         if self.is_folded:
-            return self._parameters["weight"]
-        v, g = self.weight_v, self.weight_g
+            return self.p32("weight", self._parameters["weight"])
+        v, g = self.p32("weight_v", self.weight_v), self.p32("weight_g", self.weight_g)
         if _inference_pass(v, g):
             return self._derived.get("folded", (v, g), lambda: Fn.WeightNormFn.apply(v.detach(), g.detach()))
         return Fn.WeightNormFn.apply(v, g)
@@ -165,8 +184,10 @@ class _WNConvBase(nn.Module):
 class WNConv1d(_WNConvBase):
     def forward(self, x, snake=None, res=None, tanh_out=False, next_snake=None):
         """next_snake: (log-alpha, log-beta, dilation) of the ResidualUnit that reads the output next — see ResidualUnit.forward."""
-        a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
-        return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias, res, self.stride, self.dilation,
+        a, b = (self.p32("alpha", snake.alpha), self.p32("beta", snake.beta)) if snake is not None else (None, None)
+        if next_snake is not None and next_snake[0].dtype != torch.float32:
+            next_snake = (self.p32("next_alpha", next_snake[0]), self.p32("next_beta", next_snake[1]), next_snake[2])
+        return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias32(), res, self.stride, self.dilation,
                                       self.padding, tanh_out, None, self.derived_cache(a, b), next_snake)
 
 
@@ -174,8 +195,8 @@ class WNConvTranspose1d(_WNConvBase):
     transposed = True
 
     def forward(self, x, snake=None):
-        a, b = (snake.alpha, snake.beta) if snake is not None else (None, None)
-        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias, self.stride, self.padding, None,
+        a, b = (self.p32("alpha", snake.alpha), self.p32("beta", snake.beta)) if snake is not None else (None, None)
+        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias32(), self.stride, self.padding, None,
                                         self.derived_cache(a, b))
 
 
@@ -218,8 +239,10 @@ class ResidualUnit(nn.Module):
         """next_snake: entry_snake() of the ResidualUnit that reads this unit's output next (None: something else does)."""
         s1, c1, s2, c2 = self.layers
         ca, cb = c1.derived_cache(s1.alpha, s1.beta), c2.derived_cache(s2.alpha, s2.beta)
-        return Fn.ResidualUnitFn.apply(x, s1.alpha, s1.beta, c1.folded_weight(), c1.bias,
-                                       s2.alpha, s2.beta, c2.folded_weight(), c2.bias, self.dilation, None,
+        if next_snake is not None and next_snake[0].dtype != torch.float32:
+            next_snake = (c2.p32("next_alpha", next_snake[0]), c2.p32("next_beta", next_snake[1]), next_snake[2])
+        return Fn.ResidualUnitFn.apply(x, c1.p32("alpha", s1.alpha), c1.p32("beta", s1.beta), c1.folded_weight(), c1.bias32(),
+                                       c2.p32("alpha", s2.alpha), c2.p32("beta", s2.beta), c2.folded_weight(), c2.bias32(), self.dilation, None,
                                        self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None,
                                        next_snake, self.fuse if self.fuse is not None else ("nokeep" if not torch.is_grad_enabled() else False))
 

@@ -8,6 +8,7 @@
 //   sat_gate_residual       x * sigmoid(1 - gate) + residual   :684-686, :699-701
 // One wave per token row, wavefront-shuffle reductions, 16-byte accesses where the layout allows.
 // dtype: 0 = fp32, 1 = bf16 tensors (statistics and math always fp32).
+#include <cstdio>
 #include "sat_device.h"
 
 template <typename T> struct SatIO;
@@ -522,81 +523,110 @@ extern "C" int sat_gate_residual(const void* x, const void* gate, long long gstr
 // ------------------------------------------------------------------------------------------------
 // Classifier-free-guidance combine + CFG rescale + sampler update in one pass
 // (reference: models/dit.py:400-410 — cond/uncond chunk, uncond + (cond - uncond) * scale, channel-std rescale with
-//  scale_phi; inference/sampling.py:254-307 v-DDIM update, :98-135 rectified-flow Euler update).
+//  scale_phi; inference/sampling.py — the per-step updates of EVERY sampler there are linear in (x, v, one more tensor, the
+//  unconditioned output): v-DDIM :254-307 (eta > 0: + fresh noise; cfg_pp: eps from the unconditioned output), rectified-flow
+//  Euler :98-135, RK4 stages :138-177 (third operand = the running k-sum), DPM-Solver++ :179-219 (third operand = the previous
+//  step's denoised), ping-pong :222-250 (third operand = fresh noise)).
 //   out2: (ncond * B, C, T) model output, conditioned half first (ncond = 2), or the plain output (ncond = 1)
-//   v    = ncond == 2 ? rescale(uncond + (cond - uncond) * scale) : out2
-//   y0   = c0x * x + c0v * v           (x == NULL: y0 = v)
-//   y1   = c1x * x + c1v * v           (optional second output, e.g. DDIM's `pred` beside the next x)
+//   v    = ncond == 2 ? rescale(uncond + (cond - uncond) * scale) : out2;   u = the unconditioned half (ncond 2) or v (ncond 1)
+//   y0   = c0x * x + c0v * v + c0p * p + c0u * u           (x == NULL: y0 = v)
+//   y1   = c1x * x + c1v * v + c1p * p + c1u * u           (optional second output: DDIM's `pred`, DPM++'s `denoised`, ...)
+//   coefficient order (host array or device buffer, fp32): c0x c0v c0p c0u c1x c1v c1p c1u;  p optional (its terms drop out)
 // One thread per (b, t) column, two passes over the C channels (unbiased channel std, as torch.std(dim=1)).
 // ------------------------------------------------------------------------------------------------
 struct SatCfgParams {
     const void* out2;
     const void* x;
+    const void* prev;
     void* y0;
     void* y1;
     int B, C, T, ncond;
-    float scale, phi, c0x, c0v, c1x, c1v;
-    const float* coef;    // device (c0x, c0v, c1x, c1v) overriding the by-value ones (HIP-graph replay: the launch is frozen)
+    float scale, phi;
+    float c[8];
+    const float* coef;    // device coefficients overriding the by-value ones (HIP-graph replay: the launch is frozen)
 };
 template <typename T>
 __global__ void __launch_bounds__(256) sat_cfg_step_kernel(SatCfgParams p) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)p.B * p.T) return;
-    if (p.coef) { p.c0x = p.coef[0]; p.c0v = p.coef[1]; p.c1x = p.coef[2]; p.c1v = p.coef[3]; }
+    if (p.coef) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p.c[j] = p.coef[j];
+    }
     const int b = (int)(i / p.T), t = (int)(i - (long long)b * p.T);
     const long long cbase = (long long)b * p.C * p.T + t;
     const long long ubase = cbase + (long long)p.B * p.C * p.T;
     float ratio = 1.0f;
     if (p.ncond == 2 && p.phi != 0.0f) {
-        float sc = 0.f, sc2 = 0.f, sg = 0.f, sg2 = 0.f;
+        // Welford: the one-pass sum / sum-of-squares form loses ~1e-4 of the std when |mean| is comparable to it (torch.std is two-pass)
+        float mc = 0.f, qc = 0.f, mg = 0.f, qg = 0.f;
         for (int c = 0; c < p.C; ++c) {
             const float cv = SatIO<T>::ld(p.out2, cbase + (long long)c * p.T), uv = SatIO<T>::ld(p.out2, ubase + (long long)c * p.T);
             const float g = uv + (cv - uv) * p.scale;
-            sc += cv; sc2 += cv * cv; sg += g; sg2 += g * g;
+            const float rn = 1.0f / (float)(c + 1);
+            const float dc = cv - mc, dg = g - mg;
+            mc += dc * rn; mg += dg * rn;
+            qc += dc * (cv - mc); qg += dg * (g - mg);
         }
-        const float n = (float)p.C, dn = (float)(p.C > 1 ? p.C - 1 : 1);
-        const float var_c = fmaxf(sc2 - sc * sc / n, 0.f) / dn, var_g = fmaxf(sg2 - sg * sg / n, 0.f) / dn;
+        const float dn = (float)(p.C > 1 ? p.C - 1 : 1);
+        const float var_c = fmaxf(qc, 0.f) / dn, var_g = fmaxf(qg, 0.f) / dn;
         ratio = p.phi * (sqrtf(var_c) / sqrtf(var_g)) + (1.0f - p.phi);
     }
     for (int c = 0; c < p.C; ++c) {
         const long long o = cbase + (long long)c * p.T;
         float v = SatIO<T>::ld(p.out2, o);
+        float u = v;
         if (p.ncond == 2) {
-            const float uv = SatIO<T>::ld(p.out2, ubase + (long long)c * p.T);
-            v = (uv + (v - uv) * p.scale) * ratio;
+            u = SatIO<T>::ld(p.out2, ubase + (long long)c * p.T);
+            v = (u + (v - u) * p.scale) * ratio;
         }
         if (p.x) {
             const float xv = SatIO<T>::ld(p.x, o);
-            SatIO<T>::st(p.y0, o, p.c0x * xv + p.c0v * v);
-            if (p.y1) SatIO<T>::st(p.y1, o, p.c1x * xv + p.c1v * v);
+            float r0 = p.c[0] * xv + p.c[1] * v, r1 = p.c[4] * xv + p.c[5] * v;
+            if (p.prev) {
+                const float pv = SatIO<T>::ld(p.prev, o);
+                r0 += p.c[2] * pv;
+                r1 += p.c[6] * pv;
+            }
+            if (p.c[3] != 0.f) r0 += p.c[3] * u;
+            if (p.c[7] != 0.f) r1 += p.c[7] * u;
+            SatIO<T>::st(p.y0, o, r0);
+            if (p.y1) SatIO<T>::st(p.y1, o, r1);
         } else {
             SatIO<T>::st(p.y0, o, v);
         }
     }
 }
+static int sat_cfg_launch(const char* who, const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T,
+                          int ncond, float scale, float phi, const float* host_coef, const float* dev_coef, int dtype, void* stream) {
+    char msg[96];
+    if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { snprintf(msg, sizeof msg, "%s: bad shape", who); sat_set_error(msg); return 1; }
+    if (dtype != 0 && dtype != 1) { snprintf(msg, sizeof msg, "%s: dtype must be 0 (f32) or 1 (bf16)", who); sat_set_error(msg); return 1; }
+    if (!out2 || !y0 || ((y1 || prev) && !x)) { snprintf(msg, sizeof msg, "%s: missing buffer", who); sat_set_error(msg); return 1; }
+    SatCfgParams p{out2, x, prev, y0, y1, B, C, T, ncond, scale, phi, {0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dev_coef};
+    if (host_coef) for (int j = 0; j < 8; ++j) p.c[j] = host_coef[j];
+    const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
+    if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch(who);
+}
 extern "C" int sat_cfg_step(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
                             float phi, float c0x, float c0v, float c1x, float c1v, int dtype, void* stream) {
-    if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { sat_set_error("sat_cfg_step: bad shape"); return 1; }
-    if (dtype != 0 && dtype != 1) { sat_set_error("sat_cfg_step: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
-    if (!out2 || !y0 || (y1 && !x)) { sat_set_error("sat_cfg_step: missing buffer"); return 1; }
-    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, c0x, c0v, c1x, c1v, nullptr};
-    const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
-    if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
-    else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
-    return sat_check_launch("sat_cfg_step");
+    const float c[8] = {c0x, c0v, 0.f, 0.f, c1x, c1v, 0.f, 0.f};
+    return sat_cfg_launch("sat_cfg_step", out2, x, nullptr, y0, y1, B, C, T, ncond, scale, phi, c, nullptr, dtype, stream);
 }
-// The same with the four update coefficients read from DEVICE memory (coef[4] fp32): a sampler step captured into a HIP graph is
-// replayed with new coefficients by rewriting that buffer (sampling.GraphedDenoiser).
-extern "C" int sat_cfg_step_dev(const void* out2, const void* x, void* y0, void* y1, int B, int C, int T, int ncond, float scale,
-                                float phi, const float* coef, int dtype, void* stream) {
-    if (B <= 0 || C <= 0 || T <= 0 || (ncond != 1 && ncond != 2)) { sat_set_error("sat_cfg_step_dev: bad shape"); return 1; }
-    if (dtype != 0 && dtype != 1) { sat_set_error("sat_cfg_step_dev: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
-    if (!out2 || !y0 || !x || !coef) { sat_set_error("sat_cfg_step_dev: missing buffer"); return 1; }
-    SatCfgParams p{out2, x, y0, y1, B, C, T, ncond, scale, phi, 0.f, 1.f, 0.f, 0.f, coef};
-    const dim3 grid((unsigned)sat_cdivll((long long)B * T, 256));
-    if (dtype == 0) SAT_LAUNCH(sat_cfg_step_kernel<float>, grid, dim3(256), stream, p);
-    else SAT_LAUNCH(sat_cfg_step_kernel<short>, grid, dim3(256), stream, p);
-    return sat_check_launch("sat_cfg_step_dev");
+// The general form: third operand `prev` (may be NULL) and the unconditioned-output terms; coef[8] on the HOST.
+extern "C" int sat_sampler_step(const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T, int ncond,
+                                float scale, float phi, const float* coef, int dtype, void* stream) {
+    if (!coef) { sat_set_error("sat_sampler_step: coef is NULL"); return 1; }
+    return sat_cfg_launch("sat_sampler_step", out2, x, prev, y0, y1, B, C, T, ncond, scale, phi, coef, nullptr, dtype, stream);
+}
+// The same with the coefficients read from DEVICE memory (coef[8] fp32): a sampler step captured into a HIP graph is replayed
+// with new coefficients by rewriting that buffer (sampling.GraphedDenoiser).
+extern "C" int sat_sampler_step_dev(const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T, int ncond,
+                                    float scale, float phi, const float* coef, int dtype, void* stream) {
+    if (!coef || !x) { sat_set_error("sat_sampler_step_dev: missing buffer"); return 1; }
+    return sat_cfg_launch("sat_sampler_step_dev", out2, x, prev, y0, y1, B, C, T, ncond, scale, phi, nullptr, coef, dtype, stream);
 }
 
 

@@ -103,10 +103,10 @@ class DiffusionTransformer(nn.Module):
         """to_cond_embed(cond); in inference the result is cached per (cond object, version, weights version): a sampler passes the
         same conditioning tensor at every step, and returning the same embedded tensor lets every cross-attention layer keep its
         K / V planes (transformer.Attention) instead of re-projecting the context at each step."""
-        if torch.is_grad_enabled() or not _caches.trackable(cond):       # inference tensors carry no version counter: no caching
+        if torch.is_grad_enabled() or not _caches.trackable(cond, *self.to_cond_embed.parameters()):   # inference tensors carry no version counter
             return self.to_cond_embed(cond)
-        key = (cond._version, cond.dtype, tuple(cond.shape), _caches.weight_epoch()) \
-            + tuple((q._version, q.data_ptr()) for q in self.to_cond_embed.parameters())
+        key = (_caches.version_of(cond), cond.dtype, tuple(cond.shape), _caches.epoch_of(*self.to_cond_embed.parameters())) \
+            + tuple((_caches.version_of(q), q.data_ptr()) for q in self.to_cond_embed.parameters())
         if getattr(self, "_cond_src", None) is cond and self._cond_key == key:
             return self._cond_out
         out = self.to_cond_embed(cond)
@@ -177,12 +177,19 @@ class DiffusionTransformer(nn.Module):
     def forward(self, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
                 negative_cross_attn_mask=None, input_concat_cond=None, global_embed=None, negative_global_embed=None,
                 prepend_cond=None, prepend_cond_mask=None, cfg_scale=1.0, cfg_dropout_prob=0.0, cfg_interval=(0, 1),
-                causal=False, scale_phi=0.0, mask=None, return_info=False, exit_layer_ix=None, fused_update=None, **kwargs):
-        """fused_update (native extension, never passed by reference callers): (c0x, c0v, c1x, c1v) — instead of the model
-        output v, return (c0x*x + c0v*v, c1x*x + c1v*v): the sampler's update of x folded into the guidance-combine kernel
-        (no-grad only)."""
+                causal=False, scale_phi=0.0, mask=None, return_info=False, exit_layer_ix=None, fused_update=None, fused_prev=None,
+                fused_x=None, **kwargs):
+        """fused_update (native extension, never passed by reference callers): instead of the model output v, return
+        (y0, y1) = (c0x*x + c0v*v + c0p*p + c0u*u, c1x*x + c1v*v + c1p*p + c1u*u) — the sampler's update of x folded into the
+        guidance-combine kernel (no-grad only).  fused_update = the 8 coefficients in that order (host sequence, or a device fp32
+        tensor for HIP-graph replay; 4 values = (c0x, c0v, c1x, c1v)); p = fused_prev (third operand: previous denoised, RK4 sum,
+        fresh noise); u = the unconditioned output; x = fused_x when given (RK4 stages update the step's x, not the stage input),
+        else the model input."""
         assert causal is False, "Causal mode is not supported for DiffusionTransformer"
         x_in = x
+
+        def fused_base():
+            return fused_x if fused_x is not None else x_in
         dt = next(self.parameters()).dtype
 
         def cast(a):
@@ -223,7 +230,8 @@ class DiffusionTransformer(nn.Module):
                                 prepend_cond_mask=prepend_cond_mask, **common)
             if fused_update is not None:
                 assert not return_info and not torch.is_grad_enabled()
-                return _fn._ops(None).cfg_step(out.contiguous(), 1, x=x_in.to(out.dtype).contiguous(), coef=fused_update, want_second=True)
+                return _fn._ops(None).cfg_step(out.contiguous(), 1, x=fused_base().to(out.dtype).contiguous(), coef=fused_update, want_second=True,
+                                               prev=fused_prev.to(out.dtype).contiguous() if fused_prev is not None else None)
             return out
 
         # classifier-free guidance: conditioned and unconditioned halves in one batch (dit.py:328-395)
@@ -261,7 +269,8 @@ class DiffusionTransformer(nn.Module):
             # inference: guidance combine, channel-std rescale and (optionally) the sampler update in ONE kernel (sat_cfg_step)
             ops = _fn._ops(None)
             if fused_update is not None:
-                return ops.cfg_step(out.contiguous(), 2, cfg_scale, scale_phi, x=x_in.to(out.dtype).contiguous(), coef=fused_update, want_second=True)
+                return ops.cfg_step(out.contiguous(), 2, cfg_scale, scale_phi, x=fused_base().to(out.dtype).contiguous(), coef=fused_update,
+                                    want_second=True, prev=fused_prev.to(out.dtype).contiguous() if fused_prev is not None else None)
             return ops.cfg_step(out.contiguous(), 2, cfg_scale, scale_phi)
         assert fused_update is None
         cond_output, uncond_output = torch.chunk(out, 2, dim=0)

@@ -21,18 +21,10 @@ from . import ops as _ops_mod
 from .ops import PACK_CONV_DGRAD, PACK_CONV_FWD, PACK_POLYPHASE
 
 
-# Test seam: the CPU test-suite points this at a SatOps bound to the host-side *simulator* build of
-# the kernel sources (tests/emu).  Product code never sets it; with it unset every call goes to the
-# gfx950 library or raises (ops.get_ops()).
-_TEST_OPS = None
-
-
 def _ops(ops):
-    if ops is not None:
-        return ops
-    if _TEST_OPS is not None:
-        return _TEST_OPS
-    return _ops_mod.get_ops()
+    """An explicitly passed SatOps, else the product singleton (gfx950 library, or raises).  There is no test hook in this dispatch:
+    the CPU test-suite substitutes `ops.get_ops` itself from its fixtures (tests/emu_util.use_emu_ops)."""
+    return ops if ops is not None else _ops_mod.get_ops()
 
 
 class DerivedCache:
@@ -46,7 +38,11 @@ class DerivedCache:
 
     def get(self, name, sources, make):
         from . import _caches
-        key = tuple((t.data_ptr(), t._version, t.device) for t in sources if t is not None) + (_caches.weight_epoch(),)
+        if not _caches.trackable(*sources):
+            # inference tensors (parameters created / loaded under torch.inference_mode) carry no version counter: an in-place edit
+            # would leave no trace, so nothing derived from them is kept
+            return make()
+        key = tuple((t.data_ptr(), _caches.version_of(t), t.device) for t in sources if t is not None) + _caches.epoch_of(*sources)
         hit = self.items.get(name)
         if hit is None or hit[0] != key:
             hit = (key, make())

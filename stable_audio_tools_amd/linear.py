@@ -52,7 +52,9 @@ class _WeightCache:
         self.items = {}
 
     def get(self, w, name, make):
-        key = (w.data_ptr(), w._version, w.dtype, w.device, _caches.weight_epoch())
+        if not _caches.trackable(w):          # a parameter created under torch.inference_mode: no version counter, nothing is kept
+            return make()
+        key = (w.data_ptr(), _caches.version_of(w), w.dtype, w.device, _caches.epoch_of(w))
         hit = self.items.get(name)
         if hit is None or hit[0] != key:
             hit = (key, make())

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _caches, _lib
 
 PACK_CONV_FWD = 0      # w[d0][d1][K] -> [d1][k][d0]
 PACK_CONV_DGRAD = 1    # w[d0][d1][K] -> [d0][K-1-k][d1]
@@ -20,6 +20,18 @@ def _ptr(t):
     if t is None:
         return None
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _keep_zeros(shape, dtype, device):
+    """A workspace that outlives the call (plane pools, slabs, zero pages): allocated as an ORDINARY tensor even when the first use
+    happens under torch.inference_mode — an inference tensor could not be sliced-and-zeroed by a later call outside that mode."""
+    with torch.inference_mode(False):
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def _keep_empty(shape, dtype, device):
+    with torch.inference_mode(False):
+        return torch.empty(shape, dtype=dtype, device=device)
 
 
 class SatOps:
@@ -202,7 +214,7 @@ class SatOps:
                                                       _ptr(res), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb),
                                                       b, cin, cout, tin, tout, *dims, int(tanh_out), _ptr(ehi), _ptr(elo), _ptr(ea), _ptr(eib),
                                                       erows, self._stream(x)))
-            self._emitted = {"ptr": y.data_ptr(), "shape": tuple(y.shape), "snake": self._snake_key(esnake), "hi": ehi, "lo": elo, "rows": erows}
+            self._note_emitted(y, esnake, ehi, elo, erows)
             if dsnake is not None:
                 return (y, *self._sum_pair(pda, pdb))
             return y
@@ -252,7 +264,7 @@ class SatOps:
             wkey = ("k7p", x.device, st.value if st is not None else 0)
             ws = self.__dict__.setdefault("_planes", {}).get(wkey)
             if ws is None or ws.numel() < need:
-                ws = torch.empty(need, dtype=torch.int16, device=x.device)
+                ws = _keep_empty(need, torch.int16, x.device)
                 self._planes[wkey] = ws
             hi, lo = ws[:need // 2], ws[need // 2:need]
             self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa1), _ptr(sib1), _ptr(hi), _ptr(lo), b, c, t, rows, st))
@@ -273,7 +285,7 @@ class SatOps:
                                                  _ptr(w1q[0]), _ptr(w1q[1]), _ptr(bias2), _ptr(x), _ptr(h), _ptr(y), b, c, t, k, dil, pad,
                                                  _ptr(ehi), _ptr(elo), _ptr(ea), _ptr(eib), erows, st))
         if emit is not None:
-            self._emitted = {"ptr": y.data_ptr(), "shape": tuple(y.shape), "snake": self._snake_key(emit.get("snake")), "hi": ehi, "lo": elo, "rows": erows}
+            self._note_emitted(y, emit.get("snake"), ehi, elo, erows)
         return h, y
 
     # ---- plane emission bookkeeping: producer -> the ONE k7 conv that consumes its output next ----
@@ -281,7 +293,17 @@ class SatOps:
 
     @staticmethod
     def _snake_key(snake):
-        return None if snake is None else (snake[0].data_ptr(), snake[1].data_ptr(), snake[0]._version, snake[1]._version)
+        return None if snake is None else (snake[0].data_ptr(), snake[1].data_ptr(), _caches.version_of(snake[0]), _caches.version_of(snake[1]))
+
+    def _note_emitted(self, y, snake, hi, lo, rows):
+        """Record that (hi, lo) hold act(y)'s planes — valid for exactly this storage, shape, activation and VERSION of y: an
+        in-place edit of y between producer and consumer (a forward hook) makes the consumer rebuild the planes.  Inference tensors
+        have no version counter, so their emission is never trusted (the consumer runs its planes pre-pass)."""
+        if not _caches.trackable(y, *(snake or ())):
+            self._emitted = None
+            return
+        self._emitted = {"ptr": y.data_ptr(), "shape": tuple(y.shape), "ver": _caches.version_of(y), "snake": self._snake_key(snake),
+                         "hi": hi, "lo": lo, "rows": rows}
 
     def emit_ok(self, cout, k, stride, tout, consumer_dil):
         """May the conv (k, stride) producing (B, cout, tout) emit planes for a k7 conv of dilation consumer_dil that reads it next?"""
@@ -300,7 +322,7 @@ class SatOps:
         pl = cache.get(key)
         if pl is None:
             n = b * ((c + 7) // 8) * rows * 8
-            pl = (torch.zeros(n, dtype=torch.int16, device=device), torch.zeros(n, dtype=torch.int16, device=device), rows)
+            pl = (_keep_zeros(n, torch.int16, device), _keep_zeros(n, torch.int16, device), rows)
             cache[key] = pl
         return pl
 
@@ -310,7 +332,8 @@ class SatOps:
         if e is None:
             return None
         self._emitted = None
-        if e["ptr"] == x.data_ptr() and e["shape"] == tuple(x.shape) and e["snake"] == self._snake_key(snake):
+        if (e["ptr"] == x.data_ptr() and e["shape"] == tuple(x.shape) and _caches.trackable(x) and e["ver"] == _caches.version_of(x)
+                and e["snake"] == self._snake_key(snake)):
             return e
         return None
 
@@ -355,7 +378,7 @@ class SatOps:
             wkey = ("k7p", x.device, st.value if st is not None else 0)       # one workspace per (device, stream)
             ws = self.__dict__.setdefault("_planes", {}).get(wkey)
             if ws is None or ws.numel() < need:
-                ws = torch.empty(need, dtype=torch.int16, device=x.device)
+                ws = _keep_empty(need, torch.int16, x.device)
                 self._planes[wkey] = ws
             hi, lo = ws[:need // 2], ws[need // 2:need]
             self._chk(self.lib.sat_conv1d_k7_planes(_ptr(x), _ptr(sa), _ptr(sib), _ptr(hi), _ptr(lo), b, cin, tin, rows, st))
@@ -599,7 +622,7 @@ class SatOps:
         pool = self.__dict__.setdefault("_disc_pool", {})
         e = pool.get(key)
         if e is None or e["cap"] < n:
-            e = pool[key] = {"hi": torch.zeros(n, dtype=torch.int16, device=device), "lo": torch.zeros(n, dtype=torch.int16, device=device),
+            e = pool[key] = {"hi": _keep_zeros(n, torch.int16, device), "lo": _keep_zeros(n, torch.int16, device),
                              "cap": n, "geom": (b, c8, frames, w)}
         elif e["geom"] != (b, c8, frames, w):
             for t in (e["hi"], e["lo"]):
@@ -612,14 +635,17 @@ class SatOps:
     def disc_register(self, t, planes, c, frames, w, slot):
         """Remember that `planes` (slot `slot`) hold tensor t's operand planes (consumed by disc_take if nothing wrote the slot since)."""
         key = (t.device, 0 if (c + 7) // 8 == 1 else 1, slot)
-        self._disc_emitted = {"ptr": t.data_ptr(), "ver": t._version, "key": key, "gen": self.__dict__.get("_disc_gen", {}).get(key, 0),
+        if not _caches.trackable(t):          # inference tensor: no version counter, the emission cannot be validated later
+            self._disc_emitted = None
+            return
+        self._disc_emitted = {"ptr": t.data_ptr(), "ver": _caches.version_of(t), "key": key, "gen": self.__dict__.get("_disc_gen", {}).get(key, 0),
                               "geom": (t.shape[0], (c + 7) // 8, frames, w), "planes": planes, "slot": slot}
 
     def disc_take(self, h, c, frames, w):
         """((hi, lo) planes of the pitched tensor h, their slot): the producer's emission if it is still intact, else a planes pass."""
         e = self.__dict__.get("_disc_emitted")
         self._disc_emitted = None
-        if (e is not None and e["ptr"] == h.data_ptr() and e["ver"] == h._version and e["geom"] == (h.shape[0], (c + 7) // 8, frames, w)
+        if (e is not None and e["ptr"] == h.data_ptr() and _caches.trackable(h) and e["ver"] == _caches.version_of(h) and e["geom"] == (h.shape[0], (c + 7) // 8, frames, w)
                 and self.__dict__.get("_disc_gen", {}).get(e["key"], 0) == e["gen"]):
             return e["planes"], e["slot"]
         return self.disc_planes(h, frames, w, slot=0)[1], 0
@@ -883,26 +909,38 @@ class SatOps:
         dgate = torch.stack([self._reduce_rows(part[i], nch, d) for i in range(b)])
         return dx, dgate
 
-    def cfg_step(self, out2, ncond, cfg_scale=1.0, scale_phi=0.0, x=None, coef=None, want_second=False):
+    def cfg_step(self, out2, ncond, cfg_scale=1.0, scale_phi=0.0, x=None, coef=None, want_second=False, prev=None):
         """Guidance combine (+rescale) of the batched model output and, with x/coef, the sampler update in the same pass:
-        out2 (ncond*B, C, T); returns v, or (c0x*x + c0v*v [, c1x*x + c1v*v]) for coef = (c0x, c0v, c1x, c1v)."""
+        out2 (ncond*B, C, T); returns v, or (y0 [, y1]) with
+            y0 = c0x*x + c0v*v + c0p*prev + c0u*u,   y1 = c1x*x + c1v*v + c1p*prev + c1u*u      (u = the unconditioned output)
+        coef: 4 values (c0x, c0v, c1x, c1v) or 8 values (c0x c0v c0p c0u c1x c1v c1p c1u) — a host sequence, or a DEVICE fp32
+        tensor of 8 (HIP-graph replay: the kernel reads it)."""
         dt = self._dt(out2, x)
-        if not out2.is_contiguous() or (x is not None and not x.is_contiguous()):
+        if not out2.is_contiguous() or (x is not None and not x.is_contiguous()) or (prev is not None and not prev.is_contiguous()):
             raise ValueError("cfg_step: contiguous tensors expected")
         nb2, c, t = out2.shape
         b = nb2 // ncond
+        if prev is not None and (x is None or prev.shape != x.shape or prev.dtype != out2.dtype):
+            raise ValueError("cfg_step: prev must match x")
         y0 = torch.empty(b, c, t, dtype=out2.dtype, device=out2.device)
         y1 = torch.empty_like(y0) if (want_second and x is not None) else None
-        if isinstance(coef, torch.Tensor):        # device coefficients (HIP-graph replay): 4 fp32 values read by the kernel
+        if isinstance(coef, torch.Tensor):        # device coefficients (HIP-graph replay): 8 fp32 values read by the kernel
             self._f32(coef)
-            if coef.numel() != 4 or x is None:
-                raise ValueError("cfg_step: device coef must hold (c0x, c0v, c1x, c1v) and needs x")
-            self._chk(self.lib.sat_cfg_step_dev(_ptr(out2), _ptr(x), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale), float(scale_phi),
-                                                _ptr(coef), dt, self._stream(out2)))
+            if coef.numel() != 8 or x is None:
+                raise ValueError("cfg_step: device coef must hold 8 fp32 values (c0x c0v c0p c0u c1x c1v c1p c1u) and needs x")
+            self._chk(self.lib.sat_sampler_step_dev(_ptr(out2), _ptr(x), _ptr(prev), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale),
+                                                    float(scale_phi), _ptr(coef), dt, self._stream(out2)))
             return (y0, y1) if y1 is not None else y0
-        c0x, c0v, c1x, c1v = coef if coef is not None else (0.0, 1.0, 0.0, 0.0)
-        self._chk(self.lib.sat_cfg_step(_ptr(out2), _ptr(x), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale), float(scale_phi),
-                                        float(c0x), float(c0v), float(c1x), float(c1v), dt, self._stream(out2)))
+        coef = tuple(float(v) for v in coef) if coef is not None else (0.0, 1.0, 0.0, 0.0)
+        if len(coef) == 4:
+            coef = (coef[0], coef[1], 0.0, 0.0, coef[2], coef[3], 0.0, 0.0)
+        if len(coef) != 8:
+            raise ValueError("cfg_step: coef takes 4 or 8 values")
+        if (coef[2] != 0.0 or coef[6] != 0.0) and prev is None:
+            raise ValueError("cfg_step: a coefficient on `prev` without the tensor")
+        host = (ctypes.c_float * 8)(*coef)
+        self._chk(self.lib.sat_sampler_step(_ptr(out2), _ptr(x), _ptr(prev), _ptr(y0), _ptr(y1), b, c, t, ncond, float(cfg_scale),
+                                            float(scale_phi), host, dt, self._stream(out2)))
         return (y0, y1) if y1 is not None else y0
 
     # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
@@ -912,7 +950,7 @@ class SatOps:
     def _zeros_page(self, device):
         z = getattr(self, "_zpage", None)
         if z is None or z.device != device:
-            z = torch.zeros(64, dtype=torch.int16, device=device)
+            z = _keep_zeros(64, torch.int16, device)
             self._zpage = z
         return z
 
@@ -980,7 +1018,7 @@ class SatOps:
         cache = self.__dict__.setdefault("_planes", {})
         t = cache.get(key)
         if t is None or t.shape != shape or t.device != device:
-            t = torch.zeros(shape, dtype=torch.int16, device=device)
+            t = _keep_zeros(shape, torch.int16, device)
             cache[key] = t
         return t
 
@@ -992,7 +1030,7 @@ class SatOps:
         key = ("splitk", splits, m, n, a.device, st.value if st is not None else 0)      # one slab set per (device, stream)
         slabs = self.__dict__.setdefault("_planes", {}).get(key)
         if slabs is None:
-            slabs = torch.empty(splits, m, n, dtype=torch.float32, device=a.device)
+            slabs = _keep_empty((splits, m, n), torch.float32, a.device)
             self._planes[key] = slabs
         self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(slabs), n, None, None, 0, None, 0, 0, None, 0,
                                          _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits, self._pick_tile(m, n, splits),
@@ -1062,7 +1100,7 @@ class SatOps:
         wkey = ("absmax", src.device, st.value if st is not None else 0)
         work = self.__dict__.setdefault("_planes", {}).get(wkey)
         if work is None:
-            work = torch.zeros(1 + 1024, dtype=torch.float32, device=src.device)
+            work = _keep_zeros(1 + 1024, torch.float32, src.device)
             self._planes[wkey] = work
         scales = torch.empty(2, dtype=torch.float32, device=src.device)
         self._chk(self.lib.sat_absmax_scale(_ptr(src), src.stride(0), _ptr(work), _ptr(scales), src.shape[0], src.shape[1], int(dt == 0), st))

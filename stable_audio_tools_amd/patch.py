@@ -15,6 +15,7 @@ module namespace at call time —
   models/factory.py:32-54        create_pretransform_from_config    -> pretransforms.AutoencoderPretransform
   models/factory.py:89-99        create_bottleneck_from_config      -> bottleneck.VAEBottleneck
   training/losses/auraloss.py    STFTLoss / MultiResolutionSTFTLoss / SumAndDifferenceSTFTLoss (training/autoencoders.py:142-146)
+  inference/generation.py:6, :200-206  sample_k / sample_rf   -> the in-tree samplers with the fused sampler step (sampling.py)
 — so rebinding those names is the whole integration.  Everything else (ConditionedDiffusionModelWrapper,
 conditioners, AudioAutoencoder's chunking glue, samplers, Lightning wrappers) stays the reference's code and
 only ever calls the module API the native classes mirror.
@@ -24,8 +25,17 @@ import sys
 
 
 def _registry():
-    from . import auraloss, autoencoders, bottleneck, discriminators, dit, pretransforms, transformer
+    from . import auraloss, autoencoders, bottleneck, discriminators, dit, pretransforms, sampling, transformer
     return [
+        # the in-tree samplers with the fused sampler step: what generate_diffusion_cond[_inpaint] call
+        # (inference/generation.py:200-206); sample_k is rebound separately below (its k-diffusion types stay the reference's)
+        ("inference.generation", "sample_rf", sampling.sample_rf),
+        ("inference.sampling", "sample_rf", sampling.sample_rf),
+        ("inference.sampling", "sample_discrete_euler", sampling.sample_discrete_euler),
+        ("inference.sampling", "sample_rk4", sampling.sample_rk4),
+        ("inference.sampling", "sample_flow_dpmpp", sampling.sample_flow_dpmpp),
+        ("inference.sampling", "sample_flow_pingpong", sampling.sample_flow_pingpong),
+        ("inference.sampling", "sample", sampling.sample),
         # (reference module, attribute, native object)
         ("models.dit", "DiffusionTransformer", dit.DiffusionTransformer),
         ("models.diffusion", "DiffusionTransformer", dit.DiffusionTransformer),
@@ -65,7 +75,19 @@ class PatchHandle:
         self.applied.clear()
 
 
-def patch_reference(package="stable_audio_tools", import_missing=("models",)):
+def _sample_k_dispatch(ref_sample_k):
+    """generation.sample_k while patched: the two sampler types that live in the reference itself ("v-ddim", "v-ddim-cfgpp") run on
+    the native loop with the fused step; the k-diffusion types stay the reference's own code around the (native) model."""
+    from . import sampling
+
+    def sample_k(model_fn, noise, init_data=None, steps=100, sampler_type="dpmpp-2m-sde", *args, **kwargs):
+        if sampler_type in ("v-ddim", "v-ddim-cfgpp") and not args and kwargs.get("cond_fn") is None:
+            return sampling.sample_k(model_fn, noise, init_data, steps, sampler_type, **kwargs)
+        return ref_sample_k(model_fn, noise, init_data, steps, sampler_type, *args, **kwargs)
+    return sample_k
+
+
+def patch_reference(package="stable_audio_tools", import_missing=("models", "inference")):
     """Rebind the hot-path class names inside the reference package `package` to the native classes.
 
     Modules of the reference that are already imported are always patched; those under the sub-packages named
@@ -86,6 +108,11 @@ def patch_reference(package="stable_audio_tools", import_missing=("models",)):
         handle._saved.append((mod, attr, getattr(mod, attr)))
         setattr(mod, attr, native)
         handle.applied.append((name, attr))
+    gen = sys.modules.get(f"{package}.inference.generation")
+    if gen is not None and hasattr(gen, "sample_k"):
+        handle._saved.append((gen, "sample_k", gen.sample_k))
+        gen.sample_k = _sample_k_dispatch(gen.sample_k)
+        handle.applied.append((f"{package}.inference.generation", "sample_k"))
     # the reference's training wrappers keep EMA copies of the native models and update them through `.data` (ema_pytorch:
     # training/diffusion.py:58, :240-247; training/autoencoders.py:262-270) — invisible to torch's version counters, so every
     # EMA update also bumps the invalidation epoch of the derived-weight / inference caches (_caches.py)

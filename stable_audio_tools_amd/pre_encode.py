@@ -25,14 +25,17 @@ def _jsonable(v):
 
 class PreEncoder:
     """Encodes batches of audio with `model.encode` (an AudioAutoencoder or anything with the same method) and writes them
-    as the reference's pre-encoded dataset.  `model_half` casts the audio to fp16 in the reference (pre_encode.py:83-84); the
-    native VAE runs fp32 (bf16x3), so it is rejected."""
+    as the reference's pre-encoded dataset.  `model_half` (pre_encode.py:31-32 `model.to(torch.float16)`, :84-85 the audio cast): the
+    model's parameters are stored in fp16 and the audio is rounded to fp16 as in the reference; the HIP conv stack computes at fp32
+    accuracy on those rounded values (autoencoders._WNConvBase.p32) and the latents are written as fp16, the dtype the reference's
+    half model produces."""
 
     def __init__(self, model, output_path, rank=0, is_discrete=False, model_half=False, details=None):
         if is_discrete:
             raise NotImplementedError("discrete (token) bottlenecks are out of scope")
-        if model_half:
-            raise NotImplementedError("model_half pre-encoding is not on the HIP path (the native VAE computes in fp32-accurate bf16x3)")
+        self.model_half = bool(model_half)
+        if self.model_half:
+            model.half()
         self.model = model
         self.output_path = str(output_path)
         self.rank = int(rank)
@@ -48,7 +51,11 @@ class PreEncoder:
         encode_kwargs go to model.encode (e.g. noise= for a reproducible VAE draw).  Returns the list of written latent paths."""
         if audio.ndim == 4 and audio.shape[0] == 1:                 # pre_encode.py:77-78
             audio = audio[0]
-        latents = self.model.encode(audio, **encode_kwargs).float().cpu().numpy()
+        if self.model_half:
+            audio = audio.half().float()
+            latents = self.model.encode(audio, **encode_kwargs).half().cpu().numpy()
+        else:
+            latents = self.model.encode(audio, **encode_kwargs).float().cpu().numpy()
         paths = []
         for i, latent in enumerate(latents):
             latent_id = f"{self.rank:03d}{batch_idx:06d}{i:04d}"

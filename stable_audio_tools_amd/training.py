@@ -17,8 +17,8 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import _caches
 from . import functional as _fn
-from . import linear as _linear
 
 
 class FlatParameters:
@@ -71,7 +71,13 @@ class GradAllReduce:
 
     mode 'all_reduce'     : one all_reduce per bucket
     mode 'reduce_scatter' : reduce_scatter_tensor + all_gather_into_tensor per bucket (drives every
-                            xGMI link of the 8-GPU mesh in both phases; needs bucket % world == 0)
+                            xGMI link of the 8-GPU mesh in both phases; needs bucket % world == 0).  gloo has no
+                            reduce_scatter: on that backend (decided by NAME, never by catching an error) the mode runs as
+                            all_reduce; a failure of the RCCL collective propagates.
+    comm_dtype            : None / torch.float32 exchanges the fp32 buffer in place; torch.bfloat16 exchanges a bf16 copy of each
+                            bucket (half the xGMI bytes: per-link-bound rings) and writes the summed values back into
+                            the fp32 buffer — the sum over ranks is then rounded to 8 mantissa bits per addend (opt-in: the
+                            reference's DDP exchanges the gradients' own dtype).
 
     Contract of overlap=True: exactly ONE backward pass accumulates into each parameter between two finish() calls (the hook of
     a parameter firing twice raises); with gradient accumulation or several backward() calls per step use overlap=False.  close()
@@ -81,15 +87,36 @@ class GradAllReduce:
     gradient of the bucket has landed, on a side stream fenced by an event — it runs under the backward of the layers
     in front of it (what Lightning's DDP reducer does for the reference, train.py:138).  Gradients land in the flat
     buffer from its END towards its start (backward visits the layers in reverse), so buckets are cut from the end and
-    fire in that order; `finish()` (called before the optimizer) launches whatever did not fire (parameters without a
-    gradient this step) and makes the compute stream wait for the side stream.  overlap=False: everything in finish()."""
+    fire in that order; every bucket records its own completion event on the side stream; `finish()` (called before the
+    optimizer) launches whatever did not fire (parameters without a gradient this step) and makes the compute stream wait for
+    each bucket's event (`wait_bucket(i)` is the per-bucket form).  overlap=False: everything in finish().
 
-    def __init__(self, flat: FlatParameters, group=None, bucket_bytes=256 << 20, mode="all_reduce", overlap=True):
+    single_rank_exchange (default: env SAT_DDP_SINGLE_RANK=1): with an initialised process group of ONE rank the exchange is
+    normally skipped; this flag runs it anyway — hooks, side stream, events and the RCCL collectives on a 1-rank communicator —
+    so the whole code path executes on a single-GPU box (tests/test_train_step.py::test_single_rank_rccl_exchange_gpu,
+    `bench.py --ddp-single-rank`)."""
+
+    def __init__(self, flat: FlatParameters, group=None, bucket_bytes=256 << 20, mode="all_reduce", overlap=True, comm_dtype=None,
+                 single_rank_exchange=None):
+        import os
         self.flat = flat
         self.group = group
         self.mode = mode
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"GradAllReduce: unknown mode {mode!r}")
+        initialised = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if initialised else 1
+        self.rank = dist.get_rank(group) if initialised else 0
+        if single_rank_exchange is None:
+            single_rank_exchange = os.environ.get("SAT_DDP_SINGLE_RANK", "0") == "1"
+        self.active = initialised and (self.world > 1 or bool(single_rank_exchange))
+        self.backend = dist.get_backend(group) if initialised else None
+        if comm_dtype in (None, torch.float32):
+            self.comm_dtype = None
+        elif comm_dtype == torch.bfloat16:
+            self.comm_dtype = torch.bfloat16
+        else:
+            raise ValueError("GradAllReduce: comm_dtype must be None / torch.float32 / torch.bfloat16")
         n = flat.padded
         per = max(1, bucket_bytes // 4)
         per = max(self.world, (per // self.world) * self.world)
@@ -103,10 +130,13 @@ class GradAllReduce:
             self.buckets.append((s_, e))
             e = s_
         self.grad_scale = 1.0 / self.world
-        self.overlap = bool(overlap) and self.world > 1
+        self.overlap = bool(overlap) and self.active
         self._hooks = []
         self._side = None
         self._fired = [False] * len(self.buckets)
+        self._done = [None] * len(self.buckets)          # per-bucket completion events (side stream)
+        self.launch_log = []                             # (bucket index, launched from a hook?) of the current step — read by the tests
+        self._in_hook = False
         if self.overlap:
             # parameter i covers [off, off+numel): it gates every bucket it overlaps
             self._need = [0] * len(self.buckets)
@@ -136,26 +166,30 @@ class GradAllReduce:
                                        "exchange supports ONE backward pass per step (use overlap=False for gradient accumulation "
                                        "or several backward() calls into the same parameters)")
                 if self._left[bi] == 0:
-                    self._launch(bi)
+                    self._in_hook = True
+                    try:
+                        self._launch(bi)
+                    finally:
+                        self._in_hook = False
         return hook
 
     def _exchange(self, chunk):
-        if self.mode == "reduce_scatter" and chunk.numel() % self.world == 0:
-            k = chunk.numel() // self.world
-            shard = chunk[self.rank * k:(self.rank + 1) * k]           # in place: output = this rank's slice of the input
-            try:
-                dist.reduce_scatter_tensor(shard, chunk, op=dist.ReduceOp.SUM, group=self.group)
-            except (RuntimeError, NotImplementedError):                # backend without reduce_scatter (gloo)
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-                return
-            dist.all_gather_into_tensor(chunk, shard, group=self.group)     # in place: rank r's input is slice r of the output
+        buf = chunk if self.comm_dtype is None else chunk.to(self.comm_dtype)
+        if self.mode == "reduce_scatter" and self.backend != "gloo" and buf.numel() % self.world == 0:
+            k = buf.numel() // self.world
+            shard = buf[self.rank * k:(self.rank + 1) * k]             # in place: output = this rank's slice of the input
+            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(buf, shard, group=self.group)       # in place: rank r's input is slice r of the output
         else:
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if buf is not chunk:
+            chunk.copy_(buf)
 
     def _launch(self, bi):
         if self._fired[bi]:
             return
         self._fired[bi] = True
+        self.launch_log.append((bi, self._in_hook))
         s_, e_ = self.buckets[bi]
         chunk = self.flat.grad[s_:e_]
         if chunk.is_cuda and self.overlap:
@@ -166,18 +200,30 @@ class GradAllReduce:
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 self._exchange(chunk)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            self._done[bi] = done
         else:
             self._exchange(chunk)
 
+    def wait_bucket(self, bi):
+        """The compute stream waits for bucket `bi`'s exchange only (a consumer that walks the flat buffer bucket by bucket can
+        start on the first-finished ones)."""
+        ev = self._done[bi]
+        if ev is not None:
+            torch.cuda.current_stream(self.flat.grad.device).wait_event(ev)
+
     def finish(self):
         """All buckets exchanged and visible to the compute stream; re-arms the hooks' counters for the next step."""
-        if self.world == 1:
+        if not self.active:
             return
         for bi in range(len(self.buckets)):
             self._launch(bi)
-        if self._side is not None:
-            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self._side)
+        for bi in range(len(self.buckets)):
+            self.wait_bucket(bi)
+        self.last_launch_log, self.launch_log = self.launch_log, []
         self._fired = [False] * len(self.buckets)
+        self._done = [None] * len(self.buckets)
         if self.overlap:
             self._left = list(self._need)
 
@@ -238,7 +284,7 @@ class FusedAdamW:
         ops.adamw_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, grad_scale,
                        ema=self.ema, ema_decay=ema_decay(self.t) if self.ema is not None else 0.0)
-        _linear.bump_weight_epoch()      # the kernel rewrote the parameters in place: cached bf16 weight copies are stale
+        _caches.bump_params(self.flat.params)   # the kernel rewrote THESE parameters in place: copies derived from them are stale
 
 
 class AutoencoderTrainStep:
@@ -255,7 +301,7 @@ class AutoencoderTrainStep:
     parameters do not require grad (the reference computes and discards their gradients the same way)."""
 
     def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True,
-                 use_discriminator=True):
+                 use_discriminator=True, ddp_comm_dtype=None, ddp_single_rank=None):
         from .auraloss import AutoencoderSpectralLoss
         tr = model_config["training"]
         self.model = autoencoder
@@ -280,7 +326,8 @@ class AutoencoderTrainStep:
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
-        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
+        ddp_kw = dict(bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype, single_rank_exchange=ddp_single_rank)
+        self.comm = GradAllReduce(self.flat, **ddp_kw)
         self.discriminator = None
         dcfg = lc.get("discriminator")
         if use_discriminator and dcfg is not None:
@@ -294,7 +341,7 @@ class AutoencoderTrainStep:
             self.w_fm = float(dcfg["weights"]["feature_matching"])
             self.flat_d = FlatParameters(list(self.discriminator.parameters()), pad_to=max(world, 1))
             self.opt_d, self.base_lr_d, self.sched_d = self._make_opt(self.flat_d, tr["optimizer_configs"]["discriminator"], tr, ops, use_ema=False)
-            self.comm_d = GradAllReduce(self.flat_d, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
+            self.comm_d = GradAllReduce(self.flat_d, **ddp_kw)
         self.global_step = 0
         self.gen_steps = self.disc_steps = 0
         self.use_disc = self.discriminator is not None      # switchable (bench.py times the generator-only step and the real step)
@@ -430,14 +477,16 @@ class DiTTrainStep:
     the HIP kernels in bf16 with fp32 master weights (Lightning '--precision bf16-mixed')."""
 
     def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-3, cfg_dropout_prob=0.1, timestep_sampler="uniform",
-                 use_ema=True, autocast_dtype=None, ops=None, ddp_mode="all_reduce", bucket_bytes=256 << 20, seed=0, ddp_overlap=True):
+                 use_ema=True, autocast_dtype=None, ops=None, ddp_mode="all_reduce", bucket_bytes=256 << 20, seed=0, ddp_overlap=True,
+                 ddp_comm_dtype=None, ddp_single_rank=None):
         import math
         self._math = math
         self.model = model
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.flat = FlatParameters(list(model.parameters()), pad_to=max(world, 1))
         self.opt = FusedAdamW(self.flat, lr, betas=betas, weight_decay=weight_decay, ops=ops, use_ema=use_ema)
-        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap)
+        self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype,
+                                  single_rank_exchange=ddp_single_rank)
         self.cfg_dropout_prob = cfg_dropout_prob
         self.timestep_sampler = timestep_sampler
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0

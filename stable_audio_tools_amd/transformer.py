@@ -84,7 +84,9 @@ class LayerNorm(nn.Module):
         t = getattr(self, name)
         if t.dtype == torch.float32:
             return t.detach()
-        key = (t.data_ptr(), t._version, t.device, _caches.weight_epoch())
+        if not _caches.trackable(t):
+            return t.detach().float().contiguous()
+        key = (t.data_ptr(), _caches.version_of(t), t.device, _caches.epoch_of(t))
         hit = self._f32_cache.get(name)
         if hit is None or hit[0] != key:
             hit = (key, t.detach().float().contiguous())
@@ -288,8 +290,8 @@ class Attention(nn.Module):
                 # the conditioning is the same tensor at every sampler step (dit.py caches its embedding): its K / V planes are
                 # computed once per (context object, version, weight version) and kept in this layer's own buffers
                 w = self.to_kv.weight
-                can_cache = _caches.trackable(kv_input)       # an inference tensor carries no version counter: project it every call
-                key = (_caches.version_of(kv_input), w._version, w.data_ptr(), _caches.weight_epoch(), bool(self.to_kv.fp8),
+                can_cache = _caches.trackable(kv_input, w)    # an inference tensor carries no version counter: project it every call
+                key = (_caches.version_of(kv_input), _caches.version_of(w), w.data_ptr(), _caches.epoch_of(w), bool(self.to_kv.fp8),
                        tuple(kv_input.shape), kv_input.dtype)
                 hit = can_cache and getattr(self, "_kv_ctx", None) is kv_input and self._kv_key == key
                 if hit:

@@ -23,10 +23,10 @@ def emu():
 @pytest.fixture()
 def emu_modules(emu):
     """Route the product nn.Modules through the simulator for the duration of one CPU test."""
-    from stable_audio_tools_amd import functional
-    functional._TEST_OPS = emu
+    from emu_util import use_emu_ops
+    undo = use_emu_ops()
     yield emu
-    functional._TEST_OPS = None
+    undo()
 
 
 @pytest.fixture(scope="session")
@@ -34,8 +34,8 @@ def hip():
     """The product ops singleton (gfx950 library) — GPU tests only."""
     import torch
     assert torch.cuda.is_available(), "GPU test without a GPU"
-    from stable_audio_tools_amd import functional, ops
-    assert functional._TEST_OPS is None
+    from stable_audio_tools_amd import ops
+    assert ops.get_ops.__module__ == "stable_audio_tools_amd.ops", "a simulator substitution leaked into a GPU test"
     o = ops.get_ops()
     assert not o.simulator
     return o

@@ -24,3 +24,14 @@ def emu_ops():
         assert cdll.sat_is_simulator() == 1
         _ops = ops.SatOps(cdll)
     return _ops
+
+
+def use_emu_ops():
+    """Route the product nn.Modules through the simulator: replaces `stable_audio_tools_amd.ops.get_ops` (the one place the product
+    resolves its kernel binding) with a function returning the simulator-bound SatOps.  Returns an undo callable.  Lives in the
+    test tree on purpose — the product package has no such switch."""
+    from stable_audio_tools_amd import ops
+    original = ops.get_ops
+    emu = emu_ops()
+    ops.get_ops = lambda: emu
+    return lambda: setattr(ops, "get_ops", original)

@@ -102,7 +102,8 @@ def test_argument_validation_never_launches():
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_product_path_has_no_cpu_fallback():
     from stable_audio_tools_amd import functional, ops
-    assert functional._TEST_OPS is None
+    assert not hasattr(functional, "_TEST_OPS"), "the product dispatch must not carry a test hook"
+    assert ops.get_ops.__module__ == "stable_audio_tools_amd.ops"
     o = ops.get_ops()
     assert not o.simulator
     with pytest.raises(RuntimeError, match="no CPU path"):

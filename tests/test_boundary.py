@@ -67,6 +67,14 @@ def _weight_norm_removal(device):
     fresh.load_state_dict(folded_sd)
     with torch.no_grad():
         assert rel_err(fresh.decode(fresh.encode(audio, noise=noise)), d0) < 1e-5
+    # (a') train.py `--remove-pretransform-weight-norm post_load` on that model: it is folded already (by the load) — nothing left to
+    # fold, no crash, same outputs; a second removal finds no weight norm, as torch reports for its own modules
+    _remove_weight_norm_from_model(fresh)
+    assert all(m.is_folded for m in fresh.modules() if isinstance(m, _WNConvBase))
+    with torch.no_grad():
+        assert rel_err(fresh.decode(fresh.encode(audio, noise=noise)), d0) < 1e-5
+    with pytest.raises(ValueError, match="weight_norm of 'weight' not found"):
+        torch.nn.utils.remove_weight_norm(next(m for m in fresh.modules() if isinstance(m, _WNConvBase)))
     # (b) weight-normed checkpoint into a model whose weight norm was removed first (train.py "pre_load" order)
     pre = build_native_ae("tiny", 998, device)
     _remove_weight_norm_from_model(pre)
@@ -86,6 +94,139 @@ def test_weight_norm_removal_simulator(emu_modules):
 @pytest.mark.gpu
 def test_weight_norm_removal_gpu(hip):
     _weight_norm_removal("cuda")
+
+
+def _vae_inference_mode(device):
+    """torch.inference_mode on the conv stack and the discriminator: derived weights made inside inference_mode
+    are inference tensors without a version counter — they must bypass the caches / plane side channels, not crash, and give the
+    no_grad results; calls before and after (ordinary tensors) keep working."""
+    from stable_audio_tools_amd.autoencoders import WNConv1d
+    from stable_audio_tools_amd.discriminators import EncodecDiscriminator
+    model = build_native_ae("tiny", 100, device)
+    audio, noise = _ae_inputs(device)
+    fresh_conv = WNConv1d(4, 4, kernel_size=7, padding=3).to(device)       # a layer whose FIRST call is under inference_mode
+    xs = torch.from_numpy(seeded.seeded_array((1, 4, 64), 5)).to(device)
+    with torch.inference_mode():
+        za = model.encode(audio, noise=noise)
+        da = model.decode(za)
+        za2 = model.encode(audio, noise=noise)                              # second call: whatever was kept must still be valid
+        da2 = model.decode(za2)
+        ya = fresh_conv(xs)
+        ya2 = fresh_conv(xs)
+    with torch.no_grad():
+        zb = model.encode(audio, noise=noise)
+        db = model.decode(zb)
+        yb = fresh_conv(xs)
+    assert rel_err(za, zb) < 1e-6 and rel_err(da, db) < 1e-6 and rel_err(za2, zb) < 1e-6 and rel_err(da2, db) < 1e-6
+    assert rel_err(ya, yb) < 1e-6 and rel_err(ya2, yb) < 1e-6
+    torch.manual_seed(3)
+    disc = EncodecDiscriminator(in_channels=2, filters=4, n_ffts=[64, 32], hop_lengths=[16, 8], win_lengths=[64, 32]).to(device)
+    with torch.inference_mode():
+        la = [float(v) for v in disc.loss(audio, db.clone())]
+        la2 = [float(v) for v in disc.loss(audio, db.clone())]
+    with torch.no_grad():
+        lb = [float(v) for v in disc.loss(audio, db)]
+    for a, a2, b in zip(la, la2, lb):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)) and abs(a2 - b) <= 1e-5 * max(1.0, abs(b))
+
+
+def test_vae_inference_mode_simulator(emu_modules):
+    _vae_inference_mode("cpu")
+
+
+@pytest.mark.gpu
+def test_vae_inference_mode_gpu(hip):
+    _vae_inference_mode("cuda")
+
+
+def _emitted_planes_follow_in_place_edits(device, ops):
+    """The producer -> consumer plane side channel (ops._note_emitted / _take_emitted) is valid for ONE version of the producer's
+    output: a forward hook that edits it in place must make the consuming k7 conv rebuild its planes (it used to
+    multiply the OLD values while the residual added the new ones)."""
+    from stable_audio_tools_amd.autoencoders import EncoderBlock
+    torch.manual_seed(0)
+    blk = EncoderBlock(128, 256, stride=2, use_snake=True).to(device)     # units at C = 128: the k7q + emission path
+    x = torch.from_numpy(seeded.seeded_array((1, 128, 512), 21, scale=0.5)).to(device)
+    h = blk.layers[0].register_forward_hook(lambda m, i, o: o.add_(0.5))
+    try:
+        prev = ops.k7_emit
+        with torch.no_grad():
+            ops.k7_emit = True
+            y_emit = blk(x)
+            ops.k7_emit = False
+            y_plain = blk(x)
+    finally:
+        ops.k7_emit = prev
+        h.remove()
+    assert rel_err(y_emit, y_plain) < 1e-6
+
+
+def test_emitted_planes_follow_in_place_edits_simulator(emu_modules):
+    _emitted_planes_follow_in_place_edits("cpu", emu_modules)
+
+
+@pytest.mark.gpu
+def test_emitted_planes_follow_in_place_edits_gpu(hip):
+    _emitted_planes_follow_in_place_edits("cuda", hip)
+
+
+def _pretransform_model_half(device):
+    """AutoencoderPretransform(model_half=True) (models/pretransforms.py:48-71): fp16 parameter storage and fp16-rounded inputs /
+    outputs as the reference, fp32-accurate arithmetic in between.  Checked three ways: (1) state_dict dtypes are fp16; (2) equal —
+    up to the output rounding — to the fp32 native model whose weights and inputs were rounded to fp16 by hand; (3) when the
+    reference is importable: within fp16 resolution of the reference's own half pretransform on CPU, and closer to the fp32 result."""
+    from stable_audio_tools_amd.pretransforms import AutoencoderPretransform
+    audio, noise = _ae_inputs(device)
+    full = AutoencoderPretransform(build_native_ae("tiny", 100, device), scale=0.7)
+    half = AutoencoderPretransform(build_native_ae("tiny", 100, device), scale=0.7, model_half=True)
+    assert half.model_half and all(v.dtype == torch.float16 for v in half.model.state_dict().values() if v.is_floating_point())
+    hand = build_native_ae("tiny", 100, device)
+    with torch.no_grad():
+        for p in hand.parameters():
+            p.copy_(p.half().float())
+    hand = AutoencoderPretransform(hand, scale=0.7)
+    with torch.no_grad():
+        z_half = half.encode(audio, noise=noise)
+        z_hand = hand.encode(audio.half().float(), noise=noise)
+        z_full = full.encode(audio, noise=noise)
+        d_half = half.decode(z_full)
+        d_hand = hand.decode(((z_full * 0.7).half().float()) / 0.7)
+        d_full = full.decode(z_full)
+    assert z_half.dtype == torch.float32 and d_half.dtype == torch.float32
+    assert rel_err(z_half, z_hand) < 1e-3 and rel_err(d_half, d_hand) < 1e-3          # fp16 output rounding: 2^-11
+    e_z, e_d = rel_err(z_half, z_full), rel_err(d_half, d_full)
+    assert 0 < e_z < 2e-2 and 0 < e_d < 2e-2, (e_z, e_d)
+    import refimport
+    if not refimport.available():
+        return
+    import contextlib
+    import sys
+    with contextlib.redirect_stdout(sys.stderr):
+        refimport.import_reference()
+    from stable_audio_tools.models.autoencoders import create_autoencoder_from_config
+    from stable_audio_tools.models.pretransforms import AutoencoderPretransform as RefPretransform
+    cfg = seeded.AE_CONFIGS["tiny"]
+    ref = create_autoencoder_from_config(copy.deepcopy(cfg))
+    ref.load_state_dict({k: v.float().cpu() for k, v in full.model.state_dict().items()})
+    ref_half = RefPretransform(ref, scale=0.7, model_half=True)
+    try:
+        with torch.no_grad():
+            d_ref = ref_half.decode(z_full.cpu())
+    except RuntimeError as e:        # a CPU build without half convolutions
+        pytest.skip(f"reference half path not runnable on this host: {e}")
+    assert d_ref.dtype == torch.float32
+    e_ref = rel_err(d_ref, d_full)
+    assert rel_err(d_half, d_ref) < max(2e-2, 3 * e_ref)        # both are fp16-level approximations of the same fp32 decode
+    assert e_d <= 1.5 * e_ref + 1e-3, (e_d, e_ref)              # ... and the native one is not the worse of the two
+
+
+def test_pretransform_model_half_simulator(emu_modules):
+    _pretransform_model_half("cpu")
+
+
+@pytest.mark.gpu
+def test_pretransform_model_half_gpu(hip):
+    _pretransform_model_half("cuda")
 
 
 class _Counter:
@@ -146,12 +287,20 @@ def _frozen_caches(device, ops):
         cnt.reset()
         d3 = pt.decode(z)
         assert cnt.n["wn_fold"] > 0 and rel_err(d3, d0) < 1e-5        # 1.25 * 0.8 = 1
-        # any torch optimizer step invalidates (global post-step hook)
-        e0 = _caches.weight_epoch()
-        p = torch.nn.Parameter(torch.zeros(3))
-        p.grad = torch.ones(3)
+        # a torch optimizer step invalidates what was derived from ITS parameters (global post-step hook), and only that: an
+        # optimizer of some other model (the DiT being trained next to this frozen pretransform) leaves the pretransform's copies alone
+        cnt.reset()
+        p = torch.nn.Parameter(torch.zeros(3, device=device))
+        p.grad = torch.ones(3, device=device)
+        e_p = _caches.epoch_of(p)
         torch.optim.SGD([p], lr=0.1).step()
-        assert _caches.weight_epoch() > e0
+        assert _caches.epoch_of(p) != e_p
+        assert torch.equal(pt.decode(z), d3) and cnt.total() == 0, cnt.n
+        conv.weight_g.grad = torch.zeros_like(conv.weight_g)
+        torch.optim.SGD([conv.weight_g], lr=0.1).step()               # ... while an optimizer that owns one of ITS parameters does
+        conv.weight_g.grad = None
+        pt.decode(z)
+        assert cnt.n["wn_fold"] == 1, cnt.n
         # training pass (grad enabled, trainable parameters): no caching, gradients flow to weight_g / weight_v
         model.requires_grad_(True)
         loss = model.decode(model.encode(audio, noise=noise)).square().mean()

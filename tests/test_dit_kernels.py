@@ -145,6 +145,19 @@ def _cfg_step_case(ops, dev):
     assert rel_err(y0, coef[0] * x.cpu() + coef[1] * out2[:b].cpu()) < 1e-6
     ob = ops.cfg_step(out2.bfloat16(), 2, scale, phi)
     assert ob.dtype == torch.bfloat16 and rel_err(ob.float(), ref) < 2e-2
+    # the general form (sat_sampler_step): third operand + unconditioned-output terms, host and device coefficients
+    prev = torch.randn(b, c, t).to(dev)
+    c8 = (0.3, -0.7, 0.45, 0.15, 1.1, 0.2, -0.6, 0.8)
+    want0 = c8[0] * x.cpu() + c8[1] * ref + c8[2] * prev.cpu() + c8[3] * uncond
+    want1 = c8[4] * x.cpu() + c8[5] * ref + c8[6] * prev.cpu() + c8[7] * uncond
+    y0, y1 = ops.cfg_step(out2, 2, scale, phi, x=x, coef=c8, want_second=True, prev=prev)
+    assert rel_err(y0, want0) < 1e-5 and rel_err(y1, want1) < 1e-5
+    y0d, y1d = ops.cfg_step(out2, 2, scale, phi, x=x, coef=torch.tensor(c8, dtype=torch.float32, device=dev), want_second=True, prev=prev)
+    assert torch.equal(y0d, y0) and torch.equal(y1d, y1)
+    y0n, _ = ops.cfg_step(out2[:b].contiguous(), 1, x=x, coef=c8, want_second=True, prev=prev)      # ncond 1: u = v
+    assert rel_err(y0n, c8[0] * x.cpu() + (c8[1] + c8[3]) * out2[:b].cpu() + c8[2] * prev.cpu()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.cfg_step(out2, 2, scale, phi, x=x, coef=c8, want_second=True)                           # coefficient on prev without prev
 
 
 def test_cfg_step_simulator(emu):

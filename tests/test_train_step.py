@@ -136,59 +136,72 @@ def test_generator_step_matches_oracle_gpu(hip, bf16x3):
     _check_against_oracle("cuda", hip, bf16x3)
 
 
-def _ddp_worker(rank, world, port, q, ddp_mode="all_reduce", overlap=True):
+def _ddp_worker(rank, world, port, q, ddp_mode="all_reduce", overlap=True, comm_dtype=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    from emu_util import emu_ops
-    from stable_audio_tools_amd import functional
-    functional._TEST_OPS = emu_ops()
+    from emu_util import use_emu_ops
+    use_emu_ops()
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = _model_config()
         audio, noise = _batch(2, 950)           # global batch of 2, one item per rank
         _, stepper, _ = _native_steps(cfg, [(audio[rank:rank + 1], noise[rank:rank + 1])], "cpu", ddp_mode=ddp_mode, ddp_overlap=overlap,
-                                      bucket_bytes=4096)          # tiny buckets: many of them fire from the hooks mid-backward
+                                      bucket_bytes=4096,          # tiny buckets: many of them fire from the hooks mid-backward
+                                      ddp_comm_dtype={None: None, "bf16": torch.bfloat16}[comm_dtype])
         assert len(stepper.comm.buckets) > 4
+        log = stepper.comm.last_launch_log
+        assert sorted(b for b, _ in log) == list(range(len(stepper.comm.buckets)))                 # every bucket exactly once
+        assert (sum(h for _, h in log) >= len(log) - 1) if overlap else not any(h for _, h in log)   # ... from the hooks when overlapped
         flat = stepper.flat.data.clone()
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
-        q.put((rank, [g.numpy() for g in gathered] if rank == 0 else None))
+        avg_grad = (stepper.flat.grad * stepper.comm.grad_scale).clone()        # the averaged gradient the optimizer consumed
+        q.put((rank, ([g.numpy() for g in gathered], avg_grad.numpy()) if rank == 0 else None))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ddp_mode,overlap", [("all_reduce", True), ("reduce_scatter", True), ("all_reduce", False)])
-def test_data_parallel_step_gloo_world2(emu_modules, ddp_mode, overlap):
+@pytest.mark.parametrize("ddp_mode,overlap,comm_dtype", [("all_reduce", True, None), ("reduce_scatter", True, None), ("all_reduce", False, None),
+                                                         ("all_reduce", True, "bf16")])
+def test_data_parallel_step_gloo_world2(emu_modules, ddp_mode, overlap, comm_dtype):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + 7 * ["all_reduce", "reduce_scatter"].index(ddp_mode) + int(overlap)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, ddp_mode, overlap)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + 7 * ["all_reduce", "reduce_scatter"].index(ddp_mode) + int(overlap) + 3 * int(comm_dtype is not None)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, ddp_mode, overlap, comm_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    r0, r1 = (torch.from_numpy(a) for a in results[0])
+    r0, r1 = (torch.from_numpy(a) for a in results[0][0])
+    avg_grad = torch.from_numpy(results[0][1])
     assert torch.equal(r0, r1), "ranks diverged after the all-reduced step"
     # single process, full batch: mean-of-per-rank-gradients == gradient of the batch-mean loss only if the
     # loss is a per-item mean; the spectral-convergence and KL terms are, the log-magnitude term is too.
     cfg = _model_config()
     audio, noise = _batch(2, 950)
     _, stepper, _ = _native_steps(cfg, [(audio, noise)], "cpu")
+    # the AVERAGED gradient is the single-process batch gradient (fp32 summation order only; a bf16 exchange
+    # rounds each rank's addend to 8 mantissa bits) — checked on the gradient itself: Adam's normalisation would hide a
+    # mis-scaled bucket
+    batch_grad = stepper.flat.grad
+    tol = 1e-5 if comm_dtype is None else 8e-3
+    assert float((avg_grad - batch_grad).norm() / batch_grad.norm()) < tol
+    assert float((avg_grad - batch_grad).abs().max() / batch_grad.abs().max()) < tol
     single = stepper.flat.data
     shapes_init = build_native_ae(NAME, SEED)
     init = torch.cat([p.detach().reshape(-1) for p in shapes_init.parameters()])
     n = init.numel()
     upd_ddp = r0[:n] - init
     upd_single = single[:n] - init
-    assert float((upd_ddp - upd_single).norm() / upd_single.norm()) < 5e-2
+    assert float((upd_ddp - upd_single).norm() / upd_single.norm()) < (1e-3 if comm_dtype is None else 5e-2)
 
 
 def _nccl_worker(rank, world, port, q):
@@ -212,6 +225,67 @@ def _nccl_worker(rank, world, port, q):
         q.put((rank, bool(torch.equal(gathered[0], gathered[1]))))
     finally:
         dist.destroy_process_group()
+
+
+def _single_rank_worker(port, q):
+    """ONE rank, backend nccl (= RCCL), the exchange forced on: hooks, side stream, per-bucket events, in-place reduce-scatter +
+    all-gather / all_reduce / the bf16 exchange all execute on the GPU; with one rank every collective is the identity, so each mode
+    must reproduce the no-process-group step bit for bit (fp32) / to bf16 rounding of the gradient (bf16 exchange)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    cfg = _model_config()
+    batches = [_batch(2, 950), _batch(2, 960)]
+    _, base, base_losses = _native_steps(cfg, batches, "cuda:0")            # no process group: the exchange is skipped
+    assert not base.comm.active
+    ref_data, ref_grad = base.flat.data.clone(), base.flat.grad.clone()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    out = {}
+    try:
+        for mode, overlap, cdt in (("all_reduce", True, None), ("reduce_scatter", True, None), ("all_reduce", False, None),
+                                   ("reduce_scatter", True, torch.bfloat16)):
+            _, st, losses = _native_steps(cfg, batches, "cuda:0", ddp_mode=mode, ddp_overlap=overlap, bucket_bytes=4096,
+                                          ddp_comm_dtype=cdt, ddp_single_rank=True)
+            assert st.comm.active and st.comm.backend == "nccl" and len(st.comm.buckets) > 4
+            log = st.comm.last_launch_log
+            torch.cuda.synchronize()
+            out[(mode, overlap, str(cdt))] = {
+                "every_bucket_once": sorted(b for b, _ in log) == list(range(len(st.comm.buckets))),
+                "from_hooks": sum(h for _, h in log), "buckets": len(log), "side_stream": st.comm._side is not None,
+                "data_equal": bool(torch.equal(st.flat.data, ref_data)), "grad_equal": bool(torch.equal(st.flat.grad, ref_grad)),
+                "grad_rel": float((st.flat.grad - ref_grad).norm() / ref_grad.norm()),
+                "loss_equal": losses == base_losses}
+            st.comm.close()
+    finally:
+        dist.destroy_process_group()
+    q.put(out)
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_exchange_gpu(hip):
+    """P1 on hardware that has ONE GPU: the overlapped gradient exchange on a 1-rank RCCL communicator (the world-2 twin below
+    needs two devices and is skipped on the 1-GPU box; the gloo twins above cover world 2 on CPU)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(29900 + (os.getpid() % 90), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for key, r in out.items():
+        mode, overlap, cdt = key
+        assert r["every_bucket_once"], (key, r)
+        assert r["side_stream"] == overlap and (r["from_hooks"] >= r["buckets"] - 1 if overlap else r["from_hooks"] == 0), (key, r)
+        if cdt == "None":
+            assert r["grad_equal"] and r["data_equal"] and r["loss_equal"], (key, r)      # identity collectives: bit-equal to no DDP
+        else:
+            assert 0 < r["grad_rel"] < 8e-3, (key, r)                                       # bf16 round trip of the gradient buckets
 
 
 @pytest.mark.gpu
@@ -315,9 +389,8 @@ def _ddp_disc_worker(rank, world, port, q):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    from emu_util import emu_ops
-    from stable_audio_tools_amd import functional
-    functional._TEST_OPS = emu_ops()
+    from emu_util import use_emu_ops
+    use_emu_ops()
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
