@@ -5,11 +5,19 @@ Workload (BASELINE.json configs[1], named in `config.workload`): one *generator 
 the Oobleck audio VAE on 47.55 s stereo 44.1 kHz items (sample_size 2097152): encode -> VAE sample ->
 decode -> multi-resolution STFT loss (sum/diff + L + R, 7 resolutions, A-weighted) + KL -> backward ->
 data-parallel gradient all-reduce -> fused AdamW (+EMA).  fp32, synthetic audio, random-init weights of
-the stable_audio_2_0_vae architecture.  The discriminator half of the reference step is out of scope
-this round and is NOT inside the timed region — stated in `config`.
+the stable_audio_2_0_vae architecture.  `value` times that generator step (comparable across rounds and
+across N).  The reference's REAL step alternates it with the MS-STFT discriminator update
+(training/autoencoders.py:440-515): that is built too and timed in the same run on the
+same items — top-level `real_step_samples_per_s` / `real_step_ms`, details in `config.real_step`.
+
+The same line carries `roofline` (dominant kernel, HIP events), `cpu_baseline` (ONE un-scaled generator
+step of the REFERENCE's own modules on this box's host cores — oracle/stage_ref.py ships the reference
+tree to the GPU box), `parity` (the bench item against the CPU oracle), `secondary` (the metric's second
+half: DiT sampling steps/s, configs[2]) and `long_context` (configs[4] on one GPU).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
-(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  `--ddp-single-rank` runs the N=1 step inside a
+1-rank RCCL process group with the overlapped gradient exchange forced on (the P1 path on a 1-GPU box).
 """
 import argparse
 import json
@@ -48,6 +56,11 @@ def parse():
                     help="vae_train: BASELINE.json configs[1] (default, the metric's first half); "
                          "dit_sample: configs[2] DiT sampling steps/s (the metric's second half)")
     ap.add_argument("--dit-dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--ddp-single-rank", action="store_true",
+                    help="N = 1 inside a 1-rank RCCL ('nccl') process group with the gradient exchange forced on (hooks, side stream, "
+                         "per-bucket events, collectives on a 1-rank communicator): the data-parallel code path on a single-GPU box")
+    ap.add_argument("--ddp-mode", choices=["all_reduce", "reduce_scatter"], default="all_reduce")
+    ap.add_argument("--ddp-comm-dtype", choices=["f32", "bf16"], default="f32")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.workload == "dit_train" else 1
@@ -240,7 +253,7 @@ def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
 
 def run_dit_sample(args):
     line = dit_sample_line(args.dit_dtype, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
@@ -290,7 +303,8 @@ def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
     tt = torch.linspace(1.0, 0, steps + 1)[:-1]
     al, sg = torch.cos(tt * math.pi / 2), torch.sin(tt * math.pi / 2)
     an, sn = torch.cat([al[1:], al.new_ones(1)]), torch.cat([sg[1:], sg.new_zeros(1)])
-    table = torch.stack([an * al + sn * sg, -an * sg + sn * al, al, -sg], dim=1).float().to(dev)
+    zc = torch.zeros_like(al)
+    table = torch.stack([an * al + sn * sg, -an * sg + sn * al, zc, zc, al, -sg, zc, zc], dim=1).float().to(dev)   # c0x c0v c0p c0u c1x c1v c1p c1u
     tsteps = (noise.new_ones([b])[:, None] * tt.to(dev)[None, :]).t().contiguous()
 
     @torch.no_grad()
@@ -325,9 +339,64 @@ def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
     }
     if with_cpu_baseline:
         line["cpu_baseline"] = dit_cpu_baseline(dcfg, tlat, m)
+        line["config"]["parity"] = dit_eval_parity(model, dcfg, noise, cross, glob, kw)
     del model
     torch.cuda.empty_cache()
     return line
+
+
+def dit_eval_parity(model, dcfg, x, cross, glob, kw, exit_layer_ix=None, bound=4e-2):
+    """Model evaluations of the timed native model (bf16 storage / fp8 projections as configured) against the fp32 CPU path on the
+    SAME weights widened to fp32: the reference's own DiffusionTransformer when a reference tree is importable, else the oracle port.
+    Relative L2 and max error of (a) the plain output (cfg_scale 1) — the quantity tests/test_full_width.py bounds at 4e-2 for bf16
+    storage through the depth-24 stack — and (b) the guided output the sampler consumes (CFG scale 6 + rescale: u + 6 (c - u)
+    multiplies the two halves' independent rounding errors, reported without a bound); with exit_layer_ix: the hidden state after
+    that layer only (long context: a full N = 6145 fp32 evaluation on the host takes minutes)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    xc, cc, gc = x.float().cpu(), cross.float().cpu(), glob.float().cpu()
+    t = torch.full((x.shape[0],), 0.5)
+    guided = {"cfg_scale": kw["cfg_scale"], "scale_phi": kw["scale_phi"]}
+    modes = [("hidden", {"exit_layer_ix": exit_layer_ix})] if exit_layer_ix is not None else [("plain", {}), ("guided", guided)]
+    got = {}
+    with torch.no_grad():
+        for name, mkw in modes:
+            got[name] = model(x, t.to(x.device, x.dtype), cross_attn_cond=kw["cross_attn_cond"], global_embed=kw["global_embed"], **mkw).float().cpu()
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    want = {}
+    if _reference_importable():
+        import contextlib
+        import refimport
+        with contextlib.redirect_stdout(sys.stderr):
+            refimport.import_reference()
+            from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
+            ref = RefDiT(**dcfg).float().train(False)
+        ref.load_state_dict(sd, strict=False)
+        kind = "reference"
+        with torch.no_grad():
+            for name, mkw in modes:
+                want[name] = ref(xc, t, cross_attn_cond=cc, global_embed=gc, **mkw)
+    else:
+        import dit_oracle
+        kind = "port"
+        if exit_layer_ix is not None:
+            return {"skipped": "no reference tree: the oracle port has no early exit"}
+        with torch.no_grad():
+            for name, mkw in modes:
+                want[name] = dit_oracle.dit_forward(sd, dcfg, xc, t, cc, gc, **mkw)
+    secs = time.perf_counter() - t0
+    out = {}
+    for name in got:
+        d = got[name] - want[name]
+        out[name] = {"rel_l2": float(f"{float(d.norm() / want[name].norm()):.3e}"), "rel_max": float(f"{float(d.abs().max() / want[name].abs().max()):.3e}")}
+    first = modes[0][0]
+    out.update({"bound_rel_l2": bound, "bounded": first, "ok": bool(out[first]["rel_l2"] < bound), "against": kind + " fp32 on CPU", "cpu_seconds": round(secs, 1),
+                "what": ("one model evaluation (t = 0.5): plain (cfg_scale 1, bounded) and guided (CFG scale 6 + rescale 0.75: the combination amplifies the two "
+                         "halves' rounding errors)" if exit_layer_ix is None else f"hidden state after layer {exit_layer_ix} (t = 0.5, no CFG)")
+                        + " of the timed model vs fp32 on the same (16-bit-rounded) weights"})
+    return out
 
 
 PEAK_FP8_MFMA_TFLOPS = 5000.0   # MI355X_MICROARCH.md: dense fp8 (MX) MFMA peak
@@ -379,7 +448,8 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
     tt = torch.linspace(1.0, 0, steps + 1)[:-1]
     al, sg = torch.cos(tt * math.pi / 2), torch.sin(tt * math.pi / 2)
     an, sn = torch.cat([al[1:], al.new_ones(1)]), torch.cat([sg[1:], sg.new_zeros(1)])
-    table = torch.stack([an * al + sn * sg, -an * sg + sn * al, al, -sg], dim=1).float().to(dev)
+    zc = torch.zeros_like(al)
+    table = torch.stack([an * al + sn * sg, -an * sg + sn * al, zc, zc, al, -sg, zc, zc], dim=1).float().to(dev)   # c0x c0v c0p c0u c1x c1v c1p c1u
     tsteps = (noise.new_ones([b])[:, None] * tt.to(dev)[None, :]).t().contiguous()
 
     @torch.no_grad()
@@ -412,6 +482,12 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
                           "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(attn_tf / PEAK_BF16_MFMA_TFLOPS, 4)},
             "fp8_projections": prof.gemm_summary(PEAK_FP8_MFMA_TFLOPS, fp8=True),
             "bf16_projections": prof.gemm_summary(PEAK_BF16_MFMA_TFLOPS)}
+    if with_cpu_baseline:
+        try:
+            # bound: tests/test_long_context.py FP8_BLOCK (8e-2 relative L2 per block with fp8 e4m3 projections), two blocks
+            line["parity"] = dit_eval_parity(model, dcfg, noise, cross, glob, kw, exit_layer_ix=1, bound=0.113)
+        except Exception as e:   # noqa: BLE001 — a figure, not a gate
+            line["parity"] = {"error": repr(e)[:200]}
     del model, gd
     torch.cuda.empty_cache()
     if with_cpu_baseline:
@@ -764,8 +840,13 @@ def run_dit_train(args):
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.ddp_single_rank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     from stable_audio_tools_amd.dit import DiffusionTransformer
@@ -824,7 +905,7 @@ def run_dit_train(args):
                 "roofline": prof.roofline(PEAK_BF16_MFMA_TFLOPS if mixed else PEAK_BF16_MFMA_TFLOPS / 3.0)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = dit_train_cpu_baseline(dcfg, tlat, m)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 
@@ -843,10 +924,32 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    """Rank 0 prints ONE JSON line on stdout — and nothing else: the reference's modules print optional-import notices
+    ("flash_attn not installed ...", the seed in generate_diffusion_cond) with plain print().  Everything written to file
+    descriptor 1 from here on goes to stderr; emit() writes the line to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = sys.stderr
+
+
+def emit(line):
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
+    guard_stdout()
     if args.gpus != int(os.environ.get("WORLD_SIZE", 1)):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     if args.workload == "dit_train":
@@ -858,9 +961,9 @@ def main():
             raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
         torch.cuda.set_device(0)
         lc = long_context_line(args.steps, args.warmup, not args.no_cpu_baseline)
-        print(json.dumps({"metric": "DiT sampling steps/sec", "value": lc["value"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
+        emit(({"metric": "DiT sampling steps/sec", "value": lc["value"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": lc["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "fp8(e4m3 projections) + bf16", "data": "synthetic", "config": {"workload": lc["workload"]}, "long_context": lc}), flush=True)
+                          "dtype": "fp8(e4m3 projections) + bf16", "data": "synthetic", "config": {"workload": lc["workload"]}, "long_context": lc}))
         return
     if args.workload == "dit_sample":
         if int(os.environ.get("WORLD_SIZE", 1)) > 1:
@@ -874,8 +977,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.ddp_single_rank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
@@ -891,7 +999,9 @@ def main():
         for n_, p in model.named_parameters():
             if n_.endswith("alpha") or n_.endswith("beta"):
                 p.normal_(0.0, 0.1)
-    stepper = AutoencoderTrainStep(model, cfg, use_discriminator=(world == 1 and not args.no_real_step))
+    stepper = AutoencoderTrainStep(model, cfg, use_discriminator=(world == 1 and not args.no_real_step), ddp_mode=args.ddp_mode,
+                                   ddp_comm_dtype=torch.bfloat16 if args.ddp_comm_dtype == "bf16" else None,
+                                   ddp_single_rank=True if args.ddp_single_rank else None)
     stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
     ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
     prof = ConvProfiler(ops)
@@ -932,10 +1042,14 @@ def main():
             "dtype": "f32(bf16x3)", "data": "synthetic",
             "config": {"workload": "oobleck_vae_generator_train_step(encode+vae_sample+decode+mrstft_sumdiff_LR_7res_aweighted+kl,"
                                    " backward, dp_allreduce, fused_adamw_ema); stable_audio_2_0_vae architecture, random init;"
-                                   " discriminator terms excluded (SURVEY.md 8 f-3)",
+                                   " the alternating MS-STFT-discriminator / generator step of the reference is timed beside it: real_step_*",
                        "sample_size": args.sample_size, "channels": 2, "sample_rate": 44100,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": loss},
+                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "ddp": {"process_group": (dist.get_backend() if dist.is_initialized() else None), "exchange_active": stepper.comm.active,
+                               "mode": stepper.comm.mode, "comm_dtype": args.ddp_comm_dtype, "buckets": len(stepper.comm.buckets),
+                               "overlap": stepper.comm.overlap,
+                               "buckets_launched_from_backward_hooks": sum(int(h) for _, h in getattr(stepper.comm, "last_launch_log", []))}},
             "roofline": {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
                          "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], args), "kernel": dom["kernel"],
                          "launches": dom["launches"],
@@ -1022,6 +1136,11 @@ def main():
             line["config"]["real_step"]["recompute"] = {"ms_per_step": 1e3 * dt_rc, "peak_hbm_gib": peak_rc, "steps": 2,
                                                         "what": "ResidualUnit.checkpointing = True on all 30 units"}
             stepper.use_disc = False
+            rs = line["config"]["real_step"]
+            line["real_step_samples_per_s"], line["real_step_ms"] = rs["samples_per_s"], rs["ms_per_step"]
+            dk = max(disc_k, key=lambda d: d.get("total_ms", 0.0)) if disc_k else None
+            if dk is not None:
+                line["real_step_dominant_discriminator_kernel"] = {k: dk.get(k) for k in ("kernel", "frac", "achieved", "total_ms", "launches") if k in dk}
         if world == 1 and not args.no_secondary:
             # the second half of BASELINE.json's metric ("...; DiT sampling steps/sec"), measured in the same run: configs[2]
             # (Stable Audio Open DiT, bf16, v-DDIM + CFG), with the self-attention kernel's MFMA roofline
@@ -1035,8 +1154,8 @@ def main():
                 line["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
             if not args.no_long_context:
                 line["long_context"] = long_context_line(with_cpu_baseline=not args.no_cpu_baseline)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit(line)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
