@@ -237,69 +237,111 @@ SAT_DEVICE float sat_att_halfmax(float x) {
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 #endif
 }
-// The running max is only moved when some row of the wave outgrows it by more than 2^SAT_ATT_DEFER (in the exp2 domain): P is then
-// bounded by 2^SAT_ATT_DEFER instead of 1 — harmless in fp32 / bf16 — and the O-wide rescale pass runs on the first tiles only.
+// Round 4 — the forward kernel's instruction diet (profiles/EXPERIMENTS.md: the SQ counters put the kernel's time in the SIMD's issue
+// slots, not in one pipe; what was measured to help is listed here, what was measured NOT to help is in EXPERIMENTS.md):
+//   * Q is pre-scaled by scale * log2(e) once per launch (bf16 mode: one more bf16 rounding of Q; fp32 mode: hi + lo are recombined,
+//     scaled and re-split, so the product stays at 2^-17), so the scores leave the matrix pipe in the exp2 domain;
+//   * the running row max mb (exp2 domain) enters through the C operand of the first QK^T MFMA (a 16-register block holding -mb): the
+//     accumulators ARE x = s - mb, no per-score multiply-subtract;
+//   * no per-tile row max: after the first tile (true max) the max only moves when the tile's row sum says it went stale —
+//     the sum of exp2(x) over this lane's scores above SAT_ATT_SUMLIM (32 scores of 2^SAT_ATT_DEFER each), or inf / NaN — and that rare
+//     path recomputes QK^T (the scores were overwritten by their exponentials), takes the true max, rescales O / l and goes on.  P is
+//     therefore bounded by SAT_ATT_SUMLIM instead of 1 — harmless in fp32 / bf16;
+//   * s_setprio 1 around the MFMA groups, and the file is built with -fno-slp-vectorize (v_pk_*_f32 cost more issue time than the
+//     scalar pairs they replace; Makefile).
+// Measured (tools/attn_x_bench.py, profiles/r04_experiments/): N = 1025, B*H = 48: 31.7 -> 24.0 us; N = 6145: 568 -> 492 us.
 #define SAT_ATT_DEFER 4.0f
+#define SAT_ATT_SUMLIM 512.0f      // 32 scores per lane, each <= 2^SAT_ATT_DEFER while the running max is in range
 
-// one 64-key tile (NKB = 2) or its first 32 keys (NKB = 1): S^T = K Q^T, online softmax, O^T += V^T P^T
-template <int NP, int NKB, bool MASK>
+// one 64-key tile (NKB = 2) or its first 32 keys (NKB = 1): x = K (Q c)^T - mb, P = exp2(x), O^T += V^T P^T.
+// FIRST: the wave's first tile — mb is not known yet: C = 0 and the true row max is taken.
+template <int NP, int NKB, bool MASK, bool FIRST>
 SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW], const bf16x8 (&qf)[4][NP],
-                                  f32x16 (&oacc)[2], float& m_run, float& l_run, float sl2, int l31, int hi, int kperm, int nvalid) {
+                                  f32x16 (&oacc)[2], f32x16& negm, float& mb, float& l_run, int l31, int hi, int kperm, int nvalid) {
     f32x16 sacc[NKB];
+    auto qk = [&]() {
+        SAT_SETPRIO(1);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (FIRST) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
+            }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 ka[NP];
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 ka[NP];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + kperm, 16 * s + 8 * hi);
-            sacc[kb] = sat_att_mma<NP>(ka, qf[s], sacc[kb]);
+                for (int pl = 0; pl < NP; ++pl) ka[pl] = sat_att_frag_rm(k_lds[pl], kb * 32 + kperm, 16 * s + 8 * hi);
+                // the first MFMA of the chain reads -mb straight from the negm block (no copy into the accumulator first)
+                sacc[kb] = sat_att_mma<NP>(ka, qf[s], (!FIRST && s == 0) ? negm : sacc[kb]);
+            }
         }
-    }
-    if (MASK) {                                       // only the last tile holds padded keys (block-uniform)
+        SAT_SETPRIO(0);
+    };
+    auto rowmax = [&]() {
+        float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + (r & 7) + 8 * hi + 16 * (r >> 3);
-                if (key >= nvalid) sacc[kb][r] = -INFINITY;
+                if (!MASK || key < nvalid) tmax = fmaxf(tmax, sacc[kb][r]);      // only the last tile holds padded keys (block-uniform)
             }
+        return sat_att_halfmax(tmax);
+    };
+    float ps0 = 0.0f, ps1 = 0.0f;
+    auto expsum = [&]() {
+        ps0 = 0.0f;
+        ps1 = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = sat_exp2(sacc[kb][2 * j]), c = sat_exp2(sacc[kb][2 * j + 1]);
+                if (MASK) {
+                    const int key = kb * 32 + ((2 * j) & 7) + 8 * hi + 16 * ((2 * j) >> 3);
+                    if (key >= nvalid) a = 0.0f;
+                    if (key + 1 >= nvalid) c = 0.0f;
+                }
+                ps0 += a;
+                ps1 += c;
+                sacc[kb][2 * j] = a;
+                sacc[kb][2 * j + 1] = c;
+            }
+    };
+    qk();
+    if (FIRST) {
+        const float tmax = rowmax();
+        mb = tmax;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] -= tmax;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mb;
     }
-    float tmax = sacc[0][0];
+    expsum();
+    if (!FIRST) {
+        if (sat_wave_any(!(ps0 + ps1 <= SAT_ATT_SUMLIM))) {      // stale running max in some row of the wave (rare): redo with the true one
+            qk();
+            const float d = fmaxf(rowmax(), 0.0f), alpha = sat_exp2(-d);
+            mb += d;
+            l_run *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
-    tmax = sat_att_halfmax(tmax);
-    if (sat_wave_any((tmax - m_run) * sl2 > SAT_ATT_DEFER)) {
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = sat_exp2((m_run - m_new) * sl2);
-        m_run = m_new;
-        l_run *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-    }
-    const float mb = m_run * sl2;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 sl2v = {sl2, sl2}, mbv = {mb, mb};
-    f32x2 ps = {0.0f, 0.0f};
+                for (int r = 0; r < 16; ++r) sacc[kb][r] -= d;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                  // packed fp32: scale-and-subtract and the row sum two scores at a time
-            f32x2 t = {sacc[kb][2 * j], sacc[kb][2 * j + 1]};
-            t = t * sl2v - mbv;
-            t[0] = sat_exp2(t[0]);
-            t[1] = sat_exp2(t[1]);
-            ps += t;
-            sacc[kb][2 * j] = t[0];
-            sacc[kb][2 * j + 1] = t[1];
+            for (int r = 0; r < 16; ++r) negm[r] = -mb;
+            expsum();
         }
-    l_run += ps[0] + ps[1];
+    }
+    l_run += ps0 + ps1;
+    SAT_SETPRIO(1);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -314,6 +356,7 @@ SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short 
                 oacc[t] = sat_att_mma<NP>(va, pb, oacc[t]);
             }
         }
+    SAT_SETPRIO(0);
 }
 
 template <typename T, int NP>
@@ -336,26 +379,43 @@ sat_attn_fwd_kernel(SatAttnParams p) {
     const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;   // wave-uniform: this wave owns a valid query
     const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
     const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+    const float sl2 = p.scale * 1.4426950408889634f;
 
-    bf16x8 qf[4][NP];   // B operand of S^T = K Q^T: lane (q = l31, hi) holds d = 16 s + 8 hi + e
+    bf16x8 qf[4][NP];   // B operand of x = K (Q c)^T: lane (q = l31, hi) holds d = 16 s + 8 hi + e, pre-scaled by c = scale * log2(e)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+        u32x4 w[NP];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            if (q_in) qf[s][pl] = *reinterpret_cast<const bf16x8*>(p.q_rm[pl] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
-            else {
+            if (q_in) w[pl] = *reinterpret_cast<const u32x4*>(p.q_rm[pl] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+            else w[pl] = u32x4{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qf[s][pl][e] = 0;
+        for (int j = 0; j < 4; ++j) {       // two bf16 per word: element 2j in the low half
+            float e0 = __builtin_bit_cast(float, w[0][j] << 16), e1 = __builtin_bit_cast(float, w[0][j] & 0xffff0000u);
+            if (NP == 2) {
+                e0 += __builtin_bit_cast(float, w[NP - 1][j] << 16);
+                e1 += __builtin_bit_cast(float, w[NP - 1][j] & 0xffff0000u);
+                uint32_t wh, wl;
+                sat_split2_pk(e0 * sl2, e1 * sl2, &wh, &wl);
+                w[0][j] = wh;
+                w[NP - 1][j] = wl;
+            } else {
+                w[0][j] = sat_cvt2_pk(e0 * sl2, e1 * sl2);
             }
         }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) qf[s][pl] = __builtin_bit_cast(bf16x8, w[pl]);
+    }
 
-    f32x16 oacc[2];
+    f32x16 oacc[2], negm;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-    const float sl2 = p.scale * 1.4426950408889634f;
+    for (int r = 0; r < 16; ++r) {
+        oacc[0][r] = 0.0f;
+        oacc[1][r] = 0.0f;
+        negm[r] = 0.0f;
+    }
+    float mb = 0.0f, l_run = 0.0f;      // running row max (exp2 domain) and row sum
 
     // a 64 x 64 bf16 tile = 512 16-byte pieces = 2 per thread and plane
     bf16x8 kreg[NP][2], vreg[NP][2];
@@ -384,19 +444,35 @@ sat_attn_fwd_kernel(SatAttnParams p) {
     if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
     __syncthreads();
     int buf = 0, k0 = 0;
+    if (p.Nk >= SAT_ATT_T) {      // the first full tile, peeled: it establishes the running max
+        if (SAT_ATT_T < p.Nk) {
+            tile_store(1);
+            if (2 * SAT_ATT_T < p.Nk) tile_load(2 * SAT_ATT_T);
+        }
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
+        __syncthreads();
+        k0 = SAT_ATT_T;
+        buf = 1;
+    }
     // full tiles: ONE straight-line body, so that the accumulators keep their registers around the loop; the ragged last tile is peeled
     for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
         if (k0 + SAT_ATT_T < p.Nk) {
             tile_store(buf ^ 1);                                         // tile k+1: registers -> the other buffer
             if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);   // tile k+2 -> registers (lands during this tile's math)
         }
-        if (w_ok) sat_attn_fwd_tile<NP, 2, false>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, SAT_ATT_T);
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
         __syncthreads();
     }
     if (k0 < p.Nk && w_ok) {
         const int rem = p.Nk - k0;
-        if (rem > 32) sat_attn_fwd_tile<NP, 2, true>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, rem);
-        else sat_attn_fwd_tile<NP, 1, true>(k_lds2[buf], v_lds2[buf], qf, oacc, m_run, l_run, sl2, l31, hi, kperm, rem);
+        if (k0 == 0) {            // fewer than 64 keys in all: the ragged tile is also the first
+            if (rem > 32) sat_attn_fwd_tile<NP, 2, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            else sat_attn_fwd_tile<NP, 1, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        } else if (rem > 32) {
+            sat_attn_fwd_tile<NP, 2, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        } else {
+            sat_attn_fwd_tile<NP, 1, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -413,7 +489,8 @@ sat_attn_fwd_kernel(SatAttnParams p) {
                 if (sizeof(T) == 4) *(f32x4*)((float*)p.o + idx) = v;
                 else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
             }
-        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = m_run * p.scale + logf(l_tot);
+        // natural-log LSE of the scaled scores: (mb + log2 l) ln 2   (mb lives in the exp2 domain)
+        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
 

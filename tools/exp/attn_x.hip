@@ -335,6 +335,462 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
     }
 }
 
+
+// ---- variant PIPE (needs B + C): two-tile software pipeline inside the wave — iteration k issues QK^T of tile k+1, then the PV MFMAs
+// of tile k INTERLEAVED with the exponentials / row sums of tile k+1 (sched_group_barrier pins one MFMA + one VALU slice per step);
+// P(k) lives as 4 packed bf16x8 (16 registers), so no second score tile is alive.  K stream one tile ahead of the V stream; two K and
+// two V buffers.  The ragged last tile runs un-pipelined after the drain.
+template <int FLAGS>
+SAT_DEVICE void attn_fwd_p_body(const P& p, short (*k_lds2)[TK][ROW], short (*v_lds2)[D][ROW]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = kperm_of(l31);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_in = qrow < p.Nqp, q_ok = qrow < p.Nq;
+    const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (q_in) qf[s] = *reinterpret_cast<const bf16x8*>(p.q + qplane + (size_t)qrow * D + 16 * s + 8 * hi);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = 0;
+        }
+        u32x4 w = __builtin_bit_cast(u32x4, qf[s]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __builtin_bit_cast(float, w[j] << 16) * sl2, hi2 = __builtin_bit_cast(float, w[j] & 0xffff0000u) * sl2;
+            w[j] = sat_cvt2_pk(lo, hi2);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, w);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
+    float l_run = 0.0f, mb = 0.0f;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.0f;
+
+    const int nfull = p.Nk / TK, rem = p.Nk - nfull * TK, ntiles = nfull + (rem > 0 ? 1 : 0);
+    bf16x8 kreg[2], vreg[2];
+    auto loadK = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+            kreg[j] = *reinterpret_cast<const bf16x8*>(p.k + kplane + (size_t)(t * TK + r) * D + part * 8);
+        }
+    };
+    auto loadV = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+            vreg[j] = *reinterpret_cast<const bf16x8*>(p.vt + kplane + (size_t)r * p.Nkp + t * TK + part * 8);
+        }
+    };
+    auto storeK = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+            *reinterpret_cast<bf16x8*>(&k_lds2[t & 1][r][part * 8]) = kreg[j];
+        }
+    };
+    auto storeV = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
+            *reinterpret_cast<bf16x8*>(&v_lds2[t & 1][r][part * 8]) = vreg[j];
+        }
+    };
+    if (nfull == 0) {          // fewer than 64 keys: one ragged tile, un-pipelined
+        loadK(0); loadV(0); storeK(0); storeV(0);
+        __syncthreads();
+        if (w_ok) {
+            if (rem > 32) tile_b<FLAGS, 2, true, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            else tile_b<FLAGS, 1, true, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        }
+    } else {
+        f32x16 x[2];
+        bf16x8 pb[4];
+        float ps0 = 0.f, ps1 = 0.f;
+        auto qk = [&](short (*k_lds)[ROW], bool first) {
+            if (FLAGS & 8) SAT_SETPRIO(1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (first) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[kb][r] = 0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    x[kb] = sat_mfma_32x32x16_bf16(frag(k_lds, kb * 32 + kperm, 16 * s + 8 * hi), qf[s], (!first && s == 0) ? negm : x[kb]);
+            }
+            if (FLAGS & 8) SAT_SETPRIO(0);
+        };
+        auto rowmax = [&]() {
+            float tmax = x[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
+            return halfmax(tmax);
+        };
+        auto expsum_all = [&]() {
+            ps0 = 0.f; ps1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = ex2(x[kb][2 * j]), c = ex2(x[kb][2 * j + 1]);
+                    ps0 += a; ps1 += c;
+                    x[kb][2 * j] = a; x[kb][2 * j + 1] = c;
+                }
+        };
+        auto packall = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[i] = pack8(x[i >> 1], i & 1);
+        };
+        // prologue: K0, V0 -> LDS; K1 -> registers; tile 0: true row max, exponentials, P(0)
+        loadK(0); loadV(0); storeK(0); storeV(0);
+        if (1 < ntiles) loadK(1);
+        __syncthreads();
+        if (w_ok) {
+            qk(k_lds2[0], true);
+            const float tmax = rowmax();
+            mb = tmax;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[kb][r] -= tmax;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -mb;
+            expsum_all();
+            l_run += ps0 + ps1;
+            packall();
+        }
+        if (1 < ntiles) storeK(1);
+        if (2 < ntiles) loadK(2);
+        if (1 < ntiles) loadV(1);
+        __syncthreads();
+        for (int k = 0; k + 1 < nfull; ++k) {
+            // LDS holds K(k+1), V(k); registers hold K(k+2), V(k+1)
+            if (k + 2 < ntiles) storeK(k + 2);
+            if (k + 1 < ntiles) storeV(k + 1);
+            if (k + 3 < ntiles) loadK(k + 3);
+            if (k + 2 < ntiles) loadV(k + 2);
+            if (w_ok) {
+                qk(k_lds2[(k + 1) & 1], false);
+                short (*v_lds)[ROW] = v_lds2[k & 1];
+                ps0 = 0.f; ps1 = 0.f;
+                // PV(k): 8 MFMAs, each followed by one slice (4 scores) of tile k+1's exponentials and row sum
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ks = i >> 1, t = i & 1;          // k-step (16 keys) and output d block
+                    oacc[t] = sat_mfma_32x32x16_bf16(frag(v_lds, t * 32 + l31, 16 * ks + 8 * hi), pb[ks], oacc[t]);
+                    const int kb = i >> 2, j0 = 2 * (i & 3);
+#pragma unroll
+                    for (int j = j0; j < j0 + 2; ++j) {
+                        const float a = ex2(x[kb][2 * j]), c = ex2(x[kb][2 * j + 1]);
+                        ps0 += a; ps1 += c;
+                        x[kb][2 * j] = a; x[kb][2 * j + 1] = c;
+                    }
+                    if (FLAGS & 32) {
+                        SAT_SCHED_GROUP(0x008, 1);      // one MFMA
+                        SAT_SCHED_GROUP(0x002, 8);      // its VALU slice: 4 v_exp + 4 v_add
+                    }
+                }
+                if (sat_wave_any(!(ps0 + ps1 <= SUMLIM))) {          // the running max went stale on tile k+1 (rare)
+                    qk(k_lds2[(k + 1) & 1], false);
+                    const float d = fmaxf(rowmax(), 0.0f), alpha = ex2(-d);
+                    mb += d;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) x[kb][r] -= d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[r] = -mb;
+                    expsum_all();
+                }
+                l_run += ps0 + ps1;
+                packall();
+            }
+            __syncthreads();
+        }
+        // drain: V(nfull) (the ragged tile's) -> LDS, PV of the last full tile
+        if (nfull < ntiles) storeV(nfull);
+        if (w_ok) {
+            short (*v_lds)[ROW] = v_lds2[(nfull - 1) & 1];
+            if (FLAGS & 8) SAT_SETPRIO(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ks = i >> 1, t = i & 1;
+                oacc[t] = sat_mfma_32x32x16_bf16(frag(v_lds, t * 32 + l31, 16 * ks + 8 * hi), pb[ks], oacc[t]);
+            }
+            if (FLAGS & 8) SAT_SETPRIO(0);
+        }
+        if (rem > 0) {
+            __syncthreads();
+            if (w_ok) {
+                if (rem > 32) tile_b<FLAGS, 2, true, false>(k_lds2[nfull & 1], v_lds2[nfull & 1], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+                else tile_b<FLAGS, 1, true, false>(k_lds2[nfull & 1], v_lds2[nfull & 1], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
+    if (q_ok) {
+        const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * D) + (long long)h * D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oacc[t][4 * g] * inv_l, oacc[t][4 * g + 1] * inv_l, oacc[t][4 * g + 2] * inv_l, oacc[t][4 * g + 3] * inv_l};
+                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
+            }
+        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+
+// ---- V2: issue-slot diet.  The SQ counters say the product kernel is bound by instruction ISSUE (the per-wave ACTIVE quad-cycles of
+// the three waves of a SIMD add up to the SIMD's time): every instruction, whatever its pipe, costs >= one 4-cycle slot, v_exp_f32 two.
+//   * K / V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 4 instructions per wave and tile instead of 4 global loads +
+//     4 ds_write_b128 at ~13 cycles each, and 16 staging VGPRs freed); rows are 128 B unpadded, 16-byte slot s of row r holds chunk
+//     s ^ ((r >> 1) & 7) (the swizzle rides on the DMA's per-lane SOURCE address), fragment reads stay conflict-free ds_read_b128
+//   * FLAGS & 64: the row sums run on the MATRIX pipe — four MFMAs with an all-ones A operand per tile (l[q] = sum_k P[k][q] in every
+//     accumulator row) instead of 32 v_add_f32; the sums then use the same bf16-rounded P as the numerator
+//   * B + C + setprio as before (Q pre-scaled, running max in the QK^T C operand, stale-max detection from the row sum)
+#define ROW2 64
+SAT_DEVICE bf16x8 frag2(const short* t, int row, int chunk) {      // t: [64][64] bf16, swizzled slots
+    return *reinterpret_cast<const bf16x8*>(t + row * ROW2 + ((chunk ^ ((row >> 1) & 7)) << 3));
+}
+template <int FLAGS, int NKB, bool MASK, bool FIRST>
+SAT_DEVICE void tile_v2(const short* k_lds, const short* v_lds, const bf16x8 (&qf)[4], f32x16 (&oacc)[2], f32x16& negm, f32x16& lacc, float& mb,
+                        float& l_run, int l31, int hi, int kperm, int nvalid) {
+    constexpr bool LM = (FLAGS & 64) != 0;
+    f32x16 x[NKB];
+    bf16x8 pb[2 * NKB];
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    auto qk = [&]() {
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (FIRST) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[kb][r] = 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                x[kb] = sat_mfma_32x32x16_bf16(frag2(k_lds, kb * 32 + kperm, 2 * s + hi), qf[s], (!FIRST && s == 0) ? negm : x[kb]);
+        }
+        SAT_SETPRIO(0);
+    };
+    auto rowmax = [&]() {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 7) + 8 * hi + 16 * (r >> 3);
+                if (!MASK || key < nvalid) tmax = fmaxf(tmax, x[kb][r]);
+            }
+        return halfmax(tmax);
+    };
+    float ps = 0.f;
+    auto exps = [&]() {          // exponentials (+ VALU row sum when the matrix pipe does not take it), pack to bf16
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = ex2(x[kb][2 * j]), c = ex2(x[kb][2 * j + 1]);
+                if (MASK) {
+                    const int key = kb * 32 + ((2 * j) & 7) + 8 * hi + 16 * ((2 * j) >> 3);
+                    if (key >= nvalid) a = 0.f;
+                    if (key + 1 >= nvalid) c = 0.f;
+                }
+                if (!LM) { ps0 += a; ps1 += c; }
+                x[kb][2 * j] = a; x[kb][2 * j + 1] = c;
+            }
+        ps = ps0 + ps1;
+#pragma unroll
+        for (int i = 0; i < 2 * NKB; ++i) pb[i] = pack8(x[i >> 1], i & 1);
+    };
+    qk();
+    if (FIRST) {
+        const float tmax = rowmax();
+        mb = tmax;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[kb][r] -= tmax;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mb;
+    }
+    exps();
+    float l_before = 0.f;
+    auto lsum = [&]() {          // row sums of this tile on the matrix pipe: every row of the result = sum over the tile's keys
+        l_before = lacc[0];
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int i = 0; i < 2 * NKB; ++i) lacc = sat_mfma_32x32x16_bf16(ones, pb[i], lacc);
+        SAT_SETPRIO(0);
+    };
+    if (LM) lsum();
+    if (!FIRST) {
+        const float grown = LM ? lacc[0] - l_before : ps;       // LM: the full row sum of 64 keys; else this lane's 32
+        if (sat_wave_any(!(grown <= (LM ? 2.0f * SUMLIM : SUMLIM)))) {          // stale running max (rare): redo the tile with the true one
+            if (LM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] = l_before;
+            }
+            qk();
+            const float d = fmaxf(rowmax(), 0.0f), alpha = ex2(-d);
+            mb += d;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[kb][r] -= d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -mb;
+            exps();
+            if (LM) lsum();
+        }
+    }
+    if (!LM) l_run += ps;
+    SAT_SETPRIO(1);
+#pragma unroll
+    for (int i = 0; i < 2 * NKB; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) oacc[t] = sat_mfma_32x32x16_bf16(frag2(v_lds, t * 32 + l31, 2 * i + hi), pb[i], oacc[t]);
+    SAT_SETPRIO(0);
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) attn_fwd_v2(P p) {
+    __shared__ __attribute__((aligned(1024))) short k_lds2[2][TK * ROW2];
+    __shared__ __attribute__((aligned(1024))) short v_lds2[2][D * ROW2];
+    constexpr bool LM = (FLAGS & 64) != 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = kperm_of(l31);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_in = qrow < p.Nqp, q_ok = qrow < p.Nq;
+    const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (q_in) qf[s] = *reinterpret_cast<const bf16x8*>(p.q + qplane + (size_t)qrow * D + 16 * s + 8 * hi);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = 0;
+        }
+        u32x4 w = __builtin_bit_cast(u32x4, qf[s]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __builtin_bit_cast(float, w[j] << 16) * sl2, hi2 = __builtin_bit_cast(float, w[j] & 0xffff0000u) * sl2;
+            w[j] = sat_cvt2_pk(lo, hi2);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, w);
+    }
+    f32x16 oacc[2], negm, lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; negm[r] = 0.0f; lacc[r] = 0.0f; }
+    float l_run = 0.0f, mb = 0.0f;
+
+    // DMA staging: piece pb = wave * 2 + j covers rows 8 pb .. 8 pb + 7; lane -> (row, slot); slot holds chunk slot ^ ((row >> 1) & 7)
+    int srow[2], schunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        srow[j] = 8 * (wave * 2 + j) + (lane >> 3);
+        schunk[j] = (lane & 7) ^ ((srow[j] >> 1) & 7);
+    }
+    auto stage = [&](int k0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sat_glds16(p.k + kplane + (size_t)(k0 + srow[j]) * D + schunk[j] * 8, (char*)k_lds2[buf] + (wave * 2 + j) * 1024);
+            sat_glds16(p.vt + kplane + (size_t)srow[j] * p.Nkp + k0 + schunk[j] * 8, (char*)v_lds2[buf] + (wave * 2 + j) * 1024);
+        }
+    };
+    stage(0, 0);
+    SAT_WAIT_VMCNT(0);
+    __syncthreads();
+    int buf = 0, k0 = 0;
+    if (p.Nk >= TK) {
+        if (TK < p.Nk) stage(TK, 1);
+        if (w_ok) tile_v2<FLAGS, 2, false, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, TK);
+        SAT_WAIT_VMCNT(0);
+        __syncthreads();
+        k0 = TK; buf = 1;
+    }
+    for (; k0 + TK <= p.Nk; k0 += TK, buf ^= 1) {
+        if (k0 + TK < p.Nk) stage(k0 + TK, buf ^ 1);
+        if (w_ok) tile_v2<FLAGS, 2, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, TK);
+        SAT_WAIT_VMCNT(0);
+        __syncthreads();
+    }
+    if (k0 < p.Nk && w_ok) {
+        const int rem = p.Nk - k0;
+        if (k0 == 0) {
+            if (rem > 32) tile_v2<FLAGS, 2, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, rem);
+            else tile_v2<FLAGS, 1, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, rem);
+        } else if (rem > 32) tile_v2<FLAGS, 2, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, rem);
+        else tile_v2<FLAGS, 1, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, lacc, mb, l_run, l31, hi, kperm, rem);
+    }
+    const float l_tot = LM ? lacc[0] : l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
+    if (q_ok) {
+        const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * D) + (long long)h * D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oacc[t][4 * g] * inv_l, oacc[t][4 * g + 1] * inv_l, oacc[t][4 * g + 2] * inv_l, oacc[t][4 * g + 3] * inv_l};
+                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
+            }
+        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) attn_fwd_p(P p) {
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][TK][ROW];
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][D][ROW];
+    attn_fwd_p_body<FLAGS>(p, k_lds2, v_lds2);
+}
+template <int FLAGS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) attn_fwd_p2(P p) {      // 256 registers: two waves per SIMD
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][TK][ROW];
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][D][ROW];
+    attn_fwd_p_body<FLAGS>(p, k_lds2, v_lds2);
+}
+
 extern "C" int satx_attention_fwd(int variant, const short* q, const short* k, const short* vt, void* o, float* lse, int B, int H, int Hkv,
                                   int Nq, int Nk, int Nqp, int Nkp, float scale, void* stream) {
     P p{q, k, vt, o, lse, B, H, Hkv, Nq, Nk, Nqp, Nkp, scale};
@@ -348,6 +804,16 @@ extern "C" int satx_attention_fwd(int variant, const short* q, const short* k, c
         case 8: hipLaunchKernelGGL(attn_fwd_x<8>, grid, dim3(256), 0, st, p); break;
         case 11: hipLaunchKernelGGL(attn_fwd_x<11>, grid, dim3(256), 0, st, p); break;
         case 15: hipLaunchKernelGGL(attn_fwd_x<15>, grid, dim3(256), 0, st, p); break;
+        case 200: hipLaunchKernelGGL(attn_fwd_v2<0>, grid, dim3(256), 0, st, p); break;
+        case 264: hipLaunchKernelGGL(attn_fwd_v2<64>, grid, dim3(256), 0, st, p); break;
+        case 22: hipLaunchKernelGGL(attn_fwd_p<6>, grid, dim3(256), 0, st, p); break;
+        case 30: hipLaunchKernelGGL(attn_fwd_p<14>, grid, dim3(256), 0, st, p); break;
+        case 54: hipLaunchKernelGGL(attn_fwd_p<38>, grid, dim3(256), 0, st, p); break;
+        case 62: hipLaunchKernelGGL(attn_fwd_p<46>, grid, dim3(256), 0, st, p); break;
+        case 122: hipLaunchKernelGGL(attn_fwd_p2<6>, grid, dim3(256), 0, st, p); break;
+        case 130: hipLaunchKernelGGL(attn_fwd_p2<14>, grid, dim3(256), 0, st, p); break;
+        case 154: hipLaunchKernelGGL(attn_fwd_p2<38>, grid, dim3(256), 0, st, p); break;
+        case 162: hipLaunchKernelGGL(attn_fwd_p2<46>, grid, dim3(256), 0, st, p); break;
         default: return 2;
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
