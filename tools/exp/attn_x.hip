@@ -8,6 +8,7 @@
 #include "sat_device.h"
 #include <stdlib.h>
 #include <cstdio>
+#include <type_traits>
 
 #define D 64
 #define TK 64
@@ -134,6 +135,108 @@ SAT_DEVICE void tile_b(short (*k_lds)[ROW], short (*v_lds)[ROW], const bf16x8 (&
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 x[kb] = sat_mfma_32x32x16_bf16(frag(k_lds, kb * 32 + kperm, 16 * s + 8 * hi), qf[s], (!FIRST && s == 0) ? negm : x[kb]);
+        }
+        if (FLAGS & 8) SAT_SETPRIO(0);
+    };
+    auto rowmax = [&]() {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 7) + 8 * hi + 16 * (r >> 3);
+                if (!MASK || key < nvalid) tmax = fmaxf(tmax, x[kb][r]);
+            }
+        return halfmax(tmax);
+    };
+    // move the running max by d >= 0 (per lane): rescale O and l, shift this tile's scores, refresh the C block
+    auto shift = [&](float d) {
+        const float alpha = ex2(-d);
+        mb += d;
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[kb][r] -= d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mb;
+    };
+    qk();
+    if (FIRST) {
+        const float tmax = rowmax();
+        mb = tmax;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[kb][r] -= tmax;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mb;
+    } else if (!(FLAGS & 4)) {
+        const float tmax = rowmax();
+        if (sat_wave_any(tmax > DEFER)) shift(fmaxf(tmax, 0.0f));
+    }
+    float ps0 = 0.f, ps1 = 0.f;
+    auto expsum = [&]() {
+        ps0 = 0.f; ps1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = ex2(x[kb][2 * j]), b = ex2(x[kb][2 * j + 1]);
+                if (MASK) {
+                    const int key = kb * 32 + ((2 * j) & 7) + 8 * hi + 16 * ((2 * j) >> 3);
+                    if (key >= nvalid) a = 0.f;
+                    if (key + 1 >= nvalid) b = 0.f;
+                }
+                ps0 += a; ps1 += b;
+                x[kb][2 * j] = a; x[kb][2 * j + 1] = b;
+            }
+    };
+    expsum();
+    if ((FLAGS & 4) && !FIRST) {
+        // the row sum of this lane's 32 scores bounds every one of them: above the limit (or inf) the running max is stale
+        if (sat_wave_any(!(ps0 + ps1 <= SUMLIM))) {
+            qk();                                    // rare: the scores were overwritten by their exponentials
+            const float tmax = rowmax();
+            shift(fmaxf(tmax, 0.0f));
+            expsum();
+        }
+    }
+    l_run += ps0 + ps1;
+    if (FLAGS & 8) SAT_SETPRIO(1);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pb = pack8(x[kb], u);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) oacc[t] = sat_mfma_32x32x16_bf16(frag(v_lds, t * 32 + l31, kb * 32 + 16 * u + 8 * hi), pb, oacc[t]);
+        }
+    if (FLAGS & 8) SAT_SETPRIO(0);
+}
+
+SAT_DEVICE bf16x8 fragk(const short* t, int row, int chunk) {      // [64][64] bf16, 16-byte slot s of row r holds chunk s ^ ((r >> 1) & 7)
+    return *reinterpret_cast<const bf16x8*>(t + row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3));
+}
+template <int FLAGS, int NKB, bool MASK, bool FIRST>
+SAT_DEVICE void tile_bk(const short* k_lds, short (*v_lds)[ROW], const bf16x8 (&qf)[4], f32x16 (&oacc)[2], f32x16& negm, float& mb, float& l_run,
+                       int l31, int hi, int kperm, int nvalid) {
+    f32x16 x[NKB];
+    auto qk = [&]() {
+        if (FLAGS & 8) SAT_SETPRIO(1);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (FIRST) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[kb][r] = 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                x[kb] = sat_mfma_32x32x16_bf16(fragk(k_lds, kb * 32 + kperm, 2 * s + hi), qf[s], (!FIRST && s == 0) ? negm : x[kb]);
         }
         if (FLAGS & 8) SAT_SETPRIO(0);
     };
@@ -791,11 +894,152 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) a
     attn_fwd_p_body<FLAGS>(p, k_lds2, v_lds2);
 }
 
+
+// ---- KS: key split inside the workgroup, for occupancy BALANCE at short sequences.  At N = 1025, B*H = 48 the 128-query workgroups are
+// 432 four-wave units on 256 CUs: two on 176 CUs, one on 80 — the busiest SIMD walks 2 x 17 tiles, the average one 26.  Here a workgroup
+// is 64 queries x 2 key halves (wave = (q-block, half)): 17 x 48 = 816 workgroups, three per CU, every SIMD three waves of ~8.5 tiles;
+// the two halves of a q-block merge (O, l, m) through LDS at the end.  One K / V^T buffer per half (the same 36.9 KB per workgroup as the
+// product kernel), the next tile in registers, two barriers per tile.
+template <int FLAGS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) attn_fwd_ks(P p) {
+    __shared__ __attribute__((aligned(1024))) short k_lds2[2][2][TK * 64];  // [half][buffer][key][d]: unpadded, swizzled slots, filled by LDS-DMA
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][D][ROW];        // [half][d][key]: one buffer, next tile in registers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = kperm_of(l31);
+    const int qb = wave & 1, half = wave >> 1;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 64 + qb * 32 + l31;
+    const bool q_in = qrow < p.Nqp, q_ok = qrow < p.Nq;
+    const bool w_ok = blockIdx.x * 64 + qb * 32 < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (q_in) qf[s] = *reinterpret_cast<const bf16x8*>(p.q + qplane + (size_t)qrow * D + 16 * s + 8 * hi);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = 0;
+        }
+        u32x4 w = __builtin_bit_cast(u32x4, qf[s]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __builtin_bit_cast(float, w[j] << 16) * sl2, hi2 = __builtin_bit_cast(float, w[j] & 0xffff0000u) * sl2;
+            w[j] = sat_cvt2_pk(lo, hi2);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, w);
+    }
+    f32x16 oacc[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; negm[r] = 0.0f; }
+    float l_run = 0.0f, mb = -INFINITY;
+
+    const int ntiles = (p.Nk + TK - 1) / TK, rem = p.Nk - (ntiles - 1) * TK;      // rem in 1..64: keys of the last tile
+    const int n0 = ntiles / 2;
+    const int base = half ? n0 : 0, count = half ? ntiles - n0 : n0, steps = ntiles - n0;
+    // staging: the 128 threads of a half load that half's tile: 512 K pieces + 512 V pieces of 16 bytes = 4 + 4 per thread
+    const int th = threadIdx.x & 127;
+    bf16x8 vreg[4];
+    // K: 8 DMA pieces of 1 KiB per tile, 4 per wave of the half (piece = qb * 4 + j: rows 8 piece .. 8 piece + 7)
+    auto k_dma = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = qb * 4 + j, r = piece * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            sat_glds16(p.k + kplane + (size_t)(t * TK + r) * D + c * 8, (char*)k_lds2[half][buf] + piece * 1024);
+        }
+    };
+    auto v_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = th + j * 128, r = c >> 3, part = c & 7;
+            vreg[j] = *reinterpret_cast<const bf16x8*>(p.vt + kplane + (size_t)r * p.Nkp + t * TK + part * 8);
+        }
+    };
+    auto v_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = th + j * 128, r = c >> 3, part = c & 7;
+            *reinterpret_cast<bf16x8*>(&v_lds2[half][r][part * 8]) = vreg[j];
+        }
+    };
+    if (count > 0) { k_dma(base, 0); v_load(base); }
+    // every step: [V registers -> LDS, K DMA landed] barrier [next tile: K DMA + V loads] compute barrier.  Step 0 (first tile: true max),
+    // the plain middle steps and the last step (ragged tile) are separate code so that the hot loop holds ONE tile body.
+    auto open_step = [&](int i) {
+        if (i < count) v_store();                 // (waits for the V loads of tile i)
+        SAT_WAIT_VMCNT(0);                        // this wave's K DMA pieces of tile i have landed
+        __syncthreads();
+        if (i + 1 < count) { k_dma(base + i + 1, (i + 1) & 1); v_load(base + i + 1); }
+    };
+    auto ragged_tile = [&](int i, auto first) {
+        constexpr bool F = decltype(first)::value;
+        if (rem > 32) tile_bk<FLAGS, 2, true, F>(k_lds2[half][i & 1], v_lds2[half], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        else tile_bk<FLAGS, 1, true, F>(k_lds2[half][i & 1], v_lds2[half], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+    };
+    {   // step 0
+        open_step(0);
+        if (count > 0 && w_ok) {
+            if (base == ntiles - 1 && rem < TK) ragged_tile(0, std::true_type{});
+            else tile_bk<FLAGS, 2, false, true>(k_lds2[half][0], v_lds2[half], qf, oacc, negm, mb, l_run, l31, hi, kperm, TK);
+        }
+        __syncthreads();
+    }
+    for (int i = 1; i + 1 < steps; ++i) {
+        open_step(i);
+        if (i < count && w_ok) tile_bk<FLAGS, 2, false, false>(k_lds2[half][i & 1], v_lds2[half], qf, oacc, negm, mb, l_run, l31, hi, kperm, TK);
+        __syncthreads();
+    }
+    if (steps > 1) {   // last step
+        const int i = steps - 1;
+        open_step(i);
+        if (i < count && w_ok) {
+            if (base + i == ntiles - 1 && rem < TK) ragged_tile(i, std::false_type{});
+            else tile_bk<FLAGS, 2, false, false>(k_lds2[half][i & 1], v_lds2[half], qf, oacc, negm, mb, l_run, l31, hi, kperm, TK);
+        }
+        __syncthreads();
+    }
+    // merge the two key halves of each q-block through LDS (the K buffers are free after the last barrier)
+    float l_h = l_run + __shfl_xor(l_run, 32);
+    float* mg = reinterpret_cast<float*>(&k_lds2[0][0][0]) + qb * 34 * 64;      // 17.4 KB of the 32-KB K area
+    if (half == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mg[(t * 16 + r) * 64 + lane] = oacc[t][r];
+        mg[32 * 64 + lane] = l_h;
+        mg[33 * 64 + lane] = mb;
+    }
+    __syncthreads();
+    if (half == 0 && q_ok) {
+        const float l1 = mg[32 * 64 + lane], m1 = mg[33 * 64 + lane];
+        const float m = fmaxf(mb, m1);
+        const float a0 = (count > 0) ? ex2(mb - m) : 0.0f, a1 = ex2(m1 - m);
+        const float l_tot = l_h * a0 + l1 * a1;
+        const float inv_l = 1.0f / l_tot;
+        const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * D) + (long long)h * D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (oacc[t][4 * g + e] * a0 + mg[(t * 16 + 4 * g + e) * 64 + lane] * a1) * inv_l;
+                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
+            }
+        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (m + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
 extern "C" int satx_attention_fwd(int variant, const short* q, const short* k, const short* vt, void* o, float* lse, int B, int H, int Hkv,
                                   int Nq, int Nk, int Nqp, int Nkp, float scale, void* stream) {
     P p{q, k, vt, o, lse, B, H, Hkv, Nq, Nk, Nqp, Nkp, scale};
     dim3 grid((Nq + 127) / 128, H, B);
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 415) { hipLaunchKernelGGL(attn_fwd_ks<15>, dim3((Nq + 63) / 64, H, B), dim3(256), 0, st, p); return hipGetLastError() == hipSuccess ? 0 : 1; }
     switch (variant) {
         case 0: hipLaunchKernelGGL(attn_fwd_x<0>, grid, dim3(256), 0, st, p); break;
         case 1: hipLaunchKernelGGL(attn_fwd_x<1>, grid, dim3(256), 0, st, p); break;
