@@ -61,6 +61,9 @@ def parse():
                          "per-bucket events, collectives on a 1-rank communicator): the data-parallel code path on a single-GPU box")
     ap.add_argument("--ddp-mode", choices=["all_reduce", "reduce_scatter"], default="all_reduce")
     ap.add_argument("--ddp-comm-dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager launches only (skip the HIP-graph replay of the train step)")
+    ap.add_argument("--graph-ddp", action="store_true",
+                    help="also try the HIP-graph step when a process group is active (the RCCL collectives are then captured too)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.workload == "dit_train" else 1
@@ -1029,6 +1032,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(out["loss"])
+    elapsed_eager = elapsed
+    launch = {"mode": "eager", "ms_per_step": {"eager": 1e3 * elapsed_eager / args.steps}}
+    gstep = None
+    if not args.no_graph and (world == 1 or args.graph_ddp):
+        # the same steps with every update replayed from ONE HIP graph (training.GraphedTrainStep: forward + loss + backward + gradient
+        # exchange + fused AdamW of a step captured once; the per-step optimizer scalars are read from device memory).  Identical kernels
+        # and arithmetic (tests/test_train_step.py::test_graphed_*: bit-equal parameters); what goes away are the launch gaps between the
+        # ~400 microsecond-scale kernels of a step.  Capture is outside the timed region; `value` is the faster mode, both are reported.
+        from stable_audio_tools_amd.training import GraphedTrainStep
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
+        gstep = GraphedTrainStep(stepper, eager_steps=1)
+        for i in range(max(args.warmup, 1) + 2):          # eager call, capturing call, warm replays
+            gstep(batches[i % 2])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out_g = gstep(batches[i % 2])
+        sync()
+        elapsed_graph = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed_graph], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_graph = float(t.item())
+        launch["ms_per_step"]["hip_graph"] = 1e3 * elapsed_graph / args.steps
+        launch["graph_replays"] = gstep.replays
+        if gstep.fallback:
+            launch["graph_fallback"] = list(gstep.fallback.values())
+        if gstep.replays >= args.steps and elapsed_graph < elapsed:
+            elapsed, launch["mode"] = elapsed_graph, "hip_graph"
+            loss = float(out_g["loss"])
 
     if rank == 0:
         dom, allk = prof.summary()
@@ -1045,7 +1079,7 @@ def main():
                                    " the alternating MS-STFT-discriminator / generator step of the reference is timed beside it: real_step_*",
                        "sample_size": args.sample_size, "channels": 2, "sample_rate": 44100,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "parallelism": f"dp{world}", "final_loss": loss, "launch": launch,
                        "ddp": {"process_group": (dist.get_backend() if dist.is_initialized() else None), "exchange_active": stepper.comm.active,
                                "mode": stepper.comm.mode, "comm_dtype": args.ddp_comm_dtype, "buckets": len(stepper.comm.buckets),
                                "overlap": stepper.comm.overlap,
@@ -1135,6 +1169,41 @@ def main():
                 u.checkpointing = False
             line["config"]["real_step"]["recompute"] = {"ms_per_step": 1e3 * dt_rc, "peak_hbm_gib": peak_rc, "steps": 2,
                                                         "what": "ResidualUnit.checkpointing = True on all 30 units"}
+            if gstep is not None:
+                # the same alternating updates replayed from HIP graphs (one per kind of update)
+                del gstep
+                gstep = None
+                ops.release_workspaces()
+                torch.cuda.empty_cache()
+                from stable_audio_tools_amd.training import GraphedTrainStep
+                g2 = GraphedTrainStep(stepper, eager_steps=1)
+                stepper.global_step = 0
+                for i in range(6):                      # per kind: one eager call, the capturing call, one warm replay
+                    g2(batches[i % 2])
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats()
+                t1 = time.perf_counter()
+                last_two = []
+                for i in range(4):
+                    o = g2(batches[i % 2])
+                    if i >= 2:
+                        last_two.append(o["loss"].clone())
+                torch.cuda.synchronize()
+                dt_g = (time.perf_counter() - t1) / 4
+                rg = {"ms_per_step": 1e3 * dt_g, "samples_per_s": args.batch / dt_g, "steps": 4, "graphs": len(g2.graphs), "replays": g2.replays,
+                      "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "last_loss": float(o["loss"])}
+                if g2.fallback:
+                    rg["graph_fallback"] = list(g2.fallback.values())
+                # continuity check of the replayed updates: the next two updates run eagerly from the state the graphs left
+                cont = [g2.stepper(batches[i % 2]) for i in range(2)]
+                rg["eager_continuation_losses"] = [float(c_["loss"]) for c_ in cont]
+                rg["last_two_graph_losses"] = [float(v) for v in last_two]
+                line["config"]["real_step"]["hip_graph"] = rg
+                if g2.replays >= 8 and not g2.fallback and dt_g < dt_real:
+                    line["config"]["real_step"].update(ms_per_step=1e3 * dt_g, samples_per_s=args.batch / dt_g, launch_mode="hip_graph",
+                                                       eager_ms_per_step=1e3 * dt_real)
+                del g2
+                torch.cuda.empty_cache()
             stepper.use_disc = False
             rs = line["config"]["real_step"]
             line["real_step_samples_per_s"], line["real_step_ms"] = rs["samples_per_s"], rs["ms_per_step"]

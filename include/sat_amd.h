@@ -258,6 +258,11 @@ int sat_stft_bwd(const float* x, const float* y, const float* views, const float
 int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, float* ema, float ema_decay,
                    void* stream);
+/* The same step with the per-step scalars read from DEVICE memory: hyper[5] (fp32) = {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale,
+ * ema_decay}.  A whole optimisation step captured into a HIP graph (training.GraphedTrainStep — the reference's
+ * training_step, training/autoencoders.py:367-527, as ONE graph launch) is replayed with the next step's values by rewriting 20 bytes. */
+int sat_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
+                       float eps, float weight_decay, float* ema, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DiT block operators — models/transformer.py.  dtype: 0 = fp32 tensors, 1 = bf16 tensors

@@ -36,6 +36,21 @@ def _aweighting_taps(fs, ntaps=101):
     return torch.tensor(taps.astype("float32"))
 
 
+_VIEW_W = {}
+
+
+def _view_weights(view_w, device):
+    """The per-view weights as a device tensor, built once per (weights, device): creating it from the host list at every call is a
+    pageable host->device copy — a synchronisation inside every step, and not capturable into a HIP graph (training.GraphedTrainStep)."""
+    key = (tuple(float(v) for v in view_w), str(device))
+    t = _VIEW_W.get(key)
+    if t is None:
+        with torch.inference_mode(False):
+            t = torch.tensor(key[0], dtype=torch.float32, device=device)
+        _VIEW_W[key] = t
+    return t
+
+
 class _MRSTFTFn(torch.autograd.Function):
     """total = sum_v w_v * mean_r [ mean_i sqrt(S1/S2) + sum_i S3 / (NI * bins * frames) ]
     x, y: (NI, C, T); views (NV, 2); view_w (NV,) python floats."""
@@ -52,7 +67,7 @@ class _MRSTFTFn(torch.autograd.Function):
         else:
             xf, yf = x, y
         nres = len(fft_sizes)
-        vw = torch.tensor(view_w, dtype=torch.float32, device=x.device)
+        vw = _view_weights(view_w, x.device)
         total = torch.zeros((), dtype=torch.float32, device=x.device)
         sums_all = []
         for n, h in zip(fft_sizes, hop_sizes):
@@ -74,7 +89,7 @@ class _MRSTFTFn(torch.autograd.Function):
         xf, yf, views, taps, *sums_all = ctx.saved_tensors
         ni, c, t = xf.shape
         nres = len(fft_sizes)
-        vw = torch.tensor(view_w, dtype=torch.float32, device=xf.device)
+        vw = _view_weights(view_w, xf.device)
         grads = [None, None]
         for which in (0, 1):          # 0: d/dx (first argument), 1: d/dy (second argument)
             if not ctx.needs_input_grad[which]:

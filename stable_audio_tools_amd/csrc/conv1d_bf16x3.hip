@@ -235,6 +235,7 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
         if (c + 1 < nchunks) issue_loads(c + 1);
 
         if (wave_on) {
+            SAT_MFMA_PRIO(1);
 #pragma unroll
             for (int ks = 0; ks < NG / 2; ++ks) {
                 const int g = 2 * ks + hi;                 // k-slots 0-7 <- group 2ks (lanes 0-31), 8-15 <- group 2ks+1
@@ -260,6 +261,7 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
                     }
                 }
             }
+            SAT_MFMA_PRIO(0);
         }
         __syncthreads();
     }

@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     auto mfma_phase = [&](auto buf_c) {
         auto& lo_lds = sat_pick<decltype(buf_c)::value>(lo_lds0, lo_lds1);
         auto& hi_lds = sat_pick<decltype(buf_c)::value>(hi_lds0, hi_lds1);
+        SAT_MFMA_PRIO(1);
 #pragma unroll 2
         for (int ks = 0; ks < SAT_WB_TT / 16; ++ks) {
             const int tb = 16 * ks + 8 * hi;
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
                 }
             }
         }
+        SAT_MFMA_PRIO(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

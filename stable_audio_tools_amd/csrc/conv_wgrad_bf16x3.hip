@@ -385,6 +385,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
 
     auto mfma_stage = [&]() {
         if (wave_on) {
+            SAT_MFMA_PRIO(1);
 #pragma unroll
             for (int ks = 0; ks < SAT_WS_TT / 16; ++ks) {
                 const int tb = 16 * ks + 8 * hi;
@@ -420,6 +421,7 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
                     }
                 }
             }
+            SAT_MFMA_PRIO(0);
         }
     };
 

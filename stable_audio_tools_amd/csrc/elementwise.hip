@@ -400,6 +400,50 @@ __global__ void __launch_bounds__(256) sat_adamw_kernel(SatAdamParams a) {
         a.p[i] = p; a.m[i] = m; a.v[i] = v;
     }
 }
+// The same update with the per-step scalars read from DEVICE memory — hyper[5] = {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale,
+// ema_decay} — so that a training step captured into a HIP graph (training.GraphedTrainStep) is replayed with the next step's learning
+// rate, bias corrections and EMA decay by rewriting 20 bytes.
+struct SatAdamDevParams { SatAdamParams a; const float* hyper; };
+__global__ void __launch_bounds__(256) sat_adamw_dev_kernel(SatAdamDevParams d) {
+    SatAdamParams a = d.a;
+    a.lr = d.hyper[0]; a.bc1 = d.hyper[1]; a.bc2s = d.hyper[2]; a.gscale = d.hyper[3]; a.ema_decay = d.hyper[4];
+    const long long n4 = a.n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i], m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+        if (a.ema) e = reinterpret_cast<f32x4*>(a.ema)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = p[j], mj = m[j], vj = v[j], ej = e[j];
+            sat_adamw_one(a, g[j], pj, mj, vj, a.ema ? &ej : nullptr);
+            p[j] = pj; m[j] = mj; v[j] = vj; e[j] = ej;
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+        if (a.ema) reinterpret_cast<f32x4*>(a.ema)[i] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        sat_adamw_one(a, a.g[i], p, m, v, a.ema ? a.ema + i : nullptr);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+}
+extern "C" int sat_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                                  float beta2, float eps, float weight_decay, float* ema, void* stream) {
+    if (n <= 0 || !hyper) { sat_set_error("sat_adamw_step_dev: empty buffer or no hyper-parameter buffer"); return 1; }
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0) {
+        sat_set_error("sat_adamw_step_dev: buffers must be 16-byte aligned");
+        return 1;
+    }
+    SatAdamDevParams d{{p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, ema, 0.f}, hyper};
+    long long nb = sat_cdivll(sat_cdivll(n, 4), 256);
+    if (nb > 4096) nb = 4096;
+    SAT_LAUNCH(sat_adamw_dev_kernel, dim3((unsigned)nb), dim3(256), stream, d);
+    return sat_check_launch("sat_adamw_step_dev");
+}
 extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int step, float grad_scale, float* ema,
                               float ema_decay, void* stream) {

@@ -313,6 +313,16 @@ SAT_DEVICE void sat_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 SAT_DEVICE bool sat_wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
 #endif
 
+// s_setprio around the MFMA sections of the generic conv / weight-gradient kernels (conv1d_bf16x3.hip, conv_wgrad*.hip): an A/B switch.
+// The attention forward gains 13 % from raising its MFMA groups' priority; these kernels do NOT: with it their own event times are
+// unchanged (138.6 vs 138.2 ms of conv kernels per 4 steps) and the generator step is 8 ms SLOWER (166.1 / 166.1 vs 158.0 ms, A / B / A
+// on one box, profiles/EXPERIMENTS.md round 4) — off unless built with -DSAT_WITH_MFMA_PRIO.
+#if defined(SAT_WITH_MFMA_PRIO)
+#define SAT_MFMA_PRIO(x) SAT_SETPRIO(x)
+#else
+#define SAT_MFMA_PRIO(x)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 void sat_set_error(const char* msg);
 int sat_check_launch(const char* what);

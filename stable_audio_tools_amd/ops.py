@@ -1167,6 +1167,14 @@ class SatOps:
         return dst
 
     # ------------------------------------------------------------------ optimizer
+    def adamw_step_dev(self, p, g, m, v, hyper, beta1, beta2, eps, weight_decay, ema=None):
+        """adamw_step with (lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale, ema_decay) read from the device tensor `hyper` (5 fp32)."""
+        self._f32(p, g, m, v, ema, hyper)
+        if hyper.numel() < 5:
+            raise ValueError("adamw_step_dev: hyper holds 5 fp32 values")
+        self._chk(self.lib.sat_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), beta1, beta2, eps, weight_decay,
+                                              _ptr(ema), self._stream(p)))
+
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)
         self._chk(self.lib.sat_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,

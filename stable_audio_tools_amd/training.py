@@ -277,10 +277,29 @@ class FusedAdamW:
         self.ema = flat.data.clone() if use_ema else None
         self.t = 0
         self._ops = ops
+        self.hyper_dev = None        # device (lr, bc1, bc2s, grad_scale, ema_decay): set by GraphedTrainStep
+
+    def hyper(self, lr=None, grad_scale=1.0):
+        """The per-step scalars of the NEXT step (t + 1) as the kernel wants them: (lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale, ema_decay)."""
+        import numpy as np
+        t = np.float32(self.t + 1)
+        one = np.float32(1.0)
+        # rounded exactly as sat_adamw_step rounds them on the host (1.0f - powf(beta, t), sqrtf(...)): a replayed step is then
+        # bit-identical to the eager launch of the same step
+        bc1 = one - np.power(np.float32(self.betas[0]), t)
+        bc2s = np.sqrt(one - np.power(np.float32(self.betas[1]), t))
+        return (float(self.lr if lr is None else lr), float(bc1), float(bc2s), float(grad_scale),
+                ema_decay(self.t + 1) if self.ema is not None else 0.0)
 
     def step(self, lr=None, grad_scale=1.0):
-        self.t += 1
         ops = _fn._ops(self._ops)
+        if self.hyper_dev is not None:
+            # graph mode (GraphedTrainStep): the launch is frozen in a HIP graph, the scalars come from device memory; the owner of the
+            # graph writes hyper() into `hyper_dev` before every replay and counts the steps
+            ops.adamw_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.hyper_dev, self.betas[0], self.betas[1],
+                               self.eps, self.weight_decay, ema=self.ema)
+            return
+        self.t += 1
         ops.adamw_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, grad_scale,
                        ema=self.ema, ema_decay=ema_decay(self.t) if self.ema is not None else 0.0)
@@ -387,35 +406,51 @@ class AutoencoderTrainStep:
             decoded, reals = decoded[..., :n], reals[..., :n].contiguous()
         return decoded, reals
 
-    def __call__(self, reals, noise=None):
-        """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
-        m = self.model
-        kw = {"noise": noise} if noise is not None else {}
+    # ---- one optimisation step = _kind() (which update is due) + the device work of that update + _after() (host counters) ----
+    def _kind(self):
+        """"disc" or "gen": the update the reference's manual optimisation would run at this global step (:476-483)."""
         if self.global_step >= self.warmup_steps:
             self.warmed_up = True
         if self.use_disc and self.global_step % 2 == 1 and ((self.warmup_mode == "full" and self.warmed_up) or self.warmup_mode == "adv"):
-            # ---- discriminator step (:484-497) ----
-            self.flat_d.zero_grad()
-            with torch.no_grad():
-                latents = m.encode(reals, **kw)
-                decoded, reals_t = self._trim(m.decode(latents), reals)
-            # scale by scale: one scale's graph alive at a time (the sum of the per-scale terms is loss(): discriminators.py:42-63)
-            decoded = decoded.contiguous()
-            loss_dis = torch.zeros((), device=reals.device)
-            for i in range(self.discriminator.discriminators.num_discriminators):
-                dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded, need_fm=False)
-                dis_i.backward()
-                loss_dis = loss_dis + dis_i.detach()
-            self.flat_d.gather_grads()
-            self.comm_d()
-            lr = self.base_lr_d if self.sched_d is None else inverse_lr(self.disc_steps, self.base_lr_d, **self.sched_d["config"])
-            if self.clip_grad_norm > 0.0:
-                clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale)
-            self.opt_d.step(lr=lr, grad_scale=self.comm_d.grad_scale)
+            return "disc"
+        return "gen"
+
+    def _after(self, kind):
+        if kind == "disc":
             self.disc_steps += 1
-            self.global_step += 1
-            return {"loss": loss_dis.detach(), "discriminator_loss": loss_dis.detach()}
-        # ---- generator step (:498-515) ----
+        else:
+            self.gen_steps += 1
+        self.global_step += 1
+
+    def _lr(self, kind):
+        if kind == "disc":
+            return self.base_lr_d if self.sched_d is None else inverse_lr(self.disc_steps, self.base_lr_d, **self.sched_d["config"])
+        return self.current_lr()
+
+    def _disc_body(self, reals, kw):
+        """Discriminator update (:484-497): everything that runs on the device, nothing that counts steps."""
+        m = self.model
+        self.flat_d.zero_grad()
+        with torch.no_grad():
+            latents = m.encode(reals, **kw)
+            decoded, reals_t = self._trim(m.decode(latents), reals)
+        # scale by scale: one scale's graph alive at a time (the sum of the per-scale terms is loss(): discriminators.py:42-63)
+        decoded = decoded.contiguous()
+        loss_dis = torch.zeros((), device=reals.device)
+        for i in range(self.discriminator.discriminators.num_discriminators):
+            dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded, need_fm=False)
+            dis_i.backward()
+            loss_dis = loss_dis + dis_i.detach()
+        self.flat_d.gather_grads()
+        self.comm_d()
+        if self.clip_grad_norm > 0.0:
+            clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale)
+        self.opt_d.step(lr=self._lr("disc"), grad_scale=self.comm_d.grad_scale)
+        return {"loss": loss_dis.detach(), "discriminator_loss": loss_dis.detach()}
+
+    def _gen_body(self, reals, kw):
+        """Generator update (:498-515)."""
+        m = self.model
         self.flat.zero_grad()
         if self.warmed_up and self.encoder_freeze_on_warmup:
             with torch.no_grad():
@@ -459,10 +494,114 @@ class AutoencoderTrainStep:
         self.comm()
         if self.clip_grad_norm > 0.0:
             clip_flat_grads(self.flat, self.clip_grad_norm, self.comm.grad_scale)
-        self.opt.step(lr=self.current_lr(), grad_scale=self.comm.grad_scale)
-        self.gen_steps += 1
-        self.global_step += 1
+        self.opt.step(lr=self._lr("gen"), grad_scale=self.comm.grad_scale)
         out["loss"] = loss.detach()
+        return out
+
+    def __call__(self, reals, noise=None):
+        """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
+        kw = {"noise": noise} if noise is not None else {}
+        kind = self._kind()
+        out = self._disc_body(reals, kw) if kind == "disc" else self._gen_body(reals, kw)
+        self._after(kind)
+        return out
+
+
+class GraphedTrainStep:
+    """AutoencoderTrainStep with every update replayed from ONE HIP graph (torch.cuda.CUDAGraph): a generator step of the Oobleck VAE is
+    ~1250 launches, ~400 of them a few microseconds long (weight-norm folds, weight packing, SnakeBeta constants, row sums, the gradient
+    accumulation adds of ~300 parameters), and between the millisecond-long conv kernels the host cannot issue those as fast as the GPU
+    retires them: 6–14 ms of a 150–160 ms step are launch gaps (profiles/EXPERIMENTS.md, round 4).  Capturing forward + loss + backward +
+    gradient exchange + fused AdamW(+EMA) of one update and replaying it removes them — same kernels, same arithmetic, same order.
+
+    What changes from step to step lives in device memory the captured launches read: the batch (copied into static buffers) and the five
+    optimizer scalars (learning rate, Adam bias corrections, 1 / world, EMA decay: csrc/elementwise.hip sat_adamw_step_dev).  Host-side
+    bookkeeping (step counters, the cache epochs of the rewritten parameters) runs after each replay.  One graph per kind of update the
+    step can be asked for: generator before / after the discriminator warm-up, discriminator.  The first `eager_steps` calls of a kind
+    run eagerly (lazy workspaces, allocator warm-up); a kind whose capture fails (a host synchronisation inside) stays eager — `fallback`
+    says why.  Inputs of another shape than the captured one run eagerly too.  The returned loss tensors are the graph's static buffers:
+    read them before the next call."""
+
+    def __init__(self, stepper, eager_steps=1):
+        self.stepper = stepper
+        self.eager_steps = int(eager_steps)
+        self.graphs, self.seen, self.fallback = {}, {}, {}
+        self.replays = 0
+        dev = stepper.flat.data.device
+        self._hyper = {"gen": torch.zeros(5, dtype=torch.float32, device=dev)}
+        if stepper.discriminator is not None:
+            self._hyper["disc"] = torch.zeros(5, dtype=torch.float32, device=dev)
+        self._ring = [torch.zeros(5, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self._ring_ev = [None] * 8
+        self._slot = 0
+
+    def _opt(self, kind):
+        return self.stepper.opt_d if kind == "disc" else self.stepper.opt
+
+    def _flat(self, kind):
+        return self.stepper.flat_d if kind == "disc" else self.stepper.flat
+
+    def _comm(self, kind):
+        return self.stepper.comm_d if kind == "disc" else self.stepper.comm
+
+    def _capture(self, key, kind, reals, noise):
+        s = self.stepper
+        static_reals = reals.clone()
+        static_noise = noise.clone() if noise is not None else None
+        kw = {"noise": static_noise} if static_noise is not None else {}
+        opt = self._opt(kind)
+        opt.hyper_dev = self._hyper[kind]
+        graph = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                out = s._disc_body(static_reals, kw) if kind == "disc" else s._gen_body(static_reals, kw)
+        finally:
+            opt.hyper_dev = None
+        self.graphs[key] = (graph, static_reals, static_noise, out)
+
+    def __call__(self, reals, noise=None):
+        s = self.stepper
+        kind = s._kind()
+        key = (kind, bool(s.warmed_up), bool(s.use_disc), tuple(reals.shape), None if noise is None else tuple(noise.shape))
+        entry = self.graphs.get(key)
+        if entry is None and key not in self.fallback:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n >= self.eager_steps:
+                try:
+                    self._capture(key, kind, reals, noise)
+                    entry = self.graphs[key]
+                except Exception as e:      # noqa: BLE001 — e.g. a host synchronisation inside the update: that kind stays eager
+                    self.fallback[key] = repr(e)[:300]
+        if entry is None:
+            kw = {"noise": noise} if noise is not None else {}
+            out = s._disc_body(reals, kw) if kind == "disc" else s._gen_body(reals, kw)
+            s._after(kind)
+            return out
+        graph, static_reals, static_noise, out = entry
+        if reals.data_ptr() != static_reals.data_ptr():
+            static_reals.copy_(reals)
+        if static_noise is not None and noise.data_ptr() != static_noise.data_ptr():
+            static_noise.copy_(noise)
+        opt = self._opt(kind)
+        ev = self._ring_ev[self._slot]
+        if ev is not None:
+            ev.synchronize()                 # the copy that read this pinned slot eight steps ago is done
+        host = self._ring[self._slot]
+        vals = opt.hyper(lr=s._lr(kind), grad_scale=self._comm(kind).grad_scale)
+        for i, v in enumerate(vals):
+            host[i] = v
+        self._hyper[kind].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_ev[self._slot] = ev
+        self._slot = (self._slot + 1) % len(self._ring)
+        graph.replay()
+        opt.t += 1
+        _caches.bump_params(self._flat(kind).params)      # the replayed AdamW launch rewrote these parameters in place
+        s._after(kind)
+        self.replays += 1
         return out
 
 

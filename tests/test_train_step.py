@@ -517,3 +517,53 @@ def test_warmup_and_time_losses_simulator(emu_modules):
     ref = stft_oracle.autoencoder_spectral_loss(a0, dec, sc, cfg["sample_rate"]) + 1e-4 * kl \
         + 0.5 * (a0 - dec).abs().mean() + 0.25 * ((a0 - dec) ** 2).mean()
     assert abs(float(out[0]["loss"]) - float(ref)) <= 1e-3 * abs(float(ref)), (float(out[0]["loss"]), float(ref))
+
+
+# ---- the whole update as ONE HIP graph (training.GraphedTrainStep): same kernels, same order -> bit-identical to the eager step ----
+def _graphed_vs_eager(cfg, nsteps, device="cuda"):
+    from stable_audio_tools_amd.training import AutoencoderTrainStep, GraphedTrainStep
+    batches = [_batch(2, 900 + 10 * i) for i in range(nsteps)]
+
+    def run(graphed):
+        torch.manual_seed(7)
+        model = build_native_ae(NAME, SEED, device)
+        stepper = AutoencoderTrainStep(model, cfg)
+        step = GraphedTrainStep(stepper, eager_steps=1) if graphed else stepper
+        losses = []
+        for a, n in batches:
+            out = step(a.to(device), noise=n.to(device))
+            losses.append({k: float(v) for k, v in out.items()})
+        torch.cuda.synchronize()
+        extra = (step.replays, dict(step.fallback), len(step.graphs)) if graphed else None
+        disc = stepper.flat_d.data.clone() if stepper.discriminator is not None else None
+        return stepper.flat.data.clone(), stepper.opt.ema.clone(), disc, losses, (stepper.gen_steps, stepper.disc_steps, stepper.opt.t), extra
+    pe, ee, de, le, ce, _ = run(False)
+    pg, eg, dg, lg, cg, (replays, fallback, ngraphs) = run(True)
+    assert not fallback, fallback
+    assert ce == cg and replays > 0 and ngraphs >= 1
+    # same kernels, same order, the same fp32 optimizer scalars (FusedAdamW.hyper rounds them as the eager launch does): every loss of
+    # every step is bit-identical; the parameters may differ in the last bit (the by-value and the from-memory AdamW launches are two
+    # compilations of the same expression)
+    assert le == lg, (le, lg)
+
+    def close(x, y):
+        return float((x - y).abs().max()) <= 1e-6 * float(x.abs().max())
+    assert close(pe, pg) and close(ee, eg), (float((pe - pg).abs().max()), float((ee - eg).abs().max()))
+    if de is not None:
+        assert close(de, dg), float((de - dg).abs().max())
+    return replays, ngraphs
+
+
+@pytest.mark.gpu
+def test_graphed_generator_step_equals_eager_gpu(hip):
+    """Six generator steps (InverseLR warm-up, Adam bias corrections and the EMA decay all change from step to step): replays of the
+    captured update — the per-step scalars read from device memory — reproduce the eager steps."""
+    replays, ngraphs = _graphed_vs_eager(_model_config(), 6)
+    assert replays == 5 and ngraphs == 1          # call 1 eager, call 2 captures and replays, calls 3..6 replay
+
+
+@pytest.mark.gpu
+def test_graphed_alternating_step_equals_eager_gpu(hip):
+    """The real step (generator / discriminator alternating, adversarial + feature-matching terms): one graph per kind of update."""
+    replays, ngraphs = _graphed_vs_eager(_disc_config(), 8)
+    assert ngraphs == 2 and replays == 6          # per kind: one eager call, three replays
