@@ -83,7 +83,7 @@ class AttnProfiler:
     (Nk == Nq) and cross-attention (Nk = context length) kept apart."""
 
     def __init__(self, ops, max_launches=192):
-        self.records = {"self": [], "cross": []}
+        self.records = {"self": [], "cross": [], "bwd_self": [], "bwd_cross": []}
         self.enabled = False
         self.budget = max_launches     # only the first launches of the timed region carry events: a sampler step is
         orig = ops.lib.sat_attention_fwd   # host-bound, and two event objects per launch would slow the measured loop
@@ -104,6 +104,27 @@ class AttnProfiler:
 
         self._lib, self._orig = ops.lib, orig
         ops.lib.sat_attention_fwd = timed
+        # backward (training): one entry point = the dQ kernel + the dK / dV kernel; algorithmic flops = the five matmuls of the attention
+        # backward (S, dP, dV, dK, dQ: 10 * Nq * Nk * 64 * H * B; both kernels recompute S and dP, which is not counted)
+        self.bwd_budget = max_launches
+        orig_bwd = ops.lib.sat_attention_bwd
+
+        def timed_bwd(*a):
+            if not self.enabled or self.bwd_budget <= 0:
+                return orig_bwd(*a)
+            self.bwd_budget -= 1
+            b, h, _hkv, nq, nk = a[6:11]
+            d = a[13]
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig_bwd(*a)
+            e.record()
+            self.records["bwd_self" if nq == nk else "bwd_cross"].append((s, e, 10.0 * b * h * nq * nk * d))
+            return rc
+
+        self._orig_bwd = orig_bwd
+        ops.lib.sat_attention_bwd = timed_bwd
         # the projection GEMMs (80 % of a sampler step's GPU time): same budgeted event timing, algorithmic flops 2*M*N*K
         self.gemm = []
         self.gemm_budget = 2 * max_launches     # (about two model evaluations: events cost host time in the measured loop)
@@ -139,6 +160,7 @@ class AttnProfiler:
 
     def restore(self):
         self._lib.sat_attention_fwd = self._orig
+        self._lib.sat_attention_bwd = self._orig_bwd
         for name, orig in self._gemm_orig.items():
             setattr(self._lib, name, orig)
 
@@ -171,7 +193,15 @@ class AttnProfiler:
         nl, ms, fl = self.summary("self")
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         nc, msc, flc = self.summary("cross")
-        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        bwd = {}
+        for which in ("bwd_self", "bwd_cross"):
+            nb, msb, flb = self.summary(which)
+            if nb:
+                achb = flb / (msb * 1e-3) / 1e12
+                bwd[which] = {"kernels": "sat_attn_bwd_dq_kernel + sat_attn_bwd_dkv_kernel", "launches": nb, "avg_launch_ms": msb / nb,
+                              "achieved": round(achb, 1), "frac": round(achb / peak, 4)}
+        extra = {"backward": bwd} if bwd else {}
+        return {**extra, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "kernel": "sat_attn_fwd_kernel", "launches": nl, "avg_launch_ms": ms / nl if nl else None,
                 "cross_attention": {"launches": nc, "avg_launch_ms": msc / nc if nc else None,
                                     "achieved": flc / (msc * 1e-3) / 1e12 if msc > 0 else 0.0},
@@ -611,7 +641,7 @@ def pmc_traffic(kernel, args):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     try:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 doc = json.load(open(path))
@@ -624,13 +654,15 @@ def pmc_traffic(kernel, args):
 
 def hbm_roofline(args, ms_per_step):
     """The north-star's HBM view of the whole step (BASELINE.json: >= 60 % of the HBM roofline on the conv stack): HBM bytes per step
-    summed over every kernel of the committed rocprofv3 --pmc passes of this same command (profiles/r03_pmc_traffic.json: 2 x
+    summed over every kernel of the committed rocprofv3 --pmc passes of this same command (profiles/r04_pmc_traffic.json: 2 x
     FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction; the passes profile `--steps 1 --warmup 1` = 2 steps) against the
     algorithmic bytes of SURVEY.md 8(d)'s fusion-unit convention (16.4 GB per direction per sample forward; x3 for forward +
     backward) and the 8 TB/s peak, at this run's step time."""
     if args.sample_size != 2097152 or args.batch != 1:
         return None
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
@@ -644,7 +676,7 @@ def hbm_roofline(args, ms_per_step):
     return {"counter_bytes_per_step": counter, "algorithmic_bytes_per_step": algorithmic, "peak_bytes_per_s": 8.0e12,
             "counter_rate_frac_of_8TBs": counter / t / 8.0e12, "frac_of_8TBs": algorithmic / t / 8.0e12,
             "traffic_over_algorithmic": counter / algorithmic,
-            "note": "counter bytes: every sat_* kernel of the committed --pmc passes (profiles/r03_pmc_traffic.json); algorithmic: 3 x (16.4 + 16.4) GB "
+            "note": "counter bytes: every sat_* kernel of the committed --pmc passes (profiles/r04_pmc_traffic.json); algorithmic: 3 x (16.4 + 16.4) GB "
                     "(fusion-unit convention, forward + backward); frac_of_8TBs = algorithmic bytes / this run's step time / 8 TB/s — the "
                     "step is matrix-pipe-bound (roofline.bound), this is the north-star's second view of it"}
 
@@ -1093,7 +1125,7 @@ def main():
                                  "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
                                  "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
                                  "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
-                                 "same command (profiles/r03_pmc_traffic.json; null for a non-default workload size)",
+                                 "same command (profiles/r04_pmc_traffic.json; null for a non-default workload size)",
                          "k7_family": k7_family(allk),
                          "hbm": hbm_roofline(args, 1e3 * elapsed / args.steps),
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},

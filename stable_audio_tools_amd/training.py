@@ -342,6 +342,13 @@ class AutoencoderTrainStep:
             raise ValueError("warmup_mode must be 'adv' or 'full'")
         self.encoder_freeze_on_warmup = bool(tr.get("encoder_freeze_on_warmup", False))
         self.warmed_up = False
+        # wrapper kwargs (training/autoencoders.py:45-46, :387-388, :411-413)
+        self.force_input_mono = bool(tr.get("force_input_mono", False))
+        self.latent_mask_ratio = float(tr.get("latent_mask_ratio", 0.0))
+        # LossModule.decay (training/losses/losses.py:9-24): a loss's weight is multiplied by `decay` every time the loss is evaluated
+        # — BEFORE it is applied, so evaluation k (0-based) of the generator losses sees weight * decay^(k + 1)
+        self.spectral_decay = float(lc.get("spectral", {}).get("decay", 1.0))
+        self.time_decay = float(lc.get("time", {}).get("decay", 1.0))
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
@@ -373,12 +380,10 @@ class AutoencoderTrainStep:
         for name in ("mrmel", "hubert"):                    # training/autoencoders.py:196-225
             if float(lc.get(name, {}).get("weights", {}).get(name, 0.0)) > 0.0:
                 bad.append(f"loss_configs.{name}")
-        for blk in ("spectral", "time", "hubert"):          # LossModule.decay_weight (:170, :223, :231, :238)
-            if float(lc.get(blk, {}).get("decay", 1.0)) != 1.0:
-                bad.append(f"loss_configs.{blk}.decay != 1.0")
-        for key in ("latent_mask_ratio", "force_input_mono", "teacher_model"):
-            if tr.get(key):
-                bad.append(f"training.{key}")
+        if float(lc.get("hubert", {}).get("decay", 1.0)) != 1.0:          # (spectral / time decays are restated)
+            bad.append("loss_configs.hubert.decay != 1.0")
+        if tr.get("teacher_model"):                                        # latent / decoder distillation terms (:171-179, :405-437)
+            bad.append("training.teacher_model")
         if bad:
             raise NotImplementedError("AutoencoderTrainStep does not restate: " + ", ".join(bad))
 
@@ -427,12 +432,43 @@ class AutoencoderTrainStep:
             return self.base_lr_d if self.sched_d is None else inverse_lr(self.disc_steps, self.base_lr_d, **self.sched_d["config"])
         return self.current_lr()
 
+    def _encoder_input(self, reals):
+        if self.force_input_mono and reals.shape[1] > 1:          # :387-388
+            return reals.mean(dim=1, keepdim=True)
+        return reals
+
+    @staticmethod
+    def _encode_kw(kw):
+        return {k: v for k, v in kw.items() if k != "latent_mask"}
+
+    def _mask_latents(self, latents, kw):
+        """latent_mask_ratio (:411-413): zero a random subset of the latents before decoding.  kw["latent_mask"] (bool, latents'
+        shape) injects the mask instead of drawing it (tests)."""
+        if self.latent_mask_ratio <= 0.0:
+            return latents
+        mask = kw.get("latent_mask")
+        if mask is None:
+            mask = torch.rand_like(latents) < self.latent_mask_ratio
+        return torch.where(mask, torch.zeros_like(latents), latents)
+
+    def _decays(self):
+        """Factors on the spectral / time loss weights at THIS generator step (LossModule.decay_weight runs once per evaluation,
+        before the weight is applied: losses.py:18-24, :102-104)."""
+        k = self.gen_steps + 1
+        return self.spectral_decay ** k, self.time_decay ** k
+
+    @property
+    def step_scalars_change(self):
+        """True when a value baked into the launches changes from step to step (loss-weight decay): GraphedTrainStep stays eager then."""
+        return self.spectral_decay != 1.0 or (self.time_decay != 1.0 and (self.w_l1 > 0.0 or self.w_l2 > 0.0))
+
     def _disc_body(self, reals, kw):
         """Discriminator update (:484-497): everything that runs on the device, nothing that counts steps."""
         m = self.model
         self.flat_d.zero_grad()
         with torch.no_grad():
-            latents = m.encode(reals, **kw)
+            latents = m.encode(self._encoder_input(reals), **self._encode_kw(kw))
+            latents = self._mask_latents(latents, kw)
             decoded, reals_t = self._trim(m.decode(latents), reals)
         # scale by scale: one scale's graph alive at a time (the sum of the per-scale terms is loss(): discriminators.py:42-63)
         decoded = decoded.contiguous()
@@ -452,23 +488,28 @@ class AutoencoderTrainStep:
         """Generator update (:498-515)."""
         m = self.model
         self.flat.zero_grad()
+        enc_in = self._encoder_input(reals)
         if self.warmed_up and self.encoder_freeze_on_warmup:
             with torch.no_grad():
-                latents, info = m.encode(reals, return_info=True, **kw)
+                latents, info = m.encode(enc_in, return_info=True, **self._encode_kw(kw))
         else:
-            latents, info = m.encode(reals, return_info=True, **kw)
+            latents, info = m.encode(enc_in, return_info=True, **self._encode_kw(kw))
+        latents = self._mask_latents(latents, kw)
         decoded, reals_t = self._trim(m.decode(latents), reals)
+        sdec, tdec = self._decays()
         mrstft = self.spectral(reals_t, decoded)
+        if sdec != 1.0:
+            mrstft = mrstft * sdec
         loss = mrstft + self.w_kl * info["kl"]
         out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
         if self.w_l1 > 0.0:
             l1 = (reals_t - decoded).abs().mean()
-            loss = loss + self.w_l1 * l1
-            out["l1_time_loss"] = (self.w_l1 * l1).detach()
+            loss = loss + (self.w_l1 * tdec) * l1
+            out["l1_time_loss"] = ((self.w_l1 * tdec) * l1).detach()
         if self.w_l2 > 0.0:
             l2 = ((reals_t - decoded) ** 2).mean()
-            loss = loss + self.w_l2 * l2
-            out["l2_time_loss"] = (self.w_l2 * l2).detach()
+            loss = loss + (self.w_l2 * tdec) * l2
+            out["l2_time_loss"] = ((self.w_l2 * tdec) * l2).detach()
         if self.use_disc and self.warmed_up:      # before the warm-up ends the adversarial / feature-matching terms are zero (:441-452)
             # adversarial + feature-matching terms: their gradient w.r.t. the decoded audio is collected scale by scale on a detached
             # leaf (one scale's activations alive at a time), then enters the autoencoder's single backward pass below
@@ -498,9 +539,11 @@ class AutoencoderTrainStep:
         out["loss"] = loss.detach()
         return out
 
-    def __call__(self, reals, noise=None):
+    def __call__(self, reals, noise=None, latent_mask=None):
         """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
         kw = {"noise": noise} if noise is not None else {}
+        if latent_mask is not None:
+            kw["latent_mask"] = latent_mask
         kind = self._kind()
         out = self._disc_body(reals, kw) if kind == "disc" else self._gen_body(reals, kw)
         self._after(kind)
@@ -565,6 +608,8 @@ class GraphedTrainStep:
         kind = s._kind()
         key = (kind, bool(s.warmed_up), bool(s.use_disc), tuple(reals.shape), None if noise is None else tuple(noise.shape))
         entry = self.graphs.get(key)
+        if entry is None and key not in self.fallback and s.step_scalars_change:
+            self.fallback[key] = "a loss weight decays from step to step (loss_configs.*.decay != 1): the launches cannot be frozen"
         if entry is None and key not in self.fallback:
             n = self.seen.get(key, 0)
             self.seen[key] = n + 1

@@ -82,12 +82,17 @@ def _check(case, device, mode):
     assert den.shape == g[case + "/denoised"].shape and rel_err(den, g[case + "/denoised"]) < TOL, (case, mode, "denoised")
 
 
-@pytest.mark.parametrize("case", CASES)
+# the simulator runs a DiT evaluation in seconds: the CPU suite takes one case per update rule / operand (u-term, noise operand, third
+# operand + separate base, previous-denoised operand, schedule + init data); the GPU suite runs all 15 cases in all three modes
+SIM_FUSED = ["ddim_cfgpp", "ddim_eta", "euler_shift", "rk4", "dpmpp", "pingpong", "rf_dpmpp"]
+
+
+@pytest.mark.parametrize("case", SIM_FUSED)
 def test_native_samplers_match_reference_golden_fused_simulator(emu_modules, case):
     _check(case, "cpu", "fused")
 
 
-@pytest.mark.parametrize("case", ["ddim_cfgpp", "ddim_eta", "dpmpp", "pingpong", "rk4"])
+@pytest.mark.parametrize("case", ["dpmpp", "pingpong"])
 def test_native_samplers_match_reference_golden_plain_simulator(emu_modules, case):
     _check(case, "cpu", "plain")
 
@@ -134,7 +139,7 @@ LIVE = ["ddim", "ddim_cfgpp", "euler_shift", "rk4", "dpmpp", "rf_dpmpp"]       #
 
 
 @pytest.mark.skipif(not refimport.available(), reason="no reference tree (/root/reference or oracle/_ref)")
-@pytest.mark.parametrize("case", LIVE)
+@pytest.mark.parametrize("case", ["rk4", "rf_dpmpp"])
 def test_reference_sampler_functions_on_native_model_simulator(emu_modules, case):
     _live(case, "cpu")
 

@@ -567,3 +567,59 @@ def test_graphed_alternating_step_equals_eager_gpu(hip):
     """The real step (generator / discriminator alternating, adversarial + feature-matching terms): one graph per kind of update."""
     replays, ngraphs = _graphed_vs_eager(_disc_config(), 8)
     assert ngraphs == 2 and replays == 6          # per kind: one eager call, three replays
+
+
+# ---- wrapper options of the reference's training step: force_input_mono, latent_mask_ratio, LossModule.decay ----
+def _wrapper_options(device):
+    """training/autoencoders.py:45-46, :387-388 (mono encoder input), :411-413 (latent masking), training/losses/losses.py:9-24 + :102-104
+    (the weight of a loss is multiplied by `decay` at every evaluation, before it is applied).  Two generator steps of the native step
+    against the oracle forward assembled the same way + torch.optim.AdamW."""
+    from stable_audio_tools_amd.autoencoders import create_autoencoder_from_config
+    from stable_audio_tools_amd.training import AutoencoderTrainStep, inverse_lr
+    cfg = _model_config()
+    cfg["model"]["encoder"]["config"]["in_channels"] = 1          # stereo items, mono encoder, stereo decoder
+    cfg["training"]["force_input_mono"] = True
+    cfg["training"]["latent_mask_ratio"] = 0.25
+    cfg["training"]["loss_configs"]["spectral"]["decay"] = 0.5
+    cfg["training"]["loss_configs"]["time"] = {"weights": {"l1": 0.3, "l2": 0.2}, "decay": 0.8}
+    torch.manual_seed(3)
+    model = create_autoencoder_from_config(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    init = {k: torch.from_numpy(v) for k, v in seeded.seeded_state_dict(shapes, SEED).items()}
+    model.load_state_dict(init)
+    model = model.to(device)
+    stepper = AutoencoderTrainStep(model, cfg)
+    assert stepper.step_scalars_change
+    batches = [_batch(2, 900), _batch(2, 910)]
+    masks = [torch.from_numpy(seeded.seeded_array((2, 4, 64), 77 + i)) < -0.6 for i in range(2)]
+    outs = [stepper(a.to(device), noise=n.to(device), latent_mask=mk.to(device)) for (a, n), mk in zip(batches, masks)]
+    # the same two steps from the oracle
+    sd = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    oc = cfg["training"]["optimizer_configs"]["autoencoder"]
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-3, betas=(0.8, 0.99), weight_decay=1e-3, eps=1e-3)
+    sc = cfg["training"]["loss_configs"]["spectral"]["config"]
+    for step, ((audio, noise), mk) in enumerate(zip(batches, masks)):
+        for gp in opt.param_groups:
+            gp["lr"] = inverse_lr(step, 1e-3, **oc["scheduler"]["config"])
+        z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], audio.mean(dim=1, keepdim=True), noise)
+        z = torch.where(mk, torch.zeros_like(z), z)
+        dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
+        k = step + 1
+        spec = stft_oracle.autoencoder_spectral_loss(audio, dec, sc, cfg["sample_rate"]) * 0.5 ** k
+        l1, l2 = (audio - dec).abs().mean(), ((audio - dec) ** 2).mean()
+        loss = spec + 1e-4 * kl + 0.3 * 0.8 ** k * l1 + 0.2 * 0.8 ** k * l2
+        assert abs(float(outs[step]["mrstft_loss"]) - float(spec)) <= 1e-3 * abs(float(spec)), (step, float(outs[step]["mrstft_loss"]), float(spec))
+        assert abs(float(outs[step]["l1_time_loss"]) - float(0.3 * 0.8 ** k * l1)) <= 1e-3 * abs(float(l1))
+        assert abs(float(outs[step]["loss"]) - float(loss)) <= 1e-3 * abs(float(loss)), (step, float(outs[step]["loss"]), float(loss))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+
+def test_wrapper_options_simulator(emu_modules):
+    _wrapper_options("cpu")
+
+
+@pytest.mark.gpu
+def test_wrapper_options_gpu(hip):
+    _wrapper_options("cuda")

@@ -26,7 +26,7 @@ python tools/pmc_traffic_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pm
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/real $OUT/dit_sample $OUT/dit_train
-cp $OUT/pmc_traffic.json $R/profiles/r03_pmc_traffic.json      # bench.py reads it for roofline.traffic / roofline.hbm
+cp $OUT/pmc_traffic.json $R/profiles/r04_pmc_traffic.json      # bench.py reads it for roofline.traffic / roofline.hbm
 python bench.py > $OUT/bench_vae_train.json 2> $OUT/bench_vae_train.err
 python bench.py --workload dit_train --no-cpu-baseline > $OUT/bench_dit_train.json 2> /dev/null
 SAT_TILES=0,4 SAT_SPLITS=2,3 python tools/gemm_bench.py 2050 4100 12290 > $OUT/gemm_bench.jsonl 2> /dev/null
@@ -34,5 +34,7 @@ python tools/k7_bench.py > $OUT/k7_bench.jsonl 2> /dev/null
 python tools/ru_bench.py > $OUT/ru_bench.jsonl 2> /dev/null
 python tools/disc_bench.py > $OUT/disc_bench.jsonl 2> /dev/null
 python tools/qkv_bench.py > $OUT/qkv_bench.jsonl 2> /dev/null
+python tools/attn_bench.py > $OUT/attn_bench.jsonl 2> /dev/null
+python bench.py --ddp-single-rank --ddp-mode reduce_scatter --no-secondary --no-real-step --no-batch-sweep --no-parity --no-cpu-baseline > $OUT/bench_ddp_single_rank.json 2> /dev/null
 bash tools/pmc_k7.sh > /dev/null 2>&1; cp gpurun_out/pmc_k7/summary.txt $OUT/pmc_k7_summary.txt
 tail -c 3000 $OUT/bench_vae_train.json

@@ -1034,11 +1034,250 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
     }
 }
 
+
+// ---- W64: 64 queries per wave (two q-blocks share every K / V^T fragment read and the tile's scalar / staging work), workgroup = 2 waves
+// = 128 queries, two waves per SIMD (256 registers).  Per 32-key half-tile: 4 K reads + 8 MFMAs (both q-blocks) -> 2 x 16 exponentials ->
+// 4 V^T reads + 8 MFMAs.  Issue slots per 32-query tile: 16 MFMA + 32 exp (x2) + 32 add + 16 cvt + 8 LDS + ~8 other, vs 16 + 20 + ~15 LDS /
+// scalar in the 32-query kernel.
+template <int NKB, bool MASK, bool FIRST>
+SAT_DEVICE void tile_w64(short (*k_lds)[ROW], short (*v_lds)[ROW], const bf16x8 (&qf)[2][4], f32x16 (&oacc)[2][2], f32x16 (&negm)[2], float (&mb)[2],
+                         float (&l_run)[2], int l31, int hi, int kperm, int nvalid) {
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        f32x16 x[2];
+        auto qk = [&]() {
+            SAT_SETPRIO(1);
+            if (FIRST) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { x[0][r] = 0.0f; x[1][r] = 0.0f; }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = frag(k_lds, kb * 32 + kperm, 16 * s + 8 * hi);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) x[g] = sat_mfma_32x32x16_bf16(ka, qf[g][s], (!FIRST && s == 0) ? negm[g] : x[g]);
+            }
+            SAT_SETPRIO(0);
+        };
+        auto rowmax = [&](int g) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 7) + 8 * hi + 16 * (r >> 3);
+                if (!MASK || key < nvalid) tmax = fmaxf(tmax, x[g][r]);
+            }
+            return halfmax(tmax);
+        };
+        float ps[2];
+        auto expsum = [&]() {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = ex2(x[g][2 * j]), c = ex2(x[g][2 * j + 1]);
+                    if (MASK) {
+                        const int key = kb * 32 + ((2 * j) & 7) + 8 * hi + 16 * ((2 * j) >> 3);
+                        if (key >= nvalid) a = 0.f;
+                        if (key + 1 >= nvalid) c = 0.f;
+                    }
+                    p0 += a; p1 += c;
+                    x[g][2 * j] = a; x[g][2 * j + 1] = c;
+                }
+                ps[g] = p0 + p1;
+            }
+        };
+        qk();
+        if (FIRST && kb == 0) {          // the wave's very first half-tile: true row max
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float tmax = rowmax(g);
+                mb[g] = tmax;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[g][r] -= tmax;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[g][r] = -mb[g];
+            }
+        } else if (FIRST) {              // second half of the first tile: shifted by hand (C was 0)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[g][r] -= mb[g];
+        }
+        expsum();
+        if (!(FIRST && kb == 0)) {
+            if (sat_wave_any(!(ps[0] <= 0.5f * SUMLIM) || !(ps[1] <= 0.5f * SUMLIM))) {      // 16 scores per lane and q-block here
+                const bool was_first = FIRST;
+                // rare: recompute the scores of this half-tile (C = -mb, or 0 + manual shift in the first tile), take the true max
+                SAT_SETPRIO(1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 ka = frag(k_lds, kb * 32 + kperm, 16 * s + 8 * hi);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) x[g] = sat_mfma_32x32x16_bf16(ka, qf[g][s], s == 0 ? negm[g] : x[g]);
+                }
+                SAT_SETPRIO(0);
+                (void)was_first;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float d = fmaxf(rowmax(g), 0.0f), alpha = ex2(-d);
+                    mb[g] += d;
+                    l_run[g] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[g][t][r] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[g][r] -= d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[g][r] = -mb[g];
+                }
+                expsum();
+            }
+        }
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) pb[g][u] = pack8(x[g], u);
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 va = frag(v_lds, t * 32 + l31, kb * 32 + 16 * u + 8 * hi);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) oacc[g][t] = sat_mfma_32x32x16_bf16(va, pb[g][u], oacc[g][t]);
+            }
+        SAT_SETPRIO(0);
+    }
+}
+
+SAT_DEVICE void attn_fwd_w64_body(const P& p, short (*k_lds2)[TK][ROW], short (*v_lds2)[D][ROW]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = kperm_of(l31);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int q0 = blockIdx.x * 128 + wave * 64;
+    const bool w_ok = q0 < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qrow = q0 + g * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (qrow < p.Nqp) qf[g][s] = *reinterpret_cast<const bf16x8*>(p.q + qplane + (size_t)qrow * D + 16 * s + 8 * hi);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[g][s][e] = 0;
+            }
+            u32x4 w = __builtin_bit_cast(u32x4, qf[g][s]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = __builtin_bit_cast(float, w[j] << 16) * sl2, hi2 = __builtin_bit_cast(float, w[j] & 0xffff0000u) * sl2;
+                w[j] = sat_cvt2_pk(lo, hi2);
+            }
+            qf[g][s] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    f32x16 oacc[2][2], negm[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[g][0][r] = 0.0f; oacc[g][1][r] = 0.0f; negm[g][r] = 0.0f; }
+    float l_run[2] = {0.0f, 0.0f}, mb[2] = {0.0f, 0.0f};
+
+    bf16x8 kreg[4], vreg[4];      // 512 + 512 pieces over 128 threads
+    auto tile_load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + j * 128, r = c >> 3, part = c & 7;
+            kreg[j] = *reinterpret_cast<const bf16x8*>(p.k + kplane + (size_t)(k0 + r) * D + part * 8);
+            vreg[j] = *reinterpret_cast<const bf16x8*>(p.vt + kplane + (size_t)r * p.Nkp + k0 + part * 8);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + j * 128, r = c >> 3, part = c & 7;
+            *reinterpret_cast<bf16x8*>(&k_lds2[buf][r][part * 8]) = kreg[j];
+            *reinterpret_cast<bf16x8*>(&v_lds2[buf][r][part * 8]) = vreg[j];
+        }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (TK < p.Nk) tile_load(TK);
+    __syncthreads();
+    int buf = 0, k0 = 0;
+    if (p.Nk >= TK) {
+        if (TK < p.Nk) {
+            tile_store(1);
+            if (2 * TK < p.Nk) tile_load(2 * TK);
+        }
+        if (w_ok) tile_w64<2, false, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, TK);
+        __syncthreads();
+        k0 = TK; buf = 1;
+    }
+    for (; k0 + TK <= p.Nk; k0 += TK, buf ^= 1) {
+        if (k0 + TK < p.Nk) {
+            tile_store(buf ^ 1);
+            if (k0 + 2 * TK < p.Nk) tile_load(k0 + 2 * TK);
+        }
+        if (w_ok) tile_w64<2, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, TK);
+        __syncthreads();
+    }
+    if (k0 < p.Nk && w_ok) {
+        const int rem = p.Nk - k0;
+        if (k0 == 0) {
+            if (rem > 32) tile_w64<2, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            else tile_w64<1, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        } else if (rem > 32) tile_w64<2, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        else tile_w64<1, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qrow = q0 + g * 32 + l31;
+        const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow < p.Nq) {
+            const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * D) + (long long)h * D;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const f32x4 v = {oacc[g][t][4 * gg] * inv_l, oacc[g][t][4 * gg + 1] * inv_l, oacc[g][t][4 * gg + 2] * inv_l, oacc[g][t][4 * gg + 3] * inv_l};
+                    const long long idx = obase + t * 32 + 8 * gg + 4 * hi;
+                    *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
+                }
+            if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb[g] + log2f(l_tot)) * 0.6931471805599453f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) attn_fwd_w64(P p) {
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][TK][ROW];
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][D][ROW];
+    attn_fwd_w64_body(p, k_lds2, v_lds2);
+}
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1))) attn_fwd_w64_1(P p) {      // 512 registers, one wave per SIMD
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][TK][ROW];
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][D][ROW];
+    attn_fwd_w64_body(p, k_lds2, v_lds2);
+}
+
 extern "C" int satx_attention_fwd(int variant, const short* q, const short* k, const short* vt, void* o, float* lse, int B, int H, int Hkv,
                                   int Nq, int Nk, int Nqp, int Nkp, float scale, void* stream) {
     P p{q, k, vt, o, lse, B, H, Hkv, Nq, Nk, Nqp, Nkp, scale};
     dim3 grid((Nq + 127) / 128, H, B);
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 500) { hipLaunchKernelGGL(attn_fwd_w64, dim3((Nq + 127) / 128, H, B), dim3(128), 0, st, p); return hipGetLastError() == hipSuccess ? 0 : 1; }
+    if (variant == 501) { hipLaunchKernelGGL(attn_fwd_w64_1, dim3((Nq + 127) / 128, H, B), dim3(128), 0, st, p); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (variant == 415) { hipLaunchKernelGGL(attn_fwd_ks<15>, dim3((Nq + 63) / 64, H, B), dim3(256), 0, st, p); return hipGetLastError() == hipSuccess ? 0 : 1; }
     switch (variant) {
         case 0: hipLaunchKernelGGL(attn_fwd_x<0>, grid, dim3(256), 0, st, p); break;
