@@ -153,10 +153,34 @@ class AttnProfiler:
             s.record()
             rc = orig(*a)
             e.record()
-            self.gemm.append((s, e, flops(a), name))
+            self.gemm.append((s, e, flops(a), name, self._shape_key(name, a)))
             return rc
 
         setattr(lib, name, timed)
+
+    @staticmethod
+    def _shape_key(name, a):
+        """(entry point, M, N, K, epilogue, fp32 out, splits, tile) of a projection launch — SAT_BENCH_GEMM_SHAPES=1 lists the time per shape"""
+        if name == "sat_gemm_bf16":
+            return (name, a[15], a[16], a[17], a[18], a[19], a[20], a[21])
+        if name == "sat_gemm_qkv_bf16":
+            return (name, a[10] * a[11], a[16] * a[13] * 64, a[14], 4, 0, 1, a[17])
+        if name == "sat_gemm_fp8":
+            return (name, a[16], a[17], a[18], a[19], a[20], 1, a[21])
+        if name == "sat_gemm_qkv_fp8":
+            return (name, a[11] * a[12], a[17] * a[14] * 64, a[15], 4, 0, 1, a[18])
+        return (name,)
+
+    def gemm_shapes(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for s, e, _f, _n, key in self.gemm:
+            d = agg.setdefault(key, [0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+        rows = [{"key": list(k), "launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 1), "total_ms": round(v[1], 3)} for k, v in agg.items()]
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
 
     def restore(self):
         self._lib.sat_attention_fwd = self._orig
@@ -170,13 +194,15 @@ class AttnProfiler:
         torch.cuda.synchronize()
         want = ("sat_gemm_fp8", "sat_gemm_qkv_fp8") if fp8 else ("sat_gemm_bf16", "sat_gemm_qkv_bf16")
         recs = [r for r in self.gemm if r[3] in want]
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-        fl = sum(f for _, _, f, _ in recs)
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        fl = sum(r[2] for r in recs)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out_extra = {}
         if fp8:
             q = [r for r in self.gemm if r[3] == "sat_quant_fp8"]
-            out_extra = {"quant_launches": len(q), "quant_total_ms": round(sum(s.elapsed_time(e) for s, e, _, _ in q), 3)}
+            out_extra = {"quant_launches": len(q), "quant_total_ms": round(sum(r[0].elapsed_time(r[1]) for r in q), 3)}
+        if os.environ.get("SAT_BENCH_GEMM_SHAPES") == "1":
+            out_extra["shapes"] = self.gemm_shapes()
         return {"kernel": "sat_gemm_kernel" + ("<fp8>" if fp8 else ""), "launches": len(recs), "total_ms": round(ms, 3), "achieved": round(ach, 1),
                 "peak": peak, "frac": round(ach / peak, 4), **out_extra,
                 "note": "every projection launch (sat_gemm_bf16 / sat_gemm_qkv_bf16) of the first model evaluations of the timed region: "

@@ -370,7 +370,9 @@ int sat_spec_bwd(const float* dz, float* dx, int NI, int C, int T, int n_fft, in
  * if not NULL, receives the pre-activation for the backward.  bias: fp32 (N) or NULL.  out_f32: C / res / gate / pre are
  * fp32 instead of bf16.  splits > 1 (epilogue 0, fp32, no bias): split-K partial slabs, slab z at C + z*M*ldc — sum them
  * with sat_reduce_splits.  zeros: >= 16 bytes of device zeros (source of K-tail chunks).  tile: 0 = 128x128 workgroup
- * tile (4 waves), 1 = 256x128 (8 waves).  fp32 models run this kernel on sat_split_bf16x3 operands (K' = 3K). */
+ * tile (4 waves, two workgroups per CU), 4 = 256x256 (8 waves, two wave rows one barrier apart), 6 / 7 / 8 = 128x256 / 160x256 /
+ * 128x128 on the eight-wave ring kernel (1..3, 5: experiment variants).  fp32 models run this kernel on sat_split_bf16x3
+ * operands (K' = 3K). */
 int sat_gemm_bf16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                   const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
                   long long ldp, const void* zeros, int M, int N, int K, int epilogue, int out_f32, int splits, int tile,
@@ -392,14 +394,15 @@ int sat_splitk_epilogue(const float* slabs, int S, const float* bias, const void
 
 /* fp8 (OCP e4m3) forward projections for the long-context configuration (BASELINE.json configs[4], stable_audio_2_0.json:3):
  * as sat_gemm_bf16 / sat_gemm_qkv_bf16 with A (M, K), B (N, K) in fp8 bytes (K, lda, ldb multiples of 16) on
- * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B). */
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B).
+ * tile: 0 = 128x128 (4 waves), 4 = 256x256, 7 = 160x256, 8 = 128x128 (eight-wave kernels, as sat_gemm_bf16). */
 int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                  const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
                  long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
-                 void* stream);
+                 int tile, void* stream);
 int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
                      void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
-                     int heads, int K, int sec0, int nsec, void* stream);
+                     int heads, int K, int sec0, int nsec, int tile, void* stream);
 /* dst (R, C) fp8 e4m3 = saturate_448(src * qscale[0]), round to nearest even; src fp32 | bf16; qscale a DEVICE scalar. */
 /* Dynamic per-tensor scale of the fp8 quantisation in one launch (last-arriving block reduces the per-block maxima): scales[0] =
  * 448 / max|src| (what sat_quant_fp8 takes as qscale), scales[1] = max|src| / 448 (the GEMM's de-quantisation factor).  work: >= 1 +

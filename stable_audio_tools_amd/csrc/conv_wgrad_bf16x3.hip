@@ -33,6 +33,7 @@ struct SatWgBfParams {
 };
 
 // sum of a float4 over the 16 consecutive lanes that hold one staged row (64 time steps); valid in lanes with (lane & 15) == 0
+SAT_DEVICE unsigned sat_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 SAT_DEVICE float sat_row16_sum(float4 q) {
     float s = (q.x + q.y) + (q.z + q.w);
 #pragma unroll
@@ -312,7 +313,7 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
 // =====================================================================================================================
 #define SAT_WS_TT 64
 #define SAT_WS_LOROW (SAT_WS_TT + 8)   // 144 B rows
-#define SAT_WS_HIROW (SAT_WS_TT + 16)  // 160 B rows: 64 + the tap-1 chunk overrun
+#define SAT_WS_HIROW (SAT_WS_TT + 8)   // 144 B rows like lo (conflict-free 16-byte fragment reads; 160-byte rows were 2-way): columns 0..65 are written, the tap-1 chunk reads up to 71
 
 struct SatWgSmallParams {
     const float* lo;     // (B, M, Tlo)
@@ -481,6 +482,164 @@ sat_wgrad_small_bf16x3_kernel(SatWgSmallParams p) {
             convert();
             __syncthreads();
             if (ch + 1 < c_end) issue(ch + 1);
+            mfma_stage();
+            __syncthreads();
+        }
+    } else if ((NT == 2) && sl >= 1 && sl <= 3 && (p.Tlo & 3) == 0) {
+        // K = 2 S convs with S = 2, 4, 8 (every down / up conv of the Oobleck stack), round 4: the same software pipeline as the k = 1
+        // path — the global loads of stage c+1 are in flight under the MFMAs of stage c — with the hi tile (128 virtual rows x 66
+        // columns = nc real channels x 66 S contiguous samples) read as 16-byte QUADS (2112 per stage, 8.25 per thread; dword-aligned
+        // global_load_dwordx4: the padding offset makes the rows start off the 16-byte grid) and scattered to the space-to-depth image
+        // with 4-byte LDS stores: sample u of a channel is row u % S, column u / S; a quad holds 4 rows of one column (S >= 4) and the
+        // lane QC = S / 4 quads further holds the same rows of the next column, so one cross-lane word per plane pairs (column c,
+        // column c + 1) into the two 32-bit words a lane stores; for S = 2 a quad is rows (0, 1) of two columns and needs no partner.
+        // (The first version staged this tile with 4-byte loads, 2-byte LDS stores and a division per sample pair, not overlapped
+        // with the MFMAs: 1.3 ms per launch against 0.1 ms of matrix work — profiles/EXPERIMENTS.md.)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        constexpr int NQ = 9;                                            // quads per thread and stage
+        const int qpc = 33 << (sl - 1);                                  // quads per real channel and stage
+        const unsigned magic = 0xffffffffu / (unsigned)qpc + 1u;         // Q / qpc = umulhi(Q, magic) for Q < 2^16
+        const int total_q = nc * qpc;                                    // = 2112
+        const int qcl = sl >= 2 ? sl - 2 : 0, qc = 1 << qcl;             // quads per column (S = 8: 2)
+        // quads IB .. IE-1 of this thread: global -> registers.  (tv = the thread id behind an opaque copy made inside the stage loop: the
+        // per-quad index arithmetic — ~10 VALU per quad — would otherwise be hoisted out of the loop as invariant and live across
+        // the MFMA stage: that build spilled 52 registers)
+        auto load_quads = [&](int tv, const float* shi, int th0, bool interior, f4u* vq, auto ib, auto ie) {
+            constexpr int IB = decltype(ib)::value, IE = decltype(ie)::value;
+#pragma unroll
+            for (int i = IB; i < IE; ++i) {
+                f4u v = {0.f, 0.f, 0.f, 0.f};
+                if (i < NQ - 1 || wave == 0) {                           // (wave-uniform: the last round is wave 0 only)
+                    const int Q = tv + 256 * i;
+                    const int cl = (int)sat_umulhi((unsigned)Q, magic), q = Q - cl * qpc;
+                    const int n = n_base + cl, t = th0 + 4 * q;
+                    const float* sp = shi + (size_t)(n < p.N ? n : p.N - 1) * p.Thi;
+                    // BRANCH-FREE loads (a per-lane fallback branch around each load made the compiler wait for every quad in turn): the
+                    // stage is either interior for every quad (block-uniform: all but the first and the last two stages of a batch
+                    // item) — one dword-aligned 16-byte load — or an edge stage: four clamped 4-byte loads and selects
+                    if (interior) {
+                        v = *reinterpret_cast<const f4u*>(sp + t);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int te = t + e;
+                            const int tc = te < 0 ? 0 : (te < p.Thi ? te : p.Thi - 1);
+                            const float x = sp[tc];
+                            v[e] = (te == tc) ? x : 0.0f;
+                        }
+                    }
+                    if (n >= p.N) v = f4u{0.f, 0.f, 0.f, 0.f};
+                }
+                vq[i - IB] = v;
+            }
+        };
+        // ... -> SnakeBeta, hi / lo split, space-to-depth scatter into the stage image
+        auto store_quads = [&](int tv, const f4u* vq, auto ib, auto ie) {
+            constexpr int IB = decltype(ib)::value, IE = decltype(ie)::value;
+#pragma unroll
+            for (int i = IB; i < IE; ++i) {
+                const int Q = tv + 256 * i;
+                if (i == NQ - 1 && Q >= total_q) break;                  // (wave-uniform: the last round is wave 0 only)
+                const int cl = (int)sat_umulhi((unsigned)Q, magic), q = Q - cl * qpc;
+                f4u o = vq[i - IB];
+                if (snake_hi) {
+                    const float sa = sn_a[cl], sib = sn_ib[cl];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sat_snake(o[e], sa, sib);
+                }
+                uint32_t h01, l01, h23, l23;
+                sat_split2_pk(o[0], o[1], &h01, &l01);
+                sat_split2_pk(o[2], o[3], &h23, &l23);
+                int row, col;
+                uint32_t wh0, wh1, wl0, wl1;
+                if (sl == 1) {                                           // rows (0, 1, 0, 1) of columns 2q, 2q + 1
+                    row = cl << 1;
+                    col = 2 * q;
+                    wh0 = (h01 & 0xffffu) | (h23 << 16); wh1 = (h01 >> 16) | (h23 & 0xffff0000u);
+                    wl0 = (l01 & 0xffffu) | (l23 << 16); wl1 = (l01 >> 16) | (l23 & 0xffff0000u);
+                } else {
+                    const int colq = q >> qcl, part = q & (qc - 1);      // this quad: rows 4 part .. + 4 of column colq
+                    const bool odd = colq & 1;
+                    const uint32_t rh = __shfl_xor(odd ? h01 : h23, qc), rl = __shfl_xor(odd ? l01 : l23, qc);
+                    row = (cl << sl) + 4 * part + (odd ? 2 : 0);
+                    col = colq & ~1;
+                    if (!odd) {                                          // rows 0, 1: (mine, partner's)
+                        wh0 = (h01 & 0xffffu) | (rh << 16); wh1 = (h01 >> 16) | (rh & 0xffff0000u);
+                        wl0 = (l01 & 0xffffu) | (rl << 16); wl1 = (l01 >> 16) | (rl & 0xffff0000u);
+                    } else {                                             // rows 2, 3: (partner's, mine)
+                        wh0 = (rh & 0xffffu) | (h23 << 16); wh1 = (rh >> 16) | (h23 & 0xffff0000u);
+                        wl0 = (rl & 0xffffu) | (l23 << 16); wl1 = (rl >> 16) | (l23 & 0xffff0000u);
+                    }
+                }
+                *reinterpret_cast<uint32_t*>(&hi_lds[0][row][col]) = wh0;
+                *reinterpret_cast<uint32_t*>(&hi_lds[0][row + 1][col]) = wh1;
+                *reinterpret_cast<uint32_t*>(&hi_lds[1][row][col]) = wl0;
+                *reinterpret_cast<uint32_t*>(&hi_lds[1][row + 1][col]) = wl1;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using IN = std::integral_constant<int, NQ>;
+        f4u vq[NQ];
+        auto issue_hi = [&](int ch) {
+            const int b = ch / p.nT;
+            const int tt0 = (ch - b * p.nT) * SAT_WS_TT;
+            const int th0 = (tt0 << sl) - p.pad;
+            const bool interior = th0 >= 0 && th0 + (66 << sl) <= p.Thi;     // every sample of the stage's 66 columns exists
+            int tv = tid;
+#if !defined(SAT_HIPEMU)
+            asm volatile("" : "+v"(tv));
+#endif
+            load_quads(tv, p.hi + (size_t)b * p.N * p.Thi, th0, interior, vq, I0{}, IN{});
+        };
+#if !defined(SAT_WGS_NOCARRY)
+        issue_hi(c_begin);
+#endif
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int b = ch / p.nT;
+            const int tt0 = (ch - b * p.nT) * SAT_WS_TT;
+            const float* slo = p.lo + (size_t)b * p.M * p.Tlo;
+            int tv = tid;
+#if !defined(SAT_HIPEMU)
+            asm volatile("" : "+v"(tv));
+#endif
+            const int row0 = tv >> 4, c4 = (tv & 15) * 4;
+            float4 vlo[8];
+#if defined(SAT_WGS_NOCARRY)
+            issue_hi(ch);
+#endif
+            {
+                const bool t_ok = tt0 + c4 < p.Tlo;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = m0 + row0 + 16 * u;
+                    const bool okm = t_ok && m < p.M;
+                    const float4 a = *reinterpret_cast<const float4*>(slo + (size_t)(okm ? m : 0) * p.Tlo + (okm ? tt0 + c4 : 0));
+                    vlo[u] = okm ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            SAT_SCHED_FENCE();
+            store_quads(tv, vq, I0{}, IN{});
+            SAT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = row0 + 16 * u;
+                float4 q = vlo[u];
+                if (want_rs) rsum[u] += sat_row16_sum(q);
+                if (snake_lo) {
+                    const float sa = sn_a[row], sib = sn_ib[row];
+                    q.x = sat_snake(q.x, sa, sib); q.y = sat_snake(q.y, sa, sib);
+                    q.z = sat_snake(q.z, sa, sib); q.w = sat_snake(q.w, sa, sib);
+                }
+                uint32_t h0, h1, l0, l1;
+                sat_split2_pk(q.x, q.y, &h0, &l0);
+                sat_split2_pk(q.z, q.w, &h1, &l1);
+                *reinterpret_cast<u2*>(&lo_lds[0][row][c4]) = u2{h0, h1};
+                *reinterpret_cast<u2*>(&lo_lds[1][row][c4]) = u2{l0, l1};
+            }
+            __syncthreads();
+#if !defined(SAT_WGS_NOCARRY)
+            if (ch + 1 < c_end) issue_hi(ch + 1);
+#endif
             mfma_stage();
             __syncthreads();
         }

@@ -70,6 +70,11 @@ SAT_DEVICE void sat_gemm_stage_piece(const short* base, long long ld, int row0, 
 SAT_DEVICE bf16x8 sat_gemm_frag(const char* tile, int row, int kc) {
     return *(const bf16x8*)(tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 }
+// two 16-byte fragments -> the 32-byte operand of one MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4)
+SAT_DEVICE i32x8 sat_cat8(bf16x8 lo, bf16x8 hi) {
+    const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+}
 
 // ---- epilogue helpers ----------------------------------------------------------------------------------------------
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -98,7 +103,15 @@ SAT_DEVICE void sat_store4(void* base, long long idx, f32x4 v) {
         *(u32x2*)((short*)base + idx) = u;
     }
 }
-SAT_DEVICE float sat_gemm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on the transcendental unit: v_exp_f32 (2^x, 1 ulp) + v_rcp_f32 (1 ulp) — 4 issues instead of libm's expf + an IEEE divide
+// (~25): the SwiGLU / gate epilogues evaluate it once per output element (FF1 at M = 2050: 64 per thread and tile)
+SAT_DEVICE float sat_gemm_sigmoid(float x) {
+#if defined(SAT_HIPEMU)
+    return 1.0f / (1.0f + expf(-x));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#endif
+}
 
 // ---- epilogue of one 32-row x 64-column window of a wave's accumulators ---------------------------------------------
 // The wave has put the window into its private LDS space `ep`: row-major [32][64] fp32 — or, for a window of v columns of the
@@ -487,7 +500,10 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 //     K-step (one VALU add per instruction); the K tail (K % 64 != 0) takes the general path.
 // Rows of an M-tail tile beyond M are neither read nor multiplied (a 2050-row activation costs its ninth row tile the DMA
 // stream only).
-template <int EPI, bool F32OUT, int TOUCH = 0>
+// FP8 (round 4): the stage image is the same (128-byte rows = 128 fp8 k-values, K-step = 128 of them); a wave's four 16-byte fragment
+// registers per row block are then the operands of TWO MX MFMAs (32 x 32 x 64, twice the bf16 rate): the matrix time per stage byte,
+// the DMA and the LDS traffic per interval are those of the bf16 kernel.
+template <int EPI, bool F32OUT, int TOUCH = 0, bool FP8 = false>
 __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
@@ -579,6 +595,8 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
 
     bf16x8 bfr[2][4], afr[2][4];
     const int frow = lane & 31, fkc = lane >> 5;
+    // 16-byte k-chunk of fragment register q: bf16 — k-sub-step q, half fkc; fp8 — MX MFMA u = q >> 1 takes the 32 bytes at 64 u + 32 fkc
+    auto kchunk = [&](int q) { return FP8 ? (q >> 1) * 4 + fkc * 2 + (q & 1) : q * 2 + fkc; };
     auto phase = [&](int t, auto pc) {
         constexpr int P = decltype(pc)::value;
         const char* As = smem + (t & 1) * STAGE;
@@ -589,15 +607,15 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, ks * 2 + fkc);
+                for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, kchunk(ks));
         }
         if (on0) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) afr[0][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + frow, ks * 2 + fkc);
+            for (int ks = 0; ks < 4; ++ks) afr[0][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + frow, kchunk(ks));
         }
         if (on1) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) afr[1][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + 32 + frow, ks * 2 + fkc);
+            for (int ks = 0; ks < 4; ++ks) afr[1][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + 32 + frow, kchunk(ks));
         }
         if constexpr (P == 0) { if (t + 1 < nk) stage_a(t + 1); }
         if constexpr (P == 1) {
@@ -623,6 +641,20 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         SAT_SCHED_FENCE();
         if (on0) {
             SAT_SETPRIO(1);
+            if constexpr (FP8) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
+                    const i32x8 a0 = sat_cat8(afr[0][2 * u], afr[0][2 * u + 1]);
+                    acc[P * 2][0] = sat_mfma_32x32x64_fp8(a0, b0, acc[P * 2][0]);
+                    acc[P * 2][1] = sat_mfma_32x32x64_fp8(a0, b1, acc[P * 2][1]);
+                    if (on1) {
+                        const i32x8 a1 = sat_cat8(afr[1][2 * u], afr[1][2 * u + 1]);
+                        acc[P * 2 + 1][0] = sat_mfma_32x32x64_fp8(a1, b0, acc[P * 2 + 1][0]);
+                        acc[P * 2 + 1][1] = sat_mfma_32x32x64_fp8(a1, b1, acc[P * 2 + 1][1]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -631,6 +663,7 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[P * 2 + 1][j] = sat_mfma_32x32x16_bf16(afr[1][ks], bfr[j][ks], acc[P * 2 + 1][j]);
                 }
+            }
             }
             SAT_SETPRIO(0);
         }
@@ -677,22 +710,48 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     }
 }
 
-// ---- 128 x 256 tiles, same eight waves (2 x 4, 64 x 64 per wave) --------------------------------------------------------------------
-// For shapes whose 256 x 256 tile count falls just over a multiple of the 256 CUs: the DiT's FF1 at M = 2050 is 8 x 48 = 384 full tiles =
-// TWO rounds of the chip for 1.5 rounds of work; as 16 x 48 = 768 half-size tiles it is three rounds of half the length.  One phase per
-// K-step (16 MFMAs per wave and interval, as each phase of the 256-row kernel), the two wave rows one barrier apart, and — the stage being
-// 48 KB instead of 64 — a THREE-slot ring: K-step t's read section requests all of tile t + 2 (six LDS-DMAs per wave) and waits only for
-// tile t + 1 (vmcnt(6)), two K-steps of lookahead instead of one and a half.
-template <int EPI, bool F32OUT>
-__global__ void __launch_bounds__(512) sat_gemm128_kernel(SatGemmParams p) {
-    constexpr int BM = 128, BN = 256, NST = 3;
-    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+// ---- the same eight-wave schedule on smaller tiles: ONE barrier interval pair per K-step, ring of NST >= 3 stages ---------------------
+// For the shapes the 256 x 256 tile quantises badly on 256 CUs (round 4; profiles/EXPERIMENTS.md):
+//   * QKV at M = 2050 is 8 x 18 = 144 full 256 x 256 tiles: ONE round of the chip at 56 % of its CUs.  As 160 x 256 tiles it is
+//     13 x 18 = 234 workgroups of 0.625 of the work each; FF2 (6 column tiles, 96 K-steps) becomes 78 tiles x split-K 3 = 234;
+//   * the 1536 -> 1536 projections (to_out, the cross-attention to_q) are 17 x 12 = 204 tiles of 128 x 128: on the four-wave kernel
+//     above that is one wave per SIMD, which cannot hide its own fragment reads; here the same tile is eight waves of 32 x 64.
+// Template: BN = 64 WC columns (WC = 4 or 2 wave columns, one 64-column epilogue window per wave); the waves form two GROUPS
+// (group = wave >> 2: the two waves of a SIMD are in different groups), WRG = 4 / WC wave rows per group; a wave of group g owns
+// R_g rows (NB_g = R_g / 32 MFMA row blocks) x 64 columns; BM = WRG (R0 + R1).  Instances: 128 x 256 (R 64 / 64, 3 stages of 48 KB:
+// round 3's tile 6), 160 x 256 (R 96 / 64, 3 stages of 52 KB), 128 x 128 (WC 2, R 32 / 32, 4 stages of 32 KB).
+//   * K-step t of a wave = [read section: its fragments of tile t (all four k-sub-steps), the LDS-DMA request of its pieces of tile
+//     t + NST - 1, counted wait for its pieces of tile t + 1, lgkmcnt(0)] s_barrier [MFMA section at raised priority] s_barrier.
+//     Group 1 takes one barrier before the loop and group 0 one after it, so in every interval one wave of each SIMD multiplies
+//     while its partner reads — the matrix pipe alternates between the groups, which therefore need not be the same size.
+//   * hazards.  Group 0 reads tile t in interval 2t, group 1 in interval 2t + 1.  WAR: tile t + NST - 1 goes to the slot of tile
+//     t - 1, whose last fragment read retired (lgkmcnt(0)) before the barrier that closes interval 2t - 1; it is requested in
+//     intervals 2t (group 0) and 2t + 1 (group 1).  RAW: a wave's pieces of tile t + 1 are waited for in its read section of K-step t
+//     (intervals 2t / 2t + 1), i.e. in front of a barrier every reader of tile t + 1 (intervals 2t + 2 / 2t + 3) has passed.  With
+//     two stages the wait would have to sit in the interval of the request: NST >= 3.
+//   * 1-KiB pieces p = wave + 8 q of the stage image [A tile | B tile]; (BM + BN) / 8 pieces: when that is 4 mod 8 the waves of
+//     group 0 carry one piece more (their counted waits differ by that piece).
+template <int BN, int R0, int R1, int NST, int EPI, bool F32OUT, bool FP8>
+__global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
+    constexpr int WC = BN / 64, WRG = 4 / WC;
+    constexpr int BM = WRG * (R0 + R1);
+    constexpr int NB0 = R0 / 32, NB1 = R1 / 32, NB = NB0 > NB1 ? NB0 : NB1;
+    constexpr int PA = BM / 8, PT = (BM + BN) / 8;              // 1-KiB pieces: A tile, whole stage
+    constexpr int QHI = (PT + 7) / 8, QLO = PT / 8;             // pieces per wave: group 0 / group 1
+    constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128;
     constexpr int WIN = NST * STAGE / 8;
+    constexpr int LOOK = NST - 1;
+    static_assert(WC == 4 || WC == 2, "64-column epilogue windows, eight waves");
+    static_assert(R0 % 32 == 0 && R1 % 32 == 0 && NB0 >= NB1 && NB <= 4, "wave rows in MFMA blocks; group 0 is the larger one");
+    static_assert(PT % 8 == 0 || PT % 8 == 4, "pieces split over the waves by group");
+    static_assert(NST >= 3 && NST <= 4 && NST * STAGE <= 160 * 1024, "ring of 3 or 4 stages in 160 KB");
     static_assert(WIN >= 64 * 33 * 4, "epilogue window must fit");
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
-    const int wr = wave >> 2, wc = wave & 3;
+    const int grp = wave >> 2, wrl = (wave & 3) / WC, wc = (wave & 3) % WC;
+    const int nb = grp ? NB1 : NB0;                              // this wave's MFMA row blocks
+    const int arow = grp ? WRG * R0 + wrl * R1 : wrl * R0;       // its first row of the tile
     int tm, tn;
     sat_xcd_tile((int)blockIdx.x, p.ntm, p.ntn, &tm, &tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -701,113 +760,140 @@ __global__ void __launch_bounds__(512) sat_gemm128_kernel(SatGemmParams p) {
     const int nk = (kend - kbeg + 63) >> 6;
     constexpr bool GLU = (EPI == SAT_EPI_SWIGLU);
     const int glu_f = p.N >> 1, glu_tile0 = tn * (BN / 2);
-    const int mv = p.M - m0 - wr * 64;           // valid rows of this wave's 64 (<= 0: none)
+    const int mv = p.M - m0 - arow;                              // valid rows of this wave's (<= 0: none)
 
-    f32x16 acc[2][2];
+    f32x16 acc[NB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // this wave's pieces of a tile: A pieces wave, wave + 8 (of 16), B pieces wave + 8 q (of 32); per-lane source offsets as in the 256-row kernel
-    long long aoff[2], boff[4];
+    // per-lane source address (at k = 0) of this wave's pieces: lane -> (row, 16-byte slot holding k-chunk slot ^ ((row >> 1) & 7))
+    const char* src[QHI];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QHI; ++q) {
         const int piece = wave + 8 * q;
-        const int r = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        if (q < 2) {
+        if (piece < PA) {
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
             int ga = m0 + r;
             ga = ga < p.M ? ga : p.M - 1;
-            aoff[q] = ((long long)ga * p.lda + c * 8) * 2;
+            src[q] = (const char*)p.A + ((long long)ga * p.lda + c * 8) * 2;
+        } else {
+            const int r = (piece - PA) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gb;
+            if constexpr (GLU) gb = ((r >> 5) & 1) * glu_f + glu_tile0 + (r >> 6) * 32 + (r & 31);
+            else gb = n0 + r;
+            gb = gb < p.N ? gb : p.N - 1;
+            src[q] = (const char*)p.B + ((long long)gb * p.ldb + c * 8) * 2;
         }
-        int gb;
-        if constexpr (GLU) gb = ((r >> 5) & 1) * glu_f + glu_tile0 + (r >> 6) * 32 + (r & 31);
-        else gb = n0 + r;
-        gb = gb < p.N ? gb : p.N - 1;
-        boff[q] = ((long long)gb * p.ldb + c * 8) * 2;
     }
     auto stage = [&](int kt) __attribute__((always_inline)) {
         char* s = smem + (kt % NST) * STAGE;
         const int k0 = kbeg + kt * 64;
         if (k0 + 64 <= kend) {
-            const char* ab = (const char*)p.A + (long long)k0 * 2;
-            const char* bb = (const char*)p.B + (long long)k0 * 2;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sat_glds16(bb + boff[q], s + ABYTES + (wave + 8 * q) * 1024);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) sat_glds16(ab + aoff[q], s + (wave + 8 * q) * 1024);
+            for (int q = 0; q < QHI; ++q)
+                if (q < QLO || grp == 0) sat_glds16(src[q] + (long long)k0 * 2, s + (wave + 8 * q) * 1024);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, wave + 8 * q, lane, glu_f, glu_tile0);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, wave + 8 * q, lane, 0, 0);
+            for (int q = 0; q < QHI; ++q) {
+                if (!(q < QLO || grp == 0)) continue;
+                const int piece = wave + 8 * q;
+                if (piece < PA) sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0, kend, s, p.zeros, piece, lane, 0, 0);
+                else sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0, kend, s + ABYTES, p.zeros, piece - PA, lane, glu_f, glu_tile0);
+            }
         }
     };
+    // counted wait: leave this wave's pieces of `tiles` tiles in flight
+    auto wait_tiles = [&](auto tiles) __attribute__((always_inline)) {
+        constexpr int T = decltype(tiles)::value;
+        if constexpr (QHI == QLO) { SAT_WAIT_VMCNT(T * QHI); }
+        else { if (grp == 0) { SAT_WAIT_VMCNT(T * QHI); } else { SAT_WAIT_VMCNT(T * QLO); } }
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
 
-    // prologue: tile 0 complete, tile 1 in flight
-    stage(0);
-    if (nk > 1) {
-        stage(1);
-        SAT_WAIT_VMCNT(6);
-    } else {
-        SAT_WAIT_VMCNT(0);
-    }
+    // prologue: tiles 0 .. LOOK-1 requested, tile 0 complete
+#pragma unroll
+    for (int s = 0; s < LOOK; ++s)
+        if (s < nk) stage(s);
+    if (nk >= LOOK) { if constexpr (LOOK == 3) wait_tiles(T2{}); else wait_tiles(T1{}); }
+    else if (LOOK == 3 && nk == 2) wait_tiles(T1{});
+    else wait_tiles(T0{});
     SAT_RAW_BARRIER();
-    if (wr == 1) SAT_RAW_BARRIER();              // the second wave row runs one barrier behind the first
+    if (grp == 1) SAT_RAW_BARRIER();             // the second group runs one barrier behind the first
 
-    bf16x8 bfr[2][4], afr[2][4];
+    bf16x8 bfr[2][4], afr[NB][4];
     const int frow = lane & 31, fkc = lane >> 5;
-    const bool on0 = 0 < mv, on1 = 32 < mv;
+    // 16-byte k-chunk of fragment register q: bf16 — k-sub-step q, half fkc; fp8 — MX MFMA u = q >> 1 takes the 32 bytes at 64 u + 32 fkc
+    auto kchunk = [&](int q) { return FP8 ? (q >> 1) * 4 + fkc * 2 + (q & 1) : q * 2 + fkc; };
     for (int t = 0; t < nk; ++t) {
         const char* As = smem + (t % NST) * STAGE;
         const char* Bs = As + ABYTES;
-        // ---- read section: this K-step's fragments, the request for tile t + 2, the wait for tile t + 1 ----
+        // ---- read section: this K-step's fragments, the request for tile t + LOOK, the wait for tile t + 1 ----
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, ks * 2 + fkc);
-        if (on0) {
+            for (int q = 0; q < 4; ++q) bfr[j][q] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, kchunk(q));
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) afr[0][ks] = sat_gemm_frag(As, wr * 64 + frow, ks * 2 + fkc);
-        }
-        if (on1) {
+        for (int i = 0; i < NB; ++i) {
+            if (i < nb && i * 32 < mv) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) afr[1][ks] = sat_gemm_frag(As, wr * 64 + 32 + frow, ks * 2 + fkc);
+                for (int q = 0; q < 4; ++q) afr[i][q] = sat_gemm_frag(As, arow + i * 32 + frow, kchunk(q));
+            }
         }
-        if (t + 2 < nk) { stage(t + 2); SAT_WAIT_VMCNT(6); }
-        else { SAT_WAIT_VMCNT(0); }
+        if (t + LOOK < nk) {
+            stage(t + LOOK);
+            if constexpr (LOOK == 3) wait_tiles(T2{}); else wait_tiles(T1{});
+        } else if (LOOK == 3 && t + 2 < nk) {
+            wait_tiles(T1{});
+        } else {
+            wait_tiles(T0{});
+        }
         SAT_WAIT_LGKM0();
         SAT_RAW_BARRIER();
         // ---- MFMA section ----
         SAT_SCHED_FENCE();
-        if (on0) {
-            SAT_SETPRIO(1);
+        SAT_SETPRIO(1);
+        if constexpr (FP8) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (i < nb && i * 32 < mv) {
+                        const i32x8 a = sat_cat8(afr[i][2 * u], afr[i][2 * u + 1]);
+                        acc[i][0] = sat_mfma_32x32x64_fp8(a, b0, acc[i][0]);
+                        acc[i][1] = sat_mfma_32x32x64_fp8(a, b1, acc[i][1]);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[0][j] = sat_mfma_32x32x16_bf16(afr[0][ks], bfr[j][ks], acc[0][j]);
-                if (on1) {
+                for (int i = 0; i < NB; ++i) {
+                    if (i < nb && i * 32 < mv) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[1][j] = sat_mfma_32x32x16_bf16(afr[1][ks], bfr[j][ks], acc[1][j]);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[i][j]);
+                    }
                 }
             }
-            SAT_SETPRIO(0);
         }
+        SAT_SETPRIO(0);
         SAT_SCHED_FENCE();
         SAT_RAW_BARRIER();
     }
-    if (wr == 0) SAT_RAW_BARRIER();              // pairs with the second wave row's last barrier: every LDS read is done
+    if (grp == 0) SAT_RAW_BARRIER();             // pairs with the second group's last barrier: every LDS read is done
     SAT_RAW_BARRIER();
 
     if (p.alpha) {
         const float al = *p.alpha;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -817,10 +903,10 @@ __global__ void __launch_bounds__(512) sat_gemm128_kernel(SatGemmParams p) {
     const int hi = lane >> 5, col = lane & 31;
     const int nwin = n0 + wc * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i * 32 >= mv) break;                 // (wave-uniform)
+    for (int i = 0; i < NB; ++i) {
+        if (i >= nb || i * 32 >= mv) break;      // (wave-uniform)
         sat_wave_sync();
-        const int mrow0 = m0 + wr * 64 + i * 32;
+        const int mrow0 = m0 + arow + i * 32;
         if (sat_gemm_window_is_v<EPI>(p, nwin)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -837,38 +923,42 @@ __global__ void __launch_bounds__(512) sat_gemm128_kernel(SatGemmParams p) {
     }
 }
 
-static int sat_gemm128_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream) {
-    p.ntm = sat_cdiv(p.M, 128);
-    p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
+template <int BN, int R0, int R1, int NST>
+static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, bool fp8 = false) {
+    constexpr int BM = (4 / (BN / 64)) * (R0 + R1);
+    p.ntm = sat_cdiv(p.M, BM);
+    p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
-#define SAT_GEMM128_CASE(E, F)                                                                       \
+#define SAT_GEMM8_CASE(E, F)                                                                         \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        SAT_LAUNCH((sat_gemm128_kernel<E, F>), grid, block, stream, p);                              \
-        return sat_check_launch("sat_gemm_bf16 (128x256)");                                          \
+        if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
+        else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }      \
+        return sat_check_launch("sat_gemm (eight-wave ring)");                                       \
     }
-    SAT_GEMM128_CASE(SAT_EPI_STORE, false)
-    SAT_GEMM128_CASE(SAT_EPI_STORE, true)
-    SAT_GEMM128_CASE(SAT_EPI_RES, false)
-    SAT_GEMM128_CASE(SAT_EPI_RES, true)
-    SAT_GEMM128_CASE(SAT_EPI_GATE_RES, false)
-    SAT_GEMM128_CASE(SAT_EPI_GATE_RES, true)
-    SAT_GEMM128_CASE(SAT_EPI_SWIGLU, false)
-    SAT_GEMM128_CASE(SAT_EPI_SWIGLU, true)
-    SAT_GEMM128_CASE(SAT_EPI_QKV, false)
-#undef SAT_GEMM128_CASE
-    sat_set_error("sat_gemm_bf16: unsupported epilogue / output type");
+    SAT_GEMM8_CASE(SAT_EPI_STORE, false)
+    SAT_GEMM8_CASE(SAT_EPI_STORE, true)
+    SAT_GEMM8_CASE(SAT_EPI_RES, false)
+    SAT_GEMM8_CASE(SAT_EPI_RES, true)
+    SAT_GEMM8_CASE(SAT_EPI_GATE_RES, false)
+    SAT_GEMM8_CASE(SAT_EPI_GATE_RES, true)
+    SAT_GEMM8_CASE(SAT_EPI_SWIGLU, false)
+    SAT_GEMM8_CASE(SAT_EPI_SWIGLU, true)
+    SAT_GEMM8_CASE(SAT_EPI_QKV, false)
+#undef SAT_GEMM8_CASE
+    sat_set_error("sat_gemm: unsupported epilogue / output type");
     return 1;
 }
 
-static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 0) {
+static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 0, bool fp8 = false) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
 #define SAT_GEMM256_CASE(E, F)                                                                       \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        if (touch > 0) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 2>), grid, block, stream, p); }       \
+        if (fp8) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, true>), grid, block, stream, p); }        \
+        else if (touch > 0) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 2>), grid, block, stream, p); }  \
         else { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0>), grid, block, stream, p); }                  \
-        return sat_check_launch("sat_gemm_bf16 (256x256)");                                          \
+        return sat_check_launch("sat_gemm (256x256)");                                               \
     }
     SAT_GEMM256_CASE(SAT_EPI_STORE, false)
     SAT_GEMM256_CASE(SAT_EPI_STORE, true)
@@ -880,7 +970,7 @@ static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits,
     SAT_GEMM256_CASE(SAT_EPI_SWIGLU, true)
     SAT_GEMM256_CASE(SAT_EPI_QKV, false)
 #undef SAT_GEMM256_CASE
-    sat_set_error("sat_gemm_bf16: unsupported epilogue / output type");
+    sat_set_error("sat_gemm: unsupported epilogue / output type");
     return 1;
 }
 
@@ -912,17 +1002,28 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
 
 // tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
 // 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure);
-// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel); 6 = 128x256 / 8 waves / 3-slot ring,
-// 2 intervals per K-step (sat_gemm128_kernel: shapes whose 256x256 tile count is just over a multiple of the CU count)
+// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel); 5 = 4 + the L2 touch prefetch;
+// sat_gemm8_kernel (eight waves in two groups one barrier apart, one interval pair per K-step, 3- or 4-stage ring):
+// 6 = 128x256, 7 = 160x256, 8 = 128x128
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
     if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 2);      // (A/B: WITH the L2 touch prefetch: measured -6 % in the sampler)
-    if (tile == 6) return sat_gemm128_launch(p, epi, f32out, splits, stream);
+    if (tile == 6) return sat_gemm8_launch<256, 64, 64, 3>(p, epi, f32out, splits, stream);
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, splits, stream);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, splits, stream);
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile < 0 || tile > 6) { sat_set_error("sat_gemm: tile must be 0..6"); return 1; }
+    if (tile < 0 || tile > 8) { sat_set_error("sat_gemm: tile must be 0..8"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
+}
+// fp8 operands: 0 = 128x128 / 4 waves / plain loop (round 3), 4 = 256x256, 7 = 160x256, 8 = 128x128 eight-wave ring
+static int sat_gemm_dispatch_fp8(SatGemmParams& p, int epi, int f32out, int tile, void* stream) {
+    if (tile == 4) return sat_gemm256_launch(p, epi, f32out, 1, stream, 0, true);
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, 1, stream, true);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, 1, stream, true);
+    if (tile != 0) { sat_set_error("sat_gemm_fp8: tile must be 0, 4, 7 or 8"); return 1; }
+    return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, epi, f32out, 1, stream);
 }
 
 // C = epilogue(A · B^T).  A (M, K), B (N, K) bf16 with row strides lda / ldb (elements, multiples of 8; K % 8 == 0).
@@ -1014,11 +1115,11 @@ extern "C" int sat_splitk_epilogue(const float* slabs, int S, const float* bias,
 // (BASELINE.json configs[4]): A (M, K) and B (N, K) are fp8 bytes, K a multiple of 16, lda / ldb in elements (multiples of 16);
 // products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate, half the operand bytes);
 // alpha: device scalar = (de-quantisation scale of A) x (of B), multiplied into the fp32 accumulators before the epilogue.
-// Everything else (epilogues, output types) as sat_gemm_bf16 / sat_gemm_qkv_bf16; no split-K.
+// Everything else (epilogues, output types, tile: 0 / 4 / 7 / 8) as sat_gemm_bf16 / sat_gemm_qkv_bf16; no split-K.
 extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                             const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
                             long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
-                            void* stream) {
+                            int tile, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { sat_set_error("sat_gemm_fp8: empty shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15) || (N & 7) || (ldc & 3)) { sat_set_error("sat_gemm_fp8: K, lda, ldb must be multiples of 16, N of 8"); return 1; }
     if (!zeros || !alpha) { sat_set_error("sat_gemm_fp8: zeros page and alpha required"); return 1; }
@@ -1033,11 +1134,11 @@ extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long lo
     p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc; p.ldr = ldr; p.ldg = ldg; p.ldp = ldp;
     p.M = M; p.N = N; p.K = K / 2; p.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
     p.klen = sat_cdiv(p.K, 64) * 64;
-    return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, epilogue, out_f32, 1, stream);
+    return sat_gemm_dispatch_fp8(p, epilogue, out_f32, tile, stream);
 }
 extern "C" int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
                                 void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
-                                int heads, int K, int sec0, int nsec, void* stream) {
+                                int heads, int K, int sec0, int nsec, int tile, void* stream) {
     if (nb <= 0 || ntok <= 0 || heads <= 0 || K <= 0 || npad < ntok) { sat_set_error("sat_gemm_qkv_fp8: bad shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15)) { sat_set_error("sat_gemm_qkv_fp8: K, lda, ldb must be multiples of 16"); return 1; }
     if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3 || !alpha) { sat_set_error("sat_gemm_qkv_fp8: bad section range / alpha"); return 1; }
@@ -1048,7 +1149,7 @@ extern "C" int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, lon
     p.klen = sat_cdiv(p.K, 64) * 64;
     p.rope_cs = rope_cs; p.rope_off = rope_off; p.q_rm = (short*)q_rm; p.k_rm = (short*)k_rm; p.v_tr = (short*)v_tr;
     p.ntok = ntok; p.npad = npad; p.heads = heads; p.sec0 = sec0;
-    return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, SAT_EPI_QKV, 0, 1, stream);
+    return sat_gemm_dispatch_fp8(p, SAT_EPI_QKV, 0, tile, stream);
 }
 
 // Quantise to fp8 e4m3: dst[r][c] = sat_448(src[r][c] * qscale[0]) (round to nearest even); src fp32 or bf16 (R, C), row strides in

@@ -357,7 +357,6 @@ class SatOps:
     # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
     # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
     # per (device, stream): the pre-pass and its conv are enqueued back to back on the caller's current stream.
-    gemm_tile128 = os.environ.get("SAT_GEMM_TILE128", "0") == "1"   # A/B switch, OFF: 128 x 256 GEMM tiles where they save a round of the chip (measured slower)
     k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
     k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
 
@@ -945,7 +944,7 @@ class SatOps:
 
     # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
     EPI_STORE, EPI_RES, EPI_GATE_RES, EPI_SWIGLU = 0, 1, 2, 3
-    gemm_tile = None     # None: pick per shape; 0 = 128x128 (4 waves, 2 workgroups per CU), 1..3 = experiments, 4 = 256x256 (8 waves)
+    gemm_tile = None     # None: pick per shape (_pick_tile); 0 = 128x128 (4 waves, 2 workgroups per CU), 4 = 256x256, 7 = 160x256, 8 = 128x128 (8 waves); 1..3, 5, 6: experiments
 
     def _zeros_page(self, device):
         z = getattr(self, "_zpage", None)
@@ -954,24 +953,39 @@ class SatOps:
             self._zpage = z
         return z
 
-    def _pick_tile(self, m, n, splits=1):
-        """256 x 256 tiles (sat_gemm256_kernel) when they fill most of the 256 CUs, 128 x 128 (two workgroups per CU) otherwise —
-        measured at M = 2050 / 4100 (profiles/r03_gemm_bench.jsonl): QKV 49.7 -> 42.6 us, FF1 + SwiGLU 111 -> 93 us; the few-tile
-        projections (1536 -> 1536, 6144 -> 1536) stay on the small tile (+ split-K)."""
+    # Workgroup-tile model of csrc/gemm.hip, one entry per shipped tile: (rows, columns, workgroups per CU, us per 64-deep K-step of one
+    # workgroup when <= 128 workgroups are on the chip, the same with the chip full, fixed us per workgroup: launch gap + first-tile
+    # latency + epilogue).  A projection's time is rounds-of-the-chip x (K-steps x us + fixed); fitted to tools/gemm_bench.py at
+    # M = 2050 / 4100 / 12290 (profiles/r04_gemm_bench.jsonl: within 5 % on 40 of the 48 (shape, tile) rows, worst 13 %).
+    _TILE_MODEL = {0: (128, 128, 2, 0.65, 1.00, 6.2), 4: (256, 256, 1, 1.12, 1.47, 9.5),
+                   7: (160, 256, 1, 1.05, 1.28, 7.0), 8: (128, 128, 1, 0.53, 0.56, 4.3)}
+    gemm_policy = os.environ.get("SAT_GEMM_POLICY", "model")     # "r3": round 3's rule (256 x 256 when >= 150 tiles, else 128 x 128 four-wave)
+
+    def _tile_cost(self, tile, m, n, k, splits=1):
+        bm, bn, per_cu, u_light, u_full, f = self._TILE_MODEL[tile]
+        tiles = -(-m // bm) * -(-n // bn) * splits
+        rounds = -(-tiles // (256 * per_cu))
+        # (tile 0: two workgroups of a CU share its matrix pipes once more than 256 are in flight)
+        u = u_full if tiles > (256 if per_cu > 1 else 128) else u_light
+        ksteps = -(-(-(-k // 64)) // splits)
+        t = rounds * (u * ksteps + f)
+        if tile == 8 and rounds > 2:
+            t *= 1.2                           # (its 0.56 us is the one- / two-round figure; the long weight-gradient GEMMs measured 0.65)
+        if splits > 1:
+            t += 4.0 + splits * m * n * 4 / 4e6      # sat_splitk_epilogue: launch + the slabs read back at ~4 TB/s
+        return t
+
+    def _pick_tile(self, m, n, splits=1, k=None):
+        """Workgroup tile of a projection.  Round 4: the cheapest of the shipped tiles under _TILE_MODEL — 256 x 256 (sat_gemm256_kernel)
+        for the many-tile shapes, 160 x 256 where 256-row tiles leave CUs idle (QKV at M = 2050: 144 full tiles -> 234 workgroups),
+        128 x 128 on eight waves for the 1536 -> 1536 projections (sat_gemm8_kernel), the four-wave 128 x 128 kernel for the rest."""
         if self.gemm_tile is not None:
             return self.gemm_tile
-        if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
-            # wave quantisation: FULL 256-row tiles run in rounds of 256 (one workgroup per CU; the row tile of the M tail only streams its
-            # B panel); when the count lands just over a multiple — FF1 at M = 2050: 8 x 48 = 384 = two rounds for 1.5 of work — the same
-            # structure on 128-row tiles (tile 6: 768 half-size tiles = three rounds) SHOULD be shorter; measured it is not (FF1 97.5 vs 89.0 us:
-            # a half-size tile takes 0.6 of the time, profiles/EXPERIMENTS.md), so this branch is an A/B switch (SAT_GEMM_TILE128=1)
-            nt = (n + 255) // 256
-            r256 = -(-((m // 256) * nt) // 256)
-            r128 = -(-((m // 128) * nt) // 256) * 0.5
-            if self.gemm_tile128 and m >= 256 and r128 + 0.2 < r256:
-                return 6
-            return 5 if os.environ.get("SAT_GEMM_TOUCH") == "1" else 4          # 5 = 4 + the L2 touch prefetch experiment (slower)
-        return 0
+        if self.gemm_policy == "r3" or k is None:
+            if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
+                return 5 if os.environ.get("SAT_GEMM_TOUCH") == "1" else 4          # 5 = 4 + the L2 touch prefetch experiment (slower)
+            return 0
+        return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, k, splits), t))
 
     def gemm_bf16(self, a, b, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
                   splits=1, out=None):
@@ -1007,7 +1021,7 @@ class SatOps:
                                          _ptr(res), res.stride(0) if res is not None else 0,
                                          _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_gate,
                                          _ptr(pre), n, _ptr(self._zeros_page(a.device)), m, n, k, epilogue, int(f32), splits,
-                                         self._pick_tile(m, nout if epilogue == self.EPI_SWIGLU else n, splits), self._stream(a)))
+                                         self._pick_tile(m, n, splits, k), self._stream(a)))
         if splits > 1:
             c = self._reduce_rows(c.view(splits, m * nout), splits, m * nout).view(m, nout)
         return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
@@ -1033,8 +1047,8 @@ class SatOps:
             slabs = _keep_empty((splits, m, n), torch.float32, a.device)
             self._planes[key] = slabs
         self._chk(self.lib.sat_gemm_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(slabs), n, None, None, 0, None, 0, 0, None, 0,
-                                         _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits, self._pick_tile(m, n, splits),
-                                         self._stream(a)))
+                                         _ptr(self._zeros_page(a.device)), m, n, a.shape[1], 0, 1, splits,
+                                         self._pick_tile(m, n, splits, a.shape[1]), self._stream(a)))
         c = out if out is not None else torch.empty(m, n, dtype=out_dtype, device=a.device)
         if bias is not None:
             self._f32(bias)
@@ -1043,14 +1057,16 @@ class SatOps:
         return c
 
     def splitk_for(self, m, n, k):
-        """Split count for a projection: > 1 only when the 128 x 128 tiles leave most of the 512 workgroup slots empty AND K is long
-        enough that the slab round trip (fp32, M x N x 4 B per slice) is cheap next to the saving."""
+        """Split count for a projection: > 1 only for few-tile / long-K shapes (FF2: 6144 -> 1536), where cutting K puts more workgroups
+        on the chip and the slab round trip (fp32, M x N x 4 B per slice) is cheap next to the saving — the cheapest (tile, splits) pair
+        under _TILE_MODEL; round 3's rule (two slices on the four-wave tile when <= 256 tiles and K >= 4096) with SAT_GEMM_POLICY=r3."""
         if self.gemm_splitk is not None:
             return self.gemm_splitk
-        tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        if tiles > 256 or k < 4096 or n % 4:
+        if k < 4096 or n % 4:
             return 1
-        return 2
+        if self.gemm_policy == "r3" or self.gemm_tile is not None:
+            return 1 if ((m + 127) // 128) * ((n + 127) // 128) > 256 else 2
+        return min((1, 2, 3, 4), key=lambda sp: (min(self._tile_cost(t, m, n, k, sp) for t in self._TILE_MODEL), sp))
 
     gemm_splitk = None
 
@@ -1073,7 +1089,7 @@ class SatOps:
             self._f32(cs)
         self._chk(self.lib.sat_gemm_qkv_bf16(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
                                              _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
-                                             nb, ntok, npad, heads, x.shape[1], sec0, nsec, self._pick_tile(nb * ntok, nsec * heads * 64),
+                                             nb, ntok, npad, heads, x.shape[1], sec0, nsec, self._pick_tile(nb * ntok, nsec * heads * 64, 1, x.shape[1]),
                                              self._stream(x)))
         return out
 
@@ -1108,6 +1124,16 @@ class SatOps:
         self._chk(self.lib.sat_quant_fp8(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(scales), src.shape[0], src.shape[1], int(dt == 0), st))
         return q, scales[1]
 
+    gemm_fp8_tile = None     # None: pick per shape (the fp8 instances: 0, 4, 7, 8)
+
+    def _pick_tile_fp8(self, m, n, k):
+        """As _pick_tile for the fp8 kernels (K-steps of 128 fp8 values: half as many per projection)."""
+        if self.gemm_fp8_tile is not None:
+            return self.gemm_fp8_tile
+        if self.gemm_policy == "r3":
+            return 0
+        return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, (k + 1) // 2), t))
+
     def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
                  out=None):
         """gemm_bf16 on fp8 operands: a (M, K), b (N, K) uint8 (quant_fp8), alpha = 0-dim fp32 device tensor (scale_a * scale_b)."""
@@ -1125,7 +1151,7 @@ class SatOps:
         self._chk(self.lib.sat_gemm_fp8(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), nout, _ptr(bias),
                                         _ptr(res), res.stride(0) if res is not None else 0, _ptr(gate), gate.stride(0) if gate is not None else 0,
                                         rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), m, n, k, epilogue, int(f32),
-                                        self._stream(a)))
+                                        self._pick_tile_fp8(m, n, k), self._stream(a)))
         return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
 
     def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None):
@@ -1139,7 +1165,8 @@ class SatOps:
         alpha = alpha.float().reshape(1).contiguous()
         self._chk(self.lib.sat_gemm_qkv_fp8(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
                                             _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
-                                            _ptr(alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec, self._stream(x)))
+                                            _ptr(alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec,
+                                            self._pick_tile_fp8(nb * ntok, nsec * heads * 64, x.shape[1]), self._stream(x)))
         return out
 
     def cast_bf16(self, src, transpose=False, row_pad=1, out=None):

@@ -9,10 +9,10 @@ import torch
 import dit_oracle
 from golden_util import rel_err
 
-SHAPES = [(130, 136, 72), (257, 128, 64), (70, 264, 200), (33, 64, 8), (290, 520, 328)]
+SHAPES = [(130, 136, 72), (257, 128, 64), (70, 264, 200), (33, 64, 8), (290, 520, 328), (165, 80, 456)]
 
 
-def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3, 4, 5, 6)):
+def _gemm_cases(ops, dev, shapes, tiles=(0, 1, 2, 3, 4, 5, 6, 7, 8)):
     torch.manual_seed(0)
     for (m, n, k) in shapes:
         a = torch.randn(m, k).bfloat16().to(dev)
@@ -57,7 +57,7 @@ def _heads_case(ops, dev, nb, ntok, heads, k):
     q, kk, v = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
     freqs = dit_oracle.rotary_freqs(inv, ntok + 3)[-ntok:]
     qr, kr = dit_oracle.apply_rotary(q, freqs), dit_oracle.apply_rotary(kk, freqs)
-    for tile in (0, 1, 2, 3, 4, 5, 6):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         ops.gemm_tile = tile
         try:
             pl = ops.gemm_heads_bf16(x, w, cs, heads, nb, ntok, 0, 3)
@@ -118,7 +118,7 @@ def test_gemm_epilogues_gpu(hip):
 @pytest.mark.gpu
 def test_gemm_ff_shapes_gpu(hip):
     """The feed-forward pair at full size: SwiGLU projection 1536 -> 2 x 6144 and the 6144 -> 1536 output projection."""
-    _gemm_cases(hip, "cuda", [(2050, 12288, 1536), (2050, 1536, 6144)], tiles=(0, 1, 2, 3, 4, 5, 6))
+    _gemm_cases(hip, "cuda", [(2050, 12288, 1536), (2050, 1536, 6144)], tiles=(0, 1, 2, 3, 4, 5, 6, 7, 8))
 
 
 @pytest.mark.gpu
@@ -140,22 +140,45 @@ def _fp8_case(ops, dev):
     a plain fp32 fma chain; the simulator is exact), every epilogue included; against the un-quantised fp32
     product the distance is the format's: ~4 % relative L2 for unit-variance operands (3 mantissa bits each side)."""
     torch.manual_seed(4)
-    m, n, k = 130, 144, 144
-    x, w = torch.randn(m, k).to(dev), (torch.randn(n, k) / 12).to(dev)
+    for (m, n, k) in ((130, 144, 144), (330, 272, 400)):
+        x, w = torch.randn(m, k).to(dev), (torch.randn(n, k) / 12).to(dev)
+        qx, sx = ops.quant_fp8(x)
+        qw, sw = ops.quant_fp8(w.bfloat16())
+        assert torch.equal(qx.cpu().view(torch.float8_e4m3fn).float(), (x.cpu() / sx.cpu()).to(torch.float8_e4m3fn).float())
+        xd, wd = qx.cpu().view(torch.float8_e4m3fn).float() * sx.cpu(), qw.cpu().view(torch.float8_e4m3fn).float() * sw.cpu()
+        ref = xd @ wd.t()
+        bias = torch.randn(n).to(dev)
+        res = torch.randn(m, n).to(dev)
+        full = ref + bias.cpu()
+        for tile in (None, 0, 4, 7, 8):           # None: the shape's own pick; the four fp8 instances of csrc/gemm.hip
+            ops.gemm_fp8_tile = tile
+            try:
+                assert rel_err(ops.gemm_fp8(qx, qw, sx * sw, out_dtype=torch.float32), ref) < 1e-4
+                assert rel_err(ops.gemm_fp8(qx, qw, sx * sw, bias=bias, res=res, epilogue=ops.EPI_RES, out_dtype=torch.float32), ref + bias.cpu() + res.cpu()) < 1e-4
+                c = ops.gemm_fp8(qx, qw, sx * sw, bias=bias, epilogue=ops.EPI_SWIGLU, out_dtype=torch.float32)
+                assert rel_err(c, full[:, :n // 2] * torch.nn.functional.silu(full[:, n // 2:])) < 1e-4
+            finally:
+                ops.gemm_fp8_tile = None
+        full32 = x.cpu() @ w.cpu().t()
+        assert float((ref - full32).norm() / full32.norm()) < 8e-2
+    # the head-split / plane-layout epilogue on fp8 operands (no rotary: the cross-attention to_q; with: to_qkv), every fp8 tile
+    nb, ntok, heads, k = 2, 71, 3, 80
+    x = torch.randn(nb * ntok, k).to(dev)
+    w = (torch.randn(3 * heads * 64, k) / k ** 0.5).to(dev)
     qx, sx = ops.quant_fp8(x)
-    qw, sw = ops.quant_fp8(w.bfloat16())
-    assert torch.equal(qx.cpu().view(torch.float8_e4m3fn).float(), (x.cpu() / sx.cpu()).to(torch.float8_e4m3fn).float())
+    qw, sw = ops.quant_fp8(w)
     xd, wd = qx.cpu().view(torch.float8_e4m3fn).float() * sx.cpu(), qw.cpu().view(torch.float8_e4m3fn).float() * sw.cpu()
-    ref = xd @ wd.t()
-    assert rel_err(ops.gemm_fp8(qx, qw, sx * sw, out_dtype=torch.float32), ref) < 1e-4
-    bias = torch.randn(n).to(dev)
-    res = torch.randn(m, n).to(dev)
-    assert rel_err(ops.gemm_fp8(qx, qw, sx * sw, bias=bias, res=res, epilogue=ops.EPI_RES, out_dtype=torch.float32), ref + bias.cpu() + res.cpu()) < 1e-4
-    c = ops.gemm_fp8(qx, qw, sx * sw, bias=bias, epilogue=ops.EPI_SWIGLU, out_dtype=torch.float32)
-    full = ref + bias.cpu()
-    assert rel_err(c, full[:, :n // 2] * torch.nn.functional.silu(full[:, n // 2:])) < 1e-4
-    full32 = x.cpu() @ w.cpu().t()
-    assert float((ref - full32).norm() / full32.norm()) < 8e-2
+    qkv = (xd @ wd.t()).view(nb, ntok, 3, heads, 64)
+    q, kk, v = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    for tile in (0, 4, 7, 8):
+        ops.gemm_fp8_tile = tile
+        try:
+            pl = ops.gemm_heads_fp8(qx, qw, sx * sw, None, heads, nb, ntok, 0, 3)
+            qp, kp, vp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k", "v_tr")]
+            assert rel_err(qp[:, :, :ntok], q) < 6e-3 and rel_err(kp[:, :, :ntok], kk) < 6e-3
+            assert rel_err(vp[:, :, :, :ntok], v.transpose(2, 3)) < 6e-3
+        finally:
+            ops.gemm_fp8_tile = None
 
 
 def test_gemm_fp8_simulator(emu):

@@ -29,6 +29,7 @@ def timeit(fn, reps=30, warm=5):
 
 TILES = tuple(int(t) for t in os.environ.get('SAT_TILES', '0,4').split(','))
 SPLITS = tuple(int(t) for t in os.environ.get('SAT_SPLITS', '2,3,4,5,6').split(','))
+FP8_TILES = tuple(int(t) for t in os.environ.get('SAT_FP8_TILES', '0,4,7,8').split(','))
 
 
 def main():
@@ -65,16 +66,61 @@ def main():
                 qa, sa_ = ops.quant_fp8(a)
                 qb, sb_ = ops.quant_fp8(b)
                 alpha = (sa_ * sb_)
-                t8 = timeit(lambda: ops.gemm_fp8(qa, qb, alpha))
                 tq = timeit(lambda: ops.quant_fp8(a))
-                row["fp8_gemm_us"] = round(t8, 1)
-                row["fp8_gemm_tf"] = round(fl / t8 / 1e6, 1)
                 row["fp8_quant_act_us"] = round(tq, 1)
-                row["fp8_total_us"] = round(t8 + tq, 1)
-                if name == "ff1":
-                    row["fp8_swiglu_us"] = round(timeit(lambda: ops.gemm_fp8(qa, qb, alpha, epilogue=ops.EPI_SWIGLU)), 1)
+                for tile in FP8_TILES:
+                    ops.gemm_fp8_tile = tile
+                    t8 = timeit(lambda: ops.gemm_fp8(qa, qb, alpha))
+                    row[f"fp8_t{tile}_us"] = round(t8, 1)
+                    row[f"fp8_t{tile}_tf"] = round(fl / t8 / 1e6, 1)
+                    if name == "ff1":
+                        row[f"fp8_t{tile}_swiglu_us"] = round(timeit(lambda: ops.gemm_fp8(qa, qb, alpha, epilogue=ops.EPI_SWIGLU)), 1)
+                ops.gemm_fp8_tile = None
+                row["fp8_pick"] = ops._pick_tile_fp8(mm, n, k)
+            row["pick"] = ops._pick_tile(mm, n, 1, k)
+            row["pick_splits"] = ops.splitk_for(mm, n, k)
+            if name == "qkv" and mm % 1025 == 0:
+                # the in-model form of this projection: head split + rotary + attention-plane layout in the epilogue (sat_gemm_qkv_bf16)
+                nbat = mm // 1025
+                inv = 1.0 / (10000 ** (torch.arange(0, 32, 2, device=dev).float() / 32))
+                cs = ops.rope_tables(inv, 1025)
+                for tile in TILES:
+                    ops.gemm_tile = tile
+                    row[f"native_t{tile}_heads_us"] = round(timeit(lambda: ops.gemm_heads_bf16(a, b, cs, 24, nbat, 1025, 0, 3, reuse="bench")), 1)
+                ops.gemm_tile = None
             print(json.dumps(row), flush=True)
 
 
+def train_shapes():
+    """The backward GEMMs of a DiT train step at per-GPU batch 4 (M = 4100 tokens): data gradients (bf16 out) and weight gradients
+    (fp32 out, reduction over the zero-padded token dim; the bias gradient rides as 8 extra columns) — linear.LinearFn.backward."""
+    ops = O.get_ops()
+    dev = "cuda"
+    torch.manual_seed(0)
+    mt = 4104
+    shapes = [("dgrad_qkv", 4100, 1536, 4608, False), ("dgrad_out", 4100, 1536, 1536, False), ("dgrad_ff1", 4100, 1536, 12288, False),
+              ("dgrad_ff2", 4100, 6144, 1536, False),
+              ("wgrad_qkv", 4608, 1544, mt, True), ("wgrad_out", 1536, 1544, mt, True), ("wgrad_ff1", 12288, 1544, mt, True),
+              ("wgrad_ff2", 1536, 6152, mt, True)]
+    for name, m, n, k, f32 in shapes:
+        a = torch.randn(m, k, device=dev).bfloat16()
+        b = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+        fl = 2.0 * m * n * k
+        t_ref = timeit(lambda: torch.matmul(a, b.t()))
+        row = {"shape": name, "M": m, "N": n, "K": k, "f32_out": f32, "hipblaslt_us": round(t_ref, 1)}
+        for tile in TILES:
+            ops.gemm_tile = tile
+            row[f"native_t{tile}_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, out_dtype=torch.float32 if f32 else torch.bfloat16)), 1)
+            if f32:
+                for sp in (2, 4):
+                    row[f"native_t{tile}_splits{sp}_us"] = round(timeit(lambda: ops.gemm_bf16(a, b, out_dtype=torch.float32, splits=sp)), 1)
+        ops.gemm_tile = None
+        row["pick"] = ops._pick_tile(m, n, 1, k)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("SAT_BENCH_TRAIN") == "1":
+        train_shapes()
+    else:
+        main()

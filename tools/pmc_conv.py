@@ -1,5 +1,5 @@
 """Run ONE conv configuration a few times (for rocprofv3 --pmc runs).  usage: pmc_conv.py <kind> [C] [T]
-kind: conv7 | conv7q | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | disc9 | calib"""
+kind: conv7 | conv7q | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | wgrads2 | wgrads8 | disc9 | calib"""
 import os
 import sys
 
@@ -51,6 +51,18 @@ elif kind == "wgrad7":
     fn = lambda: ops.conv_wgrad7_bf16x3(dy, x, 9, 27, snake=(la, lb))
 elif kind == "wgrad1":
     fn = lambda: ops.conv_wgrad(dy, x, 1, 1, 1, 0, snake=(la, lb), snake_on=2)
+elif kind in ("wgrads2", "wgrads8"):
+    # the strided convs' weight gradient (sat_wgrad_small_bf16x3_kernel<2>) at two Oobleck levels: block 0 (128 -> 128, stride 2,
+    # output length 1 048 576) and block 3 (512 -> 1024, stride 8, output length 8192)
+    if kind == "wgrads2":
+        co, ci, tl, s_ = 128, 128, 1048576, 2
+    else:
+        co, ci, tl, s_ = 1024, 512, 8192, 8
+    dyl = torch.randn(1, co, tl, device=dev)
+    xh = torch.randn(1, ci, tl * s_, device=dev) * 0.5
+    la2 = torch.randn(ci, device=dev) * 0.1
+    lb2 = torch.randn(ci, device=dev) * 0.1
+    fn = lambda: ops.conv_wgrad(dyl, xh, 2 * s_, s_, 1, (s_ + 1) // 2, snake=(la2, lb2), snake_on=2, lo_rowsum=True)
 elif kind == "calib":
     # known-traffic calibration launches: sat_rowsum reads C*T*4 bytes with 16-byte loads; the torch copy reads and
     # writes C*T*4 bytes
