@@ -1227,6 +1227,41 @@ def main():
                 u.checkpointing = False
             line["config"]["real_step"]["recompute"] = {"ms_per_step": 1e3 * dt_rc, "peak_hbm_gib": peak_rc, "steps": 2,
                                                         "what": "ResidualUnit.checkpointing = True on all 30 units"}
+            if args.batch == 1 and not args.no_batch_sweep:
+                # what the 288 GB buy for the REAL step: the same alternating updates at four items per GPU (two warm-up + two timed
+                # updates) — every activation resident if it fits, else with the units' recompute
+                ops.release_workspaces()
+                torch.cuda.empty_cache()
+                rs4 = None
+                for ck in (False, True):
+                    bb = None
+                    try:
+                        for u in units:
+                            u.checkpointing = ck
+                        bb = [(0.1 * torch.randn(4, 2, args.sample_size, generator=g)).to(dev) for _ in range(2)]
+                        stepper.global_step = 0
+                        for i in range(2):
+                            stepper(bb[i % 2])
+                        torch.cuda.synchronize()
+                        torch.cuda.reset_peak_memory_stats()
+                        t1 = time.perf_counter()
+                        for i in range(2):
+                            stepper(bb[i % 2])
+                        torch.cuda.synchronize()
+                        dt4 = (time.perf_counter() - t1) / 2
+                        rs4 = {"per_gpu_batch": 4, "ms_per_step": 1e3 * dt4, "samples_per_s": 4 / dt4, "steps": 2,
+                               "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "recompute": ck}
+                    except torch.cuda.OutOfMemoryError:
+                        rs4 = {"per_gpu_batch": 4, "out_of_memory": True, "recompute": ck}
+                    finally:
+                        del bb
+                        for u in units:
+                            u.checkpointing = False
+                        ops.release_workspaces()
+                        torch.cuda.empty_cache()
+                    if "ms_per_step" in rs4:
+                        break
+                line["config"]["real_step"]["batch4"] = rs4
             if gstep is not None:
                 # the same alternating updates replayed from HIP graphs (one per kind of update)
                 del gstep

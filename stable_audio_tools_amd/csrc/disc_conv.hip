@@ -239,6 +239,16 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
     const int pad_w = (kw - 1) >> 1, pad_t = (kh - 1) >> 1;
     constexpr int nph = (kw + 2) / 3;                      // phases of three taps
     constexpr int ipp = (9 + nph - 1) / nph;               // DMA issue slots (of 9) per phase
+    // kw <= 3 (the 3 x 3 layers): ONE phase per chunk — with two stages the chunk's only read section would have to request the next
+    // chunk AND wait for it (round 3: vmcnt(0) in the phase of the request: 0.24 of the peak).  Its stage is 48 KB (12 weight + 36
+    // activation pieces), so the same 144 KB hold a THREE-stage ring: chunk c's read section requests chunk c + 2 and waits for chunk
+    // c + 1 only (counted: the six pieces just issued stay in flight) — gemm.hip's sat_gemm8_kernel schedule.
+    constexpr bool RING3 = (nph == 1);
+    constexpr int WBK = RING3 ? KW * 4096 : WB;            // bytes of a stage's weight part = offset of its activation part
+    constexpr int STG = RING3 ? KW * 4096 + SAT_DC_ABYTES : STAGE;
+    constexpr int NSTG = RING3 ? 3 : 2;
+    constexpr int NPW = 5 + (KW >= 3 ? 1 : 0);             // RING3: LDS-DMA instructions per wave and chunk (slots 0-4, slot 5 for kw = 3)
+    static_assert(NSTG * STG <= 2 * STAGE, "the ring lives in the two-stage allocation");
     // tile order: the tiles are dealt round-robin to the 8 XCDs; give every XCD a CONTIGUOUS range of the sequence so that the frame
     // taps (the same plane rows, read again by the tiles dil_t * P positions earlier / later) and the halos hit in its L2
     int L = (int)blockIdx.x;
@@ -277,14 +287,14 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
     };
     auto issue = [&](int c, int st, auto slot_c) __attribute__((always_inline)) {
         constexpr int s = decltype(slot_c)::value;
-        char* stage = lds + st * STAGE;
+        char* stage = lds + st * STG;
         if constexpr (s < 4) {
             const char* src = (const char*)((s >> 1) ? p.xp_lo : p.xp_hi) + aoff[s & 1] + wave * 1024;
-            sat_glds16(src + lane16, stage + WB + (s * AROWS + wave * 64) * 16);
+            sat_glds16(src + lane16, stage + WBK + (s * AROWS + wave * 64) * 16);
         } else if constexpr (s == 4) {
             if (wave < 4) {
                 const char* src = (const char*)((wave >> 1) ? p.xp_lo : p.xp_hi) + aoff[wave & 1] + 8 * 1024;
-                sat_glds16(src + lane16, stage + WB + (wave * AROWS + 512) * 16);
+                sat_glds16(src + lane16, stage + WBK + (wave * AROWS + 512) * 16);
             } else {
                 issue_w(c, stage, wave - 4);
             }
@@ -323,7 +333,7 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             const char* wb = sb + ((tap * 2 + pl) * 2 + hi) * 1024;
             f.wa[0][pl] = *reinterpret_cast<const bf16x8*>(wb + l31 * 16);
             f.wa[1][pl] = *reinterpret_cast<const bf16x8*>(wb + (32 + l31) * 16);
-            const char* ab = sb + WB + (pl * 2 + hi) * (AROWS * 16);
+            const char* ab = sb + WBK + (pl * 2 + hi) * (AROWS * 16);
             f.xa[0][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + l31 + tap) * 16);
             f.xa[1][pl] = *reinterpret_cast<const bf16x8*>(ab + (t_w + 32 + l31 + tap) * 16);
         }
@@ -343,13 +353,53 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
     };
 
-    // prologue: chunk 0 complete in stage 0
+    // prologue: chunk 0 complete in stage 0 (RING3: chunk 1 requested as well)
     set_chunk(0);
     issue_range(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-    SAT_WAIT_VMCNT(0);
+    if constexpr (RING3) {
+        if (p.nchunks > 1) {
+            set_chunk(1);
+            issue_range(1, 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+            SAT_WAIT_VMCNT(NPW);
+        } else {
+            SAT_WAIT_VMCNT(0);
+        }
+    } else {
+        SAT_WAIT_VMCNT(0);
+    }
     SAT_RAW_BARRIER();
     if (wr == 1) SAT_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
 
+    if constexpr (RING3) {
+        // wave row 0 reads chunk c in interval 2c, row 1 in 2c + 1.  Chunk c + 2 goes to the stage of chunk c - 1, whose last fragment read
+        // retired (lgkmcnt(0)) before the barrier that closes interval 2c - 1; a wave's pieces of chunk c + 1 are waited for here, in
+        // front of a barrier every reader of chunk c + 1 (intervals 2c + 2 / 2c + 3) has passed.
+        int st = 0;
+        for (int c = 0; c < p.nchunks; ++c) {
+            const char* sb = lds + st * STG;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (u < kw) load_frags(fr[u], sb, u);
+            if (c + 2 < p.nchunks) {
+                set_chunk(c + 2);
+                issue_range(c + 2, st == 0 ? 2 : st - 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+                SAT_WAIT_VMCNT(NPW);
+            } else {
+                SAT_WAIT_VMCNT(0);
+            }
+            SAT_WAIT_LGKM0();
+            SAT_RAW_BARRIER();
+            SAT_SCHED_FENCE();
+            SAT_SETPRIO(1);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (u < kw) mfma_frags(fr[u]);
+            SAT_SETPRIO(0);
+            SAT_SCHED_FENCE();
+            SAT_RAW_BARRIER();
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else {
     // kw == 9: COUNTED waits — the last phase's three pieces per wave (weights of taps 3-8, L2-resident) stay in flight across the
     // chunk boundary and are retired by the next chunk's phase 0, one phase before they are read (as conv1d_bf16x3_k7q.h, VARIANT 1)
     constexpr bool COUNTED = (KW == 9);
@@ -385,6 +435,7 @@ __global__ void __launch_bounds__(SAT_DC_NT) sat_disc_conv_kernel(SatDiscConvPar
             SAT_SCHED_FENCE();
             SAT_RAW_BARRIER();
         }
+    }
     }
     if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
     __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue

@@ -9,7 +9,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from stable_audio_tools_amd import ops as O  # noqa: E402
+from stable_audio_tools_amd import _lib, ops as O  # noqa: E402
+
+if os.environ.get("SAT_EXP_LIB"):       # experiment builds of the library (tools/exp/): same C-ABI
+    _lib.LIB_PATH = os.path.abspath(os.environ["SAT_EXP_LIB"])
 from stable_audio_tools_amd.discriminators import conv2d_virtual  # noqa: E402
 
 
