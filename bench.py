@@ -132,10 +132,10 @@ class AttnProfiler:
         specs = {"sat_gemm_bf16": lambda a: 2.0 * a[15] * a[16] * a[17],
                  "sat_gemm_qkv_bf16": lambda a: 2.0 * (a[10] * a[11]) * (a[16] * a[13] * 64) * a[14],
                  # fp8 (e4m3, MX MFMA) forward projections of the long-context configuration
-                 "sat_gemm_fp8": lambda a: 2.0 * a[16] * a[17] * a[18],
-                 "sat_gemm_qkv_fp8": lambda a: 2.0 * (a[11] * a[12]) * (a[17] * a[14] * 64) * a[15],
-                 # activation quantisation passes in front of the fp8 GEMMs: time only
-                 "sat_quant_fp8": lambda a: 0.0}
+                 "sat_gemm_fp8": lambda a: 2.0 * a[17] * a[18] * a[19],
+                 "sat_gemm_qkv_fp8": lambda a: 2.0 * (a[12] * a[13]) * (a[18] * a[15] * 64) * a[16],
+                 # activation quantisation passes in front of the fp8 GEMMs: time only (per-row quantiser; round 3's per-tensor pair)
+                 "sat_quant_fp8_rows": lambda a: 0.0, "sat_quant_fp8": lambda a: 0.0, "sat_absmax_scale": lambda a: 0.0}
         self.kinds = {}
         for name, fl in specs.items():
             self._wrap_gemm(ops.lib, name, fl)
@@ -166,9 +166,9 @@ class AttnProfiler:
         if name == "sat_gemm_qkv_bf16":
             return (name, a[10] * a[11], a[16] * a[13] * 64, a[14], 4, 0, 1, a[17])
         if name == "sat_gemm_fp8":
-            return (name, a[16], a[17], a[18], a[19], a[20], 1, a[21])
+            return (name, a[17], a[18], a[19], a[20], a[21], 1, a[22])
         if name == "sat_gemm_qkv_fp8":
-            return (name, a[11] * a[12], a[17] * a[14] * 64, a[15], 4, 0, 1, a[18])
+            return (name, a[12] * a[13], a[18] * a[15] * 64, a[16], 4, 0, 1, a[19])
         return (name,)
 
     def gemm_shapes(self):
@@ -199,7 +199,7 @@ class AttnProfiler:
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out_extra = {}
         if fp8:
-            q = [r for r in self.gemm if r[3] == "sat_quant_fp8"]
+            q = [r for r in self.gemm if r[3] in ("sat_quant_fp8_rows", "sat_quant_fp8", "sat_absmax_scale")]
             out_extra = {"quant_launches": len(q), "quant_total_ms": round(sum(r[0].elapsed_time(r[1]) for r in q), 3)}
         if os.environ.get("SAT_BENCH_GEMM_SHAPES") == "1":
             out_extra["shapes"] = self.gemm_shapes()
@@ -464,7 +464,7 @@ PEAK_FP8_MFMA_TFLOPS = 5000.0   # MI355X_MICROARCH.md: dense fp8 (MX) MFMA peak
 def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
     """BASELINE.json configs[4] on ONE GPU: the Stable-Audio-2.0-length DiT (sample_size 12582912 -> 6144 latent frames, N = 6145
     tokens; reference configs/model_configs/txt2audio/stable_audio_2_0.json:3, :79-86) sampled with CFG (model batch 2), every
-    projection with >= 256 features in fp8 e4m3 on the MX MFMA (linear.set_fp8: per-tensor dynamic scales, sat_quant_fp8 per GEMM
+    projection with >= 256 features in fp8 e4m3 on the MX MFMA (linear.set_fp8: dynamic scales — weights per tensor, activations per row: sat_quant_fp8_rows per GEMM
     input), attention in bf16 with fp32 softmax.  Reports sampler steps/s (eager and HIP-graph), the self-attention kernel against the
     2.5 PF bf16 peak, the fp8 projections against the 5 PF fp8 peak (with the quantisation passes' time beside them), and a CPU
     baseline on ONE of the 24 layers (the oracle at N = 6145, scaled x24)."""
@@ -531,7 +531,7 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
     nl, ms, fl = prof.summary("self")
     attn_tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     line = {"workload": "stable_audio_2_0-length DiT sampling step (d=1536, 24 layers, N=6145 tokens = 285 s of audio, context 130), CFG scale 6 "
-                        "(model batch 2), fp8 e4m3 projections (MX MFMA, dynamic per-tensor scales), bf16 attention, random init; ONE GPU "
+                        "(model batch 2), fp8 e4m3 projections (MX MFMA; dynamic scales: weights per tensor, activations per token row in one pass), bf16 attention, random init; ONE GPU "
                         "(BASELINE.json configs[4] names 8: sampling is replicas-only, no collective)",
             "value": steps / elapsed, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "steps_per_s": {"eager": steps / el_eager, "hip_graph": steps / el_graph}, "fp8_linears": nfp8,

@@ -395,14 +395,15 @@ int sat_splitk_epilogue(const float* slabs, int S, const float* bias, const void
 /* fp8 (OCP e4m3) forward projections for the long-context configuration (BASELINE.json configs[4], stable_audio_2_0.json:3):
  * as sat_gemm_bf16 / sat_gemm_qkv_bf16 with A (M, K), B (N, K) in fp8 bytes (K, lda, ldb multiples of 16) on
  * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B).
+ * row_alpha (M floats, or NULL): per-row factor applied with alpha — A quantised row by row (sat_quant_fp8_rows; alpha = B's scale).
  * tile: 0 = 128x128 (4 waves), 4 = 256x256, 7 = 160x256, 8 = 128x128 (eight-wave kernels, as sat_gemm_bf16). */
 int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                  const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
-                 long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
-                 int tile, void* stream);
+                 long long ldp, const void* zeros, const float* alpha, const float* row_alpha, int M, int N, int K, int epilogue,
+                 int out_f32, int tile, void* stream);
 int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
-                     void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
-                     int heads, int K, int sec0, int nsec, int tile, void* stream);
+                     void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha, int nb,
+                     int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream);
 /* dst (R, C) fp8 e4m3 = saturate_448(src * qscale[0]), round to nearest even; src fp32 | bf16; qscale a DEVICE scalar. */
 /* Dynamic per-tensor scale of the fp8 quantisation in one launch (last-arriving block reduces the per-block maxima): scales[0] =
  * 448 / max|src| (what sat_quant_fp8 takes as qscale), scales[1] = max|src| / 448 (the GEMM's de-quantisation factor).  work: >= 1 +
@@ -411,6 +412,10 @@ int sat_absmax_scale_blocks(int R, int C);
 int sat_absmax_scale(const void* src, long long lds, float* work, float* scales, int R, int C, int src_f32, void* stream);
 int sat_quant_fp8(const void* src, long long lds, void* dst, long long ldd, const float* qscale, int R, int C, int src_f32,
                   void* stream);
+/* Per-ROW dynamic quantisation in one pass over the activation: dst[r][:] = saturate_448(src[r][:] * 448 / max|src[r][:]|) (round to
+ * nearest even), scale[r] = max|src[r][:]| / 448 — the GEMM's row_alpha.  src (R, C) fp32 | bf16, C % 8 == 0, C <= 8192. */
+int sat_quant_fp8_rows(const void* src, long long lds, void* dst, long long ldd, float* scale, int R, int C, int src_f32,
+                       void* stream);
 
 /* src (R, C) fp32 (src_f32 = 1) or bf16, row stride lds -> dst bf16: (R, C) row stride ldd; or, transpose = 1, (C, Rpad)
  * with columns R..Rpad-1 zero (reduction-dim padding of the weight-gradient GEMM). */

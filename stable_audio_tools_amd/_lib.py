@@ -91,9 +91,10 @@ SIGNATURES = {
     # gemm.hip
     "sat_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P] + [_I] * 7 + [_P]),
     "sat_gemm_qkv_bf16": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P] + [_I] * 8 + [_P]),
-    "sat_gemm_fp8": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P, _P] + [_I] * 6 + [_P]),
-    "sat_gemm_qkv_fp8": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "sat_gemm_fp8": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P, _P, _P] + [_I] * 6 + [_P]),
+    "sat_gemm_qkv_fp8": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "sat_quant_fp8": (_I, [_P, _L, _P, _L, _P, _I, _I, _I, _P]),
+    "sat_quant_fp8_rows": (_I, [_P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "sat_absmax_scale": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),
     "sat_absmax_scale_blocks": (_I, [_I, _I]),
     "sat_splitk_epilogue": (_I, [_P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _P]),

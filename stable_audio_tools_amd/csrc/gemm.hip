@@ -35,6 +35,7 @@ struct SatGemmParams {
     void* pre;            // SWIGLU: optional (M, ldp) copy of the pre-activation [x | gate] for the backward
     const short* zeros;   // >= 16 bytes of zeros: source of the k-chunks past K
     const float* alpha;   // device scalar multiplied into the accumulators before the epilogue (fp8 de-quantisation), or null
+    const float* row_alpha; // (M) per-row factor applied with it (fp8 activations quantised per row: sat_quant_fp8_rows), or null
     long long lda, ldb, ldc, ldr, ldg, ldp;
     int M, N, K;
     int rows_per_gate;
@@ -138,6 +139,10 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                 float of[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) of[e] = ep[d * 33 + tq + e];
+                if (p.row_alpha) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) of[e] *= p.row_alpha[m + e < p.M ? m + e : p.M - 1];
+                }
                 const uint32_t q01 = sat_cvt2_pk(of[0], of[1]), q23 = sat_cvt2_pk(of[2], of[3]);     // packed RNE converts
                 o[0] = (short)(q01 & 0xffffu); o[1] = (short)(q01 >> 16); o[2] = (short)(q23 & 0xffffu); o[3] = (short)(q23 >> 16);
                 const int b = m / p.ntok, t = m - b * p.ntok;
@@ -181,6 +186,11 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
             f32x4 xv = *(const f32x4*)(ep + rr * 64 + cc);
             f32x4 gv = *(const f32x4*)(ep + rr * 64 + 32 + cc);
             if (m < p.M && n < glu_f) {
+                if (p.row_alpha) {
+                    const float ra = p.row_alpha[m];
+                    xv *= ra;
+                    gv *= ra;
+                }
                 if (p.bias) {
                     xv += *(const f32x4*)(p.bias + n);
                     gv += *(const f32x4*)(p.bias + glu_f + n);
@@ -203,6 +213,7 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
             const int n = nwin + cc;
             f32x4 v = *(const f32x4*)(ep + rr * 64 + cc);
             if (m < p.M && n < p.N) {
+                if (p.row_alpha) v *= p.row_alpha[m];
                 if (p.bias) v += *(const f32x4*)(p.bias + n);
                 if constexpr (EPI == SAT_EPI_GATE_RES) {
                     const f32x4 g = sat_load4<F32OUT>(p.gate, (long long)(m / p.rows_per_gate) * p.ldg + n);
@@ -220,7 +231,8 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                     if (p.rope_cs && d < 32) {
                         // partner column d ^ 16 lives 4 lanes away in this row's 16-lane group
                         f32x4 o;
-                        const f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
+                        f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
+                        if (p.row_alpha) pv *= p.row_alpha[m];     // (the partner column comes straight from the window: same row factor)
                         const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -1114,12 +1126,13 @@ extern "C" int sat_splitk_epilogue(const float* slabs, int S, const float* bias,
 // fp8 (OCP e4m3) variants of the two entry points above for the forward projections of the long-context configuration
 // (BASELINE.json configs[4]): A (M, K) and B (N, K) are fp8 bytes, K a multiple of 16, lda / ldb in elements (multiples of 16);
 // products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate, half the operand bytes);
-// alpha: device scalar = (de-quantisation scale of A) x (of B), multiplied into the fp32 accumulators before the epilogue.
+// alpha: device scalar = (de-quantisation scale of A) x (of B), multiplied into the fp32 accumulators before the epilogue; row_alpha
+// (M floats, or NULL): a per-ROW factor applied with it — A quantised row by row (sat_quant_fp8_rows; alpha is then B's scale alone).
 // Everything else (epilogues, output types, tile: 0 / 4 / 7 / 8) as sat_gemm_bf16 / sat_gemm_qkv_bf16; no split-K.
 extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                             const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
-                            long long ldp, const void* zeros, const float* alpha, int M, int N, int K, int epilogue, int out_f32,
-                            int tile, void* stream) {
+                            long long ldp, const void* zeros, const float* alpha, const float* row_alpha, int M, int N, int K, int epilogue,
+                            int out_f32, int tile, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { sat_set_error("sat_gemm_fp8: empty shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15) || (N & 7) || (ldc & 3)) { sat_set_error("sat_gemm_fp8: K, lda, ldb must be multiples of 16, N of 8"); return 1; }
     if (!zeros || !alpha) { sat_set_error("sat_gemm_fp8: zeros page and alpha required"); return 1; }
@@ -1130,20 +1143,20 @@ extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long lo
     SatGemmParams p{};
     // two fp8 elements = one "short" of the staging code: the kernel sees (M, K/2) x (N, K/2) 16-bit matrices
     p.A = (const short*)A; p.B = (const short*)B; p.C = C; p.bias = bias; p.res = res; p.gate = gate; p.pre = pre;
-    p.zeros = (const short*)zeros; p.alpha = alpha;
+    p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha;
     p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc; p.ldr = ldr; p.ldg = ldg; p.ldp = ldp;
     p.M = M; p.N = N; p.K = K / 2; p.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
     p.klen = sat_cdiv(p.K, 64) * 64;
     return sat_gemm_dispatch_fp8(p, epilogue, out_f32, tile, stream);
 }
 extern "C" int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
-                                void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, int nb, int ntok, int npad,
-                                int heads, int K, int sec0, int nsec, int tile, void* stream) {
+                                void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha, int nb,
+                                int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream) {
     if (nb <= 0 || ntok <= 0 || heads <= 0 || K <= 0 || npad < ntok) { sat_set_error("sat_gemm_qkv_fp8: bad shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15)) { sat_set_error("sat_gemm_qkv_fp8: K, lda, ldb must be multiples of 16"); return 1; }
     if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3 || !alpha) { sat_set_error("sat_gemm_qkv_fp8: bad section range / alpha"); return 1; }
     SatGemmParams p{};
-    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros; p.alpha = alpha;
+    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha;
     p.lda = lda / 2; p.ldb = ldb / 2;
     p.M = nb * ntok; p.N = nsec * heads * 64; p.K = K / 2; p.rows_per_gate = 1;
     p.klen = sat_cdiv(p.K, 64) * 64;
@@ -1221,6 +1234,80 @@ extern "C" int sat_quant_fp8(const void* src, long long lds, void* dst, long lon
     return sat_check_launch("sat_quant_fp8");
 }
 
+// Per-ROW dynamic quantisation in ONE pass (round 4): dst[r][:] = sat_448(src[r][:] * 448 / max|src[r][:]|), scale[r] = max|src[r][:]| / 448
+// (clamped at 1e-12 / 448) — the per-token scale the GEMM's epilogue multiplies back (row_alpha).  One wave per row: the row lives in
+// registers (<= 16 chunks of 8 elements per lane: C <= 8192) between the max reduction and the conversion, so the activation is read
+// once; the per-tensor path read it twice (sat_absmax_scale + sat_quant_fp8: 35.7 + 14.7 us per projection input in the N = 6145
+// sampler, 19 % of its step — profiles/EXPERIMENTS.md) and a token's outliers no longer set every other token's step size.
+struct SatQuantRowsParams {
+    const void* src;
+    uint8_t* dst;
+    float* scale;
+    long long lds_, ldd;
+    int R, Cc, src_f32;
+};
+template <bool F32>
+__global__ void __launch_bounds__(256) sat_quant_fp8_rows_kernel(SatQuantRowsParams p) {
+    constexpr int MAXCH = 16;
+    constexpr int W = F32 ? 8 : 4;                         // dwords a lane keeps per 8-element chunk (bf16 stays packed)
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;                                  // (whole wave)
+    const int nch = p.Cc >> 3;                             // 8-element chunks of the row
+    uint32_t raw[MAXCH][W];
+    auto value = [&](int i, int e) -> float {
+        if constexpr (F32) return __builtin_bit_cast(float, raw[i][e]);
+        else return __builtin_bit_cast(float, (e & 1) ? (raw[i][e >> 1] & 0xffff0000u) : (raw[i][e >> 1] << 16));
+    };
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nch) {                                // (wave-uniform)
+#pragma unroll
+            for (int e = 0; e < W; ++e) raw[i][e] = 0u;
+            if (c < nch) {
+                if constexpr (F32) {
+                    const u32x4 a = *(const u32x4*)((const float*)p.src + (long long)r * p.lds_ + c * 8);
+                    const u32x4 b = *(const u32x4*)((const float*)p.src + (long long)r * p.lds_ + c * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { raw[i][e] = a[e]; raw[i][4 + e] = b[e]; }
+                } else {
+                    const u32x4 u = *(const u32x4*)((const short*)p.src + (long long)r * p.lds_ + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) raw[i][e] = u[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(value(i, e)));
+        }
+    }
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    const float am = fmaxf(m, 1e-12f);
+    const float qs = 448.0f / am;
+    if (lane == 0) p.scale[r] = am / 448.0f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nch && c < nch) {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            const u2 w = {sat_f32x4_to_fp8(value(i, 0) * qs, value(i, 1) * qs, value(i, 2) * qs, value(i, 3) * qs),
+                          sat_f32x4_to_fp8(value(i, 4) * qs, value(i, 5) * qs, value(i, 6) * qs, value(i, 7) * qs)};
+            *(u2*)(p.dst + (long long)r * p.ldd + c * 8) = w;
+        }
+    }
+}
+extern "C" int sat_quant_fp8_rows(const void* src, long long lds, void* dst, long long ldd, float* scale, int R, int C, int src_f32,
+                                  void* stream) {
+    if (R <= 0 || C <= 0 || (C & 7) || C > 8192 || (ldd & 7) || (lds & 7) || !scale) {
+        sat_set_error("sat_quant_fp8_rows: C, lds, ldd multiples of 8, C <= 8192");
+        return 1;
+    }
+    SatQuantRowsParams p{src, (uint8_t*)dst, scale, lds, ldd, R, C, src_f32};
+    if (src_f32) SAT_LAUNCH(sat_quant_fp8_rows_kernel<true>, dim3((unsigned)sat_cdiv(R, 4)), dim3(256), stream, p);
+    else SAT_LAUNCH(sat_quant_fp8_rows_kernel<false>, dim3((unsigned)sat_cdiv(R, 4)), dim3(256), stream, p);
+    return sat_check_launch("sat_quant_fp8_rows");
+}
 
 // Per-tensor dynamic scale of the fp8 quantisation in ONE launch: every block reduces max|x| over its share, the LAST block to
 // arrive (device-scope ticket; agent-scope release / acquire around it, cdna_hip_programming.md §6 Guideline 16) reduces the partial

@@ -16,6 +16,8 @@ One kernel computes all three GEMMs of a layer: it is "NT" (both operands K-cont
 stored; the data gradient runs on the transposed weight copy and the weight gradient on transposed activations
 (sat_cast_bf16 with transpose, zero padded along the reduction dim).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -62,11 +64,20 @@ class _WeightCache:
         return hit[1]
 
 
+# activations quantised per ROW in one pass (round 4); False / SAT_FP8_ROW_SCALES=0: round 3's per-tensor scale (absmax pass + quant pass)
+fp8_row_scales = os.environ.get("SAT_FP8_ROW_SCALES", "1") != "0"
+
+
 def _fp8_operands(ops, x2, w, cache):
-    """(A, B, alpha) in fp8 e4m3 with per-tensor dynamic scales (activations quantised per call, weights once per version)."""
-    a, sa = ops.quant_fp8(x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2))
+    """(A, B, alpha, row_alpha) in fp8 e4m3 with dynamic scales: weights per tensor, once per version; activations per call and per ROW
+    (one pass, a token's outliers do not set the other tokens' step size) — or per tensor with `fp8_row_scales = False`."""
+    xb = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2)
     b, sb = cache.get(w, "fp8", lambda: ops.quant_fp8(_pad_rows8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
-    return a, b, sa * sb
+    if fp8_row_scales and xb.shape[1] % 8 == 0 and xb.stride(0) % 8 == 0 and xb.shape[1] <= 8192:
+        a, ra = ops.quant_fp8_rows(xb)
+        return a, b, sb, ra
+    a, sa = ops.quant_fp8(xb)
+    return a, b, sa * sb, None
 
 
 def _operands(ops, x2, w, cache, lowp):
@@ -101,7 +112,7 @@ class LinearFn(torch.autograd.Function):
         out_dtype = torch.bfloat16 if lowp else torch.float32
         fp8 = bool(fp8) and lowp and k % 16 == 0
         if fp8:
-            a, b, alpha = _fp8_operands(ops, x2, weight, cache)
+            a, b, alpha, ralpha = _fp8_operands(ops, x2, weight, cache)
         else:
             a, b = _operands(ops, x2, weight, cache, lowp)
         bias32 = None
@@ -126,14 +137,14 @@ class LinearFn(torch.autograd.Function):
             if n % 16:
                 raise ValueError("SwiGLU projection needs 2F output rows with F % 8 == 0")
             if fp8:
-                y = ops.gemm_fp8(a, b, alpha, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
+                y = ops.gemm_fp8(a, b, alpha, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2, row_alpha=ralpha)
             else:
                 y = ops.gemm_bf16(a, b, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
             if need_grad:
                 y, pre = y
         elif fp8:
             y = ops.gemm_fp8(a, b, alpha, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
-                             out=out2)
+                             out=out2, row_alpha=ralpha)
         elif lowp and out2 is not None and ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]) > 1:
             y = ops.gemm_bf16_splitk(a, b, ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]), bias=bias32, res=r2, out_dtype=out_dtype, out=out2)
         else:

@@ -1124,6 +1124,18 @@ class SatOps:
         self._chk(self.lib.sat_quant_fp8(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(scales), src.shape[0], src.shape[1], int(dt == 0), st))
         return q, scales[1]
 
+    def quant_fp8_rows(self, src):
+        """src (R, C) fp32|bf16 -> (q (R, C) uint8 e4m3 bits, scale (R,) fp32 = row max / 448): per-ROW dynamic quantisation in one
+        pass over the activation (sat_quant_fp8_rows); the scales go to gemm_fp8 / gemm_heads_fp8 as `row_alpha`."""
+        dt = self._dt(src)
+        if src.dim() != 2 or src.stride(1) != 1 or src.shape[1] % 8 or src.stride(0) % 8 or src.shape[1] > 8192:
+            raise ValueError("quant_fp8_rows takes a 2-D tensor with a contiguous last dim, C % 8 == 0, C <= 8192")
+        q = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+        scale = torch.empty(src.shape[0], dtype=torch.float32, device=src.device)
+        self._chk(self.lib.sat_quant_fp8_rows(_ptr(src), src.stride(0), _ptr(q), q.stride(0), _ptr(scale), src.shape[0], src.shape[1],
+                                              int(dt == 0), self._stream(src)))
+        return q, scale
+
     gemm_fp8_tile = None     # None: pick per shape (the fp8 instances: 0, 4, 7, 8)
 
     def _pick_tile_fp8(self, m, n, k):
@@ -1135,8 +1147,9 @@ class SatOps:
         return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, (k + 1) // 2), t))
 
     def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
-                 out=None):
-        """gemm_bf16 on fp8 operands: a (M, K), b (N, K) uint8 (quant_fp8), alpha = 0-dim fp32 device tensor (scale_a * scale_b)."""
+                 out=None, row_alpha=None):
+        """gemm_bf16 on fp8 operands: a (M, K), b (N, K) uint8 (quant_fp8), alpha = 0-dim fp32 device tensor (scale_a * scale_b);
+        row_alpha (M,) fp32: a was quantised row by row (quant_fp8_rows) — alpha is then b's scale alone."""
         if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[1] != b.shape[1]:
             raise TypeError("gemm_fp8 takes (rows, K) uint8 operands")
         m, k = a.shape
@@ -1148,14 +1161,16 @@ class SatOps:
         c = out if out is not None else torch.empty(m, nout, dtype=out_dtype, device=a.device)
         pre = torch.empty(m, n, dtype=out_dtype, device=a.device) if (want_pre and epilogue == self.EPI_SWIGLU) else None
         alpha = alpha.float().reshape(1).contiguous()
+        if row_alpha is not None and (row_alpha.dtype != torch.float32 or row_alpha.numel() != m or not row_alpha.is_contiguous()):
+            raise TypeError("gemm_fp8: row_alpha is (M,) fp32")
         self._chk(self.lib.sat_gemm_fp8(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), nout, _ptr(bias),
                                         _ptr(res), res.stride(0) if res is not None else 0, _ptr(gate), gate.stride(0) if gate is not None else 0,
-                                        rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), m, n, k, epilogue, int(f32),
+                                        rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), _ptr(row_alpha), m, n, k, epilogue, int(f32),
                                         self._pick_tile_fp8(m, n, k), self._stream(a)))
         return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
 
-    def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None):
-        """gemm_heads_bf16 on fp8 operands (planes come out in bf16)."""
+    def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None, row_alpha=None):
+        """gemm_heads_bf16 on fp8 operands (planes come out in bf16); row_alpha as gemm_fp8."""
         npad = (ntok + 63) // 64 * 64
         out = {"n": ntok, "np": npad}
         for i, (name, shape) in enumerate((("q", (nb, heads, npad, 64)), ("k", (nb, heads, npad, 64)), ("v_tr", (nb, heads, 64, npad)))):
@@ -1165,7 +1180,7 @@ class SatOps:
         alpha = alpha.float().reshape(1).contiguous()
         self._chk(self.lib.sat_gemm_qkv_fp8(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
                                             _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
-                                            _ptr(alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec,
+                                            _ptr(alpha), _ptr(row_alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec,
                                             self._pick_tile_fp8(nb * ntok, nsec * heads * 64, x.shape[1]), self._stream(x)))
         return out
 

@@ -27,6 +27,7 @@ from torch import nn
 
 from . import _caches
 from . import functional as _fn
+from . import linear as _linear
 from .linear import Linear, _lowp
 
 
@@ -260,8 +261,11 @@ class Attention(nn.Module):
     def _heads(ops, lin, x2, cs, heads, nb, ntok, sec0, nsec, tag):
         """Input projection straight into attention operand planes (bf16, or fp8 operands when the layer is switched to fp8)."""
         if lin.fp8 and lin.fp8_weight() is not None:
-            qx, sx = ops.quant_fp8(x2)
             qw, sw = lin.fp8_weight()
+            if _linear.fp8_row_scales and x2.shape[1] % 8 == 0 and x2.stride(0) % 8 == 0 and x2.shape[1] <= 8192:
+                qx, rs = ops.quant_fp8_rows(x2)
+                return ops.gemm_heads_fp8(qx, qw, sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=rs)
+            qx, sx = ops.quant_fp8(x2)
             return ops.gemm_heads_fp8(qx, qw, sx * sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag)
         return ops.gemm_heads_bf16(x2, lin.lowp_weight(), cs, heads, nb, ntok, sec0, nsec, reuse=tag)
 

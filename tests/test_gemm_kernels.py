@@ -161,6 +161,36 @@ def _fp8_case(ops, dev):
                 ops.gemm_fp8_tile = None
         full32 = x.cpu() @ w.cpu().t()
         assert float((ref - full32).norm() / full32.norm()) < 8e-2
+    # per-ROW activation scales (round 4: sat_quant_fp8_rows + row_alpha): the quantiser against torch's cast of the row-scaled tensor
+    # (same fp32 arithmetic: x * (448 / row max)), the GEMM against the de-quantised operands, every epilogue, every tile; ragged row count
+    for (m, n, k) in ((130, 144, 144), (203, 272, 400)):
+        x, w = (torch.randn(m, k) * torch.rand(m, 1) * 4).to(dev), (torch.randn(n, k) / 12).to(dev)
+        qx, rs = ops.quant_fp8_rows(x.bfloat16())
+        xb = x.bfloat16().float().cpu()
+        am = xb.abs().amax(dim=1).clamp_min(1e-12)
+        assert torch.equal(rs.cpu(), am / 448.0)
+        assert torch.equal(qx.cpu().view(torch.float8_e4m3fn).float(), (xb * (torch.full_like(am, 448.0) / am)[:, None]).to(torch.float8_e4m3fn).float())   # (tensor / tensor: an IEEE division, as the kernel's; `448.0 / am` is a reciprocal + multiply in torch)
+        qx32, rs32 = ops.quant_fp8_rows(x)
+        am32 = x.cpu().abs().amax(dim=1).clamp_min(1e-12)
+        assert torch.equal(qx32.cpu().view(torch.float8_e4m3fn).float(), (x.cpu() * (torch.full_like(am32, 448.0) / am32)[:, None]).to(torch.float8_e4m3fn).float())
+        qw, sw = ops.quant_fp8(w.bfloat16())
+        xd, wd = qx.cpu().view(torch.float8_e4m3fn).float() * rs.cpu()[:, None], qw.cpu().view(torch.float8_e4m3fn).float() * sw.cpu()
+        ref = xd @ wd.t()
+        bias = torch.randn(n).to(dev)
+        res = torch.randn(m, n).to(dev)
+        full = ref + bias.cpu()
+        for tile in (None, 0, 4, 7, 8):
+            ops.gemm_fp8_tile = tile
+            try:
+                assert rel_err(ops.gemm_fp8(qx, qw, sw, out_dtype=torch.float32, row_alpha=rs), ref) < 1e-4
+                assert rel_err(ops.gemm_fp8(qx, qw, sw, bias=bias, res=res, epilogue=ops.EPI_RES, out_dtype=torch.float32, row_alpha=rs),
+                               ref + bias.cpu() + res.cpu()) < 1e-4
+                c = ops.gemm_fp8(qx, qw, sw, bias=bias, epilogue=ops.EPI_SWIGLU, out_dtype=torch.float32, row_alpha=rs)
+                assert rel_err(c, full[:, :n // 2] * torch.nn.functional.silu(full[:, n // 2:])) < 1e-4
+            finally:
+                ops.gemm_fp8_tile = None
+        full32 = xb @ w.bfloat16().float().cpu().t()
+        assert float((ref - full32).norm() / full32.norm()) < 8e-2
     # the head-split / plane-layout epilogue on fp8 operands (no rotary: the cross-attention to_q; with: to_qkv), every fp8 tile
     nb, ntok, heads, k = 2, 71, 3, 80
     x = torch.randn(nb * ntok, k).to(dev)
@@ -177,6 +207,22 @@ def _fp8_case(ops, dev):
             qp, kp, vp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k", "v_tr")]
             assert rel_err(qp[:, :, :ntok], q) < 6e-3 and rel_err(kp[:, :, :ntok], kk) < 6e-3
             assert rel_err(vp[:, :, :, :ntok], v.transpose(2, 3)) < 6e-3
+            # ... with per-row activation scales (the transposed V path multiplies four rows' factors per lane)
+            qxr, rsr = ops.quant_fp8_rows(x.bfloat16())
+            qkv_r = ((qxr.cpu().view(torch.float8_e4m3fn).float() * rsr.cpu()[:, None]) @ wd.t()).view(nb, ntok, 3, heads, 64)
+            qr_, kr_, vr_ = [qkv_r[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+            pl = ops.gemm_heads_fp8(qxr, qw, sw, None, heads, nb, ntok, 0, 3, row_alpha=rsr)
+            qp, kp, vp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k", "v_tr")]
+            assert rel_err(qp[:, :, :ntok], qr_) < 6e-3 and rel_err(kp[:, :, :ntok], kr_) < 6e-3
+            assert rel_err(vp[:, :, :, :ntok], vr_.transpose(2, 3)) < 6e-3
+            # ... and with the rotary (the partner column of a rotated pair is read from the window: it needs the row factor too)
+            inv = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+            cs = ops.rope_tables(inv.to(dev), ntok)
+            freqs = dit_oracle.rotary_freqs(inv, ntok)
+            pl = ops.gemm_heads_fp8(qxr, qw, sw, cs, heads, nb, ntok, 0, 3, row_alpha=rsr)
+            qp, kp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k")]
+            assert rel_err(qp[:, :, :ntok], dit_oracle.apply_rotary(qr_, freqs)) < 6e-3
+            assert rel_err(kp[:, :, :ntok], dit_oracle.apply_rotary(kr_, freqs)) < 6e-3
         finally:
             ops.gemm_fp8_tile = None
 
