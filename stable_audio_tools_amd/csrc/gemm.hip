@@ -126,30 +126,48 @@ SAT_DEVICE bool sat_gemm_window_is_v(const SatGemmParams& p, int nwin) {
 
 template <int EPI, bool F32OUT>
 SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep, int mrow0, int nwin, int glu_col0, int glu_f, int lane) {
+    int wb0 = 0, wt0 = 0;                              // QKV: (batch item, token) of the window's first row — ONE division per window
+    if constexpr (EPI == SAT_EPI_QKV) {                   // (round 4: the per-lane m / ntok, m % ntok of every pass were the bulk of this epilogue)
+        wb0 = mrow0 / p.ntok;
+        wt0 = mrow0 - wb0 * p.ntok;
+    }
     if constexpr (EPI == SAT_EPI_QKV) {
         // a 64-column window is one head of q, k or v (wave-uniform).  v goes out TRANSPOSED (nb, H, 64, Np): the window was
         // staged as [64 d][33] so that a lane reads 4 consecutive tokens of one head dim (odd stride: conflict free)
         if (sat_gemm_window_is_v<EPI>(p, nwin)) {
             const int h = (nwin % (p.heads * 64)) >> 6;
+            // Row groups aligned in the TOKEN index (round 4): the window's first row is token wt0 of its batch item; with an odd token
+            // count (1 + 1024) every batch item but the first starts its rows off the 8-byte grid, and groups aligned in the row index
+            // made all of their stores 2 + 4 + 2 bytes.  Lane group j takes rows a + 4j .. a + 4j + 3 (a = rows to the first token that
+            // is a multiple of 4): one aligned 8-byte store; the 4 left-over rows (a in front, 4 - a behind) go to the lanes j = 7 as
+            // single elements.  A window that crosses into the next batch item changes phase there: the general cases below stay.
+            const int va = (4 - (wt0 & 3)) & 3;
+            const int vj = lane & 7;
+            const bool vsplit = va != 0 && vj == 7;
+            const int tq = vsplit ? 0 : va + 4 * vj;
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {
-                const int d = pass * 8 + (lane >> 3), tq = (lane & 7) * 4;
-                const int m = mrow0 + tq;                 // 4 consecutive rows m .. m+3 (may straddle a batch item)
+                const int d = pass * 8 + (lane >> 3);
+                const int m = mrow0 + tq;                 // first of the lane's rows (4 consecutive rows unless vsplit; may straddle a batch item)
                 short o[4];
                 float of[4];
+                int re[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) of[e] = ep[d * 33 + tq + e];
+                for (int e = 0; e < 4; ++e) {
+                    re[e] = vsplit ? (e < va ? e : 28 + e) : tq + e;
+                    of[e] = ep[d * 33 + re[e]];
+                }
                 if (p.row_alpha) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) of[e] *= p.row_alpha[m + e < p.M ? m + e : p.M - 1];
+                    for (int e = 0; e < 4; ++e) of[e] *= p.row_alpha[mrow0 + re[e] < p.M ? mrow0 + re[e] : p.M - 1];
                 }
                 const uint32_t q01 = sat_cvt2_pk(of[0], of[1]), q23 = sat_cvt2_pk(of[2], of[3]);     // packed RNE converts
                 o[0] = (short)(q01 & 0xffffu); o[1] = (short)(q01 >> 16); o[2] = (short)(q23 & 0xffffu); o[3] = (short)(q23 >> 16);
-                const int b = m / p.ntok, t = m - b * p.ntok;
+                int b = wb0, t = wt0 + tq;                // (batch item, token) of row m: no per-lane division (window-level wb0 / wt0)
+                while (t >= p.ntok) { t -= p.ntok; ++b; }
                 short* dst = p.v_tr + (((long long)b * p.heads + h) * 64 + d) * p.npad + t;
-                if (m + 3 < p.M && t + 3 < p.ntok) {
-                    // 4 tokens of one batch item: the widest aligned stores their phase allows (ntok is odd for the DiT —
-                    // 1 + 1024 — so every batch item but the first starts its rows off the 8-byte grid)
+                if (!vsplit && m + 3 < p.M && t + 3 < p.ntok) {
+                    // 4 tokens of one batch item: the widest aligned stores their phase allows
                     const uint32_t p01 = q01, p23 = q23;
                     const uint32_t p12 = (q01 >> 16) | (q23 << 16);
                     if ((t & 3) == 0) {
@@ -165,9 +183,10 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int me = m + e;
+                        const int me = mrow0 + re[e];
                         if (me < p.M) {
-                            const int be = me / p.ntok, te = me - be * p.ntok;
+                            int be = wb0, te = wt0 + re[e];
+                            while (te >= p.ntok) { te -= p.ntok; ++be; }
                             p.v_tr[(((long long)be * p.heads + h) * 64 + d) * p.npad + te] = o[e];
                         }
                     }
@@ -206,8 +225,14 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
             }
         }
     } else {
+        // (QKV: two passes in flight — with all eight unrolled the rotary's table loads, partner columns and row factors of every pass are
+        // live at once: the 256 x 256 kernel spilled 113 registers, 239 -> 844 us at M = 12290)
+        constexpr int PU = (EPI == SAT_EPI_QKV) ? 2 : 8;
+#pragma unroll 1
+        for (int p0 = 0; p0 < 8; p0 += PU)
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
+        for (int pi = 0; pi < PU; ++pi) {
+            const int pass = p0 + pi;
             const int rr = pass * 4 + (lane >> 4), cc = (lane & 15) * 4;
             const int m = mrow0 + rr;
             const int n = nwin + cc;
@@ -226,17 +251,22 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                     // of each 64-dim head, rotate_half pairs (d, d+16)), and emit the attention kernel's operand planes:
                     // q, k row-major (nb, H, Np, 64), v transposed (nb, H, 64, Np).  A 64-column window is exactly one head.
                     const int hd = p.heads * 64;
-                    const int which = n / hd + p.sec0, h = (n % hd) >> 6, d = n & 63;     // 0 q, 1 k, 2 v
-                    const int b = m / p.ntok, t = m % p.ntok;
+                    const int nsec = nwin / hd;                                            // (wave-uniform: a window is one head)
+                    const int which = nsec + p.sec0, h = (nwin - nsec * hd) >> 6, d = n & 63;   // 0 q, 1 k, 2 v
+                    int b = wb0, t = wt0 + rr;
+                    while (t >= p.ntok) { t -= p.ntok; ++b; }
                     if (p.rope_cs && d < 32) {
                         // partner column d ^ 16 lives 4 lanes away in this row's 16-lane group
                         f32x4 o;
                         f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
                         if (p.row_alpha) pv *= p.row_alpha[m];     // (the partner column comes straight from the window: same row factor)
+                        // (cos, sin) of the lane's four dims: 8 consecutive floats, 32-byte aligned ((d & 15) is a multiple of 4)
                         const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
+                        const f32x4 cs0 = *(const f32x4*)cs, cs1 = *(const f32x4*)(cs + 4);
+                        const float cc_[4] = {cs0[0], cs0[2], cs1[0], cs1[2]}, ss_[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float c = cs[2 * e], s = cs[2 * e + 1];
+                            const float c = cc_[e], s = ss_[e];
                             o[e] = (d < 16) ? v[e] * c - pv[e] * s : v[e] * c + pv[e] * s;
                         }
                         v = o;

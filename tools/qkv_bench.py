@@ -1,9 +1,12 @@
 """Self-attention input projection (M = nb x ntok tokens, 1536 -> 3 x 24 x 64): plain-store GEMM vs the fused head-split / rotary /
 plane-layout epilogue (sat_gemm_qkv_bf16), per batch layout."""
-import json, sys
+import json, os, sys
 import torch
 sys.path.insert(0, '.')
+from stable_audio_tools_amd import _lib
 from stable_audio_tools_amd.ops import get_ops
+if os.environ.get('SAT_EXP_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['SAT_EXP_LIB'])
 o = get_ops()
 torch.manual_seed(0)
 def timeit(f, n=50):
@@ -14,7 +17,7 @@ def timeit(f, n=50):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (nb, ntok) in [(2, 1025), (2, 1024), (1, 2050), (4, 1025)]:
+for (nb, ntok) in [(2, 1025), (2, 1024), (4, 1025), (2, 6145)]:
     m = nb * ntok
     x = torch.randn(m, 1536, device='cuda').bfloat16()
     w = (torch.randn(4608, 1536, device='cuda') / 39).bfloat16()
