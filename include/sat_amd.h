@@ -298,6 +298,13 @@ int sat_attention_bwd(const short* const* planes, const float* lse, const float*
 int sat_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* scale, const void* shift,
                       long long mod_stride, void* y, float* mean, float* rstd, int rows, int D, int rows_per_batch,
                       float eps, int dtype, void* stream);
+/* The same LayerNorm (+ adaLN modulate) with its output quantised per row to fp8 e4m3 for the projection that consumes it
+ * (transformer.py:682/:697 feeding :481 / :263 in the fp8 long-context configuration): q (rows, D) bytes, qscale (rows) = row max / 448 —
+ * the row_alpha of sat_gemm_fp8 / sat_gemm_qkv_fp8.  Returns 2 (nothing launched) when the shape is outside the vector path
+ * (D % (64 lanes x 16 bytes), 16-byte aligned pointers): use sat_layernorm_fwd + sat_quant_fp8_rows then. */
+int sat_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, const void* scale, const void* shift,
+                          long long mod_stride, void* q, float* qscale, int rows, int D, int rows_per_batch, float eps,
+                          int dtype, void* stream);
 /* dx plus partial column sums part[3][sat_layernorm_bwd_nblocks()][D] = {d_gamma, d_scale, d_shift} (slabs of one
  * batch item are contiguous; reduce with sat_reduce_splits). */
 int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch);

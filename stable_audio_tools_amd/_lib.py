@@ -102,6 +102,7 @@ SIGNATURES = {
     "sat_split_bf16x3": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
     # dit_ops.hip
     "sat_layernorm_fwd": (_I, [_P] * 5 + [_L] + [_P] * 3 + [_I] * 3 + [_F, _I, _P]),
+    "sat_layernorm_fwd_fp8": (_I, [_P] * 5 + [_L] + [_P] * 2 + [_I] * 3 + [_F, _I, _P]),
     "sat_layernorm_bwd_nblocks": (_I, [_I, _I]),
     "sat_layernorm_bwd": (_I, [_P] * 5 + [_L] + [_P] * 4 + [_I] * 4 + [_P]),
     "sat_rope_tables": (_I, [_P, _P, _I, _I, _F, _P]),

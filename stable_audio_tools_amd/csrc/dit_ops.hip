@@ -40,6 +40,9 @@ struct SatLnParams {
     long long mod_stride; // element stride between batches in scale/shift (>= D)
     int rows, D, rows_per_batch;
     float eps;
+    // fp8 output (sat_layernorm_fwd_fp8): e4m3 bytes (rows, D) with one dynamic scale per row
+    uint8_t* q;
+    float* qscale;        // (rows): row max / 448
 };
 
 template <typename T>
@@ -194,6 +197,83 @@ __global__ void __launch_bounds__(256) sat_layernorm_fwd_vec_kernel(SatLnParams 
     }
 }
 
+// LayerNorm straight to the fp8 operand of the projection that consumes it (round 4; the N = 6145 sampler): the normalised (and
+// adaLN-modulated) row is kept in registers, its max |.| gives the row's dynamic scale, and the row leaves as e4m3 bytes + one fp32 scale
+// (the GEMM's row_alpha) — the bf16 LayerNorm output (written, then re-read by the quantiser) and the quantiser's launch disappear.
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_fwd_fp8_kernel(SatLnParams p) {
+    constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;   // whole wave exits together; no block barrier below
+    const long long base = (long long)row * p.D;
+    const int nc = p.D / (64 * N);
+    float xs[MAXC][N];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            SatVec<T>::ld(p.x, base + (c * 64 + lane) * N, xs[c]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s += xs[c][j];
+        }
+    }
+    const float mean = sat_wave_sum(s) / (float)p.D;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float d = xs[c][j] - mean;
+                v += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(sat_wave_sum(v) / (float)p.D + p.eps);
+    const long long mb = p.scale ? (long long)(row / p.rows_per_batch) * p.mod_stride : 0;
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            const int i0 = (c * 64 + lane) * N;
+            float g[N];
+#pragma unroll
+            for (int j = 0; j < N; j += 4) SatVec<float>::ld(p.gamma, i0 + j, g + j);
+#pragma unroll
+            for (int j = 0; j < N; ++j) xs[c][j] = (xs[c][j] - mean) * rstd * g[j];
+            if (p.beta) {
+#pragma unroll
+                for (int j = 0; j < N; j += 4) SatVec<float>::ld(p.beta, i0 + j, g + j);
+#pragma unroll
+                for (int j = 0; j < N; ++j) xs[c][j] += g[j];
+            }
+            if (p.scale) {
+                float sc[N], sh[N];
+                SatVec<T>::ld(p.scale, mb + i0, sc);
+                SatVec<T>::ld(p.shift, mb + i0, sh);
+#pragma unroll
+                for (int j = 0; j < N; ++j) xs[c][j] = xs[c][j] * (1.0f + sc[j]) + sh[j];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) am = fmaxf(am, fabsf(xs[c][j]));
+        }
+    }
+    for (int k = 32; k >= 1; k >>= 1) am = fmaxf(am, __shfl_xor(am, k));
+    am = fmaxf(am, 1e-12f);
+    const float qs = 448.0f / am;
+    if (lane == 0) p.qscale[row] = am / 448.0f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            uint8_t* dst = p.q + base + (c * 64 + lane) * N;
+#pragma unroll
+            for (int j = 0; j < N; j += 4)
+                *reinterpret_cast<uint32_t*>(dst + j) = sat_f32x4_to_fp8(xs[c][j] * qs, xs[c][j + 1] * qs, xs[c][j + 2] * qs, xs[c][j + 3] * qs);
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_vec_kernel(SatLnParams p) {
     constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
@@ -304,6 +384,25 @@ extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float*
     } else if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);
     else SAT_LAUNCH(sat_layernorm_fwd_kernel<short>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_layernorm_fwd");
+}
+
+// LayerNorm (+ adaLN modulate) with the output quantised per row to fp8 e4m3: q (rows, D) bytes, qscale (rows) = row max / 448.  Needs
+// the vector layout of the fast path (D a multiple of 64 lanes x 16 bytes, 16-byte aligned pointers): returns 2 (nothing launched, no error
+// set) when the shape does not qualify — the caller takes sat_layernorm_fwd + sat_quant_fp8_rows.
+extern "C" int sat_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, const void* scale, const void* shift,
+                                     long long mod_stride, void* q, float* qscale, int rows, int D, int rows_per_batch, float eps,
+                                     int dtype, void* stream) {
+    if (sat_ln_check(rows, D, rows_per_batch, dtype, "sat_layernorm_fwd_fp8: bad shape")) return 1;
+    if ((scale == nullptr) != (shift == nullptr) || !q || !qscale) { sat_set_error("sat_layernorm_fwd_fp8: bad arguments"); return 1; }
+    SatLnParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift;
+    p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch; p.eps = eps;
+    p.q = (uint8_t*)q; p.qscale = qscale;
+    if (!sat_ln_vec_ok(p, dtype == 0 ? 4 : 2) || ((uintptr_t)q & 7)) return 2;
+    dim3 grid(sat_cdiv(rows, 4));
+    if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_fp8_kernel<float>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_layernorm_fwd_fp8_kernel<short>, grid, dim3(256), stream, p);
+    return sat_check_launch("sat_layernorm_fwd_fp8");
 }
 
 extern "C" int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch) {

@@ -1204,40 +1204,6 @@ struct SatQuantParams {
     long long lds_, ldd;
     int R, Cc, src_f32;
 };
-SAT_DEVICE uint32_t sat_f32x4_to_fp8(float a, float b, float c, float d) {
-#if defined(SAT_HIPEMU)
-    auto enc = [](float x) -> uint32_t {
-        if (x != x) return 0x7fu;
-        const uint32_t sign = x < 0.f ? 0x80u : 0u;
-        float ax = fabsf(x);
-        if (ax > 448.f) ax = 448.f;
-        if (ax < ldexpf(1.0f, -10)) return sign;                                  // below half the smallest subnormal (2^-9)
-        int e;
-        frexpf(ax, &e);                                                           // ax = f * 2^e, f in [0.5, 1)
-        int ue = e - 1;                                                           // unbiased exponent: ax in [2^ue, 2^(ue+1))
-        if (ue < -6) ue = -6;                                                     // subnormal range shares the exponent of 2^-6
-        const float q = ldexpf(1.0f, ue - 3);                                     // spacing of representable values
-        float m = nearbyintf(ax / q);                                             // RNE (default rounding mode)
-        float v = m * q;
-        if (v > 448.f) v = 448.f;
-        if (v == 0.f) return sign;
-        frexpf(v, &e);
-        ue = e - 1;
-        uint32_t bits;
-        if (ue < -6) bits = (uint32_t)nearbyintf(v / ldexpf(1.0f, -9));           // subnormal: mantissa only
-        else bits = ((uint32_t)(ue + 7) << 3) | ((uint32_t)nearbyintf(v / ldexpf(1.0f, ue - 3)) - 8u);
-        return sign | bits;
-    };
-    return enc(a) | (enc(b) << 8) | (enc(c) << 16) | (enc(d) << 24);
-#else
-    const float lim = 448.0f;
-    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (uint32_t)w;
-#endif
-}
 __global__ void __launch_bounds__(256) sat_quant_fp8_kernel(SatQuantParams p) {
     const float qs = *p.qscale;
     const int cch = p.Cc >> 2;

@@ -146,6 +146,42 @@ SAT_DEVICE f32x4 sat_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 #endif
 
+// four fp32 -> four OCP e4m3 bytes (saturating at 448, round to nearest even): gemm.hip's quantisers, dit_ops.hip's LayerNorm -> fp8
+SAT_DEVICE uint32_t sat_f32x4_to_fp8(float a, float b, float c, float d) {
+#if defined(SAT_HIPEMU)
+    auto enc = [](float x) -> uint32_t {
+        if (x != x) return 0x7fu;
+        const uint32_t sign = x < 0.f ? 0x80u : 0u;
+        float ax = fabsf(x);
+        if (ax > 448.f) ax = 448.f;
+        if (ax < ldexpf(1.0f, -10)) return sign;                                  // below half the smallest subnormal (2^-9)
+        int e;
+        frexpf(ax, &e);                                                           // ax = f * 2^e, f in [0.5, 1)
+        int ue = e - 1;                                                           // unbiased exponent: ax in [2^ue, 2^(ue+1))
+        if (ue < -6) ue = -6;                                                     // subnormal range shares the exponent of 2^-6
+        const float q = ldexpf(1.0f, ue - 3);                                     // spacing of representable values
+        float m = nearbyintf(ax / q);                                             // RNE (default rounding mode)
+        float v = m * q;
+        if (v > 448.f) v = 448.f;
+        if (v == 0.f) return sign;
+        frexpf(v, &e);
+        ue = e - 1;
+        uint32_t bits;
+        if (ue < -6) bits = (uint32_t)nearbyintf(v / ldexpf(1.0f, -9));           // subnormal: mantissa only
+        else bits = ((uint32_t)(ue + 7) << 3) | ((uint32_t)nearbyintf(v / ldexpf(1.0f, ue - 3)) - 8u);
+        return sign | bits;
+    };
+    return enc(a) | (enc(b) << 8) | (enc(c) << 16) | (enc(d) << 24);
+#else
+    const float lim = 448.0f;
+    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+#endif
+}
+
 // round-to-nearest-even fp32 -> bf16 bits
 SAT_DEVICE short sat_f32_to_bf16(float f) {
     uint32_t u;

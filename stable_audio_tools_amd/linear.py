@@ -68,6 +68,17 @@ class _WeightCache:
 fp8_row_scales = os.environ.get("SAT_FP8_ROW_SCALES", "1") != "0"
 
 
+class Fp8Rows:
+    """An activation that already left its producer as fp8 e4m3 rows + one dynamic scale per row (LayerNorm -> fp8, round 4): what an
+    fp8 `Linear` / the attention input projection take instead of a tensor in inference.  Carries only what those two consumers read."""
+
+    def __init__(self, q, scale, shape):
+        self.q, self.scale, self.shape = q, scale, tuple(shape)       # q (rows, K) uint8, scale (rows,) fp32, logical shape (..., K)
+        self.dtype = torch.bfloat16                                   # (the precision mode the consumer runs in)
+        self.device = q.device
+        self.is_cuda = q.is_cuda
+
+
 def _fp8_operands(ops, x2, w, cache):
     """(A, B, alpha, row_alpha) in fp8 e4m3 with dynamic scales: weights per tensor, once per version; activations per call and per ROW
     (one pass, a token's outliers do not set the other tokens' step size) — or per tensor with `fp8_row_scales = False`."""
@@ -267,7 +278,32 @@ class Linear(nn.Module):
         """mode None: x W^T + b [+ res];  'swiglu': value * silu(gate) over W rows = [value | gate]."""
         if mode is None:
             mode = "res" if res is not None else "plain"
+        if isinstance(x, Fp8Rows):
+            return self._forward_fp8_rows(x, res, mode)
         return LinearFn.apply(x, self.weight, self.bias, res, mode, _lowp(x, self.weight), self._cache, self.fp8)
+
+    def _forward_fp8_rows(self, xq, res, mode):
+        """Inference on an input that arrives quantised (Fp8Rows): the fp8 branch of LinearFn.forward without the quantisation pass."""
+        if torch.is_grad_enabled() and (self.weight.requires_grad or (res is not None and res.requires_grad)):
+            raise RuntimeError("a pre-quantised input is an inference-only path")
+        ops = _ops()
+        b, sb = self.fp8_weight()
+        n = self.weight.shape[0]
+        bias32 = None
+        if self.bias is not None:
+            bias32 = self._cache.get(self.bias, "bias32", lambda: torch.nn.functional.pad(self.bias.detach().float(), (0, (-n) % 8)).contiguous())
+        nout = n // 2 if mode == "swiglu" else n
+        if b.shape[0] != n or (mode == "swiglu" and n % 16):
+            raise ValueError("pre-quantised input: the projection needs out_features % 8 == 0 (SwiGLU: % 16)")
+        y = torch.empty(*xq.shape[:-1], nout, dtype=torch.bfloat16, device=xq.device)
+        r2 = None
+        if mode == "res":
+            r2 = res.reshape(-1, n).to(torch.bfloat16)
+            if r2.stride(1) != 1:
+                r2 = r2.contiguous()
+        epi = ops.EPI_SWIGLU if mode == "swiglu" else (ops.EPI_RES if mode == "res" else ops.EPI_STORE)
+        ops.gemm_fp8(xq.q, b, sb, bias=bias32, res=r2, epilogue=epi, out_dtype=torch.bfloat16, out=y.view(-1, nout), row_alpha=xq.scale)
+        return y
 
     def fp8_weight(self):
         """(uint8 e4m3 weight, dequant scale) cached per weight version, or None when K % 16 != 0."""

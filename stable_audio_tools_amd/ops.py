@@ -835,6 +835,25 @@ class SatOps:
                                              _ptr(mean), _ptr(rstd), b * n, d, n, eps, dt, self._stream(x)))
         return (y, mean, rstd) if save_stats else y
 
+    def layernorm_fp8(self, x, gamma, beta=None, scale=None, shift=None, eps=1e-5):
+        """LayerNorm (+ adaLN modulate) with the output quantised per row to fp8 e4m3 (sat_layernorm_fwd_fp8): returns (q (B*N, D) uint8,
+        row_scale (B*N,) fp32), or None when the shape is outside the kernel's vector path (the caller then normalises and quantises
+        in two steps)."""
+        dt = self._dt(x, scale, shift)
+        self._f32(gamma, beta)
+        if not x.is_contiguous():
+            raise ValueError("expected contiguous x")
+        b, n, d = x.shape
+        q = torch.empty(b * n, d, dtype=torch.uint8, device=x.device)
+        rs = torch.empty(b * n, dtype=torch.float32, device=x.device)
+        ms = scale.stride(0) if scale is not None else 0
+        rc = self.lib.sat_layernorm_fwd_fp8(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), ms, _ptr(q), _ptr(rs),
+                                            b * n, d, n, eps, dt, self._stream(x))
+        if rc == 2:
+            return None
+        self._chk(rc)
+        return q, rs
+
     def layernorm_bwd(self, dy, x, gamma, beta, scale, mean, rstd):
         """Returns dx, dgamma (D,), dscale (B, D) or None, dshift (B, D) or None."""
         dt = self._dt(dy, x, scale)

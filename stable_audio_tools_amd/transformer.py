@@ -30,6 +30,9 @@ from . import functional as _fn
 from . import linear as _linear
 from .linear import Linear, _lowp
 
+# LayerNorm -> fp8 rows for an fp8 consumer (round 4); SAT_FP8_LN_FUSED=0: normalise to bf16, then quantise (the A/B arm)
+fp8_ln_fused = os.environ.get("SAT_FP8_LN_FUSED", "1") != "0"
+
 
 def _ops():
     return _fn._ops(None)
@@ -94,8 +97,16 @@ class LayerNorm(nn.Module):
             self._f32_cache[name] = hit
         return hit[1]
 
-    def forward(self, x, scale=None, shift=None):
-        """scale/shift: optional (B, D) adaLN modulation fused into the same pass: LN(x)*(1+scale)+shift."""
+    def forward(self, x, scale=None, shift=None, fp8_for=None):
+        """scale/shift: optional (B, D) adaLN modulation fused into the same pass: LN(x)*(1+scale)+shift.
+        fp8_for: the ONE projection that consumes the result.  In inference, when that Linear runs in fp8 with per-row activation scales, the
+        normalised rows leave the kernel as fp8 + row scales (linear.Fp8Rows): no bf16 LayerNorm output, no quantisation pass."""
+        if (fp8_for is not None and fp8_for.fp8 and _linear.fp8_row_scales and not torch.is_grad_enabled() and x.dim() == 3
+                and x.dtype == torch.bfloat16 and fp8_for.in_features % 16 == 0 and fp8_for.out_features % 8 == 0
+                and fp8_for.fp8_weight() is not None and fp8_ln_fused):
+            out = _ops().layernorm_fp8(x.contiguous(), self._as_f32("gamma"), self._as_f32("beta"), scale, shift, self.eps)
+            if out is not None:
+                return _linear.Fp8Rows(out[0], out[1], x.shape)
         return LayerNormFn.apply(x, self.gamma, self.beta, scale, shift, self.eps, self._as_f32("gamma"), self._as_f32("beta"))
 
 
@@ -260,6 +271,9 @@ class Attention(nn.Module):
     @staticmethod
     def _heads(ops, lin, x2, cs, heads, nb, ntok, sec0, nsec, tag):
         """Input projection straight into attention operand planes (bf16, or fp8 operands when the layer is switched to fp8)."""
+        if isinstance(x2, _linear.Fp8Rows):
+            qw, sw = lin.fp8_weight()
+            return ops.gemm_heads_fp8(x2.q, qw, sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=x2.scale)
         if lin.fp8 and lin.fp8_weight() is not None:
             qw, sw = lin.fp8_weight()
             if _linear.fp8_row_scales and x2.shape[1] % 8 == 0 and x2.stride(0) % 8 == 0 and x2.shape[1] <= 8192:
@@ -286,8 +300,11 @@ class Attention(nn.Module):
             # inference, bf16: head split, rotary and the attention kernel's operand planes come straight out of the
             # projection GEMM's epilogue (no qkv tensor, no rotary pass, no plane-preparation pass)
             ops = _ops()
-            x2 = x.reshape(b * n, -1)
-            x2 = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2.contiguous())
+            if isinstance(x, _linear.Fp8Rows):
+                x2 = x
+            else:
+                x2 = x.reshape(b * n, -1)
+                x2 = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2.contiguous())
             if cross:
                 m = kv_input.shape[1]
                 pq = self._heads(ops, self.to_q, x2, None, h, b, n, 0, 1, "cross")
@@ -367,17 +384,18 @@ class TransformerBlock(nn.Module):
             mod = (self.to_scale_shift_gate + global_cond).to(x.dtype).contiguous()   # (B, 6D)
             scale_self, shift_self, gate_self = mod[:, 0:d], mod[:, d:2 * d], mod[:, 2 * d:3 * d]
             scale_ff, shift_ff, gate_ff = mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], mod[:, 5 * d:6 * d]
-            h = self.self_attn(self.pre_norm(x, scale_self, shift_self), rotary_pos_emb=rotary_pos_emb)
+            h = self.self_attn(self.pre_norm(x, scale_self, shift_self, fp8_for=self.self_attn.to_qkv), rotary_pos_emb=rotary_pos_emb)
             x = _GateResidualFn.apply(h, gate_self, x)                           # h*sigmoid(1-gate)+x  (:684-686)
             if context is not None and self.cross_attend:
-                x = self.cross_attn(self.cross_attend_norm(x), context=context, res=x)   # never modulated (:688-689)
-            h = self.ff(self.ff_norm(x, scale_ff, shift_ff))
+                x = self.cross_attn(self.cross_attend_norm(x, fp8_for=self.cross_attn.to_q), context=context, res=x)   # never modulated (:688-689)
+            h = self.ff(self.ff_norm(x, scale_ff, shift_ff, fp8_for=self.ff.ff[0].proj))
             x = _GateResidualFn.apply(h, gate_ff, x)
         else:
-            x = self.self_attn(self.pre_norm(x), rotary_pos_emb=rotary_pos_emb, res=x)       # residual adds live in the
-            if context is not None and self.cross_attend:                                       # output projections' epilogues
-                x = self.cross_attn(self.cross_attend_norm(x), context=context, res=x)
-            x = self.ff(self.ff_norm(x), res=x)
+            # (fp8_for: each norm's only consumer — in fp8 inference the rows leave the LayerNorm kernel quantised)
+            x = self.self_attn(self.pre_norm(x, fp8_for=self.self_attn.to_qkv), rotary_pos_emb=rotary_pos_emb, res=x)   # residual adds live in
+            if context is not None and self.cross_attend:                                                                 # the output projections' epilogues
+                x = self.cross_attn(self.cross_attend_norm(x, fp8_for=self.cross_attn.to_q), context=context, res=x)
+            x = self.ff(self.ff_norm(x, fp8_for=self.ff.ff[0].proj), res=x)
         return x
 
 

@@ -57,6 +57,43 @@ def test_layernorm_gpu(hip):
         _ln_case(hip, "cuda", *case, seed=12)
 
 
+def _ln_fp8_case(ops, dev, b, n, d, mod, seed):
+    """LayerNorm -> fp8 rows (sat_layernorm_fwd_fp8, round 4): the de-quantised rows against the fp32 LayerNorm (+ adaLN) of the same
+    bf16 input within e4m3's half-step (2^-4 relative to the row's own scale), and the row scale = max |LN row| / 448."""
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, n, d, generator=gen).bfloat16().to(dev)
+    gamma = (1 + 0.1 * torch.randn(d, generator=gen)).to(dev)
+    beta = (0.1 * torch.randn(d, generator=gen)).to(dev)
+    sc = sh = None
+    if mod:
+        mo = (0.2 * torch.randn(b, 2 * d, generator=gen)).bfloat16().to(dev)
+        sc, sh = mo[:, :d], mo[:, d:]
+    out = ops.layernorm_fp8(x, gamma, beta, sc, sh, 1e-5)
+    assert out is not None
+    q, rs = out
+    ref = F.layer_norm(x.float().cpu(), (d,), gamma.cpu(), beta.cpu(), 1e-5)
+    if mod:
+        ref = ref * (1 + sc.float().cpu()[:, None, :]) + sh.float().cpu()[:, None, :]
+    ref = ref.reshape(b * n, d)
+    am = ref.abs().amax(dim=1)
+    assert rel_err(rs.cpu(), am / 448.0) < 1e-5
+    deq = q.cpu().view(torch.float8_e4m3fn).float() * rs.cpu()[:, None]
+    assert float(((deq - ref).abs() / am[:, None]).max()) < 2.0 ** -4 + 1e-3        # half a step of the top binade
+    assert float((deq - ref).norm() / ref.norm()) < 4e-2
+
+
+def test_layernorm_fp8_sim(emu):
+    _ln_fp8_case(emu, "cpu", 2, 5, 512, False, 21)
+    _ln_fp8_case(emu, "cpu", 2, 3, 1536, True, 22)
+    assert emu.layernorm_fp8(torch.randn(1, 3, 72).bfloat16(), torch.ones(72), None, None, None, 1e-5) is None     # outside the vector path
+
+
+@pytest.mark.gpu
+def test_layernorm_fp8_gpu(hip):
+    _ln_fp8_case(hip, "cuda", 2, 1025, 1536, False, 23)
+    _ln_fp8_case(hip, "cuda", 2, 130, 1536, True, 24)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # attention: forward and backward against F.scaled_dot_product_attention (the reference's CPU path, transformer.py:440),
 # self and GQA cross shapes, sequence lengths around the 64-wide tiles (the kernels double-buffer them)
