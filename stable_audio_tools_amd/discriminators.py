@@ -406,8 +406,10 @@ class MultiScaleSTFTDiscriminator(nn.Module):
 
 
 def get_hinge_losses(score_real, score_fake):
-    gen_loss = -score_fake.mean()
-    dis_loss = torch.relu(1 - score_real).mean() + torch.relu(1 + score_fake).mean()
+    """models/discriminators.py:13-16.  The means over the (millions of) logits of a 47 s item run on functional.mean_all
+    (ops.sum_all: why not torch's .mean())."""
+    gen_loss = -_fn.mean_all(score_fake)
+    dis_loss = _fn.mean_all(torch.relu(1 - score_real)) + _fn.mean_all(torch.relu(1 + score_fake))
     return dis_loss, gen_loss
 
 
@@ -418,7 +420,8 @@ class EncodecDiscriminator(nn.Module):
             raise NotImplementedError("only the hinge loss (the configured default) is restated")
         self.discriminators = MultiScaleSTFTDiscriminator(*args, **kwargs)
         self.normalize_losses = normalize_losses
-        self.fm_reduction = (lambda x, y: abs(x - y).mean() / (abs(x).mean() + 1e-3)) if normalize_losses else (lambda x, y: abs(x - y).mean())
+        self.fm_reduction = ((lambda x, y: _fn.mean_all(abs(x - y)) / (_fn.mean_all(abs(x)) + 1e-3)) if normalize_losses
+                             else (lambda x, y: _fn.mean_all(abs(x - y))))
         self.loss_type = loss_type
 
     def forward(self, x):
@@ -443,7 +446,7 @@ class EncodecDiscriminator(nn.Module):
                 # what the distances need of the real maps besides the maps themselves: element counts (and mean |x| when normalising);
                 # the maps are released one by one as the fake path's layers consume them (they keep sign(y - x) as int8)
                 counts = [f.shape[0] * f.shape[1] * frames * wd for f in feat_t]
-                norms = [f.abs().sum() / c + 1e-3 for f, c in zip(feat_t, counts)] if self.normalize_losses else None
+                norms = [_fn.sum_all(f.abs()) / c + 1e-3 for f, c in zip(feat_t, counts)] if self.normalize_losses else None
             logit_f, feat_f, _, sums = d.forward_pitched(fakes, fm_refs=feat_t if fused else None, exclusive=not need_fm, release_refs=fused)
             if not need_fm:
                 fm = 0.0
@@ -461,8 +464,8 @@ class EncodecDiscriminator(nn.Module):
 
     def _fm_pitched(self, x, y, frames, wd):
         count = x.shape[0] * x.shape[1] * frames * wd
-        d = (x - y).abs().sum() / count
-        return d / (x.abs().sum() / count + 1e-3) if self.normalize_losses else d
+        d = _fn.sum_all((x - y).abs()) / count
+        return d / (_fn.sum_all(x.abs()) / count + 1e-3) if self.normalize_losses else d
 
     def loss(self, reals, fakes):
         """(dis_loss, adv_loss, feature_matching_distance) / num_scales — models/discriminators.py:31-63."""

@@ -27,6 +27,28 @@ def _ops(ops):
     return ops if ops is not None else _ops_mod.get_ops()
 
 
+class SumAllFn(torch.autograd.Function):
+    """sum over every element -> 0-d tensor on ops.sum_all (deterministic two-pass row sums; no torch multi-block reduction — see its
+    docstring for why the training step avoids those).  Backward: the incoming scalar broadcast to the input's shape, as torch's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
+        return _ops(None).sum_all(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.in_dtype).expand(ctx.in_shape)
+
+
+def sum_all(x):
+    return SumAllFn.apply(x)
+
+
+def mean_all(x):
+    return SumAllFn.apply(x) / x.numel()
+
+
 class DerivedCache:
     """Derived copies of one conv layer's parameters (folded weight, packed bf16x3 planes, SnakeBeta constants) for the passes in
     which nothing is trained: each entry is valid for one (storage, torch version counter, invalidation epoch) of its sources

@@ -503,6 +503,26 @@ class SatOps:
                 return partial.view(c)
             x, b, t = partial, 1, ns
 
+    def sum_all(self, x):
+        """Sum of EVERY element of a tensor as a 0-d fp32 tensor: passes of sat_rowsum over (1, 1, N) until one partial is left —
+        deterministic, no atomics and, unlike torch's `x.sum()` / `.mean()` / `.norm()` over millions of elements, no semaphore
+        buffer zeroed by a memset in front of the kernel.  That matters under HIP-graph replay: on this stack (torch 2.10 / ROCm 7)
+        a replayed multi-block torch reduction returns stale or foreign values after a few replays — reproduced with torch ops alone
+        (tools/diag_graph_reduce.py, profiles/r04_experiments/graph_reductions/) — so no reduction to a scalar inside the training
+        step goes through one (functional.sum_all / mean_all are the autograd forms)."""
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        n = x.numel()
+        if n == 0:
+            return torch.zeros((), dtype=torch.float32, device=x.device)
+        if n >= 1 << 31:          # sat_rowsum indexes a row with 32-bit ints: sum 2^30-element pieces
+            flat = x.view(-1)
+            return torch.stack([self.sum_all(piece) for piece in flat.split(1 << 30)]).sum()
+        if x.data_ptr() % 16:
+            x = x.clone()
+        return self.rowsum(x.view(1, 1, n)).view(())
+
     # ------------------------------------------------------------------ VAE bottleneck
     def vae_sample_fwd(self, pre, noise):
         self._f32(pre, noise)

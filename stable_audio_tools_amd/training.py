@@ -258,7 +258,7 @@ def clip_flat_grads(flat, max_norm, grad_scale=1.0):
     """torch.nn.utils.clip_grad_norm_(params, max_norm) (training/autoencoders.py:491-492, :509-510) on a flat gradient buffer, without
     a host sync: the buffer holds the SUM over ranks and grad_scale = 1 / world turns its norm into that of the mean gradient the
     reference clips; the coefficient min(1, max_norm / (norm + 1e-6)) is multiplied in on the device.  Returns the (mean-gradient) norm."""
-    norm = torch.linalg.vector_norm(flat.grad) * grad_scale
+    norm = torch.sqrt(_fn.sum_all(flat.grad * flat.grad)) * grad_scale      # not torch.linalg.vector_norm: ops.sum_all says why
     flat.grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
     return norm
 
@@ -503,11 +503,11 @@ class AutoencoderTrainStep:
         loss = mrstft + self.w_kl * info["kl"]
         out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
         if self.w_l1 > 0.0:
-            l1 = (reals_t - decoded).abs().mean()
+            l1 = _fn.mean_all((reals_t - decoded).abs())
             loss = loss + (self.w_l1 * tdec) * l1
             out["l1_time_loss"] = ((self.w_l1 * tdec) * l1).detach()
         if self.w_l2 > 0.0:
-            l2 = ((reals_t - decoded) ** 2).mean()
+            l2 = _fn.mean_all((reals_t - decoded) ** 2)
             loss = loss + (self.w_l2 * tdec) * l2
             out["l2_time_loss"] = ((self.w_l2 * tdec) * l2).detach()
         if self.use_disc and self.warmed_up:      # before the warm-up ends the adversarial / feature-matching terms are zero (:441-452)

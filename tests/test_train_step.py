@@ -470,24 +470,102 @@ def test_adamw_kernel_gpu(hip):
     _adamw_case(hip, "cuda")
 
 
-def test_clip_flat_grads_matches_torch():
-    """training.clip_flat_grads == torch.nn.utils.clip_grad_norm_ (the reference's clipping, training/autoencoders.py:491-492, :509-510)
-    on the flat buffer, incl. the 1 / world scale of a summed multi-rank gradient and the no-clip case."""
+def _clip_case(device):
     from stable_audio_tools_amd.training import FlatParameters, clip_flat_grads
     gen = torch.Generator().manual_seed(5)
     for max_norm, world in ((0.5, 1), (1e3, 1), (0.25, 4)):
-        params = [torch.nn.Parameter(torch.randn(*shp, generator=gen)) for shp in ((7, 3), (5,), (2, 4, 6))]
+        params = [torch.nn.Parameter(torch.randn(*shp, generator=gen).to(device)) for shp in ((7, 3), (5,), (2, 4, 6), (300, 131))]
         refs = [torch.nn.Parameter(q.detach().clone()) for q in params]
         flat = FlatParameters(params, pad_to=world)
         for q, r in zip(params, refs):
-            g = torch.randn(q.shape, generator=gen)
+            g = torch.randn(q.shape, generator=gen).to(device)
             q.grad.copy_(g * world)                 # the flat buffer holds the SUM over ranks
             r.grad = g.clone()                      # the mean gradient the reference clips
         total = torch.nn.utils.clip_grad_norm_(refs, max_norm)
         norm = clip_flat_grads(flat, max_norm, grad_scale=1.0 / world)
-        assert torch.allclose(norm, total, rtol=1e-6)
+        assert torch.allclose(norm, total, rtol=1e-5)
         for q, r in zip(params, refs):
             assert torch.allclose(q.grad / world, r.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_clip_flat_grads_matches_torch(emu_modules):
+    """training.clip_flat_grads == torch.nn.utils.clip_grad_norm_ (the reference's clipping, training/autoencoders.py:491-492, :509-510)
+    on the flat buffer, incl. the 1 / world scale of a summed multi-rank gradient and the no-clip case.  The norm runs on ops.sum_all
+    (sat_rowsum passes), not on a torch reduction."""
+    _clip_case("cpu")
+
+
+@pytest.mark.gpu
+def test_clip_flat_grads_matches_torch_gpu(hip):
+    _clip_case("cuda")
+
+
+def _sum_all_case(device, sizes):
+    from stable_audio_tools_amd import functional as Fn
+    gen = torch.Generator().manual_seed(11)
+    for shape in sizes:
+        x = torch.randn(*shape, generator=gen).to(device).requires_grad_(True)
+        ref = x.detach().double().sum()
+        got = Fn.sum_all(x)
+        assert got.shape == () and abs(float(got) - float(ref)) <= 2e-6 * float(x.detach().abs().double().sum()), (shape, float(got), float(ref))
+        # autograd: d/dx of 3 * mean(relu(1 - x)) as torch's own mean gives it
+        (3.0 * Fn.mean_all(torch.relu(1 - x))).backward()
+        x2 = x.detach().clone().requires_grad_(True)
+        (3.0 * torch.relu(1 - x2).mean()).backward()
+        assert torch.equal(x.grad, x2.grad), shape
+    # a non-contiguous (strided) input and a 16-bit one
+    base = torch.randn(6, 50, generator=gen).to(device)
+    assert abs(float(Fn.sum_all(base[:, 3:43:2])) - float(base[:, 3:43:2].double().sum())) <= 1e-4
+    h = torch.randn(1000, generator=gen).to(device).to(torch.bfloat16)
+    assert abs(float(Fn.sum_all(h)) - float(h.double().sum())) <= 1e-3
+    assert float(Fn.sum_all(torch.zeros(0, device=device))) == 0.0
+
+
+def test_sum_all_simulator(emu_modules):
+    """functional.sum_all / mean_all (ops.sum_all: passes of sat_rowsum over (1, 1, N)) against float64 sums: sizes with and without
+    the 16-byte row path, one element, more than one pass (N > 16384)."""
+    _sum_all_case("cpu", [(1,), (7, 3), (4, 1024), (3, 5, 4099), (40000,)])
+
+
+@pytest.mark.gpu
+def test_sum_all_gpu(hip):
+    _sum_all_case("cuda", [(1,), (7, 3), (4, 1024), (3, 5, 4099), (1, 2, 2097152), (33554433,)])
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent on the diagnosis it follows from: not yet executed on an "
+                                        "MI355X (the driver's round-end run is its first); asserts strictly once it has been seen to pass")
+def test_sum_all_survives_graph_replay_gpu(hip):
+    """The reason ops.sum_all exists: replayed from a HIP graph, torch's multi-block reductions return stale / foreign values after a few
+    replays on this stack (tools/diag_graph_reduce.py reproduces it with torch ops alone; profiles/r04_experiments/graph_reductions/).
+    The row-sum passes are plain kernels without a semaphore buffer: forty replays of forty reductions over 4 M elements each, every
+    output equal to the eager evaluation of the same input."""
+    from stable_audio_tools_amd import functional as Fn
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(1)
+    src = [torch.randn(4 << 20, device=dev, generator=gen) * s for s in (0.1, 0.5, 0.25)]
+    static = src[0].clone()
+
+    def body(inp):
+        outs, y = [], inp
+        for k in range(40):
+            y = y * 1.0001 + 0.001 * k
+            outs.append(Fn.mean_all(torch.relu(1 - y)))
+            outs.append(Fn.sum_all(y.abs()))
+        return outs
+    body(static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = body(static)
+    for r in range(40):
+        static.copy_(src[r % 3] * (1.0 + 0.01 * r))
+        junk = [torch.randn((8 + (r + j) % 5) << 20, device=dev) for j in range(6)]      # allocator churn between replays
+        del junk
+        graph.replay()
+        got = [float(o) for o in outs]
+        want = [float(o) for o in body(static)]
+        assert got == want, (r, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:4])
 
 
 def test_warmup_and_time_losses_simulator(emu_modules):
