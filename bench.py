@@ -1118,9 +1118,12 @@ def main():
         launch["graph_replays"] = gstep.replays
         if gstep.fallback:
             launch["graph_fallback"] = list(gstep.fallback.values())
-        if gstep.replays >= args.steps and elapsed_graph < elapsed:
-            elapsed, launch["mode"] = elapsed_graph, "hip_graph"
-            loss = float(out_g["loss"])
+        # `value` stays on the EAGER launches (round 4, end): the replayed step is < 1 % faster (not launch-bound), and a HIP-graph replay
+        # on this stack returned stale values from torch's multi-block reductions (profiles/r04_experiments/graph_reductions/: reproduced
+        # with torch ops alone).  The step's own scalar reductions now run on ops.sum_all and its parameters never depended on one, but
+        # the headline is not the place for a launch mode with an open platform defect: the replay time is reported, not used.
+        launch["graph_loss"] = float(out_g["loss"])
+        launch["value_uses"] = "eager"
 
     if rank == 0:
         dom, allk = prof.summary()
@@ -1291,10 +1294,13 @@ def main():
                 cont = [g2.stepper(batches[i % 2]) for i in range(2)]
                 rg["eager_continuation_losses"] = [float(c_["loss"]) for c_ in cont]
                 rg["last_two_graph_losses"] = [float(v) for v in last_two]
+                # the replayed losses against the eager updates that follow them (same kind of update, next items / noise draws): the
+                # discriminator's hinge loss moves by < 1e-3 per update here, the generator's by a few per cent
+                tol = (0.25, 0.05)
+                rg["losses_consistent_with_eager"] = all(abs(a - b) <= t * max(abs(b), 1e-6) for a, b, t in
+                                                         zip(rg["last_two_graph_losses"], rg["eager_continuation_losses"], tol))
                 line["config"]["real_step"]["hip_graph"] = rg
-                if g2.replays >= 8 and not g2.fallback and dt_g < dt_real:
-                    line["config"]["real_step"].update(ms_per_step=1e3 * dt_g, samples_per_s=args.batch / dt_g, launch_mode="hip_graph",
-                                                       eager_ms_per_step=1e3 * dt_real)
+                rg["used_for_real_step_ms"] = False      # reported, not used: the real step's figures stay on eager launches (config.launch)
                 del g2
                 torch.cuda.empty_cache()
             stepper.use_disc = False
