@@ -563,7 +563,12 @@ class GraphedTrainStep:
     step can be asked for: generator before / after the discriminator warm-up, discriminator.  The first `eager_steps` calls of a kind
     run eagerly (lazy workspaces, allocator warm-up); a kind whose capture fails (a host synchronisation inside) stays eager — `fallback`
     says why.  Inputs of another shape than the captured one run eagerly too.  The returned loss tensors are the graph's static buffers:
-    read them before the next call."""
+    read them before the next call.
+
+    Platform caveat (round 4, profiles/EXPERIMENTS.md last section): on torch 2.10 / ROCm 7 a REPLAYED torch reduction of millions of
+    elements to a scalar (`.mean()`, `.sum()`, `.max()`, `.norm()`: partials + semaphores) returns stale or foreign values after a few
+    replays — reproduced with torch ops alone (tools/diag_graph_reduce.py).  Nothing inside the captured updates uses one any more
+    (ops.sum_all / functional.mean_all: row-sum passes); code added to `_gen_body` / `_disc_body` must keep it that way."""
 
     def __init__(self, stepper, eager_steps=1):
         self.stepper = stepper
