@@ -27,6 +27,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts: RCCL across processes needs it (set before HIP starts)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -317,10 +317,13 @@ class AutoencoderTrainStep:
     autoencoder on  spectral + kl + w_adv * adversarial + w_fm * feature_matching  (:165-194).  Two restatement choices that do not
     change any update: in a discriminator step the autoencoder runs under no_grad (the reference back-propagates loss_dis into the
     autoencoder too and discards those gradients at the next opt_gen.zero_grad()), and in a generator step the discriminator's
-    parameters do not require grad (the reference computes and discards their gradients the same way)."""
+    parameters do not require grad (the reference computes and discards their gradients the same way).
+    With a teacher (`teacher_model=`, or `training.teacher_model` + `teacher_model_ckpt` as training/factory.py:31-40): the distillation
+    objective of :169-179 — five terms at mrstft / 4 (latent MSE + four sum-and-difference STFT losses) instead of the reconstruction
+    terms; the teacher is a frozen native autoencoder (its folded / packed weights come from the derived-weight caches)."""
 
     def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True,
-                 use_discriminator=True, ddp_comm_dtype=None, ddp_single_rank=None):
+                 use_discriminator=True, ddp_comm_dtype=None, ddp_single_rank=None, teacher_model=None):
         from .auraloss import AutoencoderSpectralLoss
         tr = model_config["training"]
         self.model = autoencoder
@@ -352,6 +355,23 @@ class AutoencoderTrainStep:
         sample_rate = model_config["sample_rate"]
         self.spectral = AutoencoderSpectralLoss(sample_rate, weight=lc["spectral"]["weights"]["mrstft"],
                                                 **lc["spectral"]["config"]).to(self.flat.data.device)
+        # teacher distillation (training/factory.py:31-40: `training.teacher_model` is a model config, `teacher_model_ckpt` its weights;
+        # training/autoencoders.py:169-179: with a teacher the generator loss is FIVE terms at a quarter of the mrstft weight each —
+        # latent MSE, and the sum-and-difference STFT loss on four pairs — and the per-channel L / R terms are not used)
+        self.teacher = teacher_model
+        if self.teacher is None and tr.get("teacher_model"):
+            from .autoencoders import create_autoencoder_from_config
+            ckpt = tr.get("teacher_model_ckpt")
+            if ckpt is None:
+                raise ValueError("teacher_model_ckpt must be specified if teacher_model is specified")
+            self.teacher = create_autoencoder_from_config(tr["teacher_model"])
+            self.teacher.load_state_dict(torch.load(ckpt, map_location="cpu")["state_dict"])
+        if self.teacher is not None:
+            from .auraloss import MultiResolutionSTFTLoss, SumAndDifferenceSTFTLoss
+            self.teacher = self.teacher.eval().requires_grad_(False).to(self.flat.data.device)
+            sd_cls = SumAndDifferenceSTFTLoss if autoencoder.out_channels == 2 else MultiResolutionSTFTLoss      # :141-146
+            self.sdstft = sd_cls(sample_rate=sample_rate, **lc["spectral"]["config"]).to(self.flat.data.device)
+            self.w_distill = float(lc["spectral"]["weights"]["mrstft"]) * 0.25
         ddp_kw = dict(bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype, single_rank_exchange=ddp_single_rank)
         self.comm = GradAllReduce(self.flat, **ddp_kw)
         self.discriminator = None
@@ -382,8 +402,6 @@ class AutoencoderTrainStep:
                 bad.append(f"loss_configs.{name}")
         if float(lc.get("hubert", {}).get("decay", 1.0)) != 1.0:          # (spectral / time decays are restated)
             bad.append("loss_configs.hubert.decay != 1.0")
-        if tr.get("teacher_model"):                                        # latent / decoder distillation terms (:171-179, :405-437)
-            bad.append("training.teacher_model")
         if bad:
             raise NotImplementedError("AutoencoderTrainStep does not restate: " + ", ".join(bad))
 
@@ -439,7 +457,7 @@ class AutoencoderTrainStep:
 
     @staticmethod
     def _encode_kw(kw):
-        return {k: v for k, v in kw.items() if k != "latent_mask"}
+        return {k: v for k, v in kw.items() if k not in ("latent_mask", "teacher_noise")}
 
     def _mask_latents(self, latents, kw):
         """latent_mask_ratio (:411-413): zero a random subset of the latents before decoding.  kw["latent_mask"] (bool, latents'
@@ -494,14 +512,35 @@ class AutoencoderTrainStep:
                 latents, info = m.encode(enc_in, return_info=True, **self._encode_kw(kw))
         else:
             latents, info = m.encode(enc_in, return_info=True, **self._encode_kw(kw))
+        own_latents = latents                 # the latent-distillation term sees the latents BEFORE masking (:400, :411-413)
+        if self.teacher is not None:
+            with torch.no_grad():             # :405-408 — the teacher's bottleneck samples too (kw["teacher_noise"] injects its draw: tests)
+                t_latents = self.teacher.encode(enc_in, **({"noise": kw["teacher_noise"]} if "teacher_noise" in kw else {}))
         latents = self._mask_latents(latents, kw)
         decoded, reals_t = self._trim(m.decode(latents), reals)
         sdec, tdec = self._decays()
-        mrstft = self.spectral(reals_t, decoded)
-        if sdec != 1.0:
-            mrstft = mrstft * sdec
-        loss = mrstft + self.w_kl * info["kl"]
-        out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
+        if self.teacher is not None:
+            n = reals_t.shape[-1]
+            with torch.no_grad():             # :429-437: all three under no_grad — the last two terms below carry no gradient at all
+                t_decoded = self.teacher.decode(t_latents)[..., :n].contiguous()
+                own_t_decoded = self.teacher.decode(latents.detach())[..., :n].contiguous()      # own latents, teacher's decoder
+                t_own_decoded = m.decode(t_latents)[..., :n].contiguous()                        # teacher's latents, own decoder
+            w = self.w_distill * sdec
+            # AuralossLoss passes (target, input): losses.py:111 — x = the target_key tensor, y = the input_key tensor
+            terms = {"latent_distill_loss": _fn.mean_all((t_latents - own_latents) ** 2),
+                     "mrstft_loss": self.sdstft(reals_t, decoded),
+                     "mrstft_loss_distill": self.sdstft(t_decoded, decoded),
+                     "mrstft_loss_own_latents_teacher": self.sdstft(reals_t, own_t_decoded),
+                     "mrstft_loss_teacher_latents_own": self.sdstft(reals_t, t_own_decoded)}
+            out = {k: (w * v).detach() for k, v in terms.items()}
+            loss = w * sum(terms.values()) + self.w_kl * info["kl"]
+            out["kl_loss"] = (self.w_kl * info["kl"]).detach()
+        else:
+            mrstft = self.spectral(reals_t, decoded)
+            if sdec != 1.0:
+                mrstft = mrstft * sdec
+            loss = mrstft + self.w_kl * info["kl"]
+            out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
         if self.w_l1 > 0.0:
             l1 = _fn.mean_all((reals_t - decoded).abs())
             loss = loss + (self.w_l1 * tdec) * l1
@@ -539,11 +578,13 @@ class AutoencoderTrainStep:
         out["loss"] = loss.detach()
         return out
 
-    def __call__(self, reals, noise=None, latent_mask=None):
+    def __call__(self, reals, noise=None, latent_mask=None, teacher_noise=None):
         """reals: (B, C, T) on the model's device.  Returns dict of detached loss tensors (no host sync)."""
         kw = {"noise": noise} if noise is not None else {}
         if latent_mask is not None:
             kw["latent_mask"] = latent_mask
+        if teacher_noise is not None:
+            kw["teacher_noise"] = teacher_noise
         kind = self._kind()
         out = self._disc_body(reals, kw) if kind == "disc" else self._gen_body(reals, kw)
         self._after(kind)

@@ -698,6 +698,79 @@ def test_wrapper_options_simulator(emu_modules):
     _wrapper_options("cpu")
 
 
+# ---- teacher distillation (training/factory.py:31-40, training/autoencoders.py:169-179, :405-408, :429-437) ----
+def _teacher_case(device):
+    """With a teacher the generator loss is five terms at mrstft / 4 each: MSE(teacher latents, own latents before masking) and the
+    sum-and-difference STFT loss on (reals, decoded), (teacher decoded, decoded), (reals, teacher-decoder(own latents)) and
+    (reals, own-decoder(teacher latents)) — the last two computed under no_grad in the reference, i.e. value only —, no per-channel
+    L / R terms; `decay` multiplies all five.  Two steps of the native step against the oracle forward assembled that way +
+    torch.optim.AdamW (the second step's losses check the first update)."""
+    from stable_audio_tools_amd.training import AutoencoderTrainStep, inverse_lr
+    cfg = _model_config()
+    cfg["training"]["loss_configs"]["spectral"]["decay"] = 0.9
+    cfg["training"]["latent_mask_ratio"] = 0.25
+    TSEED = SEED + 7
+    model = build_native_ae(NAME, SEED, device)
+    teacher = build_native_ae(NAME, TSEED, device)
+    stepper = AutoencoderTrainStep(model, cfg, teacher_model=teacher)
+    assert not any(p.requires_grad for p in teacher.parameters()) and not teacher.training
+    batches = [_batch(2, 900), _batch(2, 910)]
+    tnoise = [torch.from_numpy(seeded.seeded_array((2, 4, 64), 55 + i)) for i in range(2)]
+    masks = [torch.from_numpy(seeded.seeded_array((2, 4, 64), 77 + i)) < -0.6 for i in range(2)]
+    outs = [stepper(a.to(device), noise=n.to(device), latent_mask=mk.to(device), teacher_noise=tn.to(device))
+            for (a, n), mk, tn in zip(batches, masks, tnoise)]
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in seeded.seeded_state_dict(shapes, SEED).items()}
+    tsd = {k: torch.from_numpy(v).clone() for k, v in seeded.seeded_state_dict(shapes, TSEED).items()}
+    oc = cfg["training"]["optimizer_configs"]["autoencoder"]
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-3, betas=(0.8, 0.99), weight_decay=1e-3, eps=1e-3)
+    sc = cfg["training"]["loss_configs"]["spectral"]["config"]
+    taps = stft_oracle.aweighting_fir_taps(cfg["sample_rate"])
+
+    def sdl(x, y):      # AuralossLoss: module(target_key tensor, input_key tensor)
+        return stft_oracle.sum_and_difference_loss(x, y, sc["fft_sizes"], sc["hop_sizes"], sc["win_lengths"], taps)
+    for step, ((audio, noise), mk, tn) in enumerate(zip(batches, masks, tnoise)):
+        for gp in opt.param_groups:
+            gp["lr"] = inverse_lr(step, 1e-3, **oc["scheduler"]["config"])
+        z, kl, _ = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
+        with torch.no_grad():
+            tz, _, _ = vae_oracle.autoencoder_encode(tsd, cfg["model"], audio, tn)
+        zm = torch.where(mk, torch.zeros_like(z), z)
+        dec = vae_oracle.autoencoder_decode(sd, cfg["model"], zm)
+        with torch.no_grad():
+            tdec = vae_oracle.autoencoder_decode(tsd, cfg["model"], tz)
+            own_t = vae_oracle.autoencoder_decode(tsd, cfg["model"], zm)
+            t_own = vae_oracle.autoencoder_decode(sd, cfg["model"], tz)
+        w = 0.25 * 0.9 ** (step + 1)
+        terms = {"latent_distill_loss": ((tz - z) ** 2).mean(), "mrstft_loss": sdl(audio, dec), "mrstft_loss_distill": sdl(tdec, dec),
+                 "mrstft_loss_own_latents_teacher": sdl(audio, own_t), "mrstft_loss_teacher_latents_own": sdl(audio, t_own)}
+        loss = w * sum(terms.values()) + 1e-4 * kl
+        for k, v in terms.items():
+            assert abs(float(outs[step][k]) - float(w * v)) <= 1e-3 * abs(float(w * v)), (step, k, float(outs[step][k]), float(w * v))
+        assert abs(float(outs[step]["loss"]) - float(loss)) <= 1e-3 * abs(float(loss)), (step, float(outs[step]["loss"]), float(loss))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    # the update itself: parameters after two steps
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    worst = max(rel_err(got[k], sd[k].detach()) for k in sd)
+    assert worst <= 1e-3, worst
+    # the config route of training/factory.py: a teacher config without its checkpoint is an error
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["training"]["teacher_model"] = copy.deepcopy(seeded.AE_CONFIGS[NAME])
+    with pytest.raises(ValueError):
+        AutoencoderTrainStep(build_native_ae(NAME, SEED, device), cfg2)
+
+
+def test_teacher_distillation_simulator(emu_modules):
+    _teacher_case("cpu")
+
+
+@pytest.mark.gpu
+def test_teacher_distillation_gpu(hip):
+    _teacher_case("cuda")
+
+
 @pytest.mark.gpu
 def test_wrapper_options_gpu(hip):
     _wrapper_options("cuda")
