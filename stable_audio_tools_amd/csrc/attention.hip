@@ -255,7 +255,20 @@ SAT_DEVICE float sat_att_halfmax(float x) {
 
 // one 64-key tile (NKB = 2) or its first 32 keys (NKB = 1): x = K (Q c)^T - mb, P = exp2(x), O^T += V^T P^T.
 // FIRST: the wave's first tile — mb is not known yet: C = 0 and the true row max is taken.
-template <int NP, int NKB, bool MASK, bool FIRST>
+// acc + the two bf16 of a packed word (v_dot2c_f32_bf16 against (1, 1)): the row sum of P taken from the ROUNDED probabilities — the values
+// the P V product multiplies — at one instruction per two scores
+SAT_DEVICE float sat_att_sum2(uint32_t w, float acc) {
+#if defined(SAT_HIPEMU)
+    return acc + sat_bf16_to_f32((short)(w & 0xffffu)) + sat_bf16_to_f32((short)(w >> 16));
+#else
+    typedef __bf16 sat_b2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sat_b2, w), __builtin_bit_cast(sat_b2, 0x3f803f80u), acc, false);
+#endif
+}
+
+// DOT2 (bf16 planes only; the lean forward kernel below): P is packed to bf16 BEFORE the row sum, which then runs on sat_att_sum2 over
+// the packed words — 16 instructions per 64-key tile instead of 32 adds; the normaliser is the sum of the rounded probabilities.
+template <int NP, int NKB, bool MASK, bool FIRST, bool DOT2 = false>
 SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW], const bf16x8 (&qf)[4][NP],
                                   f32x16 (&oacc)[2], f32x16& negm, float& mb, float& l_run, int l31, int hi, int kperm, int nvalid) {
     f32x16 sacc[NKB];
@@ -289,7 +302,9 @@ SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short 
             }
         return sat_att_halfmax(tmax);
     };
+    static_assert(!DOT2 || NP == 1, "the packed row sum needs single-plane (bf16) probabilities");
     float ps0 = 0.0f, ps1 = 0.0f;
+    bf16x8 pbs[DOT2 ? NKB : 1][2];      // DOT2: the tile's packed probabilities (the B operands of the P V MFMAs)
     auto expsum = [&]() {
         ps0 = 0.0f;
         ps1 = 0.0f;
@@ -303,11 +318,28 @@ SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short 
                     if (key >= nvalid) a = 0.0f;
                     if (key + 1 >= nvalid) c = 0.0f;
                 }
-                ps0 += a;
-                ps1 += c;
+                if (!DOT2) {
+                    ps0 += a;
+                    ps1 += c;
+                }
                 sacc[kb][2 * j] = a;
                 sacc[kb][2 * j + 1] = c;
             }
+        if (DOT2) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 one[NP];
+                    sat_att_pack<NP>(sacc[kb], u, one);
+                    pbs[DOT2 ? kb : 0][u] = one[0];
+                    const u32x4 w = __builtin_bit_cast(u32x4, one[0]);
+                    ps0 = sat_att_sum2(w[0], ps0);
+                    ps1 = sat_att_sum2(w[1], ps1);
+                    ps0 = sat_att_sum2(w[2], ps0);
+                    ps1 = sat_att_sum2(w[3], ps1);
+                }
+        }
     };
     qk();
     if (FIRST) {
@@ -347,7 +379,8 @@ SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             bf16x8 pb[NP];
-            sat_att_pack<NP>(sacc[kb], u, pb);
+            if (DOT2) pb[0] = pbs[DOT2 ? kb : 0][u];
+            else sat_att_pack<NP>(sacc[kb], u, pb);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 va[NP];
@@ -490,6 +523,159 @@ sat_attn_fwd_kernel(SatAttnParams p) {
                 else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
             }
         // natural-log LSE of the scaled scores: (mb + log2 l) ln 2   (mb lives in the exp2 domain)
+        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LEAN variant of the bf16 forward (sat_attention_fwd with SAT_ATTN_LEAN=1) — round 4, last session: built and checked on the simulator
+// and in the ISA, NOT yet timed on an MI355X (the round's GPU budget was spent): off by default, an A/B arm for the next measurement.
+// The SQ counters put the forward's time in the SIMD's issue slots (183 instructions per 64-key tile and wave: 16 MFMA, 32 v_exp, 34 adds,
+// 16 converts, 16 + 4 LDS, 4 global loads, 16 address VALU, ~44 scalar), so this variant removes instructions and changes nothing else:
+//   * row sums from the packed probabilities (sat_att_sum2: 16 v_dot2c_f32_bf16 instead of 32 + 2 v_add_f32) — tile function, DOT2;
+//   * K / V^T tile loads through raw buffer descriptors: per-lane 32-bit byte offset computed once + a scalar tile offset (the product
+//     kernel carries four 64-bit per-lane pointers: eight v_lshl_add_u64 per tile).
+// Numerics: the normaliser is the sum of the bf16-ROUNDED probabilities (what P V multiplies) instead of the fp32 ones: the output is
+// normalised consistently; the LSE moves by <= 2^-9 / sqrt(keys) relative in l (tests/test_dit_kernels.py runs both arms).
+// ---------------------------------------------------------------------------------------------
+// 16-byte load through a raw buffer descriptor: address = descriptor base + per-lane VGPR byte offset + scalar byte offset — the
+// per-tile address arithmetic is one scalar add (buffer_load_dwordx4 v, voff, s[rsrc], soff offen)
+#if defined(SAT_HIPEMU)
+struct SatBuf { const char* base; };
+SAT_DEVICE SatBuf sat_buf_make(const void* p) { return SatBuf{(const char*)p}; }
+SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const bf16x8*>(b.base + voff + soff); }
+#else
+typedef __amdgpu_buffer_rsrc_t SatBuf;
+SAT_DEVICE SatBuf sat_buf_make(const void* p) {      // raw buffer: stride 0, 2 GiB - 1 bytes, gfx9 untyped dword3 (0x00020000)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0));
+}
+#endif
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(3)))
+#endif
+sat_attn_fwd_lean_kernel(SatAttnParams p) {
+    constexpr int NP = 1;
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];   // [buffer][plane][key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][plane][d][key]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = sat_att_kperm(l31);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_in = qrow < p.Nqp;
+    const bool q_ok = qrow < p.Nq;
+    const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[4][NP];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 w = u32x4{0u, 0u, 0u, 0u};
+        if (q_in) w = *reinterpret_cast<const u32x4*>(p.q_rm[0] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float e0 = __builtin_bit_cast(float, w[j] << 16), e1 = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+            w[j] = sat_cvt2_pk(e0 * sl2, e1 * sl2);
+        }
+        qf[s][0] = __builtin_bit_cast(bf16x8, w);
+    }
+
+    f32x16 oacc[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        oacc[0][r] = 0.0f;
+        oacc[1][r] = 0.0f;
+        negm[r] = 0.0f;
+    }
+    float mb = 0.0f, l_run = 0.0f;
+
+    // this thread's two 16-byte pieces of a tile: LDS (row, part) and the byte offsets from the tile's uniform base
+    int srow[2], spart[2];
+    unsigned kob[2], vob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        srow[j] = c >> 3;
+        spart[j] = c & 7;
+        kob[j] = (unsigned)(srow[j] * SAT_ATT_D + spart[j] * 8) * 2u;
+        vob[j] = ((unsigned)srow[j] * (unsigned)p.Nkp + (unsigned)spart[j] * 8u) * 2u;      // < 64 * Nkp * 2 bytes: Nkp < 2^24 keeps it in 32 bits
+    }
+    const SatBuf kbuf = sat_buf_make(p.k_rm[0] + kplane);      // this (batch item, kv head)'s K and V^T planes: scalar registers
+    const SatBuf vbuf = sat_buf_make(p.v_tr[0] + kplane);
+    bf16x8 kreg[2], vreg[2];
+    auto tile_load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            kreg[j] = sat_buf_load16(kbuf, kob[j], (unsigned)k0 * (SAT_ATT_D * 2));
+            vreg[j] = sat_buf_load16(vbuf, vob[j], (unsigned)k0 * 2u);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x8*>(&k_lds2[buf][0][srow[j]][spart[j] * 8]) = kreg[j];
+            *reinterpret_cast<bf16x8*>(&v_lds2[buf][0][srow[j]][spart[j] * 8]) = vreg[j];
+        }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
+    __syncthreads();
+    int buf = 0, k0 = 0;
+    if (p.Nk >= SAT_ATT_T) {      // the first full tile, peeled: it establishes the running max
+        if (SAT_ATT_T < p.Nk) {
+            tile_store(1);
+            if (2 * SAT_ATT_T < p.Nk) tile_load(2 * SAT_ATT_T);
+        }
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, true, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
+        __syncthreads();
+        k0 = SAT_ATT_T;
+        buf = 1;
+    }
+    // full tiles: ONE straight-line body (the accumulators keep their registers around the loop; an unrolled-by-two body with
+    // compile-time buffers was tried here: the register allocator copies and spills the accumulators at the merge points)
+    for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
+        if (k0 + SAT_ATT_T < p.Nk) {
+            tile_store(buf ^ 1);
+            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
+        }
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
+        __syncthreads();
+    }
+    if (k0 < p.Nk && w_ok) {                                     // the ragged last tile (fewer than 64 keys)
+        const int rem = p.Nk - k0;
+        if (k0 == 0) {
+            if (rem > 32) sat_attn_fwd_tile<NP, 2, true, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            else sat_attn_fwd_tile<NP, 1, true, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        } else if (rem > 32) {
+            sat_attn_fwd_tile<NP, 2, true, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        } else {
+            sat_attn_fwd_tile<NP, 1, true, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
+    if (q_ok) {
+        const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * SAT_ATT_D) + (long long)h * SAT_ATT_D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oacc[t][4 * g] * inv_l, oacc[t][4 * g + 1] * inv_l, oacc[t][4 * g + 2] * inv_l, oacc[t][4 * g + 3] * inv_l};
+                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                if (sizeof(T) == 4) *(f32x4*)((float*)p.o + idx) = v;
+                else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
+            }
         if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
@@ -857,7 +1043,11 @@ extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const sho
     p.q_rm[0] = q_hi; p.q_rm[1] = q_lo; p.k_rm[0] = k_hi; p.k_rm[1] = k_lo; p.v_tr[0] = vt_hi; p.v_tr[1] = vt_lo;
     p.o = o; p.lse = lse; p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
     dim3 grid(sat_cdiv(Nq, 128), H, B);
+    // SAT_ATTN_LEAN=1: the lean bf16 variant above (an unmeasured A/B arm: off by default); read at every call so that one process can
+    // time both arms
+    const char* lean = getenv("SAT_ATTN_LEAN");
     if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
+    else if (lean && lean[0] == '1' && Nkp < (1 << 24)) SAT_LAUNCH((sat_attn_fwd_lean_kernel<short>), grid, dim3(256), stream, p);
     else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_attention_fwd");
 }

@@ -163,6 +163,35 @@ def test_attention_gpu(hip, dtype):
         _attn_case(hip, "cuda", dtype, case, seed=22)
 
 
+# The LEAN arm of the bf16 forward (csrc/attention.hip sat_attn_fwd_lean_kernel, SAT_ATTN_LEAN=1: row sums from the packed probabilities,
+# tile loads through buffer descriptors) — an A/B variant that is off by default until it has been timed; same cases, same bars.  The
+# backward consumes the lean forward's output and LSE, so its gradients check the LSE too.
+def _lean_cases(ops, dev, cases, spiky):
+    import os
+    old = os.environ.get("SAT_ATTN_LEAN")
+    os.environ["SAT_ATTN_LEAN"] = "1"
+    try:
+        for case in cases:
+            _attn_case(ops, dev, torch.bfloat16, case, seed=22)
+        for case, seed, sp in spiky:
+            _attn_case(ops, dev, torch.bfloat16, case, seed=seed, spikes=sp)
+    finally:
+        if old is None:
+            del os.environ["SAT_ATTN_LEAN"]
+        else:
+            os.environ["SAT_ATTN_LEAN"] = old
+
+
+def test_attention_lean_sim(emu):
+    _lean_cases(emu, "cpu", ATT_CASES, [((1, 2, 2, 130, 193), 23, SPIKES), ((1, 4, 2, 70, 200), 24, SPIKES[:4])])
+
+
+@pytest.mark.gpu
+def test_attention_lean_gpu(hip):
+    _lean_cases(hip, "cuda", ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130), (1, 4, 4, 300, 6145)],
+                [((1, 2, 2, 130, 193), 23, SPIKES), ((2, 24, 24, 1025, 1025), 25, SPIKES + [(1000, 1024, 5.0), (1024, 3, 4.0)])])
+
+
 def _cfg_step_case(ops, dev):
     """sat_cfg_step vs the reference formulas (models/dit.py:400-410 + the v-DDIM update of inference/sampling.py:254-307)."""
     torch.manual_seed(3)
