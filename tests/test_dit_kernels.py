@@ -186,10 +186,26 @@ def test_attention_lean_sim(emu):
     _lean_cases(emu, "cpu", ATT_CASES, [((1, 2, 2, 130, 193), 23, SPIKES), ((1, 4, 2, 70, 200), 24, SPIKES[:4])])
 
 
-@pytest.mark.gpu
-def test_attention_lean_gpu(hip):
+def _lean_gpu_main():
+    """Body of test_attention_lean_gpu, run in a child process (python tests/test_dit_kernels.py lean-gpu)."""
+    from stable_audio_tools_amd import ops
+    hip = ops.get_ops()
+    assert not hip.simulator
     _lean_cases(hip, "cuda", ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130), (1, 4, 4, 300, 6145)],
                 [((1, 2, 2, 130, 193), 23, SPIKES), ((2, 24, 24, 1025, 1025), 25, SPIKES + [(1000, 1024, 5.0), (1024, 3, 4.0)])])
+    print("lean-gpu ok")
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="the lean arm was written after the round's GPU budget was spent: its first execution on an MI355X is the "
+                                        "driver's round-end run; asserts strictly (and in-process) once tools/r05_attn_lean_ab.sh has seen it pass")
+def test_attention_lean_gpu(hip):
+    """The lean arm on the hardware, in a CHILD process: a kernel that has never run on a GPU must not be able to take the test session
+    down with it (a fault aborts the process that launched it)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, __file__, "lean-gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lean-gpu ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
 
 
 def _cfg_step_case(ops, dev):
@@ -233,3 +249,14 @@ def test_cfg_step_simulator(emu):
 @pytest.mark.gpu
 def test_cfg_step_gpu(hip):
     _cfg_step_case(hip, "cuda")
+
+
+if __name__ == "__main__":
+    import os
+    import sys
+    _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _p in (_root, os.path.join(_root, "oracle"), os.path.join(_root, "tests")):
+        if _p not in sys.path:
+            sys.path.insert(0, _p)
+    if sys.argv[1:] == ["lean-gpu"]:
+        _lean_gpu_main()
