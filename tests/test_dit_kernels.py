@@ -202,9 +202,12 @@ def _lean_gpu_main():
 def test_attention_lean_gpu(hip):
     """The lean arm on the hardware, in a CHILD process: a kernel that has never run on a GPU must not be able to take the test session
     down with it (a fault aborts the process that launched it)."""
+    import os
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, __file__, "lean-gpu"], capture_output=True, text=True, timeout=600)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "oracle"), os.path.join(root, "tests"), os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, __file__, "lean-gpu"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "lean-gpu ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
 
 
