@@ -813,6 +813,152 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LEAN variant of the bf16 dQ kernel (sat_attention_bwd with SAT_ATTN_BWD_LEAN=1) — round 4, last session: simulator- and ISA-checked,
+// not yet timed (off by default; tools/r05_attn_lean_ab.sh).  The product kernel issues 605 instructions per 64-key tile and wave
+// for 24 MFMAs: 162 v_accvgpr_read / write (the register allocator parks values in AGPRs: no occupancy attribute, 142 VGPRs), 96 for a
+// per-element (key < Nk && q_ok) mask on EVERY tile, 160 of softmax / dS arithmetic (fma, exp, sub, 2 mul per score), 63 of address
+// arithmetic.  Here:
+//   * amdgpu_waves_per_eu(2, 2): the 55 KB of LDS allow two workgroups per CU anyway — 256 registers, nothing parked in AGPRs;
+//   * no mask on full tiles: a column of dS^T only feeds the same query's column of dQ^T (never stored for q >= Nq), and keys >= Nk
+//     multiply zero columns of K^T; the ragged last tile is peeled and masked;
+//   * Q pre-scaled by scale * log2(e) (as the forward: the probabilities are recomputed from the operands that produced the LSE), -lse
+//     (exp2 domain) and -D enter through the C operands of the S^T and dP^T MFMA chains: per score exp2, one multiply, half a convert;
+//     the factor `scale` of dS is applied to dQ once at the end;
+//   * K / V / K^T tile loads through buffer descriptors.
+// ---------------------------------------------------------------------------------------------
+template <bool MASK>
+SAT_DEVICE void sat_attn_dq_lean_tile(short (*k_lds)[SAT_ATT_ROW], short (*v_lds)[SAT_ATT_ROW], short (*kt_lds)[SAT_ATT_ROW],
+                                      const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const f32x16& negl, const f32x16& negd,
+                                      f32x16 (&dq)[2], int l31, int hi, int nvalid) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = sat_att_frag_rm(k_lds, kb * 32 + l31, 16 * s + 8 * hi);
+            const bf16x8 va = sat_att_frag_rm(v_lds, kb * 32 + l31, 16 * s + 8 * hi);
+            sacc = sat_mfma_32x32x16_bf16(ka, qf[s], s == 0 ? negl : sacc);      // x = K (Q c)^T - lse (exp2 domain)
+            pacc = sat_mfma_32x32x16_bf16(va, gf[s], s == 0 ? negd : pacc);      // dP^T - D
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pv = sat_exp2(sacc[r]);
+            if (MASK) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= nvalid) pv = 0.0f;
+            }
+            sacc[r] = pv * pacc[r];                                               // dS^T / scale
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 sb[1];
+            sat_att_pack<1>(sacc, u, sb);
+            const int kofs = kb * 32 + 16 * u + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dq[t] = sat_mfma_32x32x16_bf16(sat_att_frag_acc(kt_lds, t * 32 + l31, kofs), sb[0], dq[t]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sat_attn_bwd_dq_lean_kernel(SatAttnParams p) {
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][SAT_ATT_T][SAT_ATT_ROW];    // [buffer][key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][SAT_ATT_T][SAT_ATT_ROW];    // [buffer][key][d]
+    __shared__ __attribute__((aligned(16))) short kt_lds2[2][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][d][key]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_in = qrow < p.Nqp, q_ok = qrow < p.Nq;
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+    const float l2e = 1.4426950408889634f;
+    const float sl2 = p.scale * l2e;
+
+    bf16x8 qf[4], gf[4];   // Q (pre-scaled) and dO fragments (d = 16 s + 8 hi + e)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 w = u32x4{0u, 0u, 0u, 0u}, g = u32x4{0u, 0u, 0u, 0u};
+        if (q_in) {
+            w = *reinterpret_cast<const u32x4*>(p.q_rm[0] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+            g = *reinterpret_cast<const u32x4*>(p.do_rm[0] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float e0 = __builtin_bit_cast(float, w[j] << 16), e1 = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+            w[j] = sat_cvt2_pk(e0 * sl2, e1 * sl2);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, w);
+        gf[s] = __builtin_bit_cast(bf16x8, g);
+    }
+    const float lse2 = q_ok ? p.lse[((long long)b * p.H + h) * p.Nq + qrow] * l2e : 0.0f;
+    const float dsum = q_ok ? p.dsum[((long long)b * p.H + h) * p.Nq + qrow] : 0.0f;
+    f32x16 negl, negd, dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        negl[r] = -lse2;
+        negd[r] = -dsum;
+        dq[0][r] = 0.0f;
+        dq[1][r] = 0.0f;
+    }
+
+    int srow[2], spart[2];
+    unsigned rmo[2], tro[2];      // byte offsets of this thread's two pieces in a row-major / a transposed tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        srow[j] = c >> 3;
+        spart[j] = c & 7;
+        rmo[j] = (unsigned)(srow[j] * SAT_ATT_D + spart[j] * 8) * 2u;
+        tro[j] = ((unsigned)srow[j] * (unsigned)p.Nkp + (unsigned)spart[j] * 8u) * 2u;
+    }
+    const SatBuf kbuf = sat_buf_make(p.k_rm[0] + kplane), vbuf = sat_buf_make(p.v_rm[0] + kplane), ktbuf = sat_buf_make(p.k_tr[0] + kplane);
+    bf16x8 rk[2], rv[2], rkt[2];
+    auto tile_load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            rk[j] = sat_buf_load16(kbuf, rmo[j], (unsigned)k0 * (SAT_ATT_D * 2));
+            rv[j] = sat_buf_load16(vbuf, rmo[j], (unsigned)k0 * (SAT_ATT_D * 2));
+            rkt[j] = sat_buf_load16(ktbuf, tro[j], (unsigned)k0 * 2u);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x8*>(&k_lds2[buf][srow[j]][spart[j] * 8]) = rk[j];
+            *reinterpret_cast<bf16x8*>(&v_lds2[buf][srow[j]][spart[j] * 8]) = rv[j];
+            *reinterpret_cast<bf16x8*>(&kt_lds2[buf][srow[j]][spart[j] * 8]) = rkt[j];
+        }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
+    __syncthreads();
+    int buf = 0, k0 = 0;
+    for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {      // full tiles: one straight-line body
+        if (k0 + SAT_ATT_T < p.Nk) {
+            tile_store(buf ^ 1);
+            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
+        }
+        sat_attn_dq_lean_tile<false>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, SAT_ATT_T);
+        __syncthreads();
+    }
+    if (k0 < p.Nk) sat_attn_dq_lean_tile<true>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, p.Nk - k0);
+    if (q_ok) {
+        const long long obase = (((long long)b * p.H + h) * p.Nq + qrow) * SAT_ATT_D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) SatOut<T>::put(p.dq, obase + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, dq[t][r] * p.scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, part 2: dK, dV.  Wave owns 32 KEYS (columns); loops over the query heads of its kv group
 // and over 64-query tiles.
 //   S = Q K^T (rows q, cols key) ; P = exp(S*scale - lse[q]) ; dV^T += dO^T P ; dP = dO V^T ;
@@ -1079,7 +1225,10 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
         SAT_LAUNCH((sat_attn_bwd_dq_kernel<float, 2>), g1, dim3(256), stream, p);
         SAT_LAUNCH((sat_attn_bwd_dkv_kernel<float, 2, 32>), g2, dim3(256), stream, p);
     } else {
-        SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
+        // SAT_ATTN_BWD_LEAN=1: the lean bf16 dQ kernel above (an unmeasured A/B arm: off by default)
+        const char* lean = getenv("SAT_ATTN_BWD_LEAN");
+        if (lean && lean[0] == '1' && Nkp < (1 << 24)) SAT_LAUNCH((sat_attn_bwd_dq_lean_kernel<short>), g1, dim3(256), stream, p);
+        else SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
         SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);
     }
     return sat_check_launch("sat_attention_bwd");

@@ -167,19 +167,25 @@ def test_attention_gpu(hip, dtype):
 # tile loads through buffer descriptors) — an A/B variant that is off by default until it has been timed; same cases, same bars.  The
 # backward consumes the lean forward's output and LSE, so its gradients check the LSE too.
 def _lean_cases(ops, dev, cases, spiky):
+    """Every case with the lean forward alone, the lean backward (SAT_ATTN_BWD_LEAN=1: the dQ kernel without AGPR parking, per-tile masks
+    or per-score scaling) alone, and both."""
     import os
-    old = os.environ.get("SAT_ATTN_LEAN")
-    os.environ["SAT_ATTN_LEAN"] = "1"
+    names = ("SAT_ATTN_LEAN", "SAT_ATTN_BWD_LEAN")
+    old = {n: os.environ.get(n) for n in names}
     try:
-        for case in cases:
-            _attn_case(ops, dev, torch.bfloat16, case, seed=22)
-        for case, seed, sp in spiky:
-            _attn_case(ops, dev, torch.bfloat16, case, seed=seed, spikes=sp)
+        for arm in (("1", "0"), ("0", "1"), ("1", "1")):
+            for n, v in zip(names, arm):
+                os.environ[n] = v
+            for case in cases:
+                _attn_case(ops, dev, torch.bfloat16, case, seed=22)
+            for case, seed, sp in spiky:
+                _attn_case(ops, dev, torch.bfloat16, case, seed=seed, spikes=sp)
     finally:
-        if old is None:
-            del os.environ["SAT_ATTN_LEAN"]
-        else:
-            os.environ["SAT_ATTN_LEAN"] = old
+        for n, v in old.items():
+            if v is None:
+                os.environ.pop(n, None)
+            else:
+                os.environ[n] = v
 
 
 def test_attention_lean_sim(emu):
