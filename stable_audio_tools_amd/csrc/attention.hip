@@ -1148,6 +1148,198 @@ sat_attn_bwd_dkv_kernel(SatAttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LEAN variant of the bf16 dK / dV kernel (SAT_ATTN_BWD_LEAN=1, with the lean dQ kernel above; same status: simulator- and ISA-checked,
+// unmeasured, off by default).  The product kernel issues ~700 instructions per 64-query tile and wave for 32 MFMAs: 192 of them a
+// BRANCHING per-element mask (v_cmp, s_and, s_and_saveexec, s_cbranch_execz, v_mov, s_or per score), 64 ds_read_b32 + as many waits for
+// the per-row lse / D broadcasts, 5 VALU per score of softmax / dS arithmetic.  Here:
+//   * no masks.  PRECONDITION (what sat_attn_prepare writes): rows [N, Np) of every operand plane are ZERO.  Then a query row
+//     q >= Nq has S = 0, dP = 0, and — its staged -lse and -D being 0 — P = 1, dS = 0: it adds exactly 0 * 1 to dV^T (dO^T is zero
+//     there) and Q^T * 0 to dK^T; a key column >= Nk is never stored;
+//   * the staged -lse (exp2 domain) and -D of a 32-query block are read as FOUR 16-byte LDS reads each; -D enters the dP MFMA chain as its
+//     C operand, -lse the one fma per score that scales the product in fp32 (pre-scaling K here was tried: with the forward's LSE built
+//     from a pre-scaled Q the two roundings disagree by |s| 2^-9 in the exponent — 3 % on the spike cases — so the arithmetic of the
+//     product kernel is kept): per score fma, exp2, one multiply and two half-converts; `scale` of dS is applied to dK once at the end;
+//   * Q / dO / Q^T / dO^T tile loads through buffer descriptors (one per plane for the whole kernel; head and tile enter as a scalar offset).
+// ---------------------------------------------------------------------------------------------
+// four 4-vectors -> one 16-register block (registers 4 g + e = v_g[e]) without element-wise copies
+SAT_DEVICE f32x16 sat_att_cat4(f32x4 v0, f32x4 v1, f32x4 v2, f32x4 v3) {
+#if defined(SAT_HIPEMU)
+    f32x16 o;
+    for (int e = 0; e < 4; ++e) {
+        o[e] = v0[e];
+        o[4 + e] = v1[e];
+        o[8 + e] = v2[e];
+        o[12 + e] = v3[e];
+    }
+    return o;
+#else
+    typedef float sat_f8v __attribute__((ext_vector_type(8)));
+    const sat_f8v lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#endif
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sat_attn_bwd_dkv_lean_kernel(SatAttnParams p) {
+    constexpr int TQ = 64, TROW = TQ + 8;
+    __shared__ __attribute__((aligned(16))) short q_lds2[2][TQ][SAT_ATT_ROW];      // [buffer][q][d]
+    __shared__ __attribute__((aligned(16))) short g_lds2[2][TQ][SAT_ATT_ROW];      // dO [q][d]
+    __shared__ __attribute__((aligned(16))) short qt_lds2[2][SAT_ATT_D][TROW];     // [d][q]
+    __shared__ __attribute__((aligned(16))) short gt_lds2[2][SAT_ATT_D][TROW];     // dO^T [d][q]
+    __shared__ __attribute__((aligned(16))) float nl_lds2[2][TQ], nd_lds2[2][TQ];  // -lse * log2(e), -D of the tile's queries
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, hk = blockIdx.y;
+    const int group = p.H / p.Hkv;
+    const int krow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool k_in = krow < p.Nkp, k_ok = krow < p.Nk;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+    const float l2e = 1.4426950408889634f;
+    const float sl2 = p.scale * l2e;
+
+    bf16x8 kf[4], vf[4];   // K and V fragments of this wave's keys (d = 16 s + 8 hi + e)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 w = u32x4{0u, 0u, 0u, 0u}, v = u32x4{0u, 0u, 0u, 0u};
+        if (k_in) {
+            w = *reinterpret_cast<const u32x4*>(p.k_rm[0] + kplane + (size_t)krow * SAT_ATT_D + 16 * s + 8 * hi);
+            v = *reinterpret_cast<const u32x4*>(p.v_rm[0] + kplane + (size_t)krow * SAT_ATT_D + 16 * s + 8 * hi);
+        }
+        kf[s] = __builtin_bit_cast(bf16x8, w);
+        vf[s] = __builtin_bit_cast(bf16x8, v);
+    }
+    f32x16 dk[2], dv[2];   // dK^T / scale, dV^T: rows d, cols key
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dk[t][r] = 0.0f;
+            dv[t][r] = 0.0f;
+        }
+
+    // this thread's two 16-byte pieces of a row-major [64][64] tile and of a transposed [64][64] tile
+    int rrow[2], rpart[2];
+    unsigned rmo[2], tro[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        rrow[j] = c >> 3;
+        rpart[j] = c & 7;
+        rmo[j] = (unsigned)(rrow[j] * SAT_ATT_D + rpart[j] * 8) * 2u;
+        tro[j] = ((unsigned)rrow[j] * (unsigned)p.Nqp + (unsigned)rpart[j] * 8u) * 2u;
+    }
+    // one descriptor per plane, based at this (batch item, kv group)'s first query head; head hg and tile q0 enter as a scalar offset
+    const size_t gplane = ((size_t)b * p.H + (size_t)hk * group) * (size_t)p.Nqp * SAT_ATT_D;
+    const SatBuf qbuf = sat_buf_make(p.q_rm[0] + gplane), gbuf = sat_buf_make(p.do_rm[0] + gplane);
+    const SatBuf qtbuf = sat_buf_make(p.q_tr[0] + gplane), gtbuf = sat_buf_make(p.do_tr[0] + gplane);
+    bf16x8 rq[2], rg[2], rqt[2], rgt[2];
+    float r_nl = 0.0f, r_nd = 0.0f;
+    const int nqt = (p.Nq + TQ - 1) / TQ, ntiles = group * nqt;
+    auto tile_load = [&](int it) {
+        const int hg = it / nqt, q0 = (it - hg * nqt) * TQ;
+        const unsigned hoff = (unsigned)hg * (unsigned)p.Nqp * (SAT_ATT_D * 2u);      // bytes: < group * Nqp * 128
+        const unsigned so_rm = hoff + (unsigned)q0 * (SAT_ATT_D * 2u), so_tr = hoff + (unsigned)q0 * 2u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            rq[j] = sat_buf_load16(qbuf, rmo[j], so_rm);
+            rg[j] = sat_buf_load16(gbuf, rmo[j], so_rm);
+            rqt[j] = sat_buf_load16(qtbuf, tro[j], so_tr);
+            rgt[j] = sat_buf_load16(gtbuf, tro[j], so_tr);
+        }
+        if (threadIdx.x < TQ) {
+            const int q = q0 + threadIdx.x;
+            const bool ok = q < p.Nq;
+            const long long i = ((long long)b * p.H + (hk * group + hg)) * p.Nq + q;
+            r_nl = ok ? -p.lse[i] * l2e : 0.0f;
+            r_nd = ok ? -p.dsum[i] : 0.0f;
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x8*>(&q_lds2[buf][rrow[j]][rpart[j] * 8]) = rq[j];
+            *reinterpret_cast<bf16x8*>(&g_lds2[buf][rrow[j]][rpart[j] * 8]) = rg[j];
+            *reinterpret_cast<bf16x8*>(&qt_lds2[buf][rrow[j]][rpart[j] * 8]) = rqt[j];
+            *reinterpret_cast<bf16x8*>(&gt_lds2[buf][rrow[j]][rpart[j] * 8]) = rgt[j];
+        }
+        if (threadIdx.x < TQ) {
+            nl_lds2[buf][threadIdx.x] = r_nl;
+            nd_lds2[buf][threadIdx.x] = r_nd;
+        }
+    };
+
+    tile_load(0);
+    tile_store(0);
+    if (ntiles > 1) tile_load(1);
+    __syncthreads();
+    for (int it = 0, buf = 0; it < ntiles; ++it, buf ^= 1) {
+        short (*q_lds)[SAT_ATT_ROW] = q_lds2[buf];
+        short (*g_lds)[SAT_ATT_ROW] = g_lds2[buf];
+        short (*qt_lds)[TROW] = qt_lds2[buf];
+        short (*gt_lds)[TROW] = gt_lds2[buf];
+        const float* nl_lds = nl_lds2[buf];
+        const float* nd_lds = nd_lds2[buf];
+        if (it + 1 < ntiles) {
+            tile_store(buf ^ 1);
+            if (it + 2 < ntiles) tile_load(it + 2);
+        }
+#pragma unroll
+        for (int qb = 0; qb < TQ / 32; ++qb) {
+            // register r = 4 g + e of an accumulator is query row qb * 32 + 8 g + 4 hi + e: four consecutive floats per g
+            f32x4 a4[4], c4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a4[g] = *reinterpret_cast<const f32x4*>(&nl_lds[qb * 32 + 8 * g + 4 * hi]);
+                c4[g] = *reinterpret_cast<const f32x4*>(&nd_lds[qb * 32 + 8 * g + 4 * hi]);
+            }
+            const f32x16 nl = sat_att_cat4(a4[0], a4[1], a4[2], a4[3]);
+            f32x16 pacc = sat_att_cat4(c4[0], c4[1], c4[2], c4[3]);
+            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            f32x16 sacc;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = sat_mfma_32x32x16_bf16(sat_att_frag_rm(q_lds, qb * 32 + l31, 16 * s + 8 * hi), kf[s], s == 0 ? zero : sacc);   // S[q][key]
+                pacc = sat_mfma_32x32x16_bf16(sat_att_frag_rm(g_lds, qb * 32 + l31, 16 * s + 8 * hi), vf[s], pacc);                   // dP[q][key] - D
+            }
+            f32x16 pr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = sat_exp2(fmaf(sacc[r], sl2, nl[r]));       // the product kernel's arithmetic: fp32 scaling of the unscaled product
+                sacc[r] = pr[r] * pacc[r];                          // dS[q][key] / scale
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 pb[1], sb[1];
+                sat_att_pack<1>(pr, u, pb);
+                sat_att_pack<1>(sacc, u, sb);
+                const int qofs = qb * 32 + 16 * u + 4 * hi;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    dv[t] = sat_mfma_32x32x16_bf16(sat_att_frag_acc(gt_lds, t * 32 + l31, qofs), pb[0], dv[t]);
+                    dk[t] = sat_mfma_32x32x16_bf16(sat_att_frag_acc(qt_lds, t * 32 + l31, qofs), sb[0], dk[t]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (k_ok) {
+        const long long obase = (((long long)b * p.Hkv + hk) * p.Nk + krow) * SAT_ATT_D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                SatOut<T>::put(p.dk, obase + d, dk[t][r] * p.scale);
+                SatOut<T>::put(p.dv, obase + d, dv[t][r]);
+            }
+    }
+}
+
 // D[b][h][q] = sum_d dO[b][q][h*64+d] * O[b][q][h*64+d]    (both (B, Nq, H*64), model dtype)
 struct SatRowdotParams {
     const void* a;
@@ -1229,7 +1421,8 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
         const char* lean = getenv("SAT_ATTN_BWD_LEAN");
         if (lean && lean[0] == '1' && Nkp < (1 << 24)) SAT_LAUNCH((sat_attn_bwd_dq_lean_kernel<short>), g1, dim3(256), stream, p);
         else SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
-        SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);
+        if (lean && lean[0] == '1' && Nqp < (1 << 24) / (H / Hkv)) SAT_LAUNCH((sat_attn_bwd_dkv_lean_kernel<short>), g2, dim3(256), stream, p);
+        else SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);
     }
     return sat_check_launch("sat_attention_bwd");
 }

@@ -2,7 +2,7 @@
 # Round-5 opener: the LEAN arm of the bf16 attention forward (csrc/attention.hip sat_attn_fwd_lean_kernel, SAT_ATTN_LEAN=1 — written and
 # simulator-checked at the end of round 4 without GPU minutes left) against the product kernel, A / B / A / B in ONE call:
 #   tests (both arms), the kernel alone (tools/attn_bench.py: N = 1025 self / cross, B = 8, N = 6145), the sampler and the long-context sampler.
-# ~4 GPU-minutes.  Output: gpurun_out/r05_attn_lean/.  If the lean arm wins: make it the default in sat_attention_fwd (SAT_ATTN_LEAN=0 to
+# ~6 GPU-minutes.  Output: gpurun_out/r05_attn_lean/.  If the lean arm wins: make it the default in sat_attention_fwd (SAT_ATTN_LEAN=0 to
 # switch back), drop the xfail-free GPU test's env juggling, record both arms in profiles/r05_experiments/attn_lean/.
 set -u
 R=$(pwd)
@@ -19,16 +19,21 @@ for i in 1 2; do
 done
 SAT_ATTN_LEAN=0 timeout 300 python bench.py --workload long_context --no-cpu-baseline >> $OUT/long_context_product.json 2>> $OUT/lc.err
 SAT_ATTN_LEAN=1 timeout 300 python bench.py --workload long_context --no-cpu-baseline >> $OUT/long_context_lean.json 2>> $OUT/lc.err
+# the backward arms (SAT_ATTN_BWD_LEAN=1: lean dQ and dK/dV kernels) in the DiT train step: roofline.backward carries the kernels' own time
+for i in 1 2; do
+  SAT_ATTN_LEAN=0 SAT_ATTN_BWD_LEAN=0 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_product.json 2>> $OUT/dt.err
+  SAT_ATTN_LEAN=1 SAT_ATTN_BWD_LEAN=1 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_lean.json 2>> $OUT/dt.err
+done
 tail -3 $OUT/tests.log
 echo "--- product"; cat $OUT/attn_product.jsonl; echo "--- lean"; cat $OUT/attn_lean.jsonl
 python - <<PY
 import json, glob
-for f in sorted(glob.glob("$OUT/dit_sample_*.json") + glob.glob("$OUT/long_context_*.json")):
+for f in sorted(glob.glob("$OUT/dit_sample_*.json") + glob.glob("$OUT/long_context_*.json") + glob.glob("$OUT/dit_train_*.json")):
     for l in open(f):
         try:
             r = json.loads(l)
         except Exception:
             continue
         a = (r.get("roofline") or r.get("long_context", {}).get("attention") or {})
-        print(f.split('/')[-1], round(r["value"], 2), r["unit"], "attention frac", a.get("frac"))
+        print(f.split('/')[-1], round(r["value"], 2), r["unit"], "attention frac", a.get("frac"), "backward", (r.get("roofline") or {}).get("backward"))
 PY
