@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
 //     two stages the wait would have to sit in the interval of the request: NST >= 3.
 //   * 1-KiB pieces p = wave + 8 q of the stage image [A tile | B tile]; (BM + BN) / 8 pieces: when that is 4 mod 8 the waves of
 //     group 0 carry one piece more (their counted waits differ by that piece).
-template <int BN, int R0, int R1, int NST, int EPI, bool F32OUT, bool FP8>
+template <int BN, int R0, int R1, int NST, int EPI, bool F32OUT, bool FP8, bool LEANK = false>
 __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     constexpr int WC = BN / 64, WRG = 4 / WC;
     constexpr int BM = WRG * (R0 + R1);
@@ -872,6 +872,92 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     const int frow = lane & 31, fkc = lane >> 5;
     // 16-byte k-chunk of fragment register q: bf16 — k-sub-step q, half fkc; fp8 — MX MFMA u = q >> 1 takes the 32 bytes at 64 u + 32 fkc
     auto kchunk = [&](int q) { return FP8 ? (q >> 1) * 4 + fkc * 2 + (q & 1) : q * 2 + fkc; };
+    if constexpr (LEANK) {
+        // LEAN K loop (SAT_GEMM_LEAN=1; round 4, last session: simulator- and ISA-checked, NOT timed — off by default).  The loop below
+        // issues 374 instructions per K-step for the 24 MFMAs of a 96-row wave (ISA of the 160 x 256 tile): ring slots by `t % NST`
+        // (mul_hi sequences), fragment addresses rebuilt per row block, a branch per (row block, k-sub-step) for `i < nb && i * 32 < mv`,
+        // group-dependent piece and wait counts decided at run time, end-of-loop conditions in every step — and at one instruction per
+        // four cycles and wave that is what bounds the read intervals (2 x ~700 instructions x 4 = the ~2700 cycles per K-step the cost
+        // model fitted; the matrix pipe needs 1280).  Here the SAME sequence of operations per wave and K-step — fragment reads, request of
+        // tile t + LOOK, counted wait, lgkmcnt(0), barrier, MFMAs, barrier: the hazard argument above is unchanged — is specialised at
+        // compile time on (group, all row blocks active), the staged steps are split from the <= LOOK steps that stage nothing, the ring
+        // slots rotate in scalar registers and every fragment address is one of eight per-lane bases + slot + an immediate.
+        static_assert(!FP8, "the lean K loop is written for the bf16 MFMA");
+        int nact = (mv + 31) >> 5;
+        nact = nact < 0 ? 0 : (nact > nb ? nb : nact);          // this wave's active row blocks (wave-uniform)
+        const int sw = (frow >> 1) & 7;                         // the same swizzle for every row block of a lane (blocks start at multiples of 32 rows)
+        int ao[4], bo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = ((q * 2 + fkc) ^ sw) << 4;
+            ao[q] = (arow + frow) * 128 + o;
+            bo[q] = ABYTES + (wc * 64 + frow) * 128 + o;
+        }
+        auto kloop = [&](auto gc, auto fullc) __attribute__((always_inline)) {
+            constexpr int G = decltype(gc)::value;
+            constexpr bool FULL = decltype(fullc)::value != 0;
+            constexpr int NBG = G ? NB1 : NB0, QG = G ? QLO : QHI;
+            int slot = 0, sslot = LOOK % NST, k0s = kbeg + LOOK * 64;
+            auto kstep = [&](auto stagec, int tail_wait) __attribute__((always_inline)) {
+                constexpr bool STAGE_IT = decltype(stagec)::value != 0;
+                const char* As = smem + slot * STAGE;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bfr[j][q] = *(const bf16x8*)(As + bo[q] + j * 4096);
+#pragma unroll
+                for (int i = 0; i < NBG; ++i) {
+                    if (FULL || i < nact) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) afr[i][q] = *(const bf16x8*)(As + ao[q] + i * 4096);
+                    }
+                }
+                if constexpr (STAGE_IT) {
+                    char* sd = smem + sslot * STAGE;
+                    if (k0s + 64 <= kend) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) sat_glds16(src[q] + (long long)k0s * 2, sd + (wave + 8 * q) * 1024);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) {
+                            const int piece = wave + 8 * q;
+                            if (piece < PA) sat_gemm_stage_piece<false>(p.A, p.lda, m0, p.M, k0s, kend, sd, p.zeros, piece, lane, 0, 0);
+                            else sat_gemm_stage_piece<GLU>(p.B, p.ldb, n0, p.N, k0s, kend, sd + ABYTES, p.zeros, piece - PA, lane, glu_f, glu_tile0);
+                        }
+                    }
+                    SAT_WAIT_VMCNT((LOOK - 1) * QG);            // tiles t + 2 .. t + LOOK stay in flight: tile t + 1 is complete
+                } else {
+                    if (tail_wait) { SAT_WAIT_VMCNT(QG); } else { SAT_WAIT_VMCNT(0); }
+                }
+                SAT_WAIT_LGKM0();
+                SAT_RAW_BARRIER();
+                SAT_SCHED_FENCE();
+                SAT_SETPRIO(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < NBG; ++i) {
+                        if (FULL || i < nact) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[i][j]);
+                        }
+                    }
+                }
+                SAT_SETPRIO(0);
+                SAT_SCHED_FENCE();
+                SAT_RAW_BARRIER();
+                slot = slot + 1 == NST ? 0 : slot + 1;
+                sslot = sslot + 1 == NST ? 0 : sslot + 1;
+                k0s += 64;
+            };
+            int t = 0;
+            for (; t + LOOK < nk; ++t) kstep(std::integral_constant<int, 1>{}, 0);                 // steps that request tile t + LOOK
+            for (; t < nk; ++t) kstep(std::integral_constant<int, 0>{}, (LOOK == 3 && t + 2 < nk) ? 1 : 0);   // the last <= LOOK steps
+        };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        if (grp == 0) { if (nact == NB0) kloop(C0{}, C1{}); else kloop(C0{}, C0{}); }
+        else { if (nact == NB1) kloop(C1{}, C1{}); else kloop(C1{}, C0{}); }
+    } else
     for (int t = 0; t < nk; ++t) {
         const char* As = smem + (t % NST) * STAGE;
         const char* Bs = As + ABYTES;
@@ -965,15 +1051,22 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     }
 }
 
-template <int BN, int R0, int R1, int NST>
+template <int BN, int R0, int R1, int NST, bool WITH_LEAN = false>
 static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, bool fp8 = false) {
     constexpr int BM = (4 / (BN / 64)) * (R0 + R1);
     p.ntm = sat_cdiv(p.M, BM);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
+    // SAT_GEMM_LEAN=1: the lean K loop of sat_gemm8_kernel (bf16, the shipped tiles 7 and 8; an unmeasured A/B arm: off by default)
+    const char* lean_env = getenv("SAT_GEMM_LEAN");
+    const bool lean = WITH_LEAN && !fp8 && lean_env && lean_env[0] == '1';
 #define SAT_GEMM8_CASE(E, F)                                                                         \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
         if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
+        else if constexpr (WITH_LEAN) {                                                              \
+            if (lean) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false, true>), grid, block, stream, p); }   \
+            else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }  \
+        }                                                                                            \
         else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }      \
         return sat_check_launch("sat_gemm (eight-wave ring)");                                       \
     }
@@ -1051,8 +1144,8 @@ static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, 
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
     if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 2);      // (A/B: WITH the L2 touch prefetch: measured -6 % in the sampler)
     if (tile == 6) return sat_gemm8_launch<256, 64, 64, 3>(p, epi, f32out, splits, stream);
-    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, splits, stream);
-    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, splits, stream);
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3, true>(p, epi, f32out, splits, stream);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4, true>(p, epi, f32out, splits, stream);
     if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
     if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
