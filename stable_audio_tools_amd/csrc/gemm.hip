@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 // FP8 (round 4): the stage image is the same (128-byte rows = 128 fp8 k-values, K-step = 128 of them); a wave's four 16-byte fragment
 // registers per row block are then the operands of TWO MX MFMAs (32 x 32 x 64, twice the bf16 rate): the matrix time per stage byte,
 // the DMA and the LDS traffic per interval are those of the bf16 kernel.
-template <int EPI, bool F32OUT, int TOUCH = 0, bool FP8 = false>
+template <int EPI, bool F32OUT, int TOUCH = 0, bool FP8 = false, bool LEANK = false>
 __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
@@ -712,6 +712,63 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         SAT_SCHED_FENCE();
         SAT_RAW_BARRIER();
     };
+    bool lean_done = false;
+    if constexpr (LEANK) {
+        // LEAN K loop (SAT_GEMM_LEAN=1; see sat_gemm8_kernel's: same idea, same status — simulator- and ISA-checked, unmeasured, off by
+        // default).  318 instructions per K-step and wave for 32 MFMAs in the loop below: per-phase `on0 / on1` conditions around the
+        // fragment reads and around every k-sub-step's MFMAs, `t + 1 < nk` / `t + 2 < nk` in every step.  For a wave whose 128 rows are all
+        // valid, the same per-wave sequence (phase 0: B + A fragments, request A of tile t + 1, barrier, MFMAs, barrier; phase 1: A fragments,
+        // request B of tile t + 2, counted wait, barrier, MFMAs, barrier) runs without the row conditions, split into the steps that request
+        // both half-tiles, the one that requests only A, and the last one; a wave with an M tail takes the loop below (the two loops have
+        // the same barriers per K-step, so the wave rows of a workgroup may differ).
+        static_assert(!FP8 && TOUCH == 0, "the lean K loop is written for the bf16 MFMA without the L2 touch experiment");
+        if (mv >= 128) {
+            int so = 0, t = 0;                       // byte offset of tile t's stage (toggles), K-step
+            auto half = [&](auto pc, auto modec) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value, MODE = decltype(modec)::value;      // MODE 2: requests A(t+1) and B(t+2); 1: A(t+1); 0: none
+                const char* As = smem + so;
+                if constexpr (P == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = sat_gemm_frag(As + ABYTES, wc * 64 + j * 32 + frow, kchunk(ks));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) afr[i][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + i * 32 + frow, kchunk(ks));
+                if constexpr (P == 0 && MODE >= 1) stage_a(t + 1);
+                if constexpr (P == 1) {
+                    if constexpr (MODE == 2) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
+                    else { SAT_WAIT_VMCNT(0); }
+                }
+                SAT_WAIT_LGKM0();
+                SAT_RAW_BARRIER();
+                SAT_SCHED_FENCE();
+                SAT_SETPRIO(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[P * 2 + i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[P * 2 + i][j]);
+                SAT_SETPRIO(0);
+                SAT_SCHED_FENCE();
+                SAT_RAW_BARRIER();
+            };
+            auto kstep = [&](auto modec) __attribute__((always_inline)) {
+                half(std::integral_constant<int, 0>{}, modec);
+                half(std::integral_constant<int, 1>{}, modec);
+                so ^= STAGE;
+                ++t;
+            };
+            for (; t + 2 < nk;) kstep(std::integral_constant<int, 2>{});
+            if (t + 1 < nk) kstep(std::integral_constant<int, 1>{});
+            if (t < nk) kstep(std::integral_constant<int, 0>{});
+            lean_done = true;
+        }
+    }
+    if (!lean_done)
     for (int t = 0; t < nk; ++t) {
         phase(t, std::integral_constant<int, 0>{});
         phase(t, std::integral_constant<int, 1>{});
@@ -1088,10 +1145,13 @@ static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits,
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
+    const char* lean_env = getenv("SAT_GEMM_LEAN");      // the lean K loop (bf16, no touch experiment): an unmeasured A/B arm, off by default
+    const bool lean = lean_env && lean_env[0] == '1';
 #define SAT_GEMM256_CASE(E, F)                                                                       \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
         if (fp8) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, true>), grid, block, stream, p); }        \
         else if (touch > 0) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 2>), grid, block, stream, p); }  \
+        else if (lean) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, false, true>), grid, block, stream, p); }  \
         else { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0>), grid, block, stream, p); }                  \
         return sat_check_launch("sat_gemm (256x256)");                                               \
     }

@@ -102,7 +102,8 @@ def test_gemm_epilogues_simulator(emu):
 
 # The LEAN K loop of the eight-wave kernels (csrc/gemm.hip sat_gemm8_kernel<..., LEANK>, SAT_GEMM_LEAN=1: the same per-wave sequence of
 # fragment reads / LDS-DMA requests / counted waits / barriers / MFMAs, specialised at compile time on (group, all row blocks active),
-# ~105 instead of ~370 instructions per K-step) — an A/B arm that is off by default until it has been timed.  Same cases, tiles 7 and 8,
+# ~105 instead of ~370 instructions per K-step; sat_gemm256_kernel likewise: ~160 instead of 318) — an A/B arm that is off by default until it
+# has been timed.  Same cases, tiles 4, 7 and 8,
 # plus shapes with more K-steps than ring stages and with K-steps < LOOK (the tail-only path).
 LEAN_SHAPES = SHAPES + [(200, 304, 1024), (161, 264, 64), (40, 520, 136), (600, 136, 448)]
 
@@ -127,8 +128,8 @@ def _lean_env():
 
 def test_gemm_lean_k_loop_simulator(emu):
     with _lean_env():
-        _gemm_cases(emu, "cpu", LEAN_SHAPES, tiles=(7, 8))
-        _heads_case(emu, "cpu", 2, 70, 2, 136, tiles=(7, 8))
+        _gemm_cases(emu, "cpu", LEAN_SHAPES, tiles=(4, 7, 8))
+        _heads_case(emu, "cpu", 2, 70, 2, 136, tiles=(4, 7, 8))
 
 
 def _lean_gpu_main():
@@ -137,8 +138,8 @@ def _lean_gpu_main():
     hip = ops.get_ops()
     assert not hip.simulator
     with _lean_env():
-        _gemm_cases(hip, "cuda", LEAN_SHAPES + [(2050, 1536, 1536), (2050, 1536, 6144), (4100, 4608, 1536)], tiles=(7, 8))
-        _heads_case(hip, "cuda", 2, 1025, 24, 1536, tiles=(7, 8))
+        _gemm_cases(hip, "cuda", LEAN_SHAPES + [(2050, 1536, 1536), (2050, 1536, 6144), (4100, 4608, 1536)], tiles=(4, 7, 8))
+        _heads_case(hip, "cuda", 2, 1025, 24, 1536, tiles=(4, 7, 8))
     print("lean-gpu ok")
 
 

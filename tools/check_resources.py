@@ -16,6 +16,9 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -fno-slp-
 ALLOW = ("sat_gemm256_kernelILi0ELb0ELi2E", "sat_gemm256_kernelILi0ELb1ELi2E", "sat_gemm256_kernelILi1ELb0ELi2E", "sat_gemm256_kernelILi1ELb1ELi2E",
          "sat_gemm256_kernelILi2ELb0ELi2E", "sat_gemm256_kernelILi2ELb1ELi2E", "sat_gemm256_kernelILi3ELb0ELi2E", "sat_gemm256_kernelILi3ELb1ELi2E",
          "sat_gemm256_kernelILi4ELb0ELi2E",      # TOUCH = 2: the L2 touch prefetch experiment (tile 5)
+         # LEANK = true variants (SAT_GEMM_LEAN=1, an unmeasured A/B arm) with the SwiGLU / head-split epilogues: 4-5 spilled registers, all
+         # outside the K loops (ISA checked: the scratch instructions sit in the prologue and between the loops)
+         "sat_gemm256_kernelILi3ELb0ELi0ELb0ELb1E", "sat_gemm256_kernelILi3ELb1ELi0ELb0ELb1E", "sat_gemm256_kernelILi4ELb0ELi0ELb0ELb1E",
          # the k = 7 weight gradient: 34-172 spilled registers, ALL in the remainder code after the stage loop (the ISA has its 35 scratch
          # instructions around the last MFMA block, none between the loop's barriers) — checked round 4, not on the steady-state path
          "sat_wgrad7_bf16x3_pipe_kernel")

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 opener: the LEAN arm of the bf16 attention forward (csrc/attention.hip sat_attn_fwd_lean_kernel, SAT_ATTN_LEAN=1 — written and
+# Round-5 opener (attention forward / backward and projection-GEMM lean arms): the LEAN arm of the bf16 attention forward (csrc/attention.hip sat_attn_fwd_lean_kernel, SAT_ATTN_LEAN=1 — written and
 # simulator-checked at the end of round 4 without GPU minutes left) against the product kernel, A / B / A / B in ONE call:
 #   tests (both arms), the kernel alone (tools/attn_bench.py: N = 1025 self / cross, B = 8, N = 6145), the sampler and the long-context sampler.
-# ~6 GPU-minutes.  Output: gpurun_out/r05_attn_lean/.  If the lean arm wins: make it the default in sat_attention_fwd (SAT_ATTN_LEAN=0 to
+# ~10 GPU-minutes.  Output: gpurun_out/r05_attn_lean/.  If the lean arm wins: make it the default in sat_attention_fwd (SAT_ATTN_LEAN=0 to
 # switch back), drop the xfail-free GPU test's env juggling, record both arms in profiles/r05_experiments/attn_lean/.
 set -u
 R=$(pwd)
@@ -24,7 +24,19 @@ for i in 1 2; do
   SAT_ATTN_LEAN=0 SAT_ATTN_BWD_LEAN=0 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_product.json 2>> $OUT/dt.err
   SAT_ATTN_LEAN=1 SAT_ATTN_BWD_LEAN=1 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_lean.json 2>> $OUT/dt.err
 done
-tail -3 $OUT/tests.log
+# the projection GEMMs' lean K loops (SAT_GEMM_LEAN=1: tiles 4, 7, 8, bf16): the kernels alone, then the sampler and the train step
+timeout 900 python -m pytest tests/test_gemm_kernels.py -m gpu -x -q > $OUT/gemm_tests.log 2>&1; echo "tests exit $?" >> $OUT/gemm_tests.log
+for i in 1 2; do
+  SAT_GEMM_LEAN=0 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_product.jsonl 2>> $OUT/gemm.err
+  SAT_GEMM_LEAN=1 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_lean.jsonl 2>> $OUT/gemm.err
+done
+for i in 1 2; do
+  SAT_GEMM_LEAN=0 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_gemm_product.json 2>> $OUT/ds.err
+  SAT_GEMM_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_gemm_lean.json 2>> $OUT/ds.err
+done
+SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 SAT_ATTN_BWD_LEAN=1 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_all_lean.json 2>> $OUT/dt.err
+SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_all_lean.json 2>> $OUT/ds.err
+tail -3 $OUT/tests.log $OUT/gemm_tests.log
 echo "--- product"; cat $OUT/attn_product.jsonl; echo "--- lean"; cat $OUT/attn_lean.jsonl
 python - <<PY
 import json, glob
