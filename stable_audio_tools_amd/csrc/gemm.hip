@@ -721,7 +721,9 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         // request B of tile t + 2, counted wait, barrier, MFMAs, barrier) runs without the row conditions, split into the steps that request
         // both half-tiles, the one that requests only A, and the last one; a wave with an M tail takes the loop below (the two loops have
         // the same barriers per K-step, so the wave rows of a workgroup may differ).
-        static_assert(!FP8 && TOUCH == 0, "the lean K loop is written for the bf16 MFMA without the L2 touch experiment");
+        // (fp8: the lean loop compiles — the MFMA section below has the branch — but its instances spill 25-32 registers at the 256 cap,
+        // so the dispatcher keeps the fp8 256 x 256 kernel on the loop below; the eight-wave kernels' fp8 instances do take their lean loop)
+        static_assert(TOUCH == 0, "the lean K loop is written without the L2 touch experiment");
         if (mv >= 128) {
             int so = 0, t = 0;                       // byte offset of tile t's stage (toggles), K-step
             auto half = [&](auto pc, auto modec) __attribute__((always_inline)) {
@@ -746,12 +748,25 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
                 SAT_RAW_BARRIER();
                 SAT_SCHED_FENCE();
                 SAT_SETPRIO(1);
+                if constexpr (FP8) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                    for (int u = 0; u < 2; ++u) {
+                        const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < 2; ++i) {
+                            const i32x8 a = sat_cat8(afr[i][2 * u], afr[i][2 * u + 1]);
+                            acc[P * 2 + i][0] = sat_mfma_32x32x64_fp8(a, b0, acc[P * 2 + i][0]);
+                            acc[P * 2 + i][1] = sat_mfma_32x32x64_fp8(a, b1, acc[P * 2 + i][1]);
+                        }
+                    }
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[P * 2 + i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[P * 2 + i][j]);
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[P * 2 + i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[P * 2 + i][j]);
+                }
                 SAT_SETPRIO(0);
                 SAT_SCHED_FENCE();
                 SAT_RAW_BARRIER();
@@ -939,14 +954,13 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
         // tile t + LOOK, counted wait, lgkmcnt(0), barrier, MFMAs, barrier: the hazard argument above is unchanged — is specialised at
         // compile time on (group, all row blocks active), the staged steps are split from the <= LOOK steps that stage nothing, the ring
         // slots rotate in scalar registers and every fragment address is one of eight per-lane bases + slot + an immediate.
-        static_assert(!FP8, "the lean K loop is written for the bf16 MFMA");
         int nact = (mv + 31) >> 5;
         nact = nact < 0 ? 0 : (nact > nb ? nb : nact);          // this wave's active row blocks (wave-uniform)
         const int sw = (frow >> 1) & 7;                         // the same swizzle for every row block of a lane (blocks start at multiples of 32 rows)
         int ao[4], bo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int o = ((q * 2 + fkc) ^ sw) << 4;
+            const int o = (kchunk(q) ^ sw) << 4;
             ao[q] = (arow + frow) * 128 + o;
             bo[q] = ABYTES + (wc * 64 + frow) * 128 + o;
         }
@@ -990,13 +1004,28 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
                 SAT_RAW_BARRIER();
                 SAT_SCHED_FENCE();
                 SAT_SETPRIO(1);
+                if constexpr (FP8) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                    for (int u = 0; u < 2; ++u) {
+                        const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
 #pragma unroll
-                    for (int i = 0; i < NBG; ++i) {
-                        if (FULL || i < nact) {
+                        for (int i = 0; i < NBG; ++i) {
+                            if (FULL || i < nact) {
+                                const i32x8 a = sat_cat8(afr[i][2 * u], afr[i][2 * u + 1]);
+                                acc[i][0] = sat_mfma_32x32x64_fp8(a, b0, acc[i][0]);
+                                acc[i][1] = sat_mfma_32x32x64_fp8(a, b1, acc[i][1]);
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[i][j]);
+                    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                        for (int i = 0; i < NBG; ++i) {
+                            if (FULL || i < nact) {
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[i][j]);
+                            }
                         }
                     }
                 }
@@ -1114,16 +1143,18 @@ static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, v
     p.ntm = sat_cdiv(p.M, BM);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
-    // SAT_GEMM_LEAN=1: the lean K loop of sat_gemm8_kernel (bf16, the shipped tiles 7 and 8; an unmeasured A/B arm: off by default)
+    // SAT_GEMM_LEAN=1: the lean K loop of sat_gemm8_kernel (bf16 and fp8, the shipped tiles 7 and 8; an unmeasured A/B arm: off by default)
     const char* lean_env = getenv("SAT_GEMM_LEAN");
-    const bool lean = WITH_LEAN && !fp8 && lean_env && lean_env[0] == '1';
+    const bool lean = WITH_LEAN && lean_env && lean_env[0] == '1';
 #define SAT_GEMM8_CASE(E, F)                                                                         \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
-        else if constexpr (WITH_LEAN) {                                                              \
-            if (lean) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false, true>), grid, block, stream, p); }   \
+        if constexpr (WITH_LEAN) {                                                                   \
+            if (lean && fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true, true>), grid, block, stream, p); }    \
+            else if (lean) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false, true>), grid, block, stream, p); }     \
+            else if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }             \
             else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }  \
         }                                                                                            \
+        else if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
         else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }      \
         return sat_check_launch("sat_gemm (eight-wave ring)");                                       \
     }
@@ -1215,8 +1246,8 @@ static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, 
 // fp8 operands: 0 = 128x128 / 4 waves / plain loop (round 3), 4 = 256x256, 7 = 160x256, 8 = 128x128 eight-wave ring
 static int sat_gemm_dispatch_fp8(SatGemmParams& p, int epi, int f32out, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, 1, stream, 0, true);
-    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, 1, stream, true);
-    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, 1, stream, true);
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3, true>(p, epi, f32out, 1, stream, true);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4, true>(p, epi, f32out, 1, stream, true);
     if (tile != 0) { sat_set_error("sat_gemm_fp8: tile must be 0, 4, 7 or 8"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, epi, f32out, 1, stream);
 }

@@ -130,6 +130,7 @@ def test_gemm_lean_k_loop_simulator(emu):
     with _lean_env():
         _gemm_cases(emu, "cpu", LEAN_SHAPES, tiles=(4, 7, 8))
         _heads_case(emu, "cpu", 2, 70, 2, 136, tiles=(4, 7, 8))
+        _fp8_case(emu, "cpu")             # the fp8 instances of tiles 4 / 7 / 8 take the lean loop too
 
 
 def _lean_gpu_main():
@@ -140,6 +141,7 @@ def _lean_gpu_main():
     with _lean_env():
         _gemm_cases(hip, "cuda", LEAN_SHAPES + [(2050, 1536, 1536), (2050, 1536, 6144), (4100, 4608, 1536)], tiles=(4, 7, 8))
         _heads_case(hip, "cuda", 2, 1025, 24, 1536, tiles=(4, 7, 8))
+        _fp8_case(hip, "cuda")
     print("lean-gpu ok")
 
 

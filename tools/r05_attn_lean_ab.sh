@@ -34,6 +34,8 @@ for i in 1 2; do
   SAT_GEMM_LEAN=0 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_gemm_product.json 2>> $OUT/ds.err
   SAT_GEMM_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_gemm_lean.json 2>> $OUT/ds.err
 done
+SAT_GEMM_LEAN=0 timeout 300 python bench.py --workload long_context --no-cpu-baseline >> $OUT/long_context_gemm_product.json 2>> $OUT/lc.err
+SAT_GEMM_LEAN=1 timeout 300 python bench.py --workload long_context --no-cpu-baseline >> $OUT/long_context_gemm_lean.json 2>> $OUT/lc.err      # fp8 on the eight-wave kernels
 SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 SAT_ATTN_BWD_LEAN=1 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_all_lean.json 2>> $OUT/dt.err
 SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_all_lean.json 2>> $OUT/ds.err
 tail -3 $OUT/tests.log $OUT/gemm_tests.log
