@@ -203,8 +203,9 @@ def _lean_gpu_main():
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="the lean arm was written after the round's GPU budget was spent: its first execution on an MI355X is the "
-                                        "driver's round-end run; asserts strictly (and in-process) once tools/r05_attn_lean_ab.sh has seen it pass")
+@pytest.mark.skipif(__import__("os").environ.get("SAT_TEST_LEAN_ARMS") != "1",
+                    reason="unmeasured A/B arms written without GPU access: run on request (SAT_TEST_LEAN_ARMS=1; tools/r05_attn_lean_ab.sh sets it) "
+                           "so that their first execution on hardware is a deliberate, separately budgeted call")
 def test_attention_lean_gpu(hip):
     """The lean arm on the hardware, in a CHILD process: a kernel that has never run on a GPU must not be able to take the test session
     down with it (a fault aborts the process that launched it)."""

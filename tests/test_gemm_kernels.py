@@ -146,8 +146,9 @@ def _lean_gpu_main():
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="the lean K loop was written after the round's GPU budget was spent: its first execution on an MI355X is the "
-                                        "driver's round-end run; asserts strictly (and in-process) once tools/r05_attn_lean_ab.sh has seen it pass")
+@pytest.mark.skipif(__import__("os").environ.get("SAT_TEST_LEAN_ARMS") != "1",
+                    reason="unmeasured A/B arms written without GPU access: run on request (SAT_TEST_LEAN_ARMS=1; tools/r05_attn_lean_ab.sh sets it) "
+                           "so that their first execution on hardware is a deliberate, separately budgeted call")
 def test_gemm_lean_k_loop_gpu(hip):
     import os
     import subprocess

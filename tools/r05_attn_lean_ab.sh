@@ -5,6 +5,7 @@
 # ~10 GPU-minutes.  Output: gpurun_out/r05_attn_lean/.  If the lean arm wins: make it the default in sat_attention_fwd (SAT_ATTN_LEAN=0 to
 # switch back), drop the xfail-free GPU test's env juggling, record both arms in profiles/r05_experiments/attn_lean/.
 set -u
+export SAT_TEST_LEAN_ARMS=1      # the lean arms' GPU tests (child processes) are skipped without it
 R=$(pwd)
 OUT=$R/gpurun_out/r05_attn_lean
 rm -rf $OUT; mkdir -p $OUT
