@@ -265,6 +265,25 @@ int sat_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n
                        float eps, float weight_decay, float* ema, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange — what Lightning's `ddp` strategy does for the reference (train.py:138, :148-164): the SUM of
+ * the flat gradient buffer over the ranks, RCCL over xGMI, one communicator per process, enqueued on the caller's stream.
+ * The default exchange of training.GradAllReduce goes through torch.distributed (backend "nccl" = RCCL); these entry points
+ * are the same collectives behind the C-ABI (`GradAllReduce(native=True)`).  RCCL is resolved at first use with dlopen (the
+ * copy already mapped into the process, else the system's) — not a load-time dependency of this library.
+ *   sat_allreduce_available   1 when an RCCL library can be loaded
+ *   sat_allreduce_unique_id   rank 0: a fresh 128-byte id, handed to every rank by the caller's side channel
+ *   sat_allreduce_init        every rank (its GPU current): join `world` ranks; *comm = opaque handle (the library's only state)
+ *   sat_allreduce_bucket      in-place SUM of `count` elements (dtype 0 fp32 | 1 bf16); mode 0 all-reduce, mode 1
+ *                             reduce-scatter + all-gather in place (count % world == 0, else mode 0)
+ *   sat_allreduce_finalize    destroy the communicator
+ * ---------------------------------------------------------------------------------------------- */
+int sat_allreduce_available(void);
+int sat_allreduce_unique_id(void* id128);
+int sat_allreduce_init(const void* id128, int world, int rank, void** comm);
+int sat_allreduce_bucket(void* comm, void* buf, long long count, int dtype, int mode, void* stream);
+int sat_allreduce_finalize(void* comm);
+
+/* ------------------------------------------------------------------------------------------------
  * DiT block operators — models/transformer.py.  dtype: 0 = fp32 tensors, 1 = bf16 tensors
  * (statistics / softmax / accumulation always fp32).
  * ---------------------------------------------------------------------------------------------- */

@@ -75,6 +75,12 @@ SIGNATURES = {
     "sat_vae_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sat_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P]),
     "sat_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
+    # comm.hip
+    "sat_allreduce_available": (_I, []),
+    "sat_allreduce_unique_id": (_I, [_P]),
+    "sat_allreduce_init": (_I, [_P, _I, _I, _P]),
+    "sat_allreduce_bucket": (_I, [_P, _P, _L, _I, _I, _P]),
+    "sat_allreduce_finalize": (_I, [_P]),
     # stft.hip
     "sat_fir": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_stft_tiles": (_I, [_I, _I, _I]),

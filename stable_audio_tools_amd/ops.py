@@ -1256,6 +1256,35 @@ class SatOps:
         self._chk(self.lib.sat_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), beta1, beta2, eps, weight_decay,
                                               _ptr(ema), self._stream(p)))
 
+    # ---- native gradient exchange (csrc/comm.hip: RCCL behind the C-ABI; training.GradAllReduce(native=True)) ----
+    def allreduce_available(self):
+        return bool(self.lib.sat_allreduce_available())
+
+    def allreduce_unique_id(self):
+        """128 bytes from rank 0's RCCL (ncclGetUniqueId) for every rank's allreduce_init."""
+        buf = ctypes.create_string_buffer(128)
+        self._chk(self.lib.sat_allreduce_unique_id(buf))
+        return buf.raw
+
+    def allreduce_init(self, uid, world, rank):
+        """Join the communicator (the current device is this rank's GPU); returns the opaque handle."""
+        if len(uid) != 128:
+            raise ValueError("allreduce_init: the unique id is 128 bytes")
+        comm = ctypes.c_void_p()
+        self._chk(self.lib.sat_allreduce_init(ctypes.create_string_buffer(bytes(uid), 128), int(world), int(rank), ctypes.byref(comm)))
+        return comm
+
+    def allreduce_bucket(self, comm, buf, mode=0):
+        """In-place SUM over the ranks of a contiguous fp32 / bf16 device tensor on its current stream (mode 1: reduce-scatter + all-gather)."""
+        if buf.dtype not in (torch.float32, torch.bfloat16) or not buf.is_contiguous():
+            raise TypeError("allreduce_bucket takes a contiguous fp32 or bf16 tensor")
+        if not self.simulator and not buf.is_cuda:
+            raise RuntimeError("stable_audio_tools_amd kernels need CUDA(HIP) tensors; there is no CPU path")
+        self._chk(self.lib.sat_allreduce_bucket(comm, _ptr(buf), buf.numel(), 0 if buf.dtype == torch.float32 else 1, int(mode), self._stream(buf)))
+
+    def allreduce_finalize(self, comm):
+        self._chk(self.lib.sat_allreduce_finalize(comm))
+
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)
         self._chk(self.lib.sat_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,

@@ -97,7 +97,7 @@ class GradAllReduce:
     `bench.py --ddp-single-rank`)."""
 
     def __init__(self, flat: FlatParameters, group=None, bucket_bytes=256 << 20, mode="all_reduce", overlap=True, comm_dtype=None,
-                 single_rank_exchange=None):
+                 single_rank_exchange=None, native=None, ops=None):
         import os
         self.flat = flat
         self.group = group
@@ -129,6 +129,22 @@ class GradAllReduce:
             s_ = max(0, e - per)
             self.buckets.append((s_, e))
             e = s_
+        # native=True (default: env SAT_DDP_NATIVE=1): the buckets go through the C-ABI's own RCCL communicator (csrc/comm.hip
+        # sat_allreduce_*: SURVEY.md §8b) instead of torch.distributed's; the process group is then only the side channel that hands
+        # rank 0's unique id to the other ranks.  Same collectives, same streams and events.
+        if native is None:
+            native = os.environ.get("SAT_DDP_NATIVE", "0") == "1"
+        self.native, self._comm, self._ops = False, None, None
+        if native and self.active:
+            if self.backend == "gloo":
+                raise RuntimeError("GradAllReduce(native=True) exchanges device buffers over RCCL: it needs GPUs (backend 'nccl')")
+            from . import ops as _ops_mod
+            self._ops = ops if ops is not None else _ops_mod.get_ops()
+            uid = [self._ops.allreduce_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self._comm = self._ops.allreduce_init(uid[0], self.world, self.rank)
+            self.native = True
         self.grad_scale = 1.0 / self.world
         self.overlap = bool(overlap) and self.active
         self._hooks = []
@@ -175,6 +191,11 @@ class GradAllReduce:
 
     def _exchange(self, chunk):
         buf = chunk if self.comm_dtype is None else chunk.to(self.comm_dtype)
+        if self.native:
+            self._ops.allreduce_bucket(self._comm, buf, mode=1 if (self.mode == "reduce_scatter" and buf.numel() % self.world == 0) else 0)
+            if buf is not chunk:
+                chunk.copy_(buf)
+            return
         if self.mode == "reduce_scatter" and self.backend != "gloo" and buf.numel() % self.world == 0:
             k = buf.numel() // self.world
             shard = buf[self.rank * k:(self.rank + 1) * k]             # in place: output = this rank's slice of the input
@@ -231,11 +252,15 @@ class GradAllReduce:
         self.finish()
 
     def close(self):
-        """Remove the autograd hooks (a second step object on the same parameters must not inherit live hooks)."""
+        """Remove the autograd hooks (a second step object on the same parameters must not inherit live hooks) and, in native mode,
+        destroy the communicator."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
         self.overlap = False
+        if self._comm is not None:
+            self._ops.allreduce_finalize(self._comm)
+            self._comm, self.native = None, False
 
 
 def inverse_lr(step, base_lr, inv_gamma=1.0, power=1.0, warmup=0.0, final_lr=0.0):
@@ -323,7 +348,7 @@ class AutoencoderTrainStep:
     terms; the teacher is a frozen native autoencoder (its folded / packed weights come from the derived-weight caches)."""
 
     def __init__(self, autoencoder, model_config, ops=None, ddp_mode="all_reduce", bucket_bytes=64 << 20, ddp_overlap=True,
-                 use_discriminator=True, ddp_comm_dtype=None, ddp_single_rank=None, teacher_model=None):
+                 use_discriminator=True, ddp_comm_dtype=None, ddp_single_rank=None, teacher_model=None, ddp_native=None):
         from .auraloss import AutoencoderSpectralLoss
         tr = model_config["training"]
         self.model = autoencoder
@@ -372,7 +397,8 @@ class AutoencoderTrainStep:
             sd_cls = SumAndDifferenceSTFTLoss if autoencoder.out_channels == 2 else MultiResolutionSTFTLoss      # :141-146
             self.sdstft = sd_cls(sample_rate=sample_rate, **lc["spectral"]["config"]).to(self.flat.data.device)
             self.w_distill = float(lc["spectral"]["weights"]["mrstft"]) * 0.25
-        ddp_kw = dict(bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype, single_rank_exchange=ddp_single_rank)
+        ddp_kw = dict(bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype, single_rank_exchange=ddp_single_rank,
+                      native=ddp_native, ops=ops)
         self.comm = GradAllReduce(self.flat, **ddp_kw)
         self.discriminator = None
         dcfg = lc.get("discriminator")

@@ -288,6 +288,88 @@ def test_single_rank_rccl_exchange_gpu(hip):
             assert 0 < r["grad_rel"] < 8e-3, (key, r)                                       # bf16 round trip of the gradient buckets
 
 
+# ---- the native exchange (csrc/comm.hip: sat_allreduce_* — RCCL behind the C-ABI; GradAllReduce(native=True)) ----
+def test_native_exchange_entry_points_host():
+    """What can be checked without a GPU: RCCL is found with dlopen (PyTorch's copy is already in the process), rank 0's unique ids are
+    128 bytes and fresh, every entry point validates its arguments, joining a communicator without a device fails with RCCL's message —
+    never a crash — and finalising a null handle is a no-op."""
+    import ctypes
+    from stable_audio_tools_amd import _lib
+    from stable_audio_tools_amd.ops import SatOps
+    o = SatOps(_lib.bind(ctypes.CDLL(_lib.LIB_PATH)))
+    assert o.allreduce_available()
+    a, b = o.allreduce_unique_id(), o.allreduce_unique_id()
+    assert len(a) == 128 and len(b) == 128 and a != b and any(a)
+    with pytest.raises(ValueError):
+        o.allreduce_init(a[:64], 1, 0)
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        o.allreduce_init(a, 2, 2)
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        o._chk(o.lib.sat_allreduce_bucket(None, None, 0, 0, 0, None))
+    o.allreduce_finalize(None)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="RCCL error"):
+            o.allreduce_init(a, 1, 0)
+
+
+def test_native_exchange_refused_on_the_simulator(emu):
+    assert not emu.allreduce_available()
+    with pytest.raises(RuntimeError, match="no RCCL"):
+        emu.allreduce_unique_id()
+
+
+def _native_single_rank_worker(port, q):
+    """_single_rank_worker with the buckets on the C-ABI's own communicator (GradAllReduce(native=True)): the 1-rank collectives are the
+    identity, so every mode must reproduce the no-process-group step bit for bit (fp32) / to bf16 rounding (bf16 exchange)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    cfg = _model_config()
+    batches = [_batch(2, 950), _batch(2, 960)]
+    _, base, base_losses = _native_steps(cfg, batches, "cuda:0")
+    ref_data, ref_grad = base.flat.data.clone(), base.flat.grad.clone()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    out = {}
+    try:
+        for mode, overlap, cdt in (("all_reduce", True, None), ("reduce_scatter", True, None), ("reduce_scatter", False, torch.bfloat16)):
+            _, st, losses = _native_steps(cfg, batches, "cuda:0", ddp_mode=mode, ddp_overlap=overlap, bucket_bytes=4096,
+                                          ddp_comm_dtype=cdt, ddp_single_rank=True, ddp_native=True)
+            torch.cuda.synchronize()
+            out[(mode, overlap, str(cdt))] = {
+                "native": bool(st.comm.native), "buckets": len(st.comm.last_launch_log),
+                "data_equal": bool(torch.equal(st.flat.data, ref_data)), "grad_equal": bool(torch.equal(st.flat.grad, ref_grad)),
+                "grad_rel": float((st.flat.grad - ref_grad).norm() / ref_grad.norm()), "loss_equal": losses == base_losses}
+            st.comm.close()
+    finally:
+        dist.destroy_process_group()
+    q.put(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SAT_TEST_LEAN_ARMS") != "1",
+                    reason="csrc/comm.hip was written without GPU access: its first execution on hardware is a deliberate call (SAT_TEST_LEAN_ARMS=1)")
+def test_native_exchange_gpu(hip):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_single_rank_worker, args=(29800 + (os.getpid() % 90), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for key, r in out.items():
+        assert r["native"] and r["buckets"] > 4, (key, r)
+        if key[2] == "None":
+            assert r["grad_equal"] and r["data_equal"] and r["loss_equal"], (key, r)
+        else:
+            assert 0 < r["grad_rel"] < 8e-3, (key, r)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the single-GPU box runs the gloo twin on CPU")
 def test_data_parallel_step_rccl_world2(hip):
