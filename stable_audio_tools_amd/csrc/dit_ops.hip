@@ -10,6 +10,7 @@
 // dtype: 0 = fp32, 1 = bf16 tensors (statistics and math always fp32).
 #include <cstdio>
 #include "sat_device.h"
+#include <stdlib.h>
 
 template <typename T> struct SatIO;
 template <> struct SatIO<float> {
@@ -197,6 +198,101 @@ __global__ void __launch_bounds__(256) sat_layernorm_fwd_vec_kernel(SatLnParams 
     }
 }
 
+// TWO rows per wave (SAT_LN_LEAN=1; round 4, last session: simulator-checked, NOT timed — off by default).  In the sampler a launch is
+// 2050 rows of 1536 bf16: 3 KB of x per row against 18 KB of gamma / beta (fp32) and adaLN scale / shift that every row re-reads from L2,
+// and 7.9 us per launch for 12.6 MB of tensor traffic (1.6 TB/s): the waves spend their time on four dependent round trips (x, two
+// reductions, the parameter vectors) at two waves per SIMD.  Here a wave owns two consecutive rows of ONE batch item (they share the
+// modulation vectors), loads both rows first, interleaves the two rows' reductions and reads every parameter chunk once for both.
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_fwd_vec2_kernel(SatLnParams p) {
+    constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ppb = (p.rows_per_batch + 1) >> 1, nb = p.rows / p.rows_per_batch;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= nb * ppb) return;      // whole wave exits together; no block barrier below
+    const int b = pair / ppb, j = pair - b * ppb;
+    const int row0 = b * p.rows_per_batch + 2 * j;
+    const bool has1 = 2 * j + 1 < p.rows_per_batch;      // wave-uniform: an odd row count leaves the last pair of a batch item single
+    const long long base0 = (long long)row0 * p.D, base1 = base0 + p.D;
+    const int nc = p.D / (64 * N);
+    float x0[MAXC][N], x1[MAXC][N];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            SatVec<T>::ld(p.x, base0 + (c * 64 + lane) * N, x0[c]);
+            if (has1) SatVec<T>::ld(p.x, base1 + (c * 64 + lane) * N, x1[c]);
+            else {
+#pragma unroll
+                for (int e = 0; e < N; ++e) x1[c][e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                s0 += x0[c][e];
+                s1 += x1[c][e];
+            }
+        }
+    }
+    const float mean0 = sat_wave_sum(s0) / (float)p.D, mean1 = sat_wave_sum(s1) / (float)p.D;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float d0 = x0[c][e] - mean0, d1 = x1[c][e] - mean1;
+                v0 += d0 * d0;
+                v1 += d1 * d1;
+            }
+        }
+    }
+    const float rstd0 = 1.0f / sqrtf(sat_wave_sum(v0) / (float)p.D + p.eps), rstd1 = 1.0f / sqrtf(sat_wave_sum(v1) / (float)p.D + p.eps);
+    const long long mb = p.scale ? (long long)b * p.mod_stride : 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nc) {
+            const int i0 = (c * 64 + lane) * N;
+            float g[N], be[N], o0[N], o1[N];
+#pragma unroll
+            for (int e = 0; e < N; e += 4) SatVec<float>::ld(p.gamma, i0 + e, g + e);
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                o0[e] = (x0[c][e] - mean0) * rstd0 * g[e];
+                o1[e] = (x1[c][e] - mean1) * rstd1 * g[e];
+            }
+            if (p.beta) {
+#pragma unroll
+                for (int e = 0; e < N; e += 4) SatVec<float>::ld(p.beta, i0 + e, be + e);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    o0[e] += be[e];
+                    o1[e] += be[e];
+                }
+            }
+            if (p.scale) {
+                float sc[N], sh[N];
+                SatVec<T>::ld(p.scale, mb + i0, sc);
+                SatVec<T>::ld(p.shift, mb + i0, sh);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    o0[e] = o0[e] * (1.0f + sc[e]) + sh[e];
+                    o1[e] = o1[e] * (1.0f + sc[e]) + sh[e];
+                }
+            }
+            SatVec<T>::st(p.y, base0 + i0, o0);
+            if (has1) SatVec<T>::st(p.y, base1 + i0, o1);
+        }
+    }
+    if (lane == 0 && p.mean) {
+        p.mean[row0] = mean0;
+        p.rstd[row0] = rstd0;
+        if (has1) {
+            p.mean[row0 + 1] = mean1;
+            p.rstd[row0 + 1] = rstd1;
+        }
+    }
+}
+
 // LayerNorm straight to the fp8 operand of the projection that consumes it (round 4; the N = 6145 sampler): the normalised (and
 // adaLN-modulated) row is kept in registers, its max |.| gives the row's dynamic scale, and the row leaves as e4m3 bytes + one fp32 scale
 // (the GEMM's row_alpha) — the bf16 LayerNorm output (written, then re-read by the quantiser) and the quantiser's launch disappear.
@@ -378,7 +474,12 @@ extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float*
     p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.y = y; p.mean = mean; p.rstd = rstd;
     p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch; p.eps = eps;
     dim3 grid(sat_cdiv(rows, 4));
-    if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {
+    const char* lean = getenv("SAT_LN_LEAN");      // two rows per wave (an unmeasured A/B arm: off by default)
+    if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2) && lean && lean[0] == '1') {
+        dim3 grid2(sat_cdiv((rows / rows_per_batch) * ((rows_per_batch + 1) / 2), 4));
+        if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<float>, grid2, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<short>, grid2, dim3(256), stream, p);
+    } else if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {
         if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<float>, grid, dim3(256), stream, p);
         else SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<short>, grid, dim3(256), stream, p);
     } else if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);

@@ -51,6 +51,33 @@ def test_layernorm_sim(emu, case):
     _ln_case(emu, "cpu", *case, seed=11)
 
 
+def _ln_lean(ops, dev, cases, seed):
+    """The two-rows-per-wave forward (SAT_LN_LEAN=1: an unmeasured A/B arm, off by default) on the vector-path shapes: odd and even row
+    counts per batch item (the last pair of an item is single), with and without the adaLN modulation; the backward consumes its statistics."""
+    import os
+    old = os.environ.get("SAT_LN_LEAN")
+    os.environ["SAT_LN_LEAN"] = "1"
+    try:
+        for case in cases:
+            _ln_case(ops, dev, *case, seed=seed)
+    finally:
+        if old is None:
+            os.environ.pop("SAT_LN_LEAN", None)
+        else:
+            os.environ["SAT_LN_LEAN"] = old
+
+
+def test_layernorm_lean_sim(emu):
+    _ln_lean(emu, "cpu", [(torch.float32, 2, 9, 1536, True), (torch.bfloat16, 2, 9, 1536, True), (torch.bfloat16, 1, 5, 1536, False),
+                          (torch.bfloat16, 3, 6, 512, True), (torch.float32, 1, 1, 256, False)], seed=13)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("SAT_TEST_LEAN_ARMS") != "1", reason="unmeasured A/B arm written without GPU access (SAT_TEST_LEAN_ARMS=1)")
+def test_layernorm_lean_gpu(hip):
+    _ln_lean(hip, "cuda", CASES + [(torch.bfloat16, 4, 1025, 1536, True), (torch.float32, 2, 1025, 1536, False), (torch.bfloat16, 2, 6145, 1536, True)], seed=14)
+
+
 @pytest.mark.gpu
 def test_layernorm_gpu(hip):
     for case in CASES + [(torch.bfloat16, 4, 1025, 1536, True), (torch.float32, 2, 1025, 1536, False)]:

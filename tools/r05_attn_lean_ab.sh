@@ -39,6 +39,12 @@ SAT_GEMM_LEAN=0 timeout 300 python bench.py --workload long_context --no-cpu-bas
 SAT_GEMM_LEAN=1 timeout 300 python bench.py --workload long_context --no-cpu-baseline >> $OUT/long_context_gemm_lean.json 2>> $OUT/lc.err      # fp8 on the eight-wave kernels
 SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 SAT_ATTN_BWD_LEAN=1 timeout 300 python bench.py --workload dit_train --no-cpu-baseline >> $OUT/dit_train_all_lean.json 2>> $OUT/dt.err
 SAT_GEMM_LEAN=1 SAT_ATTN_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_all_lean.json 2>> $OUT/ds.err
+# LayerNorm with two rows per wave (SAT_LN_LEAN=1) in the sampler
+timeout 300 python -m pytest tests/test_dit_kernels.py -m gpu -x -q -k layernorm >> $OUT/tests.log 2>&1
+for i in 1 2; do
+  SAT_LN_LEAN=0 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_ln_product.json 2>> $OUT/ds.err
+  SAT_LN_LEAN=1 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_ln_lean.json 2>> $OUT/ds.err
+done
 # the native gradient exchange (csrc/comm.hip: RCCL behind the C-ABI) on a 1-rank communicator: test + the step timed inside it
 timeout 600 python -m pytest tests/test_train_step.py -m gpu -x -q -k "native_exchange_gpu or single_rank_rccl" > $OUT/native_tests.log 2>&1; echo "tests exit $?" >> $OUT/native_tests.log
 SAT_DDP_NATIVE=0 timeout 600 python bench.py --ddp-single-rank --steps 3 --warmup 1 --no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context --no-batch-sweep --no-graph >> $OUT/ddp_torch.json 2>> $OUT/ddp.err
