@@ -28,8 +28,8 @@ done
 # the projection GEMMs' lean K loops (SAT_GEMM_LEAN=1: tiles 4, 7, 8, bf16): the kernels alone, then the sampler and the train step
 timeout 900 python -m pytest tests/test_gemm_kernels.py -m gpu -x -q > $OUT/gemm_tests.log 2>&1; echo "tests exit $?" >> $OUT/gemm_tests.log
 for i in 1 2; do
-  SAT_GEMM_LEAN=0 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_product.jsonl 2>> $OUT/gemm.err
-  SAT_GEMM_LEAN=1 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_lean.jsonl 2>> $OUT/gemm.err
+  SAT_TILES=4,7,8 SAT_GEMM_LEAN=0 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_product.jsonl 2>> $OUT/gemm.err
+  SAT_TILES=4,7,8 SAT_GEMM_LEAN=1 timeout 300 python tools/gemm_bench.py 2050 4100 >> $OUT/gemm_lean.jsonl 2>> $OUT/gemm.err
 done
 for i in 1 2; do
   SAT_GEMM_LEAN=0 timeout 300 python bench.py --workload dit_sample --no-cpu-baseline >> $OUT/dit_sample_gemm_product.json 2>> $OUT/ds.err
