@@ -718,17 +718,16 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         // default).  318 instructions per K-step and wave for 32 MFMAs in the loop below: per-phase `on0 / on1` conditions around the
         // fragment reads and around every k-sub-step's MFMAs, `t + 1 < nk` / `t + 2 < nk` in every step.  For a wave whose 128 rows are all
         // valid, the same per-wave sequence (phase 0: B + A fragments, request A of tile t + 1, barrier, MFMAs, barrier; phase 1: A fragments,
-        // request B of tile t + 2, counted wait, barrier, MFMAs, barrier) runs without the row conditions, split into the steps that request
-        // both half-tiles, the one that requests only A, and the last one; a wave with an M tail takes the loop below (the two loops have
-        // the same barriers per K-step, so the wave rows of a workgroup may differ).
-        // (fp8: the lean loop compiles — the MFMA section below has the branch — but its instances spill 25-32 registers at the 256 cap,
-        // so the dispatcher keeps the fp8 256 x 256 kernel on the loop below; the eight-wave kernels' fp8 instances do take their lean loop)
+        // request B of tile t + 2, counted wait, barrier, MFMAs, barrier) runs without the row conditions (ONE loop body: three bodies
+        // split by "requests both / only A / nothing" were tried and spill at the 256-register cap); a wave with an M tail takes the loop
+        // below (the two loops have the same barriers per K-step, so the wave rows of a workgroup may differ).
+        // (fp8: the lean loop compiles — the MFMA section below has the branch — but its instances spill ~20 registers at the 256 cap, so the
+        // dispatcher keeps the fp8 256 x 256 kernel on the loop below; the eight-wave kernels' fp8 instances do take their lean loop)
         static_assert(TOUCH == 0, "the lean K loop is written without the L2 touch experiment");
         if (mv >= 128) {
-            int so = 0, t = 0;                       // byte offset of tile t's stage (toggles), K-step
-            auto half = [&](auto pc, auto modec) __attribute__((always_inline)) {
-                constexpr int P = decltype(pc)::value, MODE = decltype(modec)::value;      // MODE 2: requests A(t+1) and B(t+2); 1: A(t+1); 0: none
-                const char* As = smem + so;
+            auto half = [&](int t, auto pc) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value;
+                const char* As = smem + (t & 1) * STAGE;
                 if constexpr (P == 0) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -739,9 +738,9 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) afr[i][ks] = sat_gemm_frag(As, wr * 128 + P * 64 + i * 32 + frow, kchunk(ks));
-                if constexpr (P == 0 && MODE >= 1) stage_a(t + 1);
+                if constexpr (P == 0) { if (t + 1 < nk) stage_a(t + 1); }
                 if constexpr (P == 1) {
-                    if constexpr (MODE == 2) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
+                    if (t + 2 < nk) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
                     else { SAT_WAIT_VMCNT(0); }
                 }
                 SAT_WAIT_LGKM0();
@@ -771,15 +770,10 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
                 SAT_SCHED_FENCE();
                 SAT_RAW_BARRIER();
             };
-            auto kstep = [&](auto modec) __attribute__((always_inline)) {
-                half(std::integral_constant<int, 0>{}, modec);
-                half(std::integral_constant<int, 1>{}, modec);
-                so ^= STAGE;
-                ++t;
-            };
-            for (; t + 2 < nk;) kstep(std::integral_constant<int, 2>{});
-            if (t + 1 < nk) kstep(std::integral_constant<int, 1>{});
-            if (t < nk) kstep(std::integral_constant<int, 0>{});
+            for (int t = 0; t < nk; ++t) {
+                half(t, std::integral_constant<int, 0>{});
+                half(t, std::integral_constant<int, 1>{});
+            }
             lean_done = true;
         }
     }
