@@ -27,6 +27,10 @@ extern "C" {
 int sat_abi_version(void);
 int sat_is_simulator(void);          /* 0 for the gfx950 library; 1 only for the CPU test-suite's simulator build */
 const char* sat_last_error(void);
+/* Launches taken so far by the env-selected A/B arms of the library (arm 0: SAT_ATTN_LEAN forward, 1: SAT_ATTN_BWD_LEAN, 2: SAT_GEMM_LEAN
+ * eight-wave kernels, 3: SAT_GEMM_LEAN 256 x 256 kernel, 4: SAT_LN_LEAN); -1 for an unknown arm.  Lets a test or an A/B script check that
+ * the switch it set was honoured. */
+long long sat_lean_launches(int arm);
 
 /* ------------------------------------------------------------------------------------------------
  * Oobleck conv stack — models/autoencoders.py:23-27 (WNConv1d / WNConvTranspose1d), :58-83

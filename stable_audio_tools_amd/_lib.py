@@ -17,6 +17,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "sat_abi_version": (_I, []),
     "sat_is_simulator": (_I, []),
+    "sat_lean_launches": (_L, [_I]),
     "sat_last_error": (ctypes.c_char_p, []),
     # conv1d.hip
     "sat_conv1d": (_I, [_P] * 12 + [_I] * 10 + [_P]),

@@ -1385,7 +1385,7 @@ extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const sho
     // time both arms
     const char* lean = getenv("SAT_ATTN_LEAN");
     if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
-    else if (lean && lean[0] == '1' && Nkp < (1 << 24)) SAT_LAUNCH((sat_attn_fwd_lean_kernel<short>), grid, dim3(256), stream, p);
+    else if (lean && lean[0] == '1' && Nkp < (1 << 24)) { sat_count_lean(0); SAT_LAUNCH((sat_attn_fwd_lean_kernel<short>), grid, dim3(256), stream, p); }
     else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_attention_fwd");
 }
@@ -1419,7 +1419,7 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
     } else {
         // SAT_ATTN_BWD_LEAN=1: the lean bf16 dQ kernel above (an unmeasured A/B arm: off by default)
         const char* lean = getenv("SAT_ATTN_BWD_LEAN");
-        if (lean && lean[0] == '1' && Nkp < (1 << 24)) SAT_LAUNCH((sat_attn_bwd_dq_lean_kernel<short>), g1, dim3(256), stream, p);
+        if (lean && lean[0] == '1' && Nkp < (1 << 24)) { sat_count_lean(1); SAT_LAUNCH((sat_attn_bwd_dq_lean_kernel<short>), g1, dim3(256), stream, p); }
         else SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
         if (lean && lean[0] == '1' && Nqp < (1 << 24) / (H / Hkv)) SAT_LAUNCH((sat_attn_bwd_dkv_lean_kernel<short>), g2, dim3(256), stream, p);
         else SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);

@@ -477,6 +477,7 @@ extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float*
     const char* lean = getenv("SAT_LN_LEAN");      // two rows per wave (an unmeasured A/B arm: off by default)
     if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2) && lean && lean[0] == '1') {
         dim3 grid2(sat_cdiv((rows / rows_per_batch) * ((rows_per_batch + 1) / 2), 4));
+        sat_count_lean(4);
         if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<float>, grid2, dim3(256), stream, p);
         else SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<short>, grid2, dim3(256), stream, p);
     } else if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {

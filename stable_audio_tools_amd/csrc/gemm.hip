@@ -1140,6 +1140,7 @@ static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, v
     // SAT_GEMM_LEAN=1: the lean K loop of sat_gemm8_kernel (bf16 and fp8, the shipped tiles 7 and 8; an unmeasured A/B arm: off by default)
     const char* lean_env = getenv("SAT_GEMM_LEAN");
     const bool lean = WITH_LEAN && lean_env && lean_env[0] == '1';
+    if (lean) sat_count_lean(2);
 #define SAT_GEMM8_CASE(E, F)                                                                         \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
         if constexpr (WITH_LEAN) {                                                                   \
@@ -1172,6 +1173,7 @@ static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits,
     dim3 grid(p.ntm * p.ntn, splits), block(512);
     const char* lean_env = getenv("SAT_GEMM_LEAN");      // the lean K loop (bf16, no touch experiment): an unmeasured A/B arm, off by default
     const bool lean = lean_env && lean_env[0] == '1';
+    if (lean && !fp8 && touch <= 0) sat_count_lean(3);
 #define SAT_GEMM256_CASE(E, F)                                                                       \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
         if (fp8) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, true>), grid, block, stream, p); }        \

@@ -58,8 +58,10 @@ def _ln_lean(ops, dev, cases, seed):
     old = os.environ.get("SAT_LN_LEAN")
     os.environ["SAT_LN_LEAN"] = "1"
     try:
+        before = ops.lib.sat_lean_launches(4)
         for case in cases:
             _ln_case(ops, dev, *case, seed=seed)
+        assert ops.lib.sat_lean_launches(4) - before >= len(cases)
     finally:
         if old is None:
             os.environ.pop("SAT_LN_LEAN", None)
@@ -203,10 +205,13 @@ def _lean_cases(ops, dev, cases, spiky):
         for arm in (("1", "0"), ("0", "1"), ("1", "1")):
             for n, v in zip(names, arm):
                 os.environ[n] = v
+            before = [ops.lib.sat_lean_launches(i) for i in (0, 1)]
             for case in cases:
                 _attn_case(ops, dev, torch.bfloat16, case, seed=22)
             for case, seed, sp in spiky:
                 _attn_case(ops, dev, torch.bfloat16, case, seed=seed, spikes=sp)
+            taken = [ops.lib.sat_lean_launches(i) - b0 for i, b0 in zip((0, 1), before)]
+            assert [t > 0 for t in taken] == [v == "1" for v in arm], (arm, taken)      # the switch that was set is the arm that ran
     finally:
         for n, v in old.items():
             if v is None:

@@ -128,7 +128,9 @@ def _lean_env():
 
 def test_gemm_lean_k_loop_simulator(emu):
     with _lean_env():
+        before = [emu.lib.sat_lean_launches(i) for i in (2, 3)]
         _gemm_cases(emu, "cpu", LEAN_SHAPES, tiles=(4, 7, 8))
+        assert all(emu.lib.sat_lean_launches(i) - b0 > 0 for i, b0 in zip((2, 3), before))      # both kernel families took their lean loop
         _heads_case(emu, "cpu", 2, 70, 2, 136, tiles=(4, 7, 8))
         _fp8_case(emu, "cpu", tiles=(7, 8), shapes=((330, 272, 400),))      # the fp8 instances of the eight-wave kernels take the lean loop too
 
