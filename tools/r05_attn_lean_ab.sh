@@ -10,6 +10,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/r05_attn_lean
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_dit_kernels.py -m gpu -x -q -k attention > $OUT/tests.log 2>&1; echo "tests exit $?" >> $OUT/tests.log
+timeout 200 python tools/fuzz_lean.py 1 45 gpu > $OUT/fuzz.log 2>&1; echo "fuzz exit $?" >> $OUT/fuzz.log      # randomised shapes through every lean arm
 for i in 1 2; do
   SAT_ATTN_LEAN=0 timeout 200 python tools/attn_bench.py >> $OUT/attn_product.jsonl 2>> $OUT/attn.err
   SAT_ATTN_LEAN=1 timeout 200 python tools/attn_bench.py >> $OUT/attn_lean.jsonl 2>> $OUT/attn.err
@@ -49,7 +50,7 @@ done
 timeout 600 python -m pytest tests/test_train_step.py -m gpu -x -q -k "native_exchange_gpu or single_rank_rccl" > $OUT/native_tests.log 2>&1; echo "tests exit $?" >> $OUT/native_tests.log
 SAT_DDP_NATIVE=0 timeout 600 python bench.py --ddp-single-rank --steps 3 --warmup 1 --no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context --no-batch-sweep --no-graph >> $OUT/ddp_torch.json 2>> $OUT/ddp.err
 SAT_DDP_NATIVE=1 timeout 600 python bench.py --ddp-single-rank --steps 3 --warmup 1 --no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context --no-batch-sweep --no-graph >> $OUT/ddp_native.json 2>> $OUT/ddp.err
-tail -3 $OUT/tests.log $OUT/gemm_tests.log $OUT/native_tests.log
+tail -3 $OUT/tests.log $OUT/gemm_tests.log $OUT/native_tests.log $OUT/fuzz.log
 echo "--- product"; cat $OUT/attn_product.jsonl; echo "--- lean"; cat $OUT/attn_lean.jsonl
 python - <<PY
 import json, glob
