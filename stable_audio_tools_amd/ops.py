@@ -516,9 +516,9 @@ class SatOps:
         n = x.numel()
         if n == 0:
             return torch.zeros((), dtype=torch.float32, device=x.device)
-        if n >= 1 << 31:          # sat_rowsum indexes a row with 32-bit ints: sum 2^30-element pieces
+        if n > 1 << 29:           # sat_rowsum splits a row into 16384-element pieces along grid.y (<= 65535): sum 2^29-element pieces
             flat = x.view(-1)
-            return torch.stack([self.sum_all(piece) for piece in flat.split(1 << 30)]).sum()
+            return torch.stack([self.sum_all(piece) for piece in flat.split(1 << 29)]).sum()
         if x.data_ptr() % 16:
             x = x.clone()
         return self.rowsum(x.view(1, 1, n)).view(())
