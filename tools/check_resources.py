@@ -19,6 +19,9 @@ ALLOW = ("sat_gemm256_kernelILi0ELb0ELi2E", "sat_gemm256_kernelILi0ELb1ELi2E", "
          # LEANK = true variants (SAT_GEMM_LEAN=1, an unmeasured A/B arm) with the SwiGLU / head-split epilogues: 4-5 spilled registers, all
          # outside the K loops (ISA checked: the scratch instructions sit in the prologue and between the loops)
          "sat_gemm256_kernelILi3ELb0ELi0ELb0ELb1E", "sat_gemm256_kernelILi3ELb1ELi0ELb0ELb1E", "sat_gemm256_kernelILi4ELb0ELi0ELb0ELb1E",
+         # the fp32 (two-plane) dK / dV kernel: 4 registers spilled in the prologue and reloaded in the epilogue (ISA checked: no scratch
+         # instruction inside the tile loop)
+         "sat_attn_bwd_dkv_kernelIfLi2ELi32E",
          # the k = 7 weight gradient: 34-172 spilled registers, ALL in the remainder code after the stage loop (the ISA has its 35 scratch
          # instructions around the last MFMA block, none between the loop's barriers) — checked round 4, not on the steady-state path
          "sat_wgrad7_bf16x3_pipe_kernel")
