@@ -998,6 +998,10 @@ class SatOps:
     # M = 2050 / 4100 / 12290 (profiles/r04_gemm_bench.jsonl: within 5 % on 40 of the 48 (shape, tile) rows, worst 13 %).
     _TILE_MODEL = {0: (128, 128, 2, 0.65, 1.00, 6.2), 4: (256, 256, 1, 1.12, 1.47, 9.5),
                    7: (160, 256, 1, 1.05, 1.28, 7.0), 8: (128, 128, 1, 0.53, 0.56, 4.3)}
+    if os.environ.get("SAT_TILE_MODEL"):      # A/B of a re-fitted model (tools/fit_tile_model.py): JSON {"7": [u_light, u_full, fixed], ...}
+        import json as _json
+        for _t, (_ul, _uf, _fx) in _json.loads(os.environ["SAT_TILE_MODEL"]).items():
+            _TILE_MODEL[int(_t)] = _TILE_MODEL[int(_t)][:3] + (float(_ul), float(_uf), float(_fx))
     gemm_policy = os.environ.get("SAT_GEMM_POLICY", "model")     # "r3": round 3's rule (256 x 256 when >= 150 tiles, else 128 x 128 four-wave)
 
     def _tile_cost(self, tile, m, n, k, splits=1):
