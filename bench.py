@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-real-step", action="store_true", help="skip the timing of the alternating discriminator / generator step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DiT sampling measurement appended to the default line")
     ap.add_argument("--no-long-context", action="store_true", help="skip the N = 6145 fp8 sampling measurement (BASELINE.json configs[4])")
+    ap.add_argument("--no-dit-train", action="store_true", help="skip the DiT training-step measurement appended to the default line (configs[2]/[3])")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the generator step at per-GPU batch 2 and 4 (config.batch_sweep)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check of the bench item (about one CPU-minute)")
     ap.add_argument("--cpu-baseline-samples", type=int, default=32768, help="length of the probe crop that picks the thread count")
@@ -287,28 +288,113 @@ def dit_cpu_baseline(dcfg, latent_len, ctx_len):
 
 
 def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
-    """Oracle DiT training evaluation (fp32 forward + autograd backward of the v-objective MSE, one sample) on <=16 host
-    threads."""
+    """One DiT training evaluation on the host cores (fp32 forward + autograd backward of the v-objective MSE, ONE sample, no optimizer
+    step): the reference's own DiffusionTransformer (models/dit.py:231-431; its per-layer checkpointing, transformer.py:840-845, is what
+    the reference trains with) when its tree is importable (kind "reference"), else the oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import dit_oracle
-    from stable_audio_tools_amd.dit import DiffusionTransformer
-    cores = min(os.cpu_count() or 1, 16)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    model = DiffusionTransformer(**dcfg)
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
     cross = torch.randn(1, ctx_len, dcfg["cond_token_dim"], generator=g)
     glob = torch.randn(1, dcfg["global_cond_dim"], generator=g)
+    target = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
     t = torch.tensor([0.5])
+    if _reference_importable():
+        import contextlib
+        import refimport
+        with contextlib.redirect_stdout(sys.stderr):
+            refimport.import_reference()
+            from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
+            ref = RefDiT(**dcfg).float().train(True)
+        t0 = time.perf_counter()
+        out = ref(x, t, cross_attn_cond=cross, global_embed=glob, cfg_dropout_prob=0.1)
+        (out - target).square().mean().backward()
+        dt = time.perf_counter() - t0
+        return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
+                "sample": f"1 sample: the reference's DiffusionTransformer forward (per-layer checkpointing as it trains) + autograd backward "
+                          f"(fp32, N={latent_len + 1}, no optimizer step), single evaluation = {dt:.2f} s at {cores} threads"}
+    import dit_oracle
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    model = DiffusionTransformer(**dcfg)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     t0 = time.perf_counter()
     out = dit_oracle.dit_forward(sd, dcfg, x, t, cross, glob, cfg_scale=1.0)
-    loss = (out - torch.randn(out.shape, generator=g)).square().mean()
-    loss.backward()
+    (out - target).square().mean().backward()
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 sample: oracle DiT forward + autograd backward (fp32, N={latent_len + 1}, no optimizer step) in {dt:.2f} s"}
+            "sample": f"1 sample: oracle DiT forward + autograd backward (fp32, N={latent_len + 1}, no optimizer step) in {dt:.2f} s at {cores} threads"}
+
+
+def dit_train_object(batches=(4, 16), steps=5, warmup=2, with_cpu_baseline=True):
+    """BASELINE.json configs[2]/[3] inside the DEFAULT line: the Stable-Audio-Open-1.0 DiT training step (training/diffusion.py:332-487
+    restated by training.DiTTrainStep: v-objective MSE, cfg_dropout 0.1, bf16-mixed, fused AdamW + EMA; every activation resident, no
+    checkpoint recompute) on ONE GPU at per-GPU batch 4 and at the larger batch the 288 GB hold — samples/s, model TFLOP/s, the
+    attention kernels' rooflines (forward and backward) by HIP events, the reference's CPU step beside it."""
+    dev = torch.device("cuda", 0)
+    from stable_audio_tools_amd import ops as O
+    from stable_audio_tools_amd.dit import DiffusionTransformer
+    from stable_audio_tools_amd.training import DiTTrainStep
+    cfg = json.load(open(os.path.join(ROOT, "stable_audio_tools_amd", "configs", "stable_audio_open_dit.json")))
+    dcfg = cfg["diffusion"]["config"]
+    torch.manual_seed(1234)
+    model = DiffusionTransformer(**dcfg)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("to_out.weight") or ".ff.ff.2." in n_ or "process_conv" in n_:
+                p.normal_(0.0, 0.02)
+    model = model.to(dev).train(True)
+    stepper = DiTTrainStep(model, lr=5e-5, cfg_dropout_prob=0.1, autocast_dtype=torch.bfloat16)
+    tlat, m = cfg["latent_length"], cfg["context_length"]
+    n, d, depth = tlat + 1, dcfg["embed_dim"], dcfg["depth"]
+    fwd = depth * (2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 2 * n * d * d + 2 * m * 768 * 2 * 768
+                   + 4 * n * m * d + 2 * n * d * d + 2 * n * d * 8 * d + 2 * n * 4 * d * d)
+    obj = {"workload": "stable_audio_open_1_0 DiT train step (v-objective MSE, cfg_dropout 0.1, fwd+bwd, fused_adamw_ema), bf16-mixed, pre-encoded latents "
+                       "(1024 frames = 47.55 s), synthetic conditioning tensors, random init, no activation checkpointing; ONE GPU "
+                       "(`bench.py --workload dit_train --gpus N` is the data-parallel form)",
+           "unit": "samples/s", "dtype": "bf16", "model_tflop_per_sample_fwd_bwd": 3 * fwd / 1e12, "batches": {}}
+    g = torch.Generator().manual_seed(0)
+    for b in batches:
+        prof = None
+        try:
+            lat = torch.randn(b, dcfg["io_channels"], tlat, generator=g).to(dev)
+            cross = torch.randn(b, m, dcfg["cond_token_dim"], generator=g).to(dev)
+            glob = torch.randn(b, dcfg["global_cond_dim"], generator=g).to(dev)
+            for _ in range(warmup):
+                stepper(lat, cross_attn_cond=cross, global_embed=glob)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            prof = AttnProfiler(O.get_ops())
+            prof.enabled = True
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = stepper(lat, cross_attn_cond=cross, global_embed=glob)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            prof.enabled = False
+            r = prof.roofline(PEAK_BF16_MFMA_TFLOPS)
+            obj["batches"][str(b)] = {"samples_per_s": b / dt, "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
+                                      "achieved_model_tflops": 3 * fwd * b / dt / 1e12, "frac_of_bf16_peak": 3 * fwd * b / dt / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                      "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "final_loss": float(out["loss"]),
+                                      "roofline": {k: r[k] for k in ("backward", "achieved", "peak", "frac", "kernel", "launches", "avg_launch_ms",
+                                                                     "cross_attention", "projections") if k in r}}
+        except torch.cuda.OutOfMemoryError:
+            obj["batches"][str(b)] = {"out_of_memory": True}
+        finally:
+            if prof is not None:
+                prof.restore()
+            lat = cross = glob = None
+            torch.cuda.empty_cache()
+    done = [(k, v) for k, v in obj["batches"].items() if "samples_per_s" in v]
+    if done:
+        best = max(done, key=lambda kv: kv[1]["samples_per_s"])
+        obj["value"], obj["per_gpu_batch"], obj["ms_per_step"] = best[1]["samples_per_s"], int(best[0]), best[1]["ms_per_step"]
+    del stepper, model
+    torch.cuda.empty_cache()
+    if with_cpu_baseline:
+        obj["cpu_baseline"] = dit_train_cpu_baseline(dcfg, tlat, m)
+    return obj
 
 
 def run_dit_sample(args):
@@ -405,26 +491,50 @@ def dit_sample_line(dit_dtype, batch, steps, warmup, with_cpu_baseline):
     return line
 
 
-def dit_eval_parity(model, dcfg, x, cross, glob, kw, exit_layer_ix=None, bound=4e-2):
-    """Model evaluations of the timed native model (bf16 storage / fp8 projections as configured) against the fp32 CPU path on the
-    SAME weights widened to fp32: the reference's own DiffusionTransformer when a reference tree is importable, else the oracle port.
-    Relative L2 and max error of (a) the plain output (cfg_scale 1) — the quantity tests/test_full_width.py bounds at 4e-2 for bf16
-    storage through the depth-24 stack — and (b) the guided output the sampler consumes (CFG scale 6 + rescale: u + 6 (c - u)
-    multiplies the two halves' independent rounding errors, reported without a bound); with exit_layer_ix: the hidden state after
-    that layer only (long context: a full N = 6145 fp32 evaluation on the host takes minutes)."""
+def _capture_halves(module):
+    """Shadow `module._forward` (the doubled-batch evaluation inside DiffusionTransformer.forward under CFG: dit.py:385-398 in the reference,
+    the same method name in the native class) so that its raw output — [conditioned half; unconditioned half] — is kept."""
+    box, orig = {}, module._forward
+
+    def wrapped(*a, **k):
+        out = orig(*a, **k)
+        box["halves"] = (out[0] if isinstance(out, tuple) else out).detach().float().cpu()
+        return out
+    module._forward = wrapped
+    return box, lambda: module.__dict__.pop("_forward", None)
+
+
+def dit_eval_parity(model, dcfg, x, cross, glob, kw, bound=4e-2):
+    """ONE guided evaluation (t = 0.5, CFG scale and rescale of the timed loop, model batch 2) of the TIMED native model — bf16 storage /
+    fp8 projections as configured, full depth, full length — against the fp32 CPU path on the same weights widened to fp32: the
+    reference's own DiffusionTransformer (models/dit.py:231-431) when a reference tree is importable, else the oracle port.  Compared
+    tensors (relative L2 and max), all FINAL outputs of the full stack:
+      plain   the conditioned half of the doubled batch  == the model output at cfg_scale 1   — bounded by `bound`
+      uncond  the unconditioned half (null conditioning)                                      — bounded by `bound`
+      guided_pre_rescale  u + s (c - u) (dit.py:402), the native combine kernel at scale_phi 0 — bounded by the triangle inequality on
+              the two measured half errors: (s |dc| + (s - 1) |du|) / |g_ref| + one bf16 output rounding (2^-8): CFG at scale 6 multiplies the halves'
+              rounding errors by up to 11, the bound says by how much at most for THIS evaluation
+      guided  the output the sampler consumes (with the channel-std rescale, scale_phi) — reported; the rescale is a ratio of two
+              statistics of the tensors above.
+    Returns the parity object; `cpu_seconds` is the wall time of the ONE reference evaluation (batch 2) — long_context uses it as its
+    un-scaled CPU baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     xc, cc, gc = x.float().cpu(), cross.float().cpu(), glob.float().cpu()
     t = torch.full((x.shape[0],), 0.5)
-    guided = {"cfg_scale": kw["cfg_scale"], "scale_phi": kw["scale_phi"]}
-    modes = [("hidden", {"exit_layer_ix": exit_layer_ix})] if exit_layer_ix is not None else [("plain", {}), ("guided", guided)]
+    s_, phi = float(kw["cfg_scale"]), float(kw["scale_phi"])
     got = {}
-    with torch.no_grad():
-        for name, mkw in modes:
-            got[name] = model(x, t.to(x.device, x.dtype), cross_attn_cond=kw["cross_attn_cond"], global_embed=kw["global_embed"], **mkw).float().cpu()
+    box, undo = _capture_halves(model)
+    try:
+        with torch.no_grad():
+            tn = t.to(x.device, x.dtype)
+            got["guided"] = model(x, tn, cross_attn_cond=kw["cross_attn_cond"], global_embed=kw["global_embed"], cfg_scale=s_, scale_phi=phi).float().cpu()
+            got["plain"], got["uncond"] = box["halves"].chunk(2, dim=0)
+            got["guided_pre_rescale"] = model(x, tn, cross_attn_cond=kw["cross_attn_cond"], global_embed=kw["global_embed"], cfg_scale=s_, scale_phi=0.0).float().cpu()
+    finally:
+        undo()
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
     want = {}
     if _reference_importable():
         import contextlib
@@ -435,82 +545,45 @@ def dit_eval_parity(model, dcfg, x, cross, glob, kw, exit_layer_ix=None, bound=4
             ref = RefDiT(**dcfg).float().train(False)
         ref.load_state_dict(sd, strict=False)
         kind = "reference"
+        rbox, rundo = _capture_halves(ref)
+        t0 = time.perf_counter()
         with torch.no_grad():
-            for name, mkw in modes:
-                want[name] = ref(xc, t, cross_attn_cond=cc, global_embed=gc, **mkw)
+            want["guided"] = ref(xc, t, cross_attn_cond=cc, global_embed=gc, cfg_scale=s_, scale_phi=phi)
+        secs = time.perf_counter() - t0
+        rundo()
+        want["plain"], want["uncond"] = rbox["halves"].chunk(2, dim=0)
+        del ref
     else:
         import dit_oracle
         kind = "port"
-        if exit_layer_ix is not None:
-            return {"skipped": "no reference tree: the oracle port has no early exit"}
+        t0 = time.perf_counter()
         with torch.no_grad():
-            for name, mkw in modes:
-                want[name] = dit_oracle.dit_forward(sd, dcfg, xc, t, cc, gc, **mkw)
-    secs = time.perf_counter() - t0
+            want["plain"] = dit_oracle.dit_forward(sd, dcfg, xc, t, cc, gc)
+            want["uncond"] = dit_oracle.dit_forward(sd, dcfg, xc, t, torch.zeros_like(cc), gc)
+        secs = time.perf_counter() - t0
+        cu, uu = want["plain"], want["uncond"]
+        g = uu + (cu - uu) * s_
+        want["guided"] = phi * (g * (cu.std(dim=1, keepdim=True) / g.std(dim=1, keepdim=True))) + (1 - phi) * g if phi != 0.0 else g
+    want["guided_pre_rescale"] = want["uncond"] + (want["plain"] - want["uncond"]) * s_        # dit.py:402 on the reference's own halves
     out = {}
-    for name in got:
+    for name in ("plain", "uncond", "guided_pre_rescale", "guided"):
         d = got[name] - want[name]
         out[name] = {"rel_l2": float(f"{float(d.norm() / want[name].norm()):.3e}"), "rel_max": float(f"{float(d.abs().max() / want[name].abs().max()):.3e}")}
-    first = modes[0][0]
-    out.update({"bound_rel_l2": bound, "bounded": first, "ok": bool(out[first]["rel_l2"] < bound), "against": kind + " fp32 on CPU", "cpu_seconds": round(secs, 1),
-                "what": ("one model evaluation (t = 0.5): plain (cfg_scale 1, bounded) and guided (CFG scale 6 + rescale 0.75: the combination amplifies the two "
-                         "halves' rounding errors)" if exit_layer_ix is None else f"hidden state after layer {exit_layer_ix} (t = 0.5, no CFG)")
-                        + " of the timed model vs fp32 on the same (16-bit-rounded) weights"})
+    dc, du = float((got["plain"] - want["plain"]).norm()), float((got["uncond"] - want["uncond"]).norm())
+    gb = (s_ * dc + (s_ - 1.0) * du) / float(want["guided_pre_rescale"].norm()) + 2.0 ** -8
+    out["plain"]["bound_rel_l2"] = out["uncond"]["bound_rel_l2"] = bound
+    out["guided_pre_rescale"]["bound_rel_l2"] = float(f"{gb:.3e}")
+    ok = out["plain"]["rel_l2"] < bound and out["uncond"]["rel_l2"] < bound and out["guided_pre_rescale"]["rel_l2"] <= gb
+    out.update({"bound_rel_l2": bound, "bounded": ["plain", "uncond", "guided_pre_rescale"], "ok": bool(ok), "against": kind + " fp32 on CPU",
+                "cpu_seconds": round(secs, 1), "cpu_threads": cores, "depth": dcfg["depth"], "tokens": int(x.shape[-1]) + 1,
+                "what": f"FINAL output (B, {dcfg['io_channels']}, {int(x.shape[-1])}) of the timed depth-{dcfg['depth']} model at t = 0.5 vs fp32 on the same (16-bit-rounded) weights: "
+                        f"conditioned half (= cfg_scale 1 output) and unconditioned half bounded by {bound:g}; guided output before the rescale (u + {s_:g} (c - u)) "
+                        "bounded by the triangle inequality on the measured half errors; guided output after the channel-std rescale reported"})
     return out
 
 
 PEAK_FP8_MFMA_TFLOPS = 5000.0   # MI355X_MICROARCH.md: dense fp8 (MX) MFMA peak
-
-
-def long_context_cpu_baseline(dcfg, tlat, m, depth, n):
-    """CPU baseline of one N = 6145 sampler step (fp32, CFG batch 2) on this box's host cores.  A depth-24 evaluation takes ~2 minutes
-    here, so the default run times the model at depth 1 and depth 2 and extrapolates the per-layer slope:
-    t(depth) = t(1) + (depth - 1) * (t(2) - t(1)) — embeddings / projections in and out counted once.  The reference's own
-    DiffusionTransformer when its tree is importable (kind "reference": /root/reference, or oracle/_ref on the GPU box), else ONE layer
-    of the oracle port scaled by the depth (round 3's figure)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    g = torch.Generator().manual_seed(0)
-    xg = torch.randn(1, dcfg["io_channels"], tlat, generator=g)
-    cg, gg = torch.randn(1, m, dcfg["cond_token_dim"], generator=g), torch.randn(1, dcfg["global_cond_dim"], generator=g)
-    t = torch.tensor([0.5])
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    if _reference_importable():
-        import contextlib
-        import refimport
-        with contextlib.redirect_stdout(sys.stderr):
-            refimport.import_reference()
-        from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
-        times = {}
-        for d in (1, 2):
-            torch.manual_seed(1234)
-            ref = RefDiT(**dict(dcfg, depth=d)).float().train(False)
-
-            def step():
-                with torch.no_grad():
-                    ref(xg, t, cross_attn_cond=cg, global_embed=gg, cfg_scale=6.0, scale_phi=0.75)
-            times[d] = _median_time(step, reps=1)
-            del ref
-        slope = max(times[2] - times[1], 0.5 * times[2] / 2)      # guard: a noisy pair must not extrapolate to a free layer
-        total = times[1] + (depth - 1) * slope
-        return {"value": 1.0 / total, "unit": "steps/s", "cores": cores, "kind": "reference", "scaled": True,
-                "sample": f"the reference's DiffusionTransformer (fp32, CFG batch 2, N={n}) at depth 1 and 2 after a warm-up each: {times[1]:.2f} s / "
-                          f"{times[2]:.2f} s at {cores} threads; {depth} layers extrapolated as t(1) + {depth - 1} x {slope:.2f} s = {total:.1f} s"}
-    import dit_oracle
-    from stable_audio_tools_amd.dit import DiffusionTransformer
-    one = dict(dcfg, depth=1)
-    with torch.device("meta"):
-        shapes = {k: (tuple(v.shape), v.dtype) for k, v in DiffusionTransformer(**one).state_dict().items()}
-    sd = {k: (torch.randn(sh) * 0.02 if dt.is_floating_point else torch.zeros(sh, dtype=dt)) for k, (sh, dt) in shapes.items()}
-    sd["transformer.rotary_pos_emb.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
-
-    def step():
-        with torch.no_grad():
-            dit_oracle.dit_forward(sd, one, xg, t, cg, gg, cfg_scale=6.0, scale_phi=0.75)
-    dt1 = _median_time(step, reps=2)
-    return {"value": 1.0 / (dt1 * depth), "unit": "steps/s", "cores": cores, "kind": "port", "scaled": True,
-            "sample": f"ONE of the {depth} layers (oracle, fp32, CFG batch 2, N={n}): median of 2 after warm-up = {dt1:.2f} s at "
-                      f"{cores} threads, scaled x{depth}"}
+FP8_DEPTH24_BOUND = 0.2         # tests/test_long_context.py FP8_DEPTH24: derivation there
 
 
 def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
@@ -519,7 +592,8 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
     projection with >= 256 features in fp8 e4m3 on the MX MFMA (linear.set_fp8: dynamic scales — weights per tensor, activations per row: sat_quant_fp8_rows per GEMM
     input), attention in bf16 with fp32 softmax.  Reports sampler steps/s (eager and HIP-graph), the self-attention kernel against the
     2.5 PF bf16 peak, the fp8 projections against the 5 PF fp8 peak (with the quantisation passes' time beside them), and a CPU
-    baseline on ONE of the 24 layers (the oracle at N = 6145, scaled x24)."""
+    baseline = ONE un-scaled evaluation of the reference's fp32 model at this configuration, which is also the parity partner of the
+    timed model's final output."""
     dev = torch.device("cuda", 0)
     from stable_audio_tools_amd import ops as O
     from stable_audio_tools_amd.dit import DiffusionTransformer
@@ -593,16 +667,20 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
                           "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(attn_tf / PEAK_BF16_MFMA_TFLOPS, 4)},
             "fp8_projections": prof.gemm_summary(PEAK_FP8_MFMA_TFLOPS, fp8=True),
             "bf16_projections": prof.gemm_summary(PEAK_BF16_MFMA_TFLOPS)}
+    del gd
     if with_cpu_baseline:
-        try:
-            # bound: tests/test_long_context.py FP8_BLOCK (8e-2 relative L2 per block with fp8 e4m3 projections), two blocks
-            line["parity"] = dit_eval_parity(model, dcfg, noise, cross, glob, kw, exit_layer_ix=1, bound=0.113)
-        except Exception as e:   # noqa: BLE001 — a figure, not a gate
-            line["parity"] = {"error": repr(e)[:200]}
-    del model, gd
+        # ONE un-scaled evaluation of the reference's fp32 DiffusionTransformer at the timed configuration (depth 24, N = 6145, CFG batch 2) on
+        # the host cores: it is both the parity partner of the timed fp8 model's FINAL output and the CPU baseline (no extrapolation).
+        # bound: tests/test_long_context.py FP8_DEPTH24 (derived there)
+        par = dit_eval_parity(model, dcfg, noise, cross, glob, kw, bound=FP8_DEPTH24_BOUND)
+        line["parity"] = par
+        line["cpu_baseline"] = {"value": 1.0 / par["cpu_seconds"], "unit": "steps/s", "cores": par["cpu_threads"],
+                                "kind": "reference" if par["against"].startswith("reference") else "port", "scaled": False,
+                                "sample": f"ONE sampler step's model evaluation, un-scaled: the {par['against'].split()[0]}'s fp32 DiffusionTransformer at depth {depth}, N={n}, CFG batch 2 "
+                                          f"(the parity partner above), single evaluation without warm-up = {par['cpu_seconds']:.1f} s at {par['cpu_threads']} threads"
+                                          + ("" if par["against"].startswith("reference") else " (no reference tree: two batch-1 evaluations of the oracle port)")}
+    del model
     torch.cuda.empty_cache()
-    if with_cpu_baseline:
-        line["cpu_baseline"] = long_context_cpu_baseline(dcfg, tlat, m, depth, n)
     return line
 
 
@@ -961,7 +1039,10 @@ def run_dit_train(args):
                 p.normal_(0.0, 0.02)
     model = model.to(dev).train(True)
     mixed = args.dit_dtype == "bf16"
-    stepper = DiTTrainStep(model, lr=5e-5, cfg_dropout_prob=0.1, autocast_dtype=torch.bfloat16 if mixed else None)
+    stepper = DiTTrainStep(model, lr=5e-5, cfg_dropout_prob=0.1, autocast_dtype=torch.bfloat16 if mixed else None,
+                           ddp_single_rank=True if args.ddp_single_rank else None, ddp_mode=args.ddp_mode,
+                           ddp_comm_dtype=torch.bfloat16 if args.ddp_comm_dtype == "bf16" else None)
+    stepper.comm.timing = stepper.comm.active
     from stable_audio_tools_amd import ops as O
     prof = AttnProfiler(O.get_ops())
     b, tlat, m = args.batch, cfg["latent_length"], cfg["context_length"]
@@ -988,6 +1069,8 @@ def run_dit_train(args):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if dist.is_initialized():
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
     if rank == 0:
         n = tlat + 1
         d, depth, mm = dcfg["embed_dim"], dcfg["depth"], m
@@ -1001,7 +1084,13 @@ def run_dit_train(args):
                                        "fused_adamw_ema), pre-encoded latents, synthetic conditioning tensors, random init, no activation checkpointing",
                            "latent_frames": tlat, "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                            "final_loss": float(out["loss"]), "model_tflop_per_sample_fwd_bwd": 3 * fwd / 1e12,
-                           "achieved_model_tflops": 3 * fwd * b * world * args.steps / elapsed / 1e12},
+                           "achieved_model_tflops": 3 * fwd * b * world * args.steps / elapsed / 1e12,
+                           "ddp": {"process_group": (dist.get_backend() if dist.is_initialized() else None), "exchange_active": stepper.comm.active,
+                                   "world_size": (dist.get_world_size() if dist.is_initialized() else 1), "mode": stepper.comm.mode,
+                                   "comm_dtype": args.ddp_comm_dtype, "buckets": len(stepper.comm.buckets), "overlap": stepper.comm.overlap,
+                                   "gradient_bytes": int(stepper.flat.padded) * 4,
+                                   "buckets_launched_from_backward_hooks": sum(int(h) for _, h in getattr(stepper.comm, "last_launch_log", [])),
+                                   "timeline": stepper.comm.timeline()}},
                 "roofline": prof.roofline(PEAK_BF16_MFMA_TFLOPS if mixed else PEAK_BF16_MFMA_TFLOPS / 3.0)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = dit_train_cpu_baseline(dcfg, tlat, m)
@@ -1102,6 +1191,7 @@ def main():
     stepper = AutoencoderTrainStep(model, cfg, use_discriminator=(world == 1 and not args.no_real_step), ddp_mode=args.ddp_mode,
                                    ddp_comm_dtype=torch.bfloat16 if args.ddp_comm_dtype == "bf16" else None,
                                    ddp_single_rank=True if args.ddp_single_rank else None)
+    stepper.comm.timing = stepper.comm.active      # exchange timeline of the last timed step (config.ddp.timeline)
     stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
     ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
     prof = ConvProfiler(ops)
@@ -1129,6 +1219,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(out["loss"])
+    ddp_timeline = stepper.comm.timeline()
+    stepper.comm.timing = False
     elapsed_eager = elapsed
     launch = {"mode": "eager", "ms_per_step": {"eager": 1e3 * elapsed_eager / args.steps}}
     gstep = None
@@ -1164,6 +1256,8 @@ def main():
         launch["graph_loss"] = float(out_g["loss"])
         launch["value_uses"] = "eager"
 
+    if dist.is_initialized():      # the line's n_gpus IS the size of the process group the exchange ran in
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
     if rank == 0:
         dom, allk = prof.summary()
         line = {
@@ -1182,8 +1276,13 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": loss, "launch": launch,
                        "ddp": {"process_group": (dist.get_backend() if dist.is_initialized() else None), "exchange_active": stepper.comm.active,
                                "mode": stepper.comm.mode, "comm_dtype": args.ddp_comm_dtype, "buckets": len(stepper.comm.buckets),
-                               "overlap": stepper.comm.overlap,
-                               "buckets_launched_from_backward_hooks": sum(int(h) for _, h in getattr(stepper.comm, "last_launch_log", []))}},
+                               "overlap": stepper.comm.overlap, "native_c_abi_exchange": bool(stepper.comm.native),
+                               "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+                               "buckets_launched_from_backward_hooks": sum(int(h) for _, h in getattr(stepper.comm, "last_launch_log", [])),
+                               "timeline": ddp_timeline,
+                               "timeline_note": "last timed step, milliseconds from the first kernel of the backward pass: ready = the bucket's gradients "
+                                                "are complete (its collective is enqueued behind that event on the side stream), done = the collective "
+                                                "finished; a bucket overlaps the backward when done_ms < backward_ms"}},
             "roofline": {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
                          "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], args), "kernel": dom["kernel"],
                          "launches": dom["launches"],
@@ -1361,6 +1460,8 @@ def main():
                 line["secondary"]["cpu_baseline"] = sec["cpu_baseline"]
             if not args.no_long_context:
                 line["long_context"] = long_context_line(with_cpu_baseline=not args.no_cpu_baseline)
+            if not args.no_dit_train:
+                line["dit_train"] = dit_train_object(with_cpu_baseline=not args.no_cpu_baseline)
         emit(line)
     if dist.is_initialized():
         dist.destroy_process_group()

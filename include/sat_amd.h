@@ -27,10 +27,6 @@ extern "C" {
 int sat_abi_version(void);
 int sat_is_simulator(void);          /* 0 for the gfx950 library; 1 only for the CPU test-suite's simulator build */
 const char* sat_last_error(void);
-/* Launches taken so far by the env-selected A/B arms of the library (arm 0: SAT_ATTN_LEAN forward, 1: SAT_ATTN_BWD_LEAN, 2: SAT_GEMM_LEAN
- * eight-wave kernels, 3: SAT_GEMM_LEAN 256 x 256 kernel, 4: SAT_LN_LEAN); -1 for an unknown arm.  Lets a test or an A/B script check that
- * the switch it set was honoured. */
-long long sat_lean_launches(int arm);
 
 /* ------------------------------------------------------------------------------------------------
  * Oobleck conv stack — models/autoencoders.py:23-27 (WNConv1d / WNConvTranspose1d), :58-83
@@ -69,7 +65,7 @@ int sat_conv1d_bf16x3(const float* x, const short* w_hi, const short* w_lo, cons
                       const float* snake_ib, const float* res, float* y, const float* x2, const float* alpha2,
                       const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
                       int K, int stride, int dil, int pad, int tanh_out, void* stream);
-/* The same conv that ALSO writes act(y) as the activation planes its consumer reads (sat_conv1d_bf16x3_planes / _planesq): em_hi /
+/* The same conv that ALSO writes act(y) as the activation planes its consumer reads (sat_conv1d_bf16x3_planesq): em_hi /
  * em_lo [B][ceil(Cout/8)][em_rows][8] bf16, row 32 + t (the caller keeps the rows around the sequence zero); em_a / em_ib = the
  * consumer's pre-exponentiated SnakeBeta constants (sat_snake_consts) or NULL for planes of y itself.  Replaces the consumer's
  * sat_conv1d_k7_planes pre-pass (ResidualUnit chains: autoencoders.py:58-83, :233-283).  K <= 4 or strided plans, Tout % 4 == 0. */
@@ -140,19 +136,15 @@ int sat_disc_wgrad_nsplit(int B, int M, int Cin, int kh, int frames, int W);
 int sat_disc_wgrad(const float* dy, const float* x, float* partial, int B, int M, int Cin, int frames, int W, int kh, int kw, int dil_t,
                    void* stream);
 
-/* The stride-1, 5 <= K <= 8 convolutions (the k = 7 convs of the ResidualUnits, autoencoders.py:58-83, and their data-gradients) with
+/* The stride-1, 5 <= K <= 7 convolutions (the k = 7 convs of the ResidualUnits, autoencoders.py:58-83, and their data-gradients) with
  * the activated input converted ONCE into bf16 hi / lo planes [B][ceil(Cin/8)][rows][8 channels] (row = 32 + t, zero rows around the
  * sequence) instead of per workgroup while staging: sat_conv1d_k7_planes writes the planes (SnakeBeta with pre-exponentiated constants
- * or no activation), sat_conv1d_bf16x3_planes is sat_conv1d_bf16x3 reading them by LDS-DMA.  rows = sat_conv1d_k7_plane_rows(...)
- * (-1: pad > 32 is not supported). */
+ * or no activation) unless the producing conv's epilogue already did (sat_conv1d_bf16x3_emit); sat_conv1d_bf16x3_planesq reads them by
+ * LDS-DMA.  rows = sat_conv1d_k7_plane_rows(...) (-1: pad > 32 is not supported). */
 int sat_conv1d_k7_plane_rows(int Tin, int Tout, int pad);
 int sat_conv1d_k7_planes(const float* x, const float* snake_a, const float* snake_ib, short* xp_hi, short* xp_lo, int B, int Cin, int Tin,
                          int rows, void* stream);
-int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo, const float* bias,
-                             const float* res, float* y, const float* x2, const float* alpha2, const float* beta2, float* part_da,
-                             float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int tanh_out,
-                             void* stream);
-/* Third-generation kernel for the same convs (csrc/conv1d_bf16x3_k7q.h: 16-channel K-chunks with one tap per MFMA k-step, two wave rows
+/* The planes kernel (csrc/conv1d_bf16x3_k7q.h: 16-channel K-chunks with one tap per MFMA k-step, two wave rows
  * one barrier apart), 5 <= K <= 7: same arguments, the weight planes packed by sat_pack_weights_k7q
  * ([chunk of 16 in-channels][tap][8-channel group][out channel padded to 128][8]; mode 0 = conv weight [out][in][K], mode 1 = the
  * data-gradient of a stride-1 conv).  sat_pack_weights_k7q_size = elements per plane (-1: unsupported). */
@@ -374,11 +366,6 @@ int sat_sampler_step(const void* out2, const void* x, const void* prev, void* y0
  * coefficients (inference/sampling.py changes them every step). */
 int sat_sampler_step_dev(const void* out2, const void* x, const void* prev, void* y0, void* y1, int B, int C, int T, int ncond,
                          float scale, float phi, const float* coef, int dtype, void* stream);
-/* Cache prefetch: reads n <= 16 read-only device buffers (ptrs / bytes: host arrays; 16-byte aligned) and discards them — launched on a
- * side stream one transformer layer ahead, it puts the next layer's weights into the memory-side cache before the projection GEMMs ask
- * for them (transformer.ContinuousTransformer, inference).  No reference counterpart: a scheduling hint, results are unaffected. */
-int sat_prefetch(const void* const* ptrs, const long long* bytes, int n, void* stream);
-
 /* Complex spectrogram of the MS-STFT discriminator — models/encodec.py:73-76, :97-102 (torchaudio Spectrogram: periodic Hann,
  * normalized by ||w||_2, center = False, onesided, power = None; real / imaginary parts concatenated on the channel axis, axes
  * swapped to (frames, freq)).  x (NI, C, T), C in {1, 2} -> z (NI, 2C, frames, n_fft/2+1), frames = sat_spec_frames().
@@ -400,8 +387,8 @@ int sat_spec_bwd(const float* dz, float* dx, int NI, int C, int T, int n_fft, in
  * if not NULL, receives the pre-activation for the backward.  bias: fp32 (N) or NULL.  out_f32: C / res / gate / pre are
  * fp32 instead of bf16.  splits > 1 (epilogue 0, fp32, no bias): split-K partial slabs, slab z at C + z*M*ldc — sum them
  * with sat_reduce_splits.  zeros: >= 16 bytes of device zeros (source of K-tail chunks).  tile: 0 = 128x128 workgroup
- * tile (4 waves, two workgroups per CU), 4 = 256x256 (8 waves, two wave rows one barrier apart), 6 / 7 / 8 = 128x256 / 160x256 /
- * 128x128 on the eight-wave ring kernel (1..3, 5: experiment variants).  fp32 models run this kernel on sat_split_bf16x3
+ * tile (4 waves, two workgroups per CU), 4 = 256x256 (8 waves, two wave rows one barrier apart), 7 / 8 = 160x256 /
+ * 128x128 on the eight-wave ring kernel (any other value is an error).  fp32 models run this kernel on sat_split_bf16x3
  * operands (K' = 3K). */
 int sat_gemm_bf16(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                   const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,

@@ -48,8 +48,17 @@ def bump_params(params):
 
 
 def _optimizer_post_hook(optimizer, *_args, **_kwargs):
+    """Per-storage bumps for plain leaf parameters; anything else in a group (a view or a tied alias whose data_ptr differs from the
+    tensor the modules read) cannot be tracked per storage, so the GLOBAL epoch moves — the conservative behaviour of rounds 1–3."""
+    plain = True
     for group in optimizer.param_groups:
-        bump_params(group["params"])
+        ps = group["params"]
+        bump_params(ps)
+        for p in ps:
+            if p is not None and (p._base is not None or not p.is_leaf):
+                plain = False
+    if not plain:
+        bump_weight_epoch()
 
 
 def version_of(t):
@@ -101,5 +110,5 @@ install_optimizer_hook()
 try:        # outside patch_reference too: an EMA-model forward between optimizer.step and the `.data` EMA update must not see stale copies
     from ema_pytorch import EMA as _EMA
     wrap_ema_update(_EMA)
-except ImportError:
+except Exception:      # noqa: BLE001 — an optional third-party package that fails to import (for whatever reason) must not break this one
     pass

@@ -17,7 +17,6 @@ _F = ctypes.c_float
 SIGNATURES = {
     "sat_abi_version": (_I, []),
     "sat_is_simulator": (_I, []),
-    "sat_lean_launches": (_L, [_I]),
     "sat_last_error": (ctypes.c_char_p, []),
     # conv1d.hip
     "sat_conv1d": (_I, [_P] * 12 + [_I] * 10 + [_P]),
@@ -43,7 +42,6 @@ SIGNATURES = {
     "sat_disc_wgrad": (_I, [_P] * 3 + [_I] * 8 + [_P]),
     "sat_conv1d_k7_plane_rows": (_I, [_I] * 3),
     "sat_conv1d_k7_planes": (_I, [_P] * 5 + [_I] * 4 + [_P]),
-    "sat_conv1d_bf16x3_planes": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),
     "sat_conv1d_bf16x3_planesq": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),
     "sat_pack_weights_k7q": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_residual_unit_fwd": (_I, [_P, _P, _I] + [_P] * 11 + [_I] * 6 + [_P] * 4 + [_I, _P]),
@@ -118,7 +116,6 @@ SIGNATURES = {
     "sat_gate_residual": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "sat_gate_residual_bwd_nchunks": (_I, [_I]),
     "sat_cfg_step": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
-    "sat_prefetch": (_I, [_P, _P, _I, _P]),
     "sat_sampler_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "sat_sampler_step_dev": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "sat_gate_residual_bwd": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),

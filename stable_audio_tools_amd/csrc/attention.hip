@@ -24,7 +24,6 @@
 // (slot (hi,e) of step u <-> row 16u + 4hi + (e&3) + 8(e>>2)) and the LDS-side operand is read in that
 // same order.
 #include "sat_device.h"
-#include <stdlib.h>
 
 #define SAT_ATT_D 64
 #define SAT_ATT_T 64              // tile width (keys in fwd/dQ, queries in dK/dV)
@@ -221,6 +220,24 @@ template <typename T> struct SatOut;
 template <> struct SatOut<float> { static SAT_DEVICE void put(void* p, long long i, float v) { ((float*)p)[i] = v; } };
 template <> struct SatOut<short> { static SAT_DEVICE void put(void* p, long long i, float v) { ((short*)p)[i] = sat_f32_to_bf16(v); } };
 
+// 16-byte load through a raw buffer descriptor: address = descriptor base + per-lane VGPR byte offset + scalar byte offset — the
+// per-tile address arithmetic of the tile loops is one scalar add (buffer_load_dwordx4 v, voff, s[rsrc], soff offen) instead of one
+// 64-bit per-lane add per piece.
+#if defined(SAT_HIPEMU)
+struct SatBuf { const char* base; };
+SAT_DEVICE SatBuf sat_buf_make(const void* p) { return SatBuf{(const char*)p}; }
+SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const bf16x8*>(b.base + voff + soff); }
+#else
+typedef __amdgpu_buffer_rsrc_t SatBuf;
+SAT_DEVICE SatBuf sat_buf_make(const void* p) {      // raw buffer: stride 0, 2 GiB - 1 bytes, gfx9 untyped dword3 (0x00020000)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0));
+}
+#endif
+
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -266,8 +283,9 @@ SAT_DEVICE float sat_att_sum2(uint32_t w, float acc) {
 #endif
 }
 
-// DOT2 (bf16 planes only; the lean forward kernel below): P is packed to bf16 BEFORE the row sum, which then runs on sat_att_sum2 over
-// the packed words — 16 instructions per 64-key tile instead of 32 adds; the normaliser is the sum of the rounded probabilities.
+// DOT2 (bf16 planes: NP == 1; round 5 — timed in profiles/r05_experiments/lean_ab/): P is packed to bf16 BEFORE the row sum, which then
+// runs on sat_att_sum2 over the packed words — 16 instructions per 64-key tile instead of 32 adds; the normaliser is the sum of the
+// ROUNDED probabilities (what P V multiplies): the output is normalised consistently, the LSE moves by <= 2^-9 / sqrt(keys) relative.
 template <int NP, int NKB, bool MASK, bool FIRST, bool DOT2 = false>
 SAT_DEVICE void sat_attn_fwd_tile(short (*k_lds)[SAT_ATT_T][SAT_ATT_ROW], short (*v_lds)[SAT_ATT_D][SAT_ATT_ROW], const bf16x8 (&qf)[4][NP],
                                   f32x16 (&oacc)[2], f32x16& negm, float& mb, float& l_run, int l31, int hi, int kperm, int nvalid) {
@@ -450,16 +468,28 @@ sat_attn_fwd_kernel(SatAttnParams p) {
     }
     float mb = 0.0f, l_run = 0.0f;      // running row max (exp2 domain) and row sum
 
-    // a 64 x 64 bf16 tile = 512 16-byte pieces = 2 per thread and plane
+    // a 64 x 64 bf16 tile = 512 16-byte pieces = 2 per thread and plane: LDS (row, part) and the byte offsets from the tile's uniform base
+    int srow[2], spart[2];
+    unsigned kob[2], vob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        srow[j] = c >> 3;
+        spart[j] = c & 7;
+        kob[j] = (unsigned)(srow[j] * SAT_ATT_D + spart[j] * 8) * 2u;
+        vob[j] = ((unsigned)srow[j] * (unsigned)p.Nkp + (unsigned)spart[j] * 8u) * 2u;      // < 64 * Nkp * 2 bytes: Nkp < 2^24 (sat_attn_check)
+    }
+    // this (batch item, kv head)'s K and V^T planes: descriptors in scalar registers (the lo planes' only exist in the two-plane mode)
+    const SatBuf kbuf0 = sat_buf_make(p.k_rm[0] + kplane), vbuf0 = sat_buf_make(p.v_tr[0] + kplane);
+    const SatBuf kbuf1 = sat_buf_make(p.k_rm[NP - 1] + kplane), vbuf1 = sat_buf_make(p.v_tr[NP - 1] + kplane);
     bf16x8 kreg[NP][2], vreg[NP][2];
     auto tile_load = [&](int k0) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
-                kreg[pl][j] = *reinterpret_cast<const bf16x8*>(p.k_rm[pl] + kplane + (size_t)(k0 + r) * SAT_ATT_D + part * 8);
-                vreg[pl][j] = *reinterpret_cast<const bf16x8*>(p.v_tr[pl] + kplane + (size_t)r * p.Nkp + k0 + part * 8);
+                kreg[pl][j] = sat_buf_load16(pl == 0 ? kbuf0 : kbuf1, kob[j], (unsigned)k0 * (SAT_ATT_D * 2));
+                vreg[pl][j] = sat_buf_load16(pl == 0 ? vbuf0 : vbuf1, vob[j], (unsigned)k0 * 2u);
             }
     };
     auto tile_store = [&](int buf) {
@@ -467,9 +497,8 @@ sat_attn_fwd_kernel(SatAttnParams p) {
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int c = threadIdx.x + j * 256, r = c >> 3, part = c & 7;
-                *reinterpret_cast<bf16x8*>(&k_lds2[buf][pl][r][part * 8]) = kreg[pl][j];
-                *reinterpret_cast<bf16x8*>(&v_lds2[buf][pl][r][part * 8]) = vreg[pl][j];
+                *reinterpret_cast<bf16x8*>(&k_lds2[buf][pl][srow[j]][spart[j] * 8]) = kreg[pl][j];
+                *reinterpret_cast<bf16x8*>(&v_lds2[buf][pl][srow[j]][spart[j] * 8]) = vreg[pl][j];
             }
     };
     tile_load(0);
@@ -482,7 +511,7 @@ sat_attn_fwd_kernel(SatAttnParams p) {
             tile_store(1);
             if (2 * SAT_ATT_T < p.Nk) tile_load(2 * SAT_ATT_T);
         }
-        if (w_ok) sat_attn_fwd_tile<NP, 2, false, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, true, NP == 1>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
         __syncthreads();
         k0 = SAT_ATT_T;
         buf = 1;
@@ -493,18 +522,18 @@ sat_attn_fwd_kernel(SatAttnParams p) {
             tile_store(buf ^ 1);                                         // tile k+1: registers -> the other buffer
             if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);   // tile k+2 -> registers (lands during this tile's math)
         }
-        if (w_ok) sat_attn_fwd_tile<NP, 2, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
+        if (w_ok) sat_attn_fwd_tile<NP, 2, false, false, NP == 1>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
         __syncthreads();
     }
     if (k0 < p.Nk && w_ok) {
         const int rem = p.Nk - k0;
         if (k0 == 0) {            // fewer than 64 keys in all: the ragged tile is also the first
-            if (rem > 32) sat_attn_fwd_tile<NP, 2, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
-            else sat_attn_fwd_tile<NP, 1, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            if (rem > 32) sat_attn_fwd_tile<NP, 2, true, true, NP == 1>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            else sat_attn_fwd_tile<NP, 1, true, true, NP == 1>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
         } else if (rem > 32) {
-            sat_attn_fwd_tile<NP, 2, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            sat_attn_fwd_tile<NP, 2, true, false, NP == 1>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
         } else {
-            sat_attn_fwd_tile<NP, 1, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
+            sat_attn_fwd_tile<NP, 1, true, false, NP == 1>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
         }
     }
 
@@ -523,159 +552,6 @@ sat_attn_fwd_kernel(SatAttnParams p) {
                 else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
             }
         // natural-log LSE of the scaled scores: (mb + log2 l) ln 2   (mb lives in the exp2 domain)
-        if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// LEAN variant of the bf16 forward (sat_attention_fwd with SAT_ATTN_LEAN=1) — round 4, last session: built and checked on the simulator
-// and in the ISA, NOT yet timed on an MI355X (the round's GPU budget was spent): off by default, an A/B arm for the next measurement.
-// The SQ counters put the forward's time in the SIMD's issue slots (183 instructions per 64-key tile and wave: 16 MFMA, 32 v_exp, 34 adds,
-// 16 converts, 16 + 4 LDS, 4 global loads, 16 address VALU, ~44 scalar), so this variant removes instructions and changes nothing else:
-//   * row sums from the packed probabilities (sat_att_sum2: 16 v_dot2c_f32_bf16 instead of 32 + 2 v_add_f32) — tile function, DOT2;
-//   * K / V^T tile loads through raw buffer descriptors: per-lane 32-bit byte offset computed once + a scalar tile offset (the product
-//     kernel carries four 64-bit per-lane pointers: eight v_lshl_add_u64 per tile).
-// Numerics: the normaliser is the sum of the bf16-ROUNDED probabilities (what P V multiplies) instead of the fp32 ones: the output is
-// normalised consistently; the LSE moves by <= 2^-9 / sqrt(keys) relative in l (tests/test_dit_kernels.py runs both arms).
-// ---------------------------------------------------------------------------------------------
-// 16-byte load through a raw buffer descriptor: address = descriptor base + per-lane VGPR byte offset + scalar byte offset — the
-// per-tile address arithmetic is one scalar add (buffer_load_dwordx4 v, voff, s[rsrc], soff offen)
-#if defined(SAT_HIPEMU)
-struct SatBuf { const char* base; };
-SAT_DEVICE SatBuf sat_buf_make(const void* p) { return SatBuf{(const char*)p}; }
-SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const bf16x8*>(b.base + voff + soff); }
-#else
-typedef __amdgpu_buffer_rsrc_t SatBuf;
-SAT_DEVICE SatBuf sat_buf_make(const void* p) {      // raw buffer: stride 0, 2 GiB - 1 bytes, gfx9 untyped dword3 (0x00020000)
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-SAT_DEVICE bf16x8 sat_buf_load16(SatBuf b, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0));
-}
-#endif
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-#if !defined(SAT_HIPEMU)
-__attribute__((amdgpu_waves_per_eu(3)))
-#endif
-sat_attn_fwd_lean_kernel(SatAttnParams p) {
-    constexpr int NP = 1;
-    __shared__ __attribute__((aligned(16))) short k_lds2[2][NP][SAT_ATT_T][SAT_ATT_ROW];   // [buffer][plane][key][d]
-    __shared__ __attribute__((aligned(16))) short v_lds2[2][NP][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][plane][d][key]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int kperm = sat_att_kperm(l31);
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int hk = h / (p.H / p.Hkv);
-    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
-    const bool q_in = qrow < p.Nqp;
-    const bool q_ok = qrow < p.Nq;
-    const bool w_ok = blockIdx.x * 128 + wave * 32 < p.Nq;
-    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
-    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
-    const float sl2 = p.scale * 1.4426950408889634f;
-
-    bf16x8 qf[4][NP];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        u32x4 w = u32x4{0u, 0u, 0u, 0u};
-        if (q_in) w = *reinterpret_cast<const u32x4*>(p.q_rm[0] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float e0 = __builtin_bit_cast(float, w[j] << 16), e1 = __builtin_bit_cast(float, w[j] & 0xffff0000u);
-            w[j] = sat_cvt2_pk(e0 * sl2, e1 * sl2);
-        }
-        qf[s][0] = __builtin_bit_cast(bf16x8, w);
-    }
-
-    f32x16 oacc[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        oacc[0][r] = 0.0f;
-        oacc[1][r] = 0.0f;
-        negm[r] = 0.0f;
-    }
-    float mb = 0.0f, l_run = 0.0f;
-
-    // this thread's two 16-byte pieces of a tile: LDS (row, part) and the byte offsets from the tile's uniform base
-    int srow[2], spart[2];
-    unsigned kob[2], vob[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = threadIdx.x + j * 256;
-        srow[j] = c >> 3;
-        spart[j] = c & 7;
-        kob[j] = (unsigned)(srow[j] * SAT_ATT_D + spart[j] * 8) * 2u;
-        vob[j] = ((unsigned)srow[j] * (unsigned)p.Nkp + (unsigned)spart[j] * 8u) * 2u;      // < 64 * Nkp * 2 bytes: Nkp < 2^24 keeps it in 32 bits
-    }
-    const SatBuf kbuf = sat_buf_make(p.k_rm[0] + kplane);      // this (batch item, kv head)'s K and V^T planes: scalar registers
-    const SatBuf vbuf = sat_buf_make(p.v_tr[0] + kplane);
-    bf16x8 kreg[2], vreg[2];
-    auto tile_load = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            kreg[j] = sat_buf_load16(kbuf, kob[j], (unsigned)k0 * (SAT_ATT_D * 2));
-            vreg[j] = sat_buf_load16(vbuf, vob[j], (unsigned)k0 * 2u);
-        }
-    };
-    auto tile_store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<bf16x8*>(&k_lds2[buf][0][srow[j]][spart[j] * 8]) = kreg[j];
-            *reinterpret_cast<bf16x8*>(&v_lds2[buf][0][srow[j]][spart[j] * 8]) = vreg[j];
-        }
-    };
-    tile_load(0);
-    tile_store(0);
-    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
-    __syncthreads();
-    int buf = 0, k0 = 0;
-    if (p.Nk >= SAT_ATT_T) {      // the first full tile, peeled: it establishes the running max
-        if (SAT_ATT_T < p.Nk) {
-            tile_store(1);
-            if (2 * SAT_ATT_T < p.Nk) tile_load(2 * SAT_ATT_T);
-        }
-        if (w_ok) sat_attn_fwd_tile<NP, 2, false, true, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
-        __syncthreads();
-        k0 = SAT_ATT_T;
-        buf = 1;
-    }
-    // full tiles: ONE straight-line body (the accumulators keep their registers around the loop; an unrolled-by-two body with
-    // compile-time buffers was tried here: the register allocator copies and spills the accumulators at the merge points)
-    for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
-        if (k0 + SAT_ATT_T < p.Nk) {
-            tile_store(buf ^ 1);
-            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
-        }
-        if (w_ok) sat_attn_fwd_tile<NP, 2, false, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, SAT_ATT_T);
-        __syncthreads();
-    }
-    if (k0 < p.Nk && w_ok) {                                     // the ragged last tile (fewer than 64 keys)
-        const int rem = p.Nk - k0;
-        if (k0 == 0) {
-            if (rem > 32) sat_attn_fwd_tile<NP, 2, true, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
-            else sat_attn_fwd_tile<NP, 1, true, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
-        } else if (rem > 32) {
-            sat_attn_fwd_tile<NP, 2, true, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
-        } else {
-            sat_attn_fwd_tile<NP, 1, true, false, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem);
-        }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.0f / l_tot;
-    if (q_ok) {
-        const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * SAT_ATT_D) + (long long)h * SAT_ATT_D;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {oacc[t][4 * g] * inv_l, oacc[t][4 * g + 1] * inv_l, oacc[t][4 * g + 2] * inv_l, oacc[t][4 * g + 3] * inv_l};
-                const long long idx = obase + t * 32 + 8 * g + 4 * hi;
-                if (sizeof(T) == 4) *(f32x4*)((float*)p.o + idx) = v;
-                else *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(v[0], v[1]), sat_cvt2_pk(v[2], v[3])};
-            }
         if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
@@ -813,11 +689,11 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LEAN variant of the bf16 dQ kernel (sat_attention_bwd with SAT_ATTN_BWD_LEAN=1) — round 4, last session: simulator- and ISA-checked,
-// not yet timed (off by default; tools/r05_attn_lean_ab.sh).  The product kernel issues 605 instructions per 64-key tile and wave
-// for 24 MFMAs: 162 v_accvgpr_read / write (the register allocator parks values in AGPRs: no occupancy attribute, 142 VGPRs), 96 for a
-// per-element (key < Nk && q_ok) mask on EVERY tile, 160 of softmax / dS arithmetic (fma, exp, sub, 2 mul per score), 63 of address
-// arithmetic.  Here:
+// The bf16 dQ kernel (round 5: round 4's "lean" arm is THE bf16 kernel — profiles/r05_experiments/lean_ab/: dQ + dK/dV per launch
+// 272 -> 195 us (self, N = 1025, B = 4), 180 -> 124 us (cross); the two-plane kernel above serves the fp32 mode only).  The general kernel
+// issues 605 instructions per 64-key tile and wave for 24 MFMAs: 162 v_accvgpr_read / write (the register allocator parks values in
+// AGPRs: no occupancy attribute, 142 VGPRs), 96 for a per-element (key < Nk && q_ok) mask on EVERY tile, 160 of softmax / dS arithmetic
+// (fma, exp, sub, 2 mul per score), 63 of address arithmetic.  Here:
 //   * amdgpu_waves_per_eu(2, 2): the 55 KB of LDS allow two workgroups per CU anyway — 256 registers, nothing parked in AGPRs;
 //   * no mask on full tiles: a column of dS^T only feeds the same query's column of dQ^T (never stored for q >= Nq), and keys >= Nk
 //     multiply zero columns of K^T; the ragged last tile is peeled and masked;
@@ -827,7 +703,7 @@ __global__ void __launch_bounds__(256) sat_attn_bwd_dq_kernel(SatAttnParams p) {
 //   * K / V / K^T tile loads through buffer descriptors.
 // ---------------------------------------------------------------------------------------------
 template <bool MASK>
-SAT_DEVICE void sat_attn_dq_lean_tile(short (*k_lds)[SAT_ATT_ROW], short (*v_lds)[SAT_ATT_ROW], short (*kt_lds)[SAT_ATT_ROW],
+SAT_DEVICE void sat_attn_dq_bf16_tile(short (*k_lds)[SAT_ATT_ROW], short (*v_lds)[SAT_ATT_ROW], short (*kt_lds)[SAT_ATT_ROW],
                                       const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], const f32x16& negl, const f32x16& negd,
                                       f32x16 (&dq)[2], int l31, int hi, int nvalid) {
 #pragma unroll
@@ -865,7 +741,7 @@ __global__ void __launch_bounds__(256)
 #if !defined(SAT_HIPEMU)
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-sat_attn_bwd_dq_lean_kernel(SatAttnParams p) {
+sat_attn_bwd_dq_bf16_kernel(SatAttnParams p) {
     __shared__ __attribute__((aligned(16))) short k_lds2[2][SAT_ATT_T][SAT_ATT_ROW];    // [buffer][key][d]
     __shared__ __attribute__((aligned(16))) short v_lds2[2][SAT_ATT_T][SAT_ATT_ROW];    // [buffer][key][d]
     __shared__ __attribute__((aligned(16))) short kt_lds2[2][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][d][key]
@@ -945,10 +821,10 @@ sat_attn_bwd_dq_lean_kernel(SatAttnParams p) {
             tile_store(buf ^ 1);
             if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
         }
-        sat_attn_dq_lean_tile<false>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, SAT_ATT_T);
+        sat_attn_dq_bf16_tile<false>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, SAT_ATT_T);
         __syncthreads();
     }
-    if (k0 < p.Nk) sat_attn_dq_lean_tile<true>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, p.Nk - k0);
+    if (k0 < p.Nk) sat_attn_dq_bf16_tile<true>(k_lds2[buf], v_lds2[buf], kt_lds2[buf], qf, gf, negl, negd, dq, l31, hi, p.Nk - k0);
     if (q_ok) {
         const long long obase = (((long long)b * p.H + h) * p.Nq + qrow) * SAT_ATT_D;
 #pragma unroll
@@ -1149,17 +1025,17 @@ sat_attn_bwd_dkv_kernel(SatAttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LEAN variant of the bf16 dK / dV kernel (SAT_ATTN_BWD_LEAN=1, with the lean dQ kernel above; same status: simulator- and ISA-checked,
-// unmeasured, off by default).  The product kernel issues ~700 instructions per 64-query tile and wave for 32 MFMAs: 192 of them a
-// BRANCHING per-element mask (v_cmp, s_and, s_and_saveexec, s_cbranch_execz, v_mov, s_or per score), 64 ds_read_b32 + as many waits for
-// the per-row lse / D broadcasts, 5 VALU per score of softmax / dS arithmetic.  Here:
+// The bf16 dK / dV kernel (round 5: THE bf16 kernel, as the dQ kernel above; the two-plane kernel serves the fp32 mode).  The general
+// kernel issues ~700 instructions per 64-query tile and wave for 32 MFMAs: 192 of them a BRANCHING per-element mask (v_cmp, s_and,
+// s_and_saveexec, s_cbranch_execz, v_mov, s_or per score), 64 ds_read_b32 + as many waits for the per-row lse / D broadcasts, 5 VALU per
+// score of softmax / dS arithmetic.  Here:
 //   * no masks.  PRECONDITION (what sat_attn_prepare writes): rows [N, Np) of every operand plane are ZERO.  Then a query row
 //     q >= Nq has S = 0, dP = 0, and — its staged -lse and -D being 0 — P = 1, dS = 0: it adds exactly 0 * 1 to dV^T (dO^T is zero
 //     there) and Q^T * 0 to dK^T; a key column >= Nk is never stored;
 //   * the staged -lse (exp2 domain) and -D of a 32-query block are read as FOUR 16-byte LDS reads each; -D enters the dP MFMA chain as its
 //     C operand, -lse the one fma per score that scales the product in fp32 (pre-scaling K here was tried: with the forward's LSE built
-//     from a pre-scaled Q the two roundings disagree by |s| 2^-9 in the exponent — 3 % on the spike cases — so the arithmetic of the
-//     product kernel is kept): per score fma, exp2, one multiply and two half-converts; `scale` of dS is applied to dK once at the end;
+//     from a pre-scaled Q the two roundings disagree by |s| 2^-9 in the exponent — 3 % on the spike cases — so the general kernel's
+//     arithmetic is kept): per score fma, exp2, one multiply and two half-converts; `scale` of dS is applied to dK once at the end;
 //   * Q / dO / Q^T / dO^T tile loads through buffer descriptors (one per plane for the whole kernel; head and tile enter as a scalar offset).
 // ---------------------------------------------------------------------------------------------
 // four 4-vectors -> one 16-register block (registers 4 g + e = v_g[e]) without element-wise copies
@@ -1185,7 +1061,7 @@ __global__ void __launch_bounds__(256)
 #if !defined(SAT_HIPEMU)
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-sat_attn_bwd_dkv_lean_kernel(SatAttnParams p) {
+sat_attn_bwd_dkv_bf16_kernel(SatAttnParams p) {
     constexpr int TQ = 64, TROW = TQ + 8;
     __shared__ __attribute__((aligned(16))) short q_lds2[2][TQ][SAT_ATT_ROW];      // [buffer][q][d]
     __shared__ __attribute__((aligned(16))) short g_lds2[2][TQ][SAT_ATT_ROW];      // dO [q][d]
@@ -1370,6 +1246,8 @@ static int sat_attn_check(int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nk
     if (H % Hkv != 0) { sat_set_error("attention: H must be a multiple of Hkv"); return 1; }
     if (Nqp < Nq || Nkp < Nk || Nqp % SAT_ATT_T || Nkp % SAT_ATT_T) { sat_set_error("attention: padded lengths must be multiples of 64 and cover N"); return 1; }
     if (dtype != 0 && dtype != 1) { sat_set_error("attention: dtype must be 0 (f32, split planes) or 1 (bf16)"); return 1; }
+    // tile loads go through buffer descriptors with 32-bit byte offsets: 64 rows of a transposed plane, and a kv group's query heads
+    if (Nkp >= (1 << 24) || (long long)Nqp * (H / Hkv) >= (1 << 24)) { sat_set_error("attention: sequences of 2^24 tokens or more are not supported"); return 1; }
     return 0;
 }
 
@@ -1381,11 +1259,7 @@ extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const sho
     p.q_rm[0] = q_hi; p.q_rm[1] = q_lo; p.k_rm[0] = k_hi; p.k_rm[1] = k_lo; p.v_tr[0] = vt_hi; p.v_tr[1] = vt_lo;
     p.o = o; p.lse = lse; p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
     dim3 grid(sat_cdiv(Nq, 128), H, B);
-    // SAT_ATTN_LEAN=1: the lean bf16 variant above (an unmeasured A/B arm: off by default); read at every call so that one process can
-    // time both arms
-    const char* lean = getenv("SAT_ATTN_LEAN");
     if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
-    else if (lean && lean[0] == '1' && Nkp < (1 << 24)) { sat_count_lean(0); SAT_LAUNCH((sat_attn_fwd_lean_kernel<short>), grid, dim3(256), stream, p); }
     else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_attention_fwd");
 }
@@ -1413,16 +1287,12 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
     p.lse = const_cast<float*>(lse); p.dsum = dsum; p.dq = dq; p.dk = dk; p.dv = dv;
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
     dim3 g1(sat_cdiv(Nq, 128), H, B), g2(sat_cdiv(Nk, 128), Hkv, B);
-    if (dtype == 0) {
+    if (dtype == 0) {      // fp32 mode: two bf16 planes per operand, three MFMAs per product
         SAT_LAUNCH((sat_attn_bwd_dq_kernel<float, 2>), g1, dim3(256), stream, p);
         SAT_LAUNCH((sat_attn_bwd_dkv_kernel<float, 2, 32>), g2, dim3(256), stream, p);
     } else {
-        // SAT_ATTN_BWD_LEAN=1: the lean bf16 dQ kernel above (an unmeasured A/B arm: off by default)
-        const char* lean = getenv("SAT_ATTN_BWD_LEAN");
-        if (lean && lean[0] == '1' && Nkp < (1 << 24)) { sat_count_lean(1); SAT_LAUNCH((sat_attn_bwd_dq_lean_kernel<short>), g1, dim3(256), stream, p); }
-        else SAT_LAUNCH((sat_attn_bwd_dq_kernel<short, 1>), g1, dim3(256), stream, p);
-        if (lean && lean[0] == '1' && Nqp < (1 << 24) / (H / Hkv)) SAT_LAUNCH((sat_attn_bwd_dkv_lean_kernel<short>), g2, dim3(256), stream, p);
-        else SAT_LAUNCH((sat_attn_bwd_dkv_kernel<short, 1, 64>), g2, dim3(256), stream, p);
+        SAT_LAUNCH((sat_attn_bwd_dq_bf16_kernel<short>), g1, dim3(256), stream, p);
+        SAT_LAUNCH((sat_attn_bwd_dkv_bf16_kernel<short>), g2, dim3(256), stream, p);
     }
     return sat_check_launch("sat_attention_bwd");
 }

@@ -7,8 +7,8 @@
 // mapped into the process (`librccl.so`, RTLD_NOLOAD: one RCCL, one HIP runtime), then the system one — so a box without RCCL loads the
 // conv / attention / GEMM kernels as before and only these four entry points fail (with a message).  The enum values and the 128-byte
 // unique id are RCCL's public ABI (rccl.h: ncclSum = 0, ncclFloat32 = 7, ncclBfloat16 = 9, NCCL_UNIQUE_ID_BYTES = 128).
-// Status (end of round 4): written without GPU access — the symbols, the id generation and the error paths are tested on the host; the
-// collectives themselves first run in round 5 (tests/test_train_step.py::test_native_exchange_gpu, SAT_TEST_LEAN_ARMS=1).
+// Status: the symbols, the id generation and the error paths are tested on the host; the collectives run on the MI355X on a 1-rank
+// communicator (tests/test_train_step.py::test_native_exchange_gpu: bit-equal to the step without an exchange; round 5).
 #include "sat_device.h"
 #include <stdio.h>
 #include <string.h>

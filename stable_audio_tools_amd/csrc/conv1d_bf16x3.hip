@@ -18,9 +18,8 @@
 //     so a chunk's slab is a straight 16-byte-per-lane copy into padded LDS rows.
 #include "conv_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
-#define SAT_K7P_LEAD_ROWS 32  // zero rows before t = 0 in an activation plane (= SAT_K7P_LEAD of conv1d_bf16x3_k7p.h)
+#define SAT_K7P_LEAD_ROWS 32  // zero rows before t = 0 in an activation plane (= SAT_K7P_LEAD of conv1d_planes.h)
 #define SAT_BF_AROWS1 192  // CS == 1: max staged time rows: 128 + (K-1)*dil <= 128 + 7*9 = 191
 #define SAT_BF_AROWSN 136  // CS  > 1: 128 + (taps-1) rows, taps <= 4, dil = 1
 
@@ -35,7 +34,7 @@ struct SatConvBfLaunch {
     int sout_log2;         // depth-to-space of the output: y[co][q*S + r - out_shift] = y'[co*S + r][q]  (transposed conv)
     int in_shift, out_shift;
     int nq;                // virtual output positions
-    // conv1d_bf16x3_k7p.h: the activation as pre-split planes [B][xp_c8][xp_rows][8] (null: convert from p.x while staging)
+    // conv1d_planes.h: the activation as pre-split planes [B][xp_c8][xp_rows][8] (null: convert from p.x while staging)
     const short* xp_hi = nullptr;
     const short* xp_lo = nullptr;
     int xp_rows = 0, xp_c8 = 0;
@@ -539,13 +538,12 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
 }
 
 #include "conv1d_bf16x3_k7.h"     // the pipelined kernel of the (8, 1) plan
-#include "conv1d_bf16x3_k7p.h"    // the same plan fed from pre-split activation planes by LDS-DMA
+#include "conv1d_planes.h"        // activation planes [B][Cin/8][rows][8] (pre-pass kernel; layout constants)
 #include "conv1d_bf16x3_k7q.h"    // planes, 16-channel chunks (one tap per MFMA k-step), two wave rows one barrier apart
 
 static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& pl, void* stream) {
     if (pl.ng == 8 && pl.cs == 1 && a.sin_log2 == 0 && a.sout_log2 == 0) {
         if (a.xp_hi && a.wq) sat_bf_launch_k7q(a, stream);
-        else if (a.xp_hi) sat_bf_launch_k7p(a, stream);
         else sat_bf_launch_k7(a, stream);
         return sat_check_launch(what);
     }
@@ -625,7 +623,7 @@ extern "C" int sat_conv1d_bf16x3_emit(const float* x, const short* w_hi, const s
                                   B, Cin, Cout, Tin, Tout, K, stride, dil, pad, tanh_out, (short*)em_hi, (short*)em_lo, em_a, em_ib, em_rows, stream);
 }
 
-// ---- the k = 5..8 stride-1 convs from pre-split activation planes (conv1d_bf16x3_k7p.h) ----
+// ---- the k = 5..7 stride-1 convs from pre-split activation planes (conv1d_planes.h, conv1d_bf16x3_k7q.h) ----
 // rows of one (batch, 8-channel chunk) plane: 32 zero rows, the sequence, zero rows up to the last window's halo
 extern "C" int sat_conv1d_k7_plane_rows(int Tin, int Tout, int pad) {
     if (Tin <= 0 || Tout <= 0 || pad < 0 || pad > SAT_K7P_LEAD) return -1;
@@ -642,39 +640,8 @@ extern "C" int sat_conv1d_k7_planes(const float* x, const float* snake_a, const 
     SAT_LAUNCH(sat_k7_planes_kernel, dim3(sat_cdiv(rows, 256), p.c8, B), dim3(256), stream, p);
     return sat_check_launch("sat_conv1d_k7_planes");
 }
-// sat_conv1d_bf16x3 for stride 1, 5 <= K <= 8, with the (activated) input given as sat_conv1d_k7_planes planes
-extern "C" int sat_conv1d_bf16x3_planes(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo,
-                                        const float* bias, const float* res, float* y, const float* x2, const float* alpha2,
-                                        const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
-                                        int K, int dil, int pad, int tanh_out, void* stream) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3_planes: empty shape"); return 1; }
-    SatBfPlan pl;
-    if (!sat_bf_plan(K, 1, 0, &pl) || !(pl.ng == 8 && pl.cs == 1) || dil < 1 || (pl.kv - 1) * dil > 62) {
-        sat_set_error("sat_conv1d_bf16x3_planes: needs stride 1, 5 <= K <= 8, (K-1)*dil <= 62");
-        return 1;
-    }
-    if (rows < sat_conv1d_k7_plane_rows(Tin, Tout, pad)) { sat_set_error("sat_conv1d_bf16x3_planes: rows must be >= sat_conv1d_k7_plane_rows(Tin, Tout, pad)"); return 1; }
-    if (x2 && (!alpha2 || !beta2 || !part_da || !part_db)) { sat_set_error("sat_conv1d_bf16x3_planes: backward epilogue needs alpha2/beta2/partials"); return 1; }
-    SatConvBfLaunch a;
-    a.p = SatConvParams{nullptr, nullptr, bias, nullptr, nullptr, res, y, x2, alpha2, beta2, part_da, part_db,
-                        B, Cin, Cout, Tin, Tout, pl.kv, 1, dil, pad, tanh_out};
-    a.w_hi = w_hi;
-    a.w_lo = w_lo;
-    a.cout_v = Cout;
-    a.cout_pad = sat_cdiv(Cout, SAT_CO_T) * SAT_CO_T;
-    a.cin_v = Cin;
-    a.sin_log2 = 0;
-    a.sout_log2 = 0;
-    a.in_shift = 0;
-    a.out_shift = 0;
-    a.nq = Tout;
-    a.xp_hi = xp_hi;
-    a.xp_lo = xp_lo;
-    a.xp_rows = rows;
-    a.xp_c8 = sat_cdiv(Cin, 8);
-    return sat_bf_launch("sat_conv1d_bf16x3_planes", a, pl, stream);
-}
-// The same with the weights packed by sat_pack_weights_k7q (mode 0, or mode 1 for a data-gradient): conv1d_bf16x3_k7q.h, 5 <= K <= 7.
+// sat_conv1d_bf16x3 for stride 1, 5 <= K <= 7, with the (activated) input given as planes (sat_conv1d_k7_planes or a producer's emission)
+// and the weights packed by sat_pack_weights_k7q (mode 0, or mode 1 for a data-gradient): conv1d_bf16x3_k7q.h.
 extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo,
                                          const float* bias, const float* res, float* y, const float* x2, const float* alpha2,
                                          const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,

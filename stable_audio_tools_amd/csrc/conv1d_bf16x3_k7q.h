@@ -524,10 +524,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     const long long total = (long long)(a.cout_pad / SAT_K7_CO) * sat_cdiv(a.nq, SAT_K7_T) * a.p.B;
     a.stagger = 1;                                         // measured: -1 % forward, -2.5 % data-gradient (tools/kq_ab.py); 2 and 4 lose
-    if (const char* es = getenv("SAT_K7Q_STAGGER")) a.stagger = atoi(es);
     if (total < 1024) a.stagger = 0;                       // few tiles per CU: the delay would not be paid back
     if (a.ru_w1_hi) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, true>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); return; }
-    const char* ev = getenv("SAT_K7Q_VARIANT");            // A/B switch (tools/kq_ab.py)
-    if (ev && atoi(ev) == 0) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<0>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
-    else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
+    SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a);
 }

@@ -16,7 +16,7 @@
 #define SAT_WP_NT 512
 #define SAT_WP_NI 64                 // input channels per workgroup
 
-template <int DIL, bool RS = false>
+template <int DIL>
 __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWgBfParams p) {
     constexpr int NCH = (6 * DIL + 7) / 8 + 1;                       // aligned 8-element chunks covering all 7 taps
     constexpr int HSPAN = SAT_WB_TT + 6 * DIL;                       // activation samples needed per stage
@@ -70,14 +70,6 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     // MFMA phase (~1 us) to arrive before it is converted, and 32 registers fewer are live (7 accumulator tiles = 112)
     float4 dyv[1][NDY];
     float xv[1][NXP][2];
-    // RS (A/B variant, SAT_WG_ROWSUM=1; NOT the default): bias gradient (sum over (b, t) of the dy rows) by the workgroups of the first
-    // column block — every stage is converted exactly once (write_lds), so each thread adds its four columns there and the 16 lanes of a
-    // row are reduced once at the end.  Saves the separate sat_rowsum pass over dy (13 GB of HBM reads per train step) but the four extra
-    // live registers cost the whole kernel ~13 % in situ (profiles/EXPERIMENTS.md): compiled out unless asked for.
-    const bool want_rs = RS && p.rowsum != nullptr && n0 == 0;      // block-uniform
-    float rs[NDY];
-#pragma unroll
-    for (int u = 0; u < NDY; ++u) rs[u] = 0.0f;
     auto issue_loads = [&](int c) {
         constexpr int st = 0;
         const int ch = c_begin + c;
@@ -118,7 +110,6 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
             const int row = (tid >> 4) + u * 32, c4 = (tid & 15) * 4;
-            if (want_rs) rs[u] += (dyv[st][u].x + dyv[st][u].y) + (dyv[st][u].z + dyv[st][u].w);
             uint32_t h0, h1, l0, l1;
             sat_split2_pk(dyv[st][u].x, dyv[st][u].y, &h0, &l0);
             sat_split2_pk(dyv[st][u].z, dyv[st][u].w, &h1, &l1);
@@ -228,16 +219,6 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
         mfma_phase(I0{});
     }
 
-    if (want_rs) {
-#pragma unroll
-        for (int u = 0; u < NDY; ++u) {
-            float v = rs[u];
-#pragma unroll
-            for (int m = 1; m <= 8; m <<= 1) v += __shfl_xor(v, m);
-            const int row = m0 + (tid >> 4) + u * 32;
-            if ((tid & 15) == 0 && row < p.M) p.rowsum[(size_t)row * p.nsplit + split] = v;
-        }
-    }
     if (m0 + m_w < p.M) {
         float* ob = p.out + (size_t)split * p.so_split;
         const int n = n0 + n_w + l31;

@@ -13,7 +13,6 @@
 // register selection + v_alignbit (dil is a template parameter: 1, 3, 9).
 #include "conv_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 #define SAT_WB_TT 64                 // time steps per LDS stage (4 MFMA k-steps)
 #define SAT_WB_LOROW (SAT_WB_TT + 8) // 144 B rows: conflict-free b128
@@ -264,9 +263,8 @@ extern "C" int sat_conv_wgrad7_bf16x3_nsplit(int B, int M, int N, int T) {
 extern "C" int sat_conv_wgrad7_bf16x3_fuses_rowsum(int B, int M, int N, int T) {
     SatWgBfPlan pl;
     sat_wgbf_plan(B, M, N, T, &pl);
-    // the 4-wave kernel produces dy_rowsum; the pipelined one only in its A/B variant (SAT_WG_ROWSUM=1: measured slower in the step)
-    if (pl.pipe) { const char* e = getenv("SAT_WG_ROWSUM"); return (e && atoi(e) == 1) ? 1 : 0; }
-    return 1;
+    // the 4-wave kernel produces dy_rowsum; the pipelined one does not (four more live registers cost it ~13 % in situ: profiles/EXPERIMENTS.md)
+    return pl.pipe ? 0 : 1;
 }
 // dW[m][n][k] for a K = 7, stride-1 conv with dilation in {1, 3, 9}: dy (B, M, T), x (B, N, T) pre-activation,
 // alpha/beta = SnakeBeta log-params of the conv input (or NULL).  Writes nsplit slabs (element (m,n,k) at
@@ -283,15 +281,10 @@ extern "C" int sat_conv_wgrad7_bf16x3(const float* dy, const float* x, const flo
                     dy_rowsum, pl.nsplit};
     if (pl.pipe) {
         dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, SAT_WP_NI), pl.nsplit);
-        if (dy_rowsum) {
-            if (dil == 1) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<1, true>), grid, dim3(SAT_WP_NT), stream, p);
-            else if (dil == 3) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<3, true>), grid, dim3(SAT_WP_NT), stream, p);
-            else SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<9, true>), grid, dim3(SAT_WP_NT), stream, p);
-        } else {
-            if (dil == 1) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<1, false>), grid, dim3(SAT_WP_NT), stream, p);
-            else if (dil == 3) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<3, false>), grid, dim3(SAT_WP_NT), stream, p);
-            else SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<9, false>), grid, dim3(SAT_WP_NT), stream, p);
-        }
+        if (dy_rowsum) { sat_set_error("sat_conv_wgrad7_bf16x3: this shape's kernel does not fuse the row sums (sat_conv_wgrad7_bf16x3_fuses_rowsum)"); return 1; }
+        if (dil == 1) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<1>), grid, dim3(SAT_WP_NT), stream, p);
+        else if (dil == 3) SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<3>), grid, dim3(SAT_WP_NT), stream, p);
+        else SAT_LAUNCH((sat_wgrad7_bf16x3_pipe_kernel<9>), grid, dim3(SAT_WP_NT), stream, p);
         return sat_check_launch("sat_conv_wgrad7_bf16x3");
     }
     dim3 grid(sat_cdiv(M, SAT_CO_T), sat_cdiv(N, 32), pl.nsplit);

@@ -19,7 +19,6 @@
 //       (global loads of stage c+2 | MFMAs of stage c | hi/lo split of stage c+1 into LDS) re-tiled for 64 output channels:
 //       64(co) x 64(virtual ci) x kw taps per workgroup, the two halves of a 128-position stage on different waves.
 #include "sat_device.h"
-#include <stdlib.h>
 
 #define SAT_DC_CO 64
 #define SAT_DC_T 512

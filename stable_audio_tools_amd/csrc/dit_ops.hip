@@ -10,7 +10,6 @@
 // dtype: 0 = fp32, 1 = bf16 tensors (statistics and math always fp32).
 #include <cstdio>
 #include "sat_device.h"
-#include <stdlib.h>
 
 template <typename T> struct SatIO;
 template <> struct SatIO<float> {
@@ -198,101 +197,6 @@ __global__ void __launch_bounds__(256) sat_layernorm_fwd_vec_kernel(SatLnParams 
     }
 }
 
-// TWO rows per wave (SAT_LN_LEAN=1; round 4, last session: simulator-checked, NOT timed — off by default).  In the sampler a launch is
-// 2050 rows of 1536 bf16: 3 KB of x per row against 18 KB of gamma / beta (fp32) and adaLN scale / shift that every row re-reads from L2,
-// and 7.9 us per launch for 12.6 MB of tensor traffic (1.6 TB/s): the waves spend their time on four dependent round trips (x, two
-// reductions, the parameter vectors) at two waves per SIMD.  Here a wave owns two consecutive rows of ONE batch item (they share the
-// modulation vectors), loads both rows first, interleaves the two rows' reductions and reads every parameter chunk once for both.
-template <typename T>
-__global__ void __launch_bounds__(256) sat_layernorm_fwd_vec2_kernel(SatLnParams p) {
-    constexpr int N = SatVec<T>::N, MAXC = SatVec<T>::MAXC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ppb = (p.rows_per_batch + 1) >> 1, nb = p.rows / p.rows_per_batch;
-    const int pair = blockIdx.x * 4 + wave;
-    if (pair >= nb * ppb) return;      // whole wave exits together; no block barrier below
-    const int b = pair / ppb, j = pair - b * ppb;
-    const int row0 = b * p.rows_per_batch + 2 * j;
-    const bool has1 = 2 * j + 1 < p.rows_per_batch;      // wave-uniform: an odd row count leaves the last pair of a batch item single
-    const long long base0 = (long long)row0 * p.D, base1 = base0 + p.D;
-    const int nc = p.D / (64 * N);
-    float x0[MAXC][N], x1[MAXC][N];
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < nc) {
-            SatVec<T>::ld(p.x, base0 + (c * 64 + lane) * N, x0[c]);
-            if (has1) SatVec<T>::ld(p.x, base1 + (c * 64 + lane) * N, x1[c]);
-            else {
-#pragma unroll
-                for (int e = 0; e < N; ++e) x1[c][e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < N; ++e) {
-                s0 += x0[c][e];
-                s1 += x1[c][e];
-            }
-        }
-    }
-    const float mean0 = sat_wave_sum(s0) / (float)p.D, mean1 = sat_wave_sum(s1) / (float)p.D;
-    float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < nc) {
-#pragma unroll
-            for (int e = 0; e < N; ++e) {
-                const float d0 = x0[c][e] - mean0, d1 = x1[c][e] - mean1;
-                v0 += d0 * d0;
-                v1 += d1 * d1;
-            }
-        }
-    }
-    const float rstd0 = 1.0f / sqrtf(sat_wave_sum(v0) / (float)p.D + p.eps), rstd1 = 1.0f / sqrtf(sat_wave_sum(v1) / (float)p.D + p.eps);
-    const long long mb = p.scale ? (long long)b * p.mod_stride : 0;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < nc) {
-            const int i0 = (c * 64 + lane) * N;
-            float g[N], be[N], o0[N], o1[N];
-#pragma unroll
-            for (int e = 0; e < N; e += 4) SatVec<float>::ld(p.gamma, i0 + e, g + e);
-#pragma unroll
-            for (int e = 0; e < N; ++e) {
-                o0[e] = (x0[c][e] - mean0) * rstd0 * g[e];
-                o1[e] = (x1[c][e] - mean1) * rstd1 * g[e];
-            }
-            if (p.beta) {
-#pragma unroll
-                for (int e = 0; e < N; e += 4) SatVec<float>::ld(p.beta, i0 + e, be + e);
-#pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    o0[e] += be[e];
-                    o1[e] += be[e];
-                }
-            }
-            if (p.scale) {
-                float sc[N], sh[N];
-                SatVec<T>::ld(p.scale, mb + i0, sc);
-                SatVec<T>::ld(p.shift, mb + i0, sh);
-#pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    o0[e] = o0[e] * (1.0f + sc[e]) + sh[e];
-                    o1[e] = o1[e] * (1.0f + sc[e]) + sh[e];
-                }
-            }
-            SatVec<T>::st(p.y, base0 + i0, o0);
-            if (has1) SatVec<T>::st(p.y, base1 + i0, o1);
-        }
-    }
-    if (lane == 0 && p.mean) {
-        p.mean[row0] = mean0;
-        p.rstd[row0] = rstd0;
-        if (has1) {
-            p.mean[row0 + 1] = mean1;
-            p.rstd[row0 + 1] = rstd1;
-        }
-    }
-}
-
 // LayerNorm straight to the fp8 operand of the projection that consumes it (round 4; the N = 6145 sampler): the normalised (and
 // adaLN-modulated) row is kept in registers, its max |.| gives the row's dynamic scale, and the row leaves as e4m3 bytes + one fp32 scale
 // (the GEMM's row_alpha) — the bf16 LayerNorm output (written, then re-read by the quantiser) and the quantiser's launch disappear.
@@ -474,13 +378,7 @@ extern "C" int sat_layernorm_fwd(const void* x, const float* gamma, const float*
     p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.y = y; p.mean = mean; p.rstd = rstd;
     p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch; p.eps = eps;
     dim3 grid(sat_cdiv(rows, 4));
-    const char* lean = getenv("SAT_LN_LEAN");      // two rows per wave (an unmeasured A/B arm: off by default)
-    if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2) && lean && lean[0] == '1') {
-        dim3 grid2(sat_cdiv((rows / rows_per_batch) * ((rows_per_batch + 1) / 2), 4));
-        sat_count_lean(4);
-        if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<float>, grid2, dim3(256), stream, p);
-        else SAT_LAUNCH(sat_layernorm_fwd_vec2_kernel<short>, grid2, dim3(256), stream, p);
-    } else if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {
+    if (sat_ln_vec_ok(p, dtype == 0 ? 4 : 2)) {
         if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<float>, grid, dim3(256), stream, p);
         else SAT_LAUNCH(sat_layernorm_fwd_vec_kernel<short>, grid, dim3(256), stream, p);
     } else if (dtype == 0) SAT_LAUNCH(sat_layernorm_fwd_kernel<float>, grid, dim3(256), stream, p);
@@ -828,57 +726,4 @@ extern "C" int sat_sampler_step_dev(const void* out2, const void* x, const void*
                                     float scale, float phi, const float* coef, int dtype, void* stream) {
     if (!coef || !x) { sat_set_error("sat_sampler_step_dev: missing buffer"); return 1; }
     return sat_cfg_launch("sat_sampler_step_dev", out2, x, prev, y0, y1, B, C, T, ncond, scale, phi, nullptr, coef, dtype, stream);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Cache prefetch of read-only buffers (the NEXT transformer layer's weights).  A sampler step streams ~2 GB of bf16 weights through a
-// 256-MB memory-side cache and 8 x 4 MB of L2: inside the sampler every projection GEMM finds its B operand in HBM, and with
-// ~1.5 K-steps of LDS-DMA lookahead the HBM latency sits in its K loop (QKV at M = 2050: 77 us in the sampler, 46 us with warm
-// weights — profiles/).  This kernel just READS up to 16 buffers (16 bytes per lane, 8 loads in flight per lane, 64 workgroups — a
-// few CUs' worth of waves next to the GEMMs' one LDS-bound workgroup per CU) on a side stream one layer ahead, so that the lines are in
-// the memory-side cache when the GEMM asks for them.  Nothing is written (a never-true store keeps the loads alive).
-// MEASURED (round 3): the sampler got SLOWER with it (105.6 vs 110.9 steps/s) — like the in-kernel L2 touch of gemm.hip — so
-// transformer.ContinuousTransformer leaves it off (SAT_WEIGHT_PREFETCH=1 switches it on for A/B runs): the in-situ slowdown of the
-// projections is not their weights' HBM latency.
-#define SAT_PF_MAX 16
-struct SatPrefetchParams {
-    const void* ptr[SAT_PF_MAX];
-    long long n16[SAT_PF_MAX];       // 16-byte units
-    int n;
-    unsigned* sink;                  // any device word (only written if the xor of everything read equals an impossible pattern)
-};
-__global__ void __launch_bounds__(256) sat_prefetch_kernel(SatPrefetchParams p) {
-    u32x4 acc = {0u, 0u, 0u, 0u};
-    const long long stride = (long long)gridDim.x * 256;
-    for (int i = 0; i < p.n; ++i) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(p.ptr[i]);
-        const long long n = p.n16[i];
-        long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-        for (; j + 7 * stride < n; j += 8 * stride) {
-            u32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[j + u * stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc ^= v[u];
-        }
-        for (; j < n; j += stride) acc ^= src[j];
-    }
-    const unsigned x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
-    if (x == 0x9e3779b9u && p.sink && threadIdx.x == 257) p.sink[0] = x;      // (never true: threadIdx.x < 256)
-}
-// ptrs / bytes: HOST arrays of n <= 16 device buffers (16-byte aligned; the tail bytes % 16 are skipped)
-extern "C" int sat_prefetch(const void* const* ptrs, const long long* bytes, int n, void* stream) {
-    if (n < 0 || n > SAT_PF_MAX || (n > 0 && (!ptrs || !bytes))) { sat_set_error("sat_prefetch: 0 <= n <= 16 buffers"); return 1; }
-    if (n == 0) return 0;
-    SatPrefetchParams p{};
-    for (int i = 0; i < n; ++i) {
-        if (!ptrs[i] || bytes[i] < 0 || ((uintptr_t)ptrs[i] & 15)) { sat_set_error("sat_prefetch: null / misaligned buffer"); return 1; }
-        p.ptr[i] = ptrs[i];
-        p.n16[i] = bytes[i] >> 4;
-    }
-    p.n = n;
-    p.sink = nullptr;
-    SAT_LAUNCH(sat_prefetch_kernel, dim3(64), dim3(256), stream, p);
-    return sat_check_launch("sat_prefetch");
 }

@@ -24,11 +24,6 @@ int sat_check_launch(const char* what) {
 }
 extern "C" const char* sat_last_error() { return g_sat_err; }
 
-static long long g_sat_lean[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-void sat_count_lean(int arm) {
-    if (arm >= 0 && arm < 8) ++g_sat_lean[arm];
-}
-extern "C" long long sat_lean_launches(int arm) { return (arm >= 0 && arm < 8) ? g_sat_lean[arm] : -1; }
 extern "C" int sat_abi_version() { return 1; }
 extern "C" int sat_is_simulator() {
 #if defined(SAT_HIPEMU)

@@ -325,10 +325,6 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
         }
     };
     auto stage = [&](int kt, int buf) { stage_range(kt, buf, std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}); };
-    auto stage_part = [&](int kt, int buf, auto part) {      // one of the 4 portions of a tile's LDS-DMA instructions
-        constexpr int Q = decltype(part)::value;
-        stage_range(kt, buf, std::integral_constant<int, (G * Q) / 4>{}, std::integral_constant<int, (G * (Q + 1)) / 4>{});
-    };
     auto frags = [&](const char* As, int ks, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
         const int kc = ks * 2 + (lane >> 5);
         const char* Bs = As + ABYTES;
@@ -343,55 +339,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
     };
-    if constexpr (PIPE == 2) {
-        // As PIPE == 1, with the refill of a drained slot spread over the K-step: a quarter of the tile's LDS-DMA instructions
-        // goes out behind each k-substep's MFMAs instead of all of them in one burst right after the barrier (32 back-to-back
-        // 1-KiB requests per workgroup stall the issuing waves on the memory pipeline's queue).  Slot of tile kt is drained at
-        // the hand-over of K-step kt; tile kt+NSTAGE is issued in quarters: one right there, three during K-step kt+1.
-        static_assert(NSTAGE >= 2, "spread refill: tile kt+NSTAGE-1 goes to the slot drained at the previous hand-over");
-#pragma unroll
-        for (int s = 0; s < NSTAGE; ++s)
-            if (s < nk) stage(s, s);
-        if (nk >= NSTAGE) { SAT_WAIT_VMCNT((NSTAGE - 1) * G); } else { SAT_WAIT_VMCNT(0); }
-        SAT_RAW_BARRIER();
-        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-        frags(smem, 0, a0, b0);
-        int rd = 0, prev = NSTAGE - 1;
-        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
-        using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* As = smem + rd * STAGE;
-            const int nx = (rd + 1 == NSTAGE) ? 0 : rd + 1;
-            const bool refill_prev = kt >= 1 && kt - 1 + NSTAGE < nk;      // tile kt-1+NSTAGE goes to slot `prev`
-            frags(As, 1, a1, b1);
-            mfmas(a0, b0);
-            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q1{});
-            SAT_SCHED_FENCE();
-            frags(As, 2, a0, b0);
-            mfmas(a1, b1);
-            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q2{});
-            SAT_SCHED_FENCE();
-            frags(As, 3, a1, b1);
-            mfmas(a0, b0);
-            if (refill_prev) stage_part(kt - 1 + NSTAGE, prev, Q3{});
-            SAT_SCHED_FENCE();
-            if (kt + 1 < nk) {
-                SAT_WAIT_LGKM0();
-                // outstanding, oldest first: [tile kt+1 .. kt+NSTAGE-2 complete][tile kt+NSTAGE-1: all G pieces]  -> keep the tiles
-                // after kt+1 in flight
-                if (kt + NSTAGE - 1 < nk) { SAT_WAIT_VMCNT((NSTAGE - 2) * G); } else { SAT_WAIT_VMCNT(0); }
-                SAT_RAW_BARRIER();
-                SAT_SCHED_FENCE();
-                if (kt + NSTAGE < nk) stage_part(kt + NSTAGE, rd, Q0{});
-                frags(smem + nx * STAGE, 0, a0, b0);
-            }
-            SAT_SCHED_FENCE();
-            mfmas(a1, b1);
-            prev = rd;
-            rd = nx;
-        }
-        SAT_WAIT_LGKM0();
-    } else if constexpr (PIPE == 1) {
+    if constexpr (PIPE == 1) {
         // Software pipeline: fragments of k-substep s+1 are read from LDS while the MFMAs of substep s run, and the hand-over to
         // the next tile (counted wait on the LDS-DMA queue, barrier, refill of the slot just drained, first fragments of the new
         // tile) sits between substeps 2 and 3, under the MFMAs of substep 2 and in front of those of substep 3.
@@ -545,17 +493,12 @@ __global__ void __launch_bounds__(WGM * WGN * 64) sat_gemm_kernel(SatGemmParams 
 // FP8 (round 4): the stage image is the same (128-byte rows = 128 fp8 k-values, K-step = 128 of them); a wave's four 16-byte fragment
 // registers per row block are then the operands of TWO MX MFMAs (32 x 32 x 64, twice the bf16 rate): the matrix time per stage byte,
 // the DMA and the LDS traffic per interval are those of the bf16 kernel.
-template <int EPI, bool F32OUT, int TOUCH = 0, bool FP8 = false, bool LEANK = false>
+template <int EPI, bool F32OUT, bool FP8 = false>
 __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
     constexpr int WIN = 2 * STAGE / 8;
-    // TOUCH > 0 (experiment, NOT shipped: the sampler ran 103.7 vs 110.8 steps/s with it): L2 prefetch TOUCH K-steps ahead of the LDS-DMA front.  The two 64-KB stages bound the DMA lookahead at ~1.5 K-steps
-    // (~1.5 us), which covers an L2 hit but not an HBM miss — and inside the sampler every layer's weights come from HBM (2 GB of
-    // weights against a 256-MB Infinity Cache: the in-situ launches run 10-60 % slower than the warm micro-benchmark).  Each wave
-    // therefore also issues, per K-step, its 8 pieces' addresses of K-step t + 2 + TOUCH as 4-byte LDS-DMAs into a 256-byte dummy
-    // window (no VGPR destination, counted in vmcnt like the real ones): the lines are in L2 when the real DMA asks for them.
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (TOUCH > 0 ? 8 * 256 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = SAT_UNIFORM((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
@@ -663,19 +606,6 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         if constexpr (P == 1) {
             if (t + 2 < nk) { stage_b(t + 2); SAT_WAIT_VMCNT(4); }
             else { SAT_WAIT_VMCNT(0); }
-            if constexpr (TOUCH > 0) {
-                // (issued AFTER the counted wait: they are older than the next K-step's DMAs and retired by its wait, ~2 K-steps later)
-                const int kt = t + 2 + TOUCH;
-                if (kt < nk && kbeg + kt * 64 + 64 <= kend) {
-                    char* dummy = smem + 2 * STAGE + wave * 256;
-                    const long long ko = (long long)(kbeg + kt * 64) * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        sat_glds4((const char*)p.A + aoff[q] + ko, dummy);
-                        sat_glds4((const char*)p.B + boff[q] + ko, dummy);
-                    }
-                }
-            }
         }
         SAT_WAIT_LGKM0();
         SAT_RAW_BARRIER();
@@ -712,18 +642,17 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
         SAT_SCHED_FENCE();
         SAT_RAW_BARRIER();
     };
-    bool lean_done = false;
-    if constexpr (LEANK) {
-        // LEAN K loop (SAT_GEMM_LEAN=1; see sat_gemm8_kernel's: same idea, same status — simulator- and ISA-checked, unmeasured, off by
-        // default).  318 instructions per K-step and wave for 32 MFMAs in the loop below: per-phase `on0 / on1` conditions around the
-        // fragment reads and around every k-sub-step's MFMAs, `t + 1 < nk` / `t + 2 < nk` in every step.  For a wave whose 128 rows are all
-        // valid, the same per-wave sequence (phase 0: B + A fragments, request A of tile t + 1, barrier, MFMAs, barrier; phase 1: A fragments,
-        // request B of tile t + 2, counted wait, barrier, MFMAs, barrier) runs without the row conditions (ONE loop body: three bodies
-        // split by "requests both / only A / nothing" were tried and spill at the 256-register cap); a wave with an M tail takes the loop
-        // below (the two loops have the same barriers per K-step, so the wave rows of a workgroup may differ).
-        // (fp8: the lean loop compiles — the MFMA section below has the branch — but its instances spill ~20 registers at the 256 cap, so the
-        // dispatcher keeps the fp8 256 x 256 kernel on the loop below; the eight-wave kernels' fp8 instances do take their lean loop)
-        static_assert(TOUCH == 0, "the lean K loop is written without the L2 touch experiment");
+    bool full_done = false;
+    if constexpr (!FP8) {
+        // Full waves (all 128 rows valid) — round 5: THE K loop of the bf16 kernel (round 4's "lean" arm, timed in
+        // profiles/r05_experiments/lean_ab/: never slower than the general loop, FF1 + SwiGLU 87.4 -> 83.7 us at M = 2050).  The general
+        // loop below spends 318 instructions per K-step and wave on 32 MFMAs: per-phase `on0 / on1` conditions around the fragment reads
+        // and around every k-sub-step's MFMAs.  For a wave whose 128 rows are all valid the same per-wave sequence (phase 0: B + A
+        // fragments, request A of tile t + 1, barrier, MFMAs, barrier; phase 1: A fragments, request B of tile t + 2, counted wait,
+        // barrier, MFMAs, barrier) runs without the row conditions (ONE loop body: three bodies split by "requests both / only A /
+        // nothing" spill at the 256-register cap); a wave with an M tail takes the general loop (same barriers per K-step, so the wave
+        // rows of a workgroup may differ).  fp8: this loop's instances spill ~20 registers at the 256 cap — the fp8 256 x 256 kernel
+        // keeps the general loop (the eight-wave kernels' fp8 instances do take theirs).
         if (mv >= 128) {
             auto half = [&](int t, auto pc) __attribute__((always_inline)) {
                 constexpr int P = decltype(pc)::value;
@@ -747,25 +676,12 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
                 SAT_RAW_BARRIER();
                 SAT_SCHED_FENCE();
                 SAT_SETPRIO(1);
-                if constexpr (FP8) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const i32x8 a = sat_cat8(afr[i][2 * u], afr[i][2 * u + 1]);
-                            acc[P * 2 + i][0] = sat_mfma_32x32x64_fp8(a, b0, acc[P * 2 + i][0]);
-                            acc[P * 2 + i][1] = sat_mfma_32x32x64_fp8(a, b1, acc[P * 2 + i][1]);
-                        }
-                    }
-                } else {
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[P * 2 + i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[P * 2 + i][j]);
-                }
+                        for (int j = 0; j < 2; ++j) acc[P * 2 + i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[P * 2 + i][j]);
                 SAT_SETPRIO(0);
                 SAT_SCHED_FENCE();
                 SAT_RAW_BARRIER();
@@ -774,10 +690,10 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
                 half(t, std::integral_constant<int, 0>{});
                 half(t, std::integral_constant<int, 1>{});
             }
-            lean_done = true;
+            full_done = true;
         }
     }
-    if (!lean_done)
+    if (!full_done)
     for (int t = 0; t < nk; ++t) {
         phase(t, std::integral_constant<int, 0>{});
         phase(t, std::integral_constant<int, 1>{});
@@ -839,7 +755,7 @@ __global__ void __launch_bounds__(512) sat_gemm256_kernel(SatGemmParams p) {
 //     two stages the wait would have to sit in the interval of the request: NST >= 3.
 //   * 1-KiB pieces p = wave + 8 q of the stage image [A tile | B tile]; (BM + BN) / 8 pieces: when that is 4 mod 8 the waves of
 //     group 0 carry one piece more (their counted waits differ by that piece).
-template <int BN, int R0, int R1, int NST, int EPI, bool F32OUT, bool FP8, bool LEANK = false>
+template <int BN, int R0, int R1, int NST, int EPI, bool F32OUT, bool FP8>
 __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     constexpr int WC = BN / 64, WRG = 4 / WC;
     constexpr int BM = WRG * (R0 + R1);
@@ -938,16 +854,17 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     const int frow = lane & 31, fkc = lane >> 5;
     // 16-byte k-chunk of fragment register q: bf16 — k-sub-step q, half fkc; fp8 — MX MFMA u = q >> 1 takes the 32 bytes at 64 u + 32 fkc
     auto kchunk = [&](int q) { return FP8 ? (q >> 1) * 4 + fkc * 2 + (q & 1) : q * 2 + fkc; };
-    if constexpr (LEANK) {
-        // LEAN K loop (SAT_GEMM_LEAN=1; round 4, last session: simulator- and ISA-checked, NOT timed — off by default).  The loop below
-        // issues 374 instructions per K-step for the 24 MFMAs of a 96-row wave (ISA of the 160 x 256 tile): ring slots by `t % NST`
-        // (mul_hi sequences), fragment addresses rebuilt per row block, a branch per (row block, k-sub-step) for `i < nb && i * 32 < mv`,
-        // group-dependent piece and wait counts decided at run time, end-of-loop conditions in every step — and at one instruction per
-        // four cycles and wave that is what bounds the read intervals (2 x ~700 instructions x 4 = the ~2700 cycles per K-step the cost
-        // model fitted; the matrix pipe needs 1280).  Here the SAME sequence of operations per wave and K-step — fragment reads, request of
-        // tile t + LOOK, counted wait, lgkmcnt(0), barrier, MFMAs, barrier: the hazard argument above is unchanged — is specialised at
-        // compile time on (group, all row blocks active), the staged steps are split from the <= LOOK steps that stage nothing, the ring
-        // slots rotate in scalar registers and every fragment address is one of eight per-lane bases + slot + an immediate.
+    {
+        // THE K loop (round 5; round 4's "lean" arm, timed in profiles/r05_experiments/lean_ab/: 160 x 256 tile QKV 40.5 -> 35.3 us and
+        // FF2 104.6 -> 86.9 us at M = 2050, 128 x 128 tile FF2 54 -> 48 us; the general loop it replaces is gone).  That loop issued 374
+        // instructions per K-step for the 24 MFMAs of a 96-row wave: ring slots by `t % NST` (mul_hi sequences), fragment addresses
+        // rebuilt per row block, a branch per (row block, k-sub-step) for `i < nb && i * 32 < mv`, group-dependent piece and wait counts
+        // decided at run time, end-of-loop conditions in every step — at one instruction per four cycles and wave that bounded the read
+        // intervals (2 x ~700 instructions x 4 = the ~2700 cycles per K-step the cost model had fitted; the matrix pipe needs 1280).
+        // Here the sequence of operations per wave and K-step — fragment reads, request of tile t + LOOK, counted wait, lgkmcnt(0),
+        // barrier, MFMAs, barrier: the hazard argument above — is specialised at compile time on (group, all row blocks active), the
+        // staged steps are split from the <= LOOK steps that stage nothing, the ring slots rotate in scalar registers and every fragment
+        // address is one of eight per-lane bases + slot + an immediate.
         int nact = (mv + 31) >> 5;
         nact = nact < 0 ? 0 : (nact > nb ? nb : nact);          // this wave's active row blocks (wave-uniform)
         const int sw = (frow >> 1) & 7;                         // the same swizzle for every row block of a lane (blocks start at multiples of 32 rows)
@@ -1037,63 +954,6 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
         if (grp == 0) { if (nact == NB0) kloop(C0{}, C1{}); else kloop(C0{}, C0{}); }
         else { if (nact == NB1) kloop(C1{}, C1{}); else kloop(C1{}, C0{}); }
-    } else
-    for (int t = 0; t < nk; ++t) {
-        const char* As = smem + (t % NST) * STAGE;
-        const char* Bs = As + ABYTES;
-        // ---- read section: this K-step's fragments, the request for tile t + LOOK, the wait for tile t + 1 ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[j][q] = sat_gemm_frag(Bs, wc * 64 + j * 32 + frow, kchunk(q));
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (i < nb && i * 32 < mv) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) afr[i][q] = sat_gemm_frag(As, arow + i * 32 + frow, kchunk(q));
-            }
-        }
-        if (t + LOOK < nk) {
-            stage(t + LOOK);
-            if constexpr (LOOK == 3) wait_tiles(T2{}); else wait_tiles(T1{});
-        } else if (LOOK == 3 && t + 2 < nk) {
-            wait_tiles(T1{});
-        } else {
-            wait_tiles(T0{});
-        }
-        SAT_WAIT_LGKM0();
-        SAT_RAW_BARRIER();
-        // ---- MFMA section ----
-        SAT_SCHED_FENCE();
-        SAT_SETPRIO(1);
-        if constexpr (FP8) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const i32x8 b0 = sat_cat8(bfr[0][2 * u], bfr[0][2 * u + 1]), b1 = sat_cat8(bfr[1][2 * u], bfr[1][2 * u + 1]);
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    if (i < nb && i * 32 < mv) {
-                        const i32x8 a = sat_cat8(afr[i][2 * u], afr[i][2 * u + 1]);
-                        acc[i][0] = sat_mfma_32x32x64_fp8(a, b0, acc[i][0]);
-                        acc[i][1] = sat_mfma_32x32x64_fp8(a, b1, acc[i][1]);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    if (i < nb && i * 32 < mv) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = sat_mfma_32x32x16_bf16(afr[i][ks], bfr[j][ks], acc[i][j]);
-                    }
-                }
-            }
-        }
-        SAT_SETPRIO(0);
-        SAT_SCHED_FENCE();
-        SAT_RAW_BARRIER();
     }
     if (grp == 0) SAT_RAW_BARRIER();             // pairs with the second group's last barrier: every LDS read is done
     SAT_RAW_BARRIER();
@@ -1131,25 +991,15 @@ __global__ void __launch_bounds__(512) sat_gemm8_kernel(SatGemmParams p) {
     }
 }
 
-template <int BN, int R0, int R1, int NST, bool WITH_LEAN = false>
+template <int BN, int R0, int R1, int NST>
 static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, bool fp8 = false) {
     constexpr int BM = (4 / (BN / 64)) * (R0 + R1);
     p.ntm = sat_cdiv(p.M, BM);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? BN / 2 : BN);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
-    // SAT_GEMM_LEAN=1: the lean K loop of sat_gemm8_kernel (bf16 and fp8, the shipped tiles 7 and 8; an unmeasured A/B arm: off by default)
-    const char* lean_env = getenv("SAT_GEMM_LEAN");
-    const bool lean = WITH_LEAN && lean_env && lean_env[0] == '1';
-    if (lean) sat_count_lean(2);
 #define SAT_GEMM8_CASE(E, F)                                                                         \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        if constexpr (WITH_LEAN) {                                                                   \
-            if (lean && fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true, true>), grid, block, stream, p); }    \
-            else if (lean) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false, true>), grid, block, stream, p); }     \
-            else if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }             \
-            else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }  \
-        }                                                                                            \
-        else if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
+        if (fp8) { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, true>), grid, block, stream, p); }   \
         else { SAT_LAUNCH((sat_gemm8_kernel<BN, R0, R1, NST, E, F, false>), grid, block, stream, p); }      \
         return sat_check_launch("sat_gemm (eight-wave ring)");                                       \
     }
@@ -1167,19 +1017,14 @@ static int sat_gemm8_launch(SatGemmParams& p, int epi, int f32out, int splits, v
     return 1;
 }
 
-static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, int touch = 0, bool fp8 = false) {
+static int sat_gemm256_launch(SatGemmParams& p, int epi, int f32out, int splits, void* stream, bool fp8 = false) {
     p.ntm = sat_cdiv(p.M, 256);
     p.ntn = sat_cdiv(epi == SAT_EPI_SWIGLU ? p.N / 2 : p.N, epi == SAT_EPI_SWIGLU ? 128 : 256);
     dim3 grid(p.ntm * p.ntn, splits), block(512);
-    const char* lean_env = getenv("SAT_GEMM_LEAN");      // the lean K loop (bf16, no touch experiment): an unmeasured A/B arm, off by default
-    const bool lean = lean_env && lean_env[0] == '1';
-    if (lean && !fp8 && touch <= 0) sat_count_lean(3);
 #define SAT_GEMM256_CASE(E, F)                                                                       \
     if (epi == E && f32out == (F ? 1 : 0)) {                                                         \
-        if (fp8) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, true>), grid, block, stream, p); }        \
-        else if (touch > 0) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 2>), grid, block, stream, p); }  \
-        else if (lean) { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0, false, true>), grid, block, stream, p); }  \
-        else { SAT_LAUNCH((sat_gemm256_kernel<E, F, 0>), grid, block, stream, p); }                  \
+        if (fp8) { SAT_LAUNCH((sat_gemm256_kernel<E, F, true>), grid, block, stream, p); }           \
+        else { SAT_LAUNCH((sat_gemm256_kernel<E, F>), grid, block, stream, p); }                     \
         return sat_check_launch("sat_gemm (256x256)");                                               \
     }
     SAT_GEMM256_CASE(SAT_EPI_STORE, false)
@@ -1222,28 +1067,23 @@ static int sat_gemm_launch(SatGemmParams& p, int epi, int f32out, int splits, vo
     return 1;
 }
 
-// tile: 0 = 128x128 / 4 waves / 2-slot ring / software-pipelined (2 workgroups per CU); 1 = 256x128 / 8 waves / 3 slots / pipelined;
-// 2 = 128x128 / 4 waves / 3 slots / pipelined; 3 = 128x128 / 4 waves / 2 slots / plain loop (one barrier per K-step, reference structure);
-// 4 = 256x256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel); 5 = 4 + the L2 touch prefetch;
-// sat_gemm8_kernel (eight waves in two groups one barrier apart, one interval pair per K-step, 3- or 4-stage ring):
-// 6 = 128x256, 7 = 160x256, 8 = 128x128
+// The shipped workgroup tiles (round 5: the experiments 1, 2, 3, 5, 6 of rounds 2-4 are gone — profiles/EXPERIMENTS.md keeps their numbers):
+//   0 = 128 x 128 / 4 waves / 2-slot ring / software-pipelined, two workgroups per CU (sat_gemm_kernel): few-tile shapes, split-K;
+//   4 = 256 x 256 / 8 waves / two wave rows one barrier apart, 4 intervals per K-step (sat_gemm256_kernel);
+//   sat_gemm8_kernel (eight waves in two groups one barrier apart, one interval pair per K-step, 3- or 4-stage ring):
+//   7 = 160 x 256, 8 = 128 x 128.
 static int sat_gemm_dispatch(SatGemmParams& p, int epi, int f32out, int splits, int tile, void* stream) {
     if (tile == 4) return sat_gemm256_launch(p, epi, f32out, splits, stream);
-    if (tile == 5) return sat_gemm256_launch(p, epi, f32out, splits, stream, 2);      // (A/B: WITH the L2 touch prefetch: measured -6 % in the sampler)
-    if (tile == 6) return sat_gemm8_launch<256, 64, 64, 3>(p, epi, f32out, splits, stream);
-    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3, true>(p, epi, f32out, splits, stream);
-    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4, true>(p, epi, f32out, splits, stream);
-    if (tile == 1) return sat_gemm_launch<256, 128, 4, 2, 3, 2>(p, epi, f32out, splits, stream);
-    if (tile == 2) return sat_gemm_launch<128, 128, 2, 2, 3, 2>(p, epi, f32out, splits, stream);
-    if (tile == 3) return sat_gemm_launch<128, 128, 2, 2, 2, 0>(p, epi, f32out, splits, stream);
-    if (tile < 0 || tile > 8) { sat_set_error("sat_gemm: tile must be 0..8"); return 1; }
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, splits, stream);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, splits, stream);
+    if (tile != 0) { sat_set_error("sat_gemm: tile must be 0, 4, 7 or 8"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 1>(p, epi, f32out, splits, stream);
 }
 // fp8 operands: 0 = 128x128 / 4 waves / plain loop (round 3), 4 = 256x256, 7 = 160x256, 8 = 128x128 eight-wave ring
 static int sat_gemm_dispatch_fp8(SatGemmParams& p, int epi, int f32out, int tile, void* stream) {
-    if (tile == 4) return sat_gemm256_launch(p, epi, f32out, 1, stream, 0, true);
-    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3, true>(p, epi, f32out, 1, stream, true);
-    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4, true>(p, epi, f32out, 1, stream, true);
+    if (tile == 4) return sat_gemm256_launch(p, epi, f32out, 1, stream, true);
+    if (tile == 7) return sat_gemm8_launch<256, 96, 64, 3>(p, epi, f32out, 1, stream, true);
+    if (tile == 8) return sat_gemm8_launch<128, 32, 32, 4>(p, epi, f32out, 1, stream, true);
     if (tile != 0) { sat_set_error("sat_gemm_fp8: tile must be 0, 4, 7 or 8"); return 1; }
     return sat_gemm_launch<128, 128, 2, 2, 2, 0, true>(p, epi, f32out, 1, stream);
 }

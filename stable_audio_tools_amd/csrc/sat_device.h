@@ -361,9 +361,6 @@ SAT_DEVICE bool sat_wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 
 
 // ---------------------------------------------------------------------------------------------
 void sat_set_error(const char* msg);
-// launches taken by the env-selected A/B arms (0 attention fwd, 1 attention bwd, 2 eight-wave GEMM, 3 256 x 256 GEMM, 4 LayerNorm):
-// read back through sat_lean_launches() so that a test (or an A/B script) can see that the switch it set was honoured
-void sat_count_lean(int arm);
 int sat_check_launch(const char* what);
 
 #if defined(SAT_HIPEMU)

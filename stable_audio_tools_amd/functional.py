@@ -29,24 +29,25 @@ def _ops(ops):
 
 class SumAllFn(torch.autograd.Function):
     """sum over every element -> 0-d tensor on ops.sum_all (deterministic two-pass row sums; no torch multi-block reduction — see its
-    docstring for why the training step avoids those).  Backward: the incoming scalar broadcast to the input's shape, as torch's."""
+    docstring for why the training step avoids those).  Backward: the incoming scalar broadcast to the input's shape, as torch's.
+    `ops`: the SatOps handle of the caller (None = the product singleton), as every other Function of this module takes it."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, ops=None):
         ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
-        return _ops(None).sum_all(x.detach())
+        return _ops(ops).sum_all(x.detach())
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(ctx.in_dtype).expand(ctx.in_shape)
+        return g.to(ctx.in_dtype).expand(ctx.in_shape), None
 
 
-def sum_all(x):
-    return SumAllFn.apply(x)
+def sum_all(x, ops=None):
+    return SumAllFn.apply(x, ops)
 
 
-def mean_all(x):
-    return SumAllFn.apply(x) / x.numel()
+def mean_all(x, ops=None):
+    return SumAllFn.apply(x, ops) / x.numel()
 
 
 class DerivedCache:

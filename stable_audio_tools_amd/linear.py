@@ -16,7 +16,6 @@ One kernel computes all three GEMMs of a layer: it is "NT" (both operands K-cont
 stored; the data gradient runs on the transposed weight copy and the weight gradient on transposed activations
 (sat_cast_bf16 with transpose, zero padded along the reduction dim).
 """
-import os
 
 import torch
 from torch import nn
@@ -64,8 +63,8 @@ class _WeightCache:
         return hit[1]
 
 
-# activations quantised per ROW in one pass (round 4); False / SAT_FP8_ROW_SCALES=0: round 3's per-tensor scale (absmax pass + quant pass)
-fp8_row_scales = os.environ.get("SAT_FP8_ROW_SCALES", "1") != "0"
+# activations quantised per ROW in one pass (round 4); False (set by an A/B script): round 3's per-tensor scale (absmax pass + quant pass)
+fp8_row_scales = True
 
 
 class Fp8Rows:
@@ -263,16 +262,6 @@ class Linear(nn.Module):
             return None
         w = self.weight
         return self._cache.get(w, "bf16", lambda: _pad_rows8(w.detach() if w.dtype == torch.bfloat16 else _ops().cast_bf16(w.detach())))
-
-    def prefetch_tensor(self):
-        """The tensor the forward GEMM reads as its B operand right now (cached low-precision copy or the bf16 parameter itself), or
-        None before the first call created it — what ContinuousTransformer's weight prefetch touches one layer ahead."""
-        items = self._cache.items
-        if self.fp8 and "fp8" in items:
-            return items["fp8"][1][0]
-        if "bf16" in items:
-            return items["bf16"][1]
-        return self.weight.detach() if self.weight.dtype == torch.bfloat16 else None
 
     def forward(self, x, res=None, mode=None):
         """mode None: x W^T + b [+ res];  'swiglu': value * silu(gate) over W rows = [value | gate]."""

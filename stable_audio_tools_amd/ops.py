@@ -5,7 +5,6 @@ device pointers + shapes to the HIP library on ``torch.cuda.current_stream()``; 
 PyTorch caching allocator) owns all buffers including workspaces.
 """
 import ctypes
-import os
 
 import torch
 
@@ -139,18 +138,22 @@ class SatOps:
             return k == 2 * stride and stride & (stride - 1) == 0 and dil == 1
         return k == 1 or (2 <= k <= 4 and dil == 1) or (5 <= k <= 8 and (k - 1) * dil <= 62)
 
-    # third-generation k7 kernel (csrc/conv1d_bf16x3_k7q.h): planes + 16-channel chunks + two wave rows one barrier apart
-    k7q = os.environ.get("SAT_K7Q", "1") != "0"
-    k7q_min_cin = int(os.environ.get("SAT_K7Q_MIN", "64"))
-
-    k7q_min_cout = int(os.environ.get("SAT_K7Q_MIN_COUT", "128"))
+    # the k7 kernel (csrc/conv1d_bf16x3_k7q.h): activation planes + 16-channel chunks + two wave rows one barrier apart.  Plain class
+    # attributes (an A/B script sets them on the ops object; no environment switches: round 5)
+    k7q = True
+    k7q_min_cin = 64
+    k7q_min_cout = 128
+    k7q_wide_cin = 512      # from this many input channels on, fewer than k7q_min_cout output channels still take the planes kernel
 
     def k7q_applicable(self, cin, k, stride, dil, pad, cout=None):
         """The ResidualUnit convs (C -> C, C >= 128) and their data-gradients.  Convs with fewer than k7q_min_cout output channels
         stay on the direct kernel: the MS-STFT discriminator's (64 filters: half of the 128-row channel tile would be empty, and the
-        planes pre-pass is not paid back — measured, profiles/EXPERIMENTS.md) and the decoder's last conv (128 -> 2)."""
-        return (self.k7q and self.k7_planes and self.use_bf16x3 and stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32
-                and (k - 1) * dil <= 62 and cin >= self.k7q_min_cin and (cout is None or cout >= self.k7q_min_cout))
+        planes pre-pass is not paid back — measured, profiles/EXPERIMENTS.md) and the decoder's last conv (128 -> 2) — unless the
+        INPUT is wide (the data-gradient of the decoder's first conv: 2048 -> 64 channels on 1024 steps is four workgroups whose
+        time is the K loop over 2048 channels; round 2's k7p kernel served it until round 5)."""
+        return (self.k7q and self.use_bf16x3 and stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32
+                and (k - 1) * dil <= 62 and cin >= self.k7q_min_cin
+                and (cout is None or cout >= self.k7q_min_cout or cin >= self.k7q_wide_cin))
 
     def pack_bf16x3(self, w, mode=0, stride=1, q=False):
         """w: (D0, D1, K) fp32 -> (hi, lo) int16 planes.  mode 0: conv weight [out][in][K]; mode 1: data-gradient of a
@@ -226,10 +229,10 @@ class SatOps:
         return y
 
     # ---- fused ResidualUnit forward (csrc/conv1d_bf16x3_k7q.h, FUSED): one launch for snake -> conv7 -> snake -> conv1 -> + x ----
-    ru_fused = os.environ.get("SAT_RU_FUSED", "1") != "0"
+    ru_fused = True
 
     def ru_fused_ok(self, c, k, dil, t):
-        return (self.ru_fused and self.use_bf16x3 and self.k7q and self.k7_planes and self.k7q_min_cin <= c <= 128
+        return (self.ru_fused and self.use_bf16x3 and self.k7q and self.k7q_min_cin <= c <= 128
                 and 5 <= k <= 7 and (k - 1) * dil <= 62 and (k - 1) * dil % 2 == 0 and (k - 1) * dil // 2 <= 32 and t % 4 == 0)
 
     def pack_k7q(self, w, mode=0):
@@ -289,7 +292,7 @@ class SatOps:
         return h, y
 
     # ---- plane emission bookkeeping: producer -> the ONE k7 conv that consumes its output next ----
-    k7_emit = os.environ.get("SAT_K7_EMIT", "1") != "0"
+    k7_emit = True
 
     @staticmethod
     def _snake_key(snake):
@@ -348,19 +351,15 @@ class SatOps:
         if len(w_planes) == 3:          # sat_pack_weights_k7q layout (pack_bf16x3(q=True) after k7q_applicable)
             if not (stride == 1 and 5 <= k <= 7 and 0 <= pad <= 32 and (k - 1) * dil <= 62):
                 raise ValueError("conv1d_bf16x3: q-packed weights need stride 1, 5 <= K <= 7, pad <= 32, (K-1)*dil <= 62")
-            return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts, q=True)
-        if self.k7_planes and stride == 1 and 5 <= k <= 8 and pad <= 32 and (k - 1) * dil <= 62 and cin >= self.k7_planes_min_cin:
             return self._k7_planes_call(rows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out, sconsts)
         return self._bf16x3_call(self.lib.sat_conv1d_bf16x3, rows, x, w_planes, cout, tout, (k, stride, dil, pad),
                                  bias, snake, res, tanh_out, dsnake, out, sconsts, emit)
 
-    # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes (conv1d_bf16x3_k7p.h): one
-    # conversion pass per conv instead of one per workgroup.  The two planes live in a cached workspace of the largest size seen, one
-    # per (device, stream): the pre-pass and its conv are enqueued back to back on the caller's current stream.
-    k7_planes = os.environ.get("SAT_K7_PLANES", "1") != "0"     # A/B switch (tools/, profiles/EXPERIMENTS.md)
-    k7_planes_min_cin = int(os.environ.get("SAT_K7_PLANES_MIN", "512"))      # measured (tools/k7_bench.py; profiles/EXPERIMENTS.md): the pre-pass pays from C = 512 up
-
-    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None, q=False):
+    # the k = 7 convs of the ResidualUnits read their (activated) input as pre-split bf16 planes: written by the producer's epilogue
+    # (plane emission) or by one conversion pass per conv (sat_conv1d_k7_planes) instead of one per workgroup.  The two planes live in
+    # a cached workspace of the largest size seen, one per (device, stream): the pre-pass and its conv are enqueued back to back on
+    # the caller's current stream.
+    def _k7_planes_call(self, prows, x, w_planes, cout, tout, k, dil, pad, bias, snake, res, tanh_out, dsnake, out=None, sconsts=None):
         b, cin, tin = x.shape
         self._f32(x, bias, res)
         sa = sib = None
@@ -387,10 +386,9 @@ class SatOps:
             x2, a2, b2 = dsnake
             self._f32(x2, a2, b2)
             pda, pdb = torch.empty(2, cout, prows, dtype=torch.float32, device=x.device).unbind(0)
-        fn = self.lib.sat_conv1d_bf16x3_planesq if q else self.lib.sat_conv1d_bf16x3_planes
-        self._chk(fn(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
-                     _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
-                     k, dil, pad, int(tanh_out), st))
+        self._chk(self.lib.sat_conv1d_bf16x3_planesq(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
+                                                     _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
+                                                     k, dil, pad, int(tanh_out), st))
         if dsnake is not None:
             return (y, *self._sum_pair(pda, pdb))
         return y
@@ -604,16 +602,6 @@ class SatOps:
                 d.clear()
         self._emitted = None
         self._disc_emitted = None
-
-    def prefetch(self, tensors, stream):
-        """Read (and discard) up to 16 device tensors on `stream` (a torch.cuda.Stream): cache prefetch of the next layer's weights."""
-        ts = [t for t in tensors if t is not None and t.numel() > 0][:16]
-        if not ts:
-            return
-        n = len(ts)
-        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-        sizes = (ctypes.c_longlong * n)(*[t.numel() * t.element_size() for t in ts])
-        self._chk(self.lib.sat_prefetch(ptrs, sizes, n, ctypes.c_void_p(stream.cuda_stream) if stream is not None else None))
 
     # ---- the discriminator's Conv2d layers on the pitched-rows layout (csrc/disc_conv.hip; discriminators._DiscConvFn) ----
     def disc_geom(self, frames, w):
@@ -983,7 +971,7 @@ class SatOps:
 
     # ------------------------------------------------------------------ dense projections (csrc/gemm.hip)
     EPI_STORE, EPI_RES, EPI_GATE_RES, EPI_SWIGLU = 0, 1, 2, 3
-    gemm_tile = None     # None: pick per shape (_pick_tile); 0 = 128x128 (4 waves, 2 workgroups per CU), 4 = 256x256, 7 = 160x256, 8 = 128x128 (8 waves); 1..3, 5, 6: experiments
+    gemm_tile = None     # None: pick per shape (_pick_tile); 0 = 128x128 (4 waves, 2 workgroups per CU), 4 = 256x256, 7 = 160x256, 8 = 128x128 (8 waves)
 
     def _zeros_page(self, device):
         z = getattr(self, "_zpage", None)
@@ -994,15 +982,11 @@ class SatOps:
 
     # Workgroup-tile model of csrc/gemm.hip, one entry per shipped tile: (rows, columns, workgroups per CU, us per 64-deep K-step of one
     # workgroup when <= 128 workgroups are on the chip, the same with the chip full, fixed us per workgroup: launch gap + first-tile
-    # latency + epilogue).  A projection's time is rounds-of-the-chip x (K-steps x us + fixed); fitted to tools/gemm_bench.py at
-    # M = 2050 / 4100 / 12290 (profiles/r04_gemm_bench.jsonl: within 5 % on 40 of the 48 (shape, tile) rows, worst 13 %).
-    _TILE_MODEL = {0: (128, 128, 2, 0.65, 1.00, 6.2), 4: (256, 256, 1, 1.12, 1.47, 9.5),
-                   7: (160, 256, 1, 1.05, 1.28, 7.0), 8: (128, 128, 1, 0.53, 0.56, 4.3)}
-    if os.environ.get("SAT_TILE_MODEL"):      # A/B of a re-fitted model (tools/fit_tile_model.py): JSON {"7": [u_light, u_full, fixed], ...}
-        import json as _json
-        for _t, (_ul, _uf, _fx) in _json.loads(os.environ["SAT_TILE_MODEL"]).items():
-            _TILE_MODEL[int(_t)] = _TILE_MODEL[int(_t)][:3] + (float(_ul), float(_uf), float(_fx))
-    gemm_policy = os.environ.get("SAT_GEMM_POLICY", "model")     # "r3": round 3's rule (256 x 256 when >= 150 tiles, else 128 x 128 four-wave)
+    # latency + epilogue).  A projection's time is rounds-of-the-chip x (K-steps x us + fixed).  Round 5: tiles 4, 7 and 8 re-fitted
+    # (tools/fit_tile_model.py) to the specialised K loops that replaced round 4's (profiles/r05_experiments/lean_ab/gemm_lean.jsonl,
+    # M = 260 .. 4100: median error 3.6 / 5.2 / 2.4 %, worst 20 %); tile 0 keeps round 4's fit (profiles/r04_gemm_bench.jsonl).
+    _TILE_MODEL = {0: (128, 128, 2, 0.65, 1.00, 6.2), 4: (256, 256, 1, 1.18, 1.36, 8.0),
+                   7: (160, 256, 1, 0.79, 0.94, 10.0), 8: (128, 128, 1, 0.53, 0.485, 4.75)}
 
     def _tile_cost(self, tile, m, n, k, splits=1):
         bm, bn, per_cu, u_light, u_full, f = self._TILE_MODEL[tile]
@@ -1012,8 +996,6 @@ class SatOps:
         u = u_full if tiles > (256 if per_cu > 1 else 128) else u_light
         ksteps = -(-(-(-k // 64)) // splits)
         t = rounds * (u * ksteps + f)
-        if tile == 8 and rounds > 2:
-            t *= 1.2                           # (its 0.56 us is the one- / two-round figure; the long weight-gradient GEMMs measured 0.65)
         if splits > 1:
             t += 4.0 + splits * m * n * 4 / 4e6      # sat_splitk_epilogue: launch + the slabs read back at ~4 TB/s
         return t
@@ -1024,10 +1006,8 @@ class SatOps:
         128 x 128 on eight waves for the 1536 -> 1536 projections (sat_gemm8_kernel), the four-wave 128 x 128 kernel for the rest."""
         if self.gemm_tile is not None:
             return self.gemm_tile
-        if self.gemm_policy == "r3" or k is None:
-            if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150:
-                return 5 if os.environ.get("SAT_GEMM_TOUCH") == "1" else 4          # 5 = 4 + the L2 touch prefetch experiment (slower)
-            return 0
+        if k is None:
+            return 4 if splits == 1 and ((m + 255) // 256) * ((n + 255) // 256) >= 150 else 0
         return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, k, splits), t))
 
     def gemm_bf16(self, a, b, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
@@ -1102,12 +1082,12 @@ class SatOps:
     def splitk_for(self, m, n, k):
         """Split count for a projection: > 1 only for few-tile / long-K shapes (FF2: 6144 -> 1536), where cutting K puts more workgroups
         on the chip and the slab round trip (fp32, M x N x 4 B per slice) is cheap next to the saving — the cheapest (tile, splits) pair
-        under _TILE_MODEL; round 3's rule (two slices on the four-wave tile when <= 256 tiles and K >= 4096) with SAT_GEMM_POLICY=r3."""
+        under _TILE_MODEL."""
         if self.gemm_splitk is not None:
             return self.gemm_splitk
         if k < 4096 or n % 4:
             return 1
-        if self.gemm_policy == "r3" or self.gemm_tile is not None:
+        if self.gemm_tile is not None:
             return 1 if ((m + 127) // 128) * ((n + 127) // 128) > 256 else 2
         return min((1, 2, 3, 4), key=lambda sp: (min(self._tile_cost(t, m, n, k, sp) for t in self._TILE_MODEL), sp))
 
@@ -1185,8 +1165,6 @@ class SatOps:
         """As _pick_tile for the fp8 kernels (K-steps of 128 fp8 values: half as many per projection)."""
         if self.gemm_fp8_tile is not None:
             return self.gemm_fp8_tile
-        if self.gemm_policy == "r3":
-            return 0
         return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, (k + 1) // 2), t))
 
     def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,

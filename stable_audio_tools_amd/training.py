@@ -91,14 +91,13 @@ class GradAllReduce:
     optimizer) launches whatever did not fire (parameters without a gradient this step) and makes the compute stream wait for
     each bucket's event (`wait_bucket(i)` is the per-bucket form).  overlap=False: everything in finish().
 
-    single_rank_exchange (default: env SAT_DDP_SINGLE_RANK=1): with an initialised process group of ONE rank the exchange is
+    single_rank_exchange: with an initialised process group of ONE rank the exchange is
     normally skipped; this flag runs it anyway — hooks, side stream, events and the RCCL collectives on a 1-rank communicator —
     so the whole code path executes on a single-GPU box (tests/test_train_step.py::test_single_rank_rccl_exchange_gpu,
     `bench.py --ddp-single-rank`)."""
 
     def __init__(self, flat: FlatParameters, group=None, bucket_bytes=256 << 20, mode="all_reduce", overlap=True, comm_dtype=None,
                  single_rank_exchange=None, native=None, ops=None):
-        import os
         self.flat = flat
         self.group = group
         self.mode = mode
@@ -107,8 +106,7 @@ class GradAllReduce:
         initialised = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if initialised else 1
         self.rank = dist.get_rank(group) if initialised else 0
-        if single_rank_exchange is None:
-            single_rank_exchange = os.environ.get("SAT_DDP_SINGLE_RANK", "0") == "1"
+        single_rank_exchange = bool(single_rank_exchange)
         self.active = initialised and (self.world > 1 or bool(single_rank_exchange))
         self.backend = dist.get_backend(group) if initialised else None
         if comm_dtype in (None, torch.float32):
@@ -129,11 +127,12 @@ class GradAllReduce:
             s_ = max(0, e - per)
             self.buckets.append((s_, e))
             e = s_
-        # native=True (default: env SAT_DDP_NATIVE=1): the buckets go through the C-ABI's own RCCL communicator (csrc/comm.hip
-        # sat_allreduce_*: SURVEY.md §8b) instead of torch.distributed's; the process group is then only the side channel that hands
-        # rank 0's unique id to the other ranks.  Same collectives, same streams and events.
-        if native is None:
-            native = os.environ.get("SAT_DDP_NATIVE", "0") == "1"
+        # ONE exchange path by default (round 5): torch.distributed's RCCL communicator.  native=True (explicit argument only — no
+        # environment switch) sends the same buckets through the C-ABI's own RCCL communicator instead (csrc/comm.hip sat_allreduce_*:
+        # SURVEY.md §8b; executed on the MI355X in round 5 — tests/test_train_step.py::test_native_exchange_gpu, and
+        # profiles/r05_experiments/lean_ab/ddp_{torch,native}.json: 159.80 vs 159.81 ms per step); the process group is then only the
+        # side channel that hands rank 0's unique id to the other ranks.  Same collectives, same streams and events.
+        native = bool(native)
         self.native, self._comm, self._ops = False, None, None
         if native and self.active:
             if self.backend == "gloo":
@@ -153,6 +152,12 @@ class GradAllReduce:
         self._done = [None] * len(self.buckets)          # per-bucket completion events (side stream)
         self.launch_log = []                             # (bucket index, launched from a hook?) of the current step — read by the tests
         self._in_hook = False
+        # timing=True (bench.py --ddp-single-rank / --gpus N): the per-bucket events are created with timing enabled and kept, together
+        # with the events mark_backward_start() / mark_backward_end() record, until timeline() reads them — evidence of the overlap
+        # (when each bucket's exchange was enqueued and when it completed, relative to the backward pass that produced it)
+        self.timing = False
+        self._timeline = []
+        self._bwd_ev = [None, None]
         if self.overlap:
             # parameter i covers [off, off+numel): it gates every bucket it overlaps
             self._need = [0] * len(self.buckets)
@@ -216,14 +221,16 @@ class GradAllReduce:
         if chunk.is_cuda and self.overlap:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=chunk.device)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(torch.cuda.current_stream(chunk.device))      # the bucket's gradients are complete at this point
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 self._exchange(chunk)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=self.timing)
                 done.record(self._side)
             self._done[bi] = done
+            if self.timing:
+                self._timeline.append((bi, self._in_hook, ev, done, (e_ - s_) * 4))
         else:
             self._exchange(chunk)
 
@@ -250,6 +257,41 @@ class GradAllReduce:
 
     def __call__(self):
         self.finish()
+
+    def mark_backward_start(self):
+        if self.timing and self.flat.grad.is_cuda:
+            self._timeline = []
+            self._bwd_ev[0] = torch.cuda.Event(enable_timing=True)
+            self._bwd_ev[0].record()
+
+    def mark_backward_end(self):
+        if self.timing and self.flat.grad.is_cuda:
+            self._bwd_ev[1] = torch.cuda.Event(enable_timing=True)
+            self._bwd_ev[1].record()
+
+    def timeline(self):
+        """(timing=True) The last step's exchange against its backward pass, in milliseconds from the backward's first kernel:
+        {"backward_ms": ..., "buckets": [{"bucket", "bytes", "from_hook", "ready_ms", "done_ms"}, ...]} — `ready` = the bucket's
+        gradients complete on the compute stream (its collective is enqueued behind that event on the side stream), `done` = the
+        collective finished.  Synchronises the device."""
+        if not (self.timing and self._bwd_ev[0] is not None and self._bwd_ev[1] is not None):
+            return None
+        torch.cuda.synchronize()
+        t0 = self._bwd_ev[0]
+        rows = [{"bucket": bi, "bytes": nbytes, "from_hook": bool(h), "ready_ms": round(t0.elapsed_time(ev), 3), "done_ms": round(t0.elapsed_time(done), 3)}
+                for bi, h, ev, done, nbytes in self._timeline]
+        return {"backward_ms": round(t0.elapsed_time(self._bwd_ev[1]), 3), "buckets": rows}
+
+    def rearm(self):
+        """Forget what the hooks of an ABORTED backward already did (a failed HIP-graph capture, an exception inside the step): the next
+        backward starts from fresh counters.  Collectives already enqueued on the side stream are joined first."""
+        for bi in range(len(self.buckets)):
+            self.wait_bucket(bi)
+        self.launch_log = []
+        self._fired = [False] * len(self.buckets)
+        self._done = [None] * len(self.buckets)
+        if self.overlap:
+            self._left = list(self._need)
 
     def close(self):
         """Remove the autograd hooks (a second step object on the same parameters must not inherit live hooks) and, in native mode,
@@ -279,11 +321,18 @@ def ema_decay(step, beta=0.9999, power=0.75, inv_gamma=1.0, update_after_step=1,
     return min(max(value, min_value), beta)
 
 
-def clip_flat_grads(flat, max_norm, grad_scale=1.0):
+def clip_flat_grads(flat, max_norm, grad_scale=1.0, ops=None):
     """torch.nn.utils.clip_grad_norm_(params, max_norm) (training/autoencoders.py:491-492, :509-510) on a flat gradient buffer, without
     a host sync: the buffer holds the SUM over ranks and grad_scale = 1 / world turns its norm into that of the mean gradient the
     reference clips; the coefficient min(1, max_norm / (norm + 1e-6)) is multiplied in on the device.  Returns the (mean-gradient) norm."""
-    norm = torch.sqrt(_fn.sum_all(flat.grad * flat.grad)) * grad_scale      # not torch.linalg.vector_norm: ops.sum_all says why
+    # not torch.linalg.vector_norm: ops.sum_all says why.  The squares are formed slice by slice so the temporary stays at 256 MB whatever
+    # the size of the flat buffer (4.2 GB of DiT gradients would otherwise cost a 4.2 GB scratch tensor and a full extra write pass).
+    g, total, step = flat.grad, None, 1 << 26
+    for lo in range(0, g.numel(), step):
+        c = g[lo:lo + step]
+        part = _fn.sum_all(c * c, ops)
+        total = part if total is None else total + part
+    norm = torch.sqrt(total) * grad_scale
     flat.grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
     return norm
 
@@ -524,7 +573,7 @@ class AutoencoderTrainStep:
         self.flat_d.gather_grads()
         self.comm_d()
         if self.clip_grad_norm > 0.0:
-            clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale)
+            clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale, self.ops)
         self.opt_d.step(lr=self._lr("disc"), grad_scale=self.comm_d.grad_scale)
         return {"loss": loss_dis.detach(), "discriminator_loss": loss_dis.detach()}
 
@@ -553,7 +602,7 @@ class AutoencoderTrainStep:
                 t_own_decoded = m.decode(t_latents)[..., :n].contiguous()                        # teacher's latents, own decoder
             w = self.w_distill * sdec
             # AuralossLoss passes (target, input): losses.py:111 — x = the target_key tensor, y = the input_key tensor
-            terms = {"latent_distill_loss": _fn.mean_all((t_latents - own_latents) ** 2),
+            terms = {"latent_distill_loss": _fn.mean_all((t_latents - own_latents) ** 2, self.ops),
                      "mrstft_loss": self.sdstft(reals_t, decoded),
                      "mrstft_loss_distill": self.sdstft(t_decoded, decoded),
                      "mrstft_loss_own_latents_teacher": self.sdstft(reals_t, own_t_decoded),
@@ -568,11 +617,11 @@ class AutoencoderTrainStep:
             loss = mrstft + self.w_kl * info["kl"]
             out = {"mrstft_loss": mrstft.detach(), "kl_loss": (self.w_kl * info["kl"]).detach()}
         if self.w_l1 > 0.0:
-            l1 = _fn.mean_all((reals_t - decoded).abs())
+            l1 = _fn.mean_all((reals_t - decoded).abs(), self.ops)
             loss = loss + (self.w_l1 * tdec) * l1
             out["l1_time_loss"] = ((self.w_l1 * tdec) * l1).detach()
         if self.w_l2 > 0.0:
-            l2 = _fn.mean_all((reals_t - decoded) ** 2)
+            l2 = _fn.mean_all((reals_t - decoded) ** 2, self.ops)
             loss = loss + (self.w_l2 * tdec) * l2
             out["l2_time_loss"] = ((self.w_l2 * tdec) * l2).detach()
         if self.use_disc and self.warmed_up:      # before the warm-up ends the adversarial / feature-matching terms are zero (:441-452)
@@ -591,15 +640,18 @@ class AutoencoderTrainStep:
             finally:
                 for p in self.flat_d.params:
                     p.requires_grad_(True)
+            self.comm.mark_backward_start()
             torch.autograd.backward([loss, decoded], [torch.ones_like(loss), leaf.grad])
             loss = loss.detach() + self.w_adv * loss_adv + self.w_fm * fm
             out.update(loss_adv=(self.w_adv * loss_adv).detach(), feature_matching=(self.w_fm * fm).detach())
         else:
+            self.comm.mark_backward_start()
             loss.backward()
+        self.comm.mark_backward_end()
         self.flat.gather_grads()
         self.comm()
         if self.clip_grad_norm > 0.0:
-            clip_flat_grads(self.flat, self.clip_grad_norm, self.comm.grad_scale)
+            clip_flat_grads(self.flat, self.clip_grad_norm, self.comm.grad_scale, self.ops)
         self.opt.step(lr=self._lr("gen"), grad_scale=self.comm.grad_scale)
         out["loss"] = loss.detach()
         return out
@@ -667,12 +719,25 @@ class GraphedTrainStep:
         opt = self._opt(kind)
         opt.hyper_dev = self._hyper[kind]
         graph = torch.cuda.CUDAGraph()
+        # Capture must not depend on host-side cache state: a derived-weight cache HIT (an eager no_grad forward at this parameter epoch
+        # just before — demo, validation) would leave the fold / pack launches out of the graph and every replay would read a stale,
+        # later freed buffer.  Dropping every derived copy first makes the captured update rebuild (and therefore capture) them all.
+        _caches.bump_weight_epoch()
         try:
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
                 out = s._disc_body(static_reals, kw) if kind == "disc" else s._gen_body(static_reals, kw)
+        except BaseException:
+            # entries created during the aborted capture point at graph-pool tensors that never executed: drop them, and re-arm the
+            # gradient exchange whose hooks already fired inside the aborted backward (the eager retry of this step runs them again)
+            _caches.bump_weight_epoch()
+            for c in (s.comm, getattr(s, "comm_d", None)):
+                if c is not None and hasattr(c, "rearm"):
+                    c.rearm()
+            raise
         finally:
             opt.hyper_dev = None
+        _caches.bump_weight_epoch()      # the pool-resident copies made during capture hold garbage until the first replay
         self.graphs[key] = (graph, static_reals, static_noise, out)
 
     def __call__(self, reals, noise=None):
@@ -779,7 +844,9 @@ class DiTTrainStep:
         else:
             out = self.model(noised, t, **kw)
         loss = torch.nn.functional.mse_loss(out.float(), targets.float())
+        self.comm.mark_backward_start()
         loss.backward()
+        self.comm.mark_backward_end()
         self.flat.gather_grads()
         self.comm()
         self.opt.step(grad_scale=self.comm.grad_scale)

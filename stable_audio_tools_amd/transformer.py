@@ -20,7 +20,6 @@ weight gradients run on the same native GEMM (linear.LinearFn.backward).  Per-la
 of the reference (transformer.py:28-30, :840-845) is optional here: off by default (288 GB of HBM), on with
 `use_checkpointing=True` / `ContinuousTransformer.checkpointing = True` when the batch does not fit.
 """
-import os
 
 import torch
 from torch import nn
@@ -30,8 +29,8 @@ from . import functional as _fn
 from . import linear as _linear
 from .linear import Linear, _lowp
 
-# LayerNorm -> fp8 rows for an fp8 consumer (round 4); SAT_FP8_LN_FUSED=0: normalise to bf16, then quantise (the A/B arm)
-fp8_ln_fused = os.environ.get("SAT_FP8_LN_FUSED", "1") != "0"
+# LayerNorm -> fp8 rows for an fp8 consumer (round 4); False (set by an A/B script): normalise to bf16, then quantise
+fp8_ln_fused = True
 
 
 def _ops():
@@ -442,18 +441,7 @@ class ContinuousTransformer(nn.Module):
             global_cond = self.global_cond_embedder(global_cond)
         x = x.contiguous()
         ckpt = self.checkpointing and use_checkpointing and torch.is_grad_enabled()
-        # experiment switch (SAT_WEIGHT_PREFETCH=1; OFF by default — measured slower: 105.6 vs 110.9 sampler steps/s eager, 100.9 vs 110.9
-        # in a HIP graph, profiles/EXPERIMENTS.md): the NEXT layer's projection weights are read into the memory-side cache on a side
-        # stream while this layer runs (ops.prefetch / csrc/dit_ops.hip sat_prefetch: a scheduling hint, results unaffected)
-        pf = self.weight_prefetch and x.is_cuda and not torch.is_grad_enabled() and len(self.layers) > 1
-        if pf:
-            cur = torch.cuda.current_stream()
-            side = self._prefetch_stream(x.device)
-            pf_ops = _fn._ops(None)
         for layer_ix, layer in enumerate(self.layers):
-            if pf and layer_ix + 1 < len(self.layers):
-                side.wait_stream(cur)
-                pf_ops.prefetch(self._layer_weights(layer_ix + 1), side)
             if ckpt:
                 x = torch.utils.checkpoint.checkpoint(layer, x, rotary_pos_emb=rotary, global_cond=global_cond, use_reentrant=False, **kwargs)
             else:
@@ -462,23 +450,5 @@ class ContinuousTransformer(nn.Module):
                 info["hidden_states"].append(x)
             if exit_layer_ix is not None and layer_ix == exit_layer_ix:
                 return (x, info) if return_info else x
-        if pf:
-            cur.wait_stream(side)                 # (joins the side stream: required when this forward is being captured into a HIP graph)
         x = self.project_out(x)
         return (x, info) if return_info else x
-
-    weight_prefetch = os.environ.get("SAT_WEIGHT_PREFETCH", "0") == "1"
-
-    def _prefetch_stream(self, device):
-        st = self.__dict__.get("_pf_streams")
-        if st is None:
-            st = self.__dict__["_pf_streams"] = {}
-        if device not in st:
-            st[device] = torch.cuda.Stream(device=device)
-        return st[device]
-
-    def _layer_weights(self, ix):
-        mods = self.__dict__.get("_pf_linears")
-        if mods is None:
-            mods = self.__dict__["_pf_linears"] = [[m for m in layer.modules() if isinstance(m, Linear)] for layer in self.layers]
-        return [m.prefetch_tensor() for m in mods[ix]]

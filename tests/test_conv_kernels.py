@@ -123,19 +123,15 @@ def test_conv_up_sim(emu, case):
     _run_up(emu, "cpu", case, True)
 
 
-def _run_planes(ops, dev, cases, q_min=None):
-    """The k = 7 convs fed from pre-split activation planes (conv1d_bf16x3_k7p.h: sat_conv1d_k7_planes + sat_conv1d_bf16x3_planes) —
-    the path the C >= 512 levels take — forced on for every channel count: forward and all gradients vs torch, and bit-identical
-    outputs to the direct kernel (same split, same MFMA order)."""
-    keep = (ops.k7_planes, ops.k7_planes_min_cin)
+def _run_planes(ops, dev, cases):
+    """The k = 7 convs fed from pre-split activation planes (conv1d_planes.h: sat_conv1d_k7_planes; conv1d_bf16x3_k7q.h:
+    sat_conv1d_bf16x3_planesq) — the path every C >= 64 level takes — forced on for every channel count: forward and all gradients vs
+    torch, and outputs equal to the direct kernel's up to the accumulation order (16-channel chunks, one tap per k-step)."""
     keepq = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout)
     try:
         for case in cases:
-            ops.k7_planes, ops.k7_planes_min_cin = True, 1
-            ops.k7q = False
-            _run_s1(ops, dev, case, True)               # autograd units through the planes kernel (k7p)
             ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = True, 1, 1
-            _run_s1(ops, dev, case, True)               # ... and through the third-generation kernel (k7q)
+            _run_s1(ops, dev, case, True)               # autograd units through the planes kernel
             B, Cin, Cout, T, K, dil = case
             gen = torch.Generator().manual_seed(7)
             x = torch.randn(B, Cin, T, generator=gen).to(dev)
@@ -145,23 +141,15 @@ def _run_planes(ops, dev, cases, q_min=None):
             a2, b2 = (torch.randn(Cout, generator=gen) * .3).to(dev), (torch.randn(Cout, generator=gen) * .3).to(dev)
             wp = ops.pack_bf16x3(w, 0, 1)
             pad = dil * (K - 1) // 2
-            outs = []
-            for flag in (True, False):
-                ops.k7_planes = flag
-                outs.append((ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, snake=(la, lb)),
-                             *ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2))))
-            for a, b in zip(*outs):
-                assert torch.equal(a, b)
-            # third-generation kernel (conv1d_bf16x3_k7q.h): another accumulation order (16-channel chunks, one tap per k-step)
+            direct = (ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, snake=(la, lb)),
+                      *ops.conv1d_bf16x3(x, wp, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
             if 5 <= K <= 7:
-                ops.k7_planes = True
                 wq = ops.pack_bf16x3(w, 0, 1, q=True)
                 outq = (ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, snake=(la, lb)),
                         *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
-                for a, b in zip(outq, outs[1]):
+                for a, b in zip(outq, direct):
                     assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), (case, (a - b).abs().max().item())
     finally:
-        ops.k7_planes, ops.k7_planes_min_cin = keep
         ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = keepq
 
 
@@ -169,32 +157,28 @@ def test_conv_k7_planes_sim(emu):
     _run_planes(emu, "cpu", [c for c in S1_CASES if c[4] == 7][:6] + [(1, 20, 5, 90, 5, 2), (2, 16, 130, 517, 7, 3)])
 
 
-def test_conv_k7_planes_persistent_sim(emu, monkeypatch):
-    """The planes kernel is persistent (a workgroup walks several tiles, requesting the next tile's first chunks before its epilogue):
-    with the workgroup count capped at 1 / 3 the same cases run 2..12 tiles per workgroup, incl. a change of channel tile."""
-    for cap in ("1", "3"):
-        monkeypatch.setenv("SAT_K7P_MAX_WGS", cap)
-        _run_planes(emu, "cpu", [(2, 16, 130, 517, 7, 3), (1, 8, 8, 1300, 7, 9), (3, 24, 200, 300, 7, 1)])
-
-
-@pytest.mark.gpu
-def test_conv_k7_planes_persistent_gpu(hip, monkeypatch):
-    for cap in ("2", "7"):
-        monkeypatch.setenv("SAT_K7P_MAX_WGS", cap)
-        _run_planes(hip, "cuda", [(2, 16, 130, 517, 7, 3), (1, 128, 128, 8192, 7, 9), (3, 24, 200, 300, 7, 1)])
-    monkeypatch.delenv("SAT_K7P_MAX_WGS")
-    _run_planes(hip, "cuda", [(1, 128, 128, 300000, 7, 3)])      # 1172 tiles on 256 workgroups
+def test_conv_k7_wide_input_few_outputs_sim(emu):
+    """The data-gradient of the decoder's first conv (2048 -> 64 channels, 1024 steps; here 520 -> 40): fewer output channels than
+    k7q_min_cout still take the planes kernel when the input is wide (ops.k7q_wide_cin) — round 2's k7p kernel served this plan."""
+    keep = emu.k7q_wide_cin
+    try:
+        emu.k7q_wide_cin = 512
+        assert emu.k7q_applicable(520, 7, 1, 1, 3, 40) and not emu.k7q_applicable(128, 7, 1, 1, 3, 40)
+        _run_s1(emu, "cpu", (1, 520, 40, 200, 7, 1), True)
+    finally:
+        emu.k7q_wide_cin = keep
 
 
 @pytest.mark.gpu
 def test_conv_k7_planes_gpu(hip):
-    _run_planes(hip, "cuda", [c for c in S1_CASES if c[4] == 7] + [(1, 128, 128, 8192, 7, 9), (1, 1024, 1024, 512, 7, 3), (2, 512, 512, 1000, 7, 1)])
+    _run_planes(hip, "cuda", [c for c in S1_CASES if c[4] == 7] + [(1, 128, 128, 8192, 7, 9), (1, 1024, 1024, 512, 7, 3), (2, 512, 512, 1000, 7, 1),
+                              (1, 128, 128, 300000, 7, 3), (1, 2048, 64, 1024, 7, 1)])
 
 
 def _run_ru(ops, dev, cases):
     """The fused ResidualUnit forward (csrc/conv1d_bf16x3_k7q.h, FUSED: one launch) vs torch's conv1d chain: y, the kept intermediate
     through every gradient, with and without the plane emission for a following unit (whose k7 conv then consumes those planes)."""
-    keep = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit)
+    keep = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.ru_fused, ops.k7_emit)
     calls = {"n": 0}
     orig = ops.lib.sat_residual_unit_fwd
 
@@ -203,7 +187,7 @@ def _run_ru(ops, dev, cases):
         return orig(*a)
     ops.lib.sat_residual_unit_fwd = counted
     try:
-        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit = True, 1, 1, True, True, True
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.ru_fused, ops.k7_emit = True, 1, 1, True, True
         for (B, C, T, dil) in cases:
             gen = torch.Generator().manual_seed(C * 1000 + T + dil)
             x = _leaf(gen, dev, B, C, T)
@@ -224,7 +208,7 @@ def _run_ru(ops, dev, cases):
                 y3 = Fn.ResidualUnitFn.apply(x, ps[0], ps[1], w1, bias1, ps[2], ps[3], w2, bias2, dil, ops, False, None, None, "nokeep")
             assert calls["n"] == n0 + 2 and torch.equal(y3, y1.detach())
     finally:
-        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7_planes, ops.ru_fused, ops.k7_emit = keep
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.ru_fused, ops.k7_emit = keep
         ops.lib.sat_residual_unit_fwd = orig
 
 
@@ -301,26 +285,23 @@ def test_conv_random_shapes_sim(emu, kind, case):
         FLOOR[0] = 1e-3
 
 
-def _fused_rowsum_case(ops, dev):
-    """The A/B variant of the pipelined k7 weight-gradient kernel that also sums the dy rows (SAT_WG_ROWSUM=1): same dW and bias gradient."""
-    import os
+def _wgrad7_bias_case(ops, dev):
+    """conv_wgrad7_bf16x3(dy_rowsum=True): dW and the bias gradient, on a shape the pipelined kernel takes (row sums by sat_rowsum) and on
+    one the four-wave kernel takes (row sums fused)."""
     gen = torch.Generator().manual_seed(5)
-    dy = torch.randn(2, 130, 152, generator=gen).to(dev)
-    x = torch.randn(2, 64, 152, generator=gen).to(dev)
-    ref_w = ops.conv_wgrad7_bf16x3(dy, x, 1, 3)
-    os.environ["SAT_WG_ROWSUM"] = "1"
-    try:
+    for (m, n, t) in ((130, 64, 152), (70, 24, 152)):
+        dy = torch.randn(2, m, t, generator=gen).to(dev)
+        x = torch.randn(2, n, t, generator=gen).to(dev)
+        ref_w = ops.conv_wgrad7_bf16x3(dy, x, 1, 3)
         dw, db = ops.conv_wgrad7_bf16x3(dy, x, 1, 3, dy_rowsum=True)
-    finally:
-        os.environ.pop("SAT_WG_ROWSUM")
-    assert torch.equal(dw, ref_w)
-    assert (db.cpu() - dy.sum(dim=(0, 2)).cpu()).abs().max().item() <= 1e-4 * dy.abs().sum(dim=(0, 2)).max().item()
+        assert torch.equal(dw, ref_w)
+        assert (db.cpu() - dy.sum(dim=(0, 2)).cpu()).abs().max().item() <= 1e-4 * dy.abs().sum(dim=(0, 2)).max().item()
 
 
-def test_wgrad7_pipe_fused_rowsum_sim(emu):
-    _fused_rowsum_case(emu, "cpu")
+def test_wgrad7_bias_gradient_sim(emu):
+    _wgrad7_bias_case(emu, "cpu")
 
 
 @pytest.mark.gpu
-def test_wgrad7_pipe_fused_rowsum_gpu(hip):
-    _fused_rowsum_case(hip, "cuda")
+def test_wgrad7_bias_gradient_gpu(hip):
+    _wgrad7_bias_case(hip, "cuda")

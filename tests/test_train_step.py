@@ -351,8 +351,6 @@ def _native_single_rank_worker(port, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SAT_TEST_LEAN_ARMS") != "1",
-                    reason="csrc/comm.hip was written without GPU access: its first execution on hardware is a deliberate call (SAT_TEST_LEAN_ARMS=1)")
 def test_native_exchange_gpu(hip):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -615,8 +613,6 @@ def test_sum_all_gpu(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent on the diagnosis it follows from: not yet executed on an "
-                                        "MI355X (the driver's round-end run is its first); asserts strictly once it has been seen to pass")
 def test_sum_all_survives_graph_replay_gpu(hip):
     """The reason ops.sum_all exists: replayed from a HIP graph, torch's multi-block reductions return stale / foreign values after a few
     replays on this stack (tools/diag_graph_reduce.py reproduces it with torch ops alone; profiles/r04_experiments/graph_reductions/).
@@ -680,7 +676,7 @@ def test_warmup_and_time_losses_simulator(emu_modules):
 
 
 # ---- the whole update as ONE HIP graph (training.GraphedTrainStep): same kernels, same order -> bit-identical to the eager step ----
-def _graphed_vs_eager(cfg, nsteps, device="cuda"):
+def _graphed_vs_eager(cfg, nsteps, device="cuda", demo_between=False):
     from stable_audio_tools_amd.training import AutoencoderTrainStep, GraphedTrainStep
     batches = [_batch(2, 900 + 10 * i) for i in range(nsteps)]
 
@@ -691,6 +687,11 @@ def _graphed_vs_eager(cfg, nsteps, device="cuda"):
         step = GraphedTrainStep(stepper, eager_steps=1) if graphed else stepper
         losses = []
         for a, n in batches:
+            if demo_between and graphed:
+                # a demo / validation pass at the CURRENT parameter epoch right before the update (and therefore right before the capture):
+                # its derived-weight cache entries must not be what the captured update reads (capture froze cache hits)
+                with torch.no_grad():
+                    model.decode(model.encode(a.to(device), noise=n.to(device)))
             out = step(a.to(device), noise=n.to(device))
             losses.append({k: float(v) for k, v in out.items()})
         torch.cuda.synchronize()
@@ -727,6 +728,15 @@ def test_graphed_alternating_step_equals_eager_gpu(hip):
     """The real step (generator / discriminator alternating, adversarial + feature-matching terms): one graph per kind of update."""
     replays, ngraphs = _graphed_vs_eager(_disc_config(), 8)
     assert ngraphs == 2 and replays == 6          # per kind: one eager call, three replays
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_demo_passes_between_gpu(hip):
+    """no_grad encode / decode passes between the updates (what the wrapper's demo callback and validation do) fill the derived-weight
+    caches at the parameter epoch the capture runs at; the captured update must still contain its own fold / pack launches: losses of
+    every replayed step equal the eager stepper's."""
+    replays, ngraphs = _graphed_vs_eager(_disc_config(), 8, demo_between=True)
+    assert ngraphs == 2 and replays == 6
 
 
 # ---- wrapper options of the reference's training step: force_input_mono, latent_mask_ratio, LossModule.decay ----

@@ -67,7 +67,7 @@ def _emission_case(ops, device):
     reads planes — written by its producer's epilogue where the producer is a k1 / strided conv of the generic kernel (forward: the
     previous unit's k1 conv or the block's down conv; backward: the unit's own k1 data-gradient), by the sat_conv1d_k7_planes pre-pass
     otherwise — and the golden comparison (forward + every gradient) must still hold."""
-    keep = (ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout)
+    keep = (ops.k7q, ops.k7q_min_cin, ops.k7_emit, ops.k7q_min_cout)
     counts = {"emit": 0, "prepass": 0, "q": 0, "fused": 0}
     orig = {n: getattr(ops.lib, n) for n in ("sat_conv1d_bf16x3_emit", "sat_conv1d_k7_planes", "sat_conv1d_bf16x3_planesq", "sat_residual_unit_fwd")}
 
@@ -84,7 +84,7 @@ def _emission_case(ops, device):
     keep_f = (ops.ru_fused, ResidualUnit.fuse)
     ResidualUnit.fuse = True                                # (default: fused only under no_grad)
     try:
-        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = True, 1, True, True, 1
+        ops.k7q, ops.k7q_min_cin, ops.k7_emit, ops.k7q_min_cout = True, 1, True, 1
         for name, batch, in_len, seed in CASES[:2]:
             _run_case(name, batch, in_len, seed, device)
         with_emit = dict(counts)
@@ -100,7 +100,7 @@ def _emission_case(ops, device):
         _run_case(*CASES[0], device)
         assert counts["emit"] == 0 and counts["prepass"] == counts["q"] > 0          # without emission / fusion: one pre-pass per k7 conv
     finally:
-        ops.k7q, ops.k7q_min_cin, ops.k7_planes, ops.k7_emit, ops.k7q_min_cout = keep
+        ops.k7q, ops.k7q_min_cin, ops.k7_emit, ops.k7q_min_cout = keep
         ops.ru_fused, ResidualUnit.fuse = keep_f
         for n, f in orig.items():
             setattr(ops.lib, n, f)

@@ -13,18 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "stable_audio_tools_amd", "csrc")
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -fno-slp-vectorize".split()
 # experiment variants that are known to spill and are not on the default path
-ALLOW = ("sat_gemm256_kernelILi0ELb0ELi2E", "sat_gemm256_kernelILi0ELb1ELi2E", "sat_gemm256_kernelILi1ELb0ELi2E", "sat_gemm256_kernelILi1ELb1ELi2E",
-         "sat_gemm256_kernelILi2ELb0ELi2E", "sat_gemm256_kernelILi2ELb1ELi2E", "sat_gemm256_kernelILi3ELb0ELi2E", "sat_gemm256_kernelILi3ELb1ELi2E",
-         "sat_gemm256_kernelILi4ELb0ELi2E",      # TOUCH = 2: the L2 touch prefetch experiment (tile 5)
-         # LEANK = true variants (SAT_GEMM_LEAN=1, an unmeasured A/B arm) with the SwiGLU / head-split epilogues: 4-5 spilled registers, all
-         # outside the K loops (ISA checked: the scratch instructions sit in the prologue and between the loops)
-         "sat_gemm256_kernelILi3ELb0ELi0ELb0ELb1E", "sat_gemm256_kernelILi3ELb1ELi0ELb0ELb1E", "sat_gemm256_kernelILi4ELb0ELi0ELb0ELb1E",
-         # the fp32 (two-plane) dK / dV kernel: 4 registers spilled in the prologue and reloaded in the epilogue (ISA checked: no scratch
-         # instruction inside the tile loop)
-         "sat_attn_bwd_dkv_kernelIfLi2ELi32E",
-         # the k = 7 weight gradient: 34-172 spilled registers, ALL in the remainder code after the stage loop (the ISA has its 35 scratch
-         # instructions around the last MFMA block, none between the loop's barriers) — checked round 4, not on the steady-state path
-         "sat_wgrad7_bf16x3_pipe_kernel")
+# kernels known to use scratch OUTSIDE their steady-state loops (ISA checked); everything else must not spill
+ALLOW = (
+    # the 256 x 256 projection kernel with the SwiGLU / head-split epilogues: 4-5 spilled registers, all outside the K loops (the scratch
+    # instructions sit in the prologue and between the loops)
+    "sat_gemm256_kernelILi3E", "sat_gemm256_kernelILi4E",
+    # the fp32 (two-plane) dK / dV kernel: 4 registers spilled in the prologue and reloaded in the epilogue (no scratch instruction inside
+    # the tile loop)
+    "sat_attn_bwd_dkv_kernelIfLi2ELi32E",
+    # the k = 7 weight gradient: 34-172 spilled registers, ALL in the remainder code after the stage loop (its 35 scratch instructions sit
+    # around the last MFMA block, none between the loop's barriers) — not on the steady-state path
+    "sat_wgrad7_bf16x3_pipe_kernel")
 
 
 def one(path):
