@@ -63,6 +63,8 @@ def parse():
                          "per-bucket events, collectives on a 1-rank communicator): the data-parallel code path on a single-GPU box")
     ap.add_argument("--ddp-mode", choices=["all_reduce", "reduce_scatter"], default="all_reduce")
     ap.add_argument("--ddp-comm-dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--ops-set", action="append", default=[], metavar="ATTR=VALUE",
+                    help="A/B knob: set an attribute of the SatOps object before the run (e.g. ru_k1_fused=0); recorded in config.ops_set")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launches only (skip the HIP-graph replay of the train step)")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="also try the HIP-graph step when a process group is active (the RCCL collectives are then captured too)")
@@ -697,8 +699,9 @@ class ConvProfiler:
         "sat_conv1d_bf16x3": (lambda a: "sat_conv1d_bf16x3_k7_kernel" if (a[18] >= 5 and a[19] == 1) else "sat_conv1d_bf16x3_kernel",
                               X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_conv1d_k7_planes": ("sat_k7_planes_kernel", X3, lambda a: 0.0),     # the planes kernel's pre-pass: time, no flops of its own
-        "sat_conv1d_bf16x3_planes": ("sat_conv1d_bf16x3_k7p_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
         "sat_conv1d_bf16x3_planesq": ("sat_conv1d_bf16x3_k7q_kernel", X3, lambda a: 2.0 * a[13] * a[14] * a[15] * a[18] * a[17]),
+        # the fused backward of a unit's 1x1 conv (csrc/ru_k1_bwd.hip): data gradient + weight gradient = 4 * C * C * T * B flop, HBM-bound
+        "sat_ru_k1_bwd": ("sat_ru_k1_bwd_kernel", X3, lambda a: 4.0 * a[13] * a[13] * a[14] * a[12]),
         # the fused ResidualUnit forward (C <= 128): conv7 + conv1 in one launch of the k7q kernel
         "sat_residual_unit_fwd": ("sat_conv1d_bf16x3_k7q_kernel", X3, lambda a: 2.0 * a[14] * a[15] * a[15] * (a[17] + 1) * a[16]),
         # the k1 / strided convs that also write their consumer's activation planes (generic kernel, plane emission)
@@ -1194,6 +1197,11 @@ def main():
     stepper.comm.timing = stepper.comm.active      # exchange timeline of the last timed step (config.ddp.timeline)
     stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
     ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
+    for kv in args.ops_set:
+        name, val = kv.split("=", 1)
+        if not hasattr(ops, name):
+            raise SystemExit(f"--ops-set: SatOps has no attribute {name!r}")
+        setattr(ops, name, type(getattr(type(ops), name))(int(val)) if isinstance(getattr(type(ops), name), (bool, int)) else val)
     prof = ConvProfiler(ops)
 
     g = torch.Generator().manual_seed(rank)     # per-rank data (train.py:30-33 seeds ranks differently)
@@ -1273,7 +1281,7 @@ def main():
                                    " the alternating MS-STFT-discriminator / generator step of the reference is timed beside it: real_step_*",
                        "sample_size": args.sample_size, "channels": 2, "sample_rate": 44100,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": loss, "launch": launch,
+                       "parallelism": f"dp{world}", "final_loss": loss, "launch": launch, "ops_set": list(args.ops_set),
                        "ddp": {"process_group": (dist.get_backend() if dist.is_initialized() else None), "exchange_active": stepper.comm.active,
                                "mode": stepper.comm.mode, "comm_dtype": args.ddp_comm_dtype, "buckets": len(stepper.comm.buckets),
                                "overlap": stepper.comm.overlap, "native_c_abi_exchange": bool(stepper.comm.native),

@@ -200,6 +200,21 @@ int sat_conv_wgrad_bf16x3(const float* lo, const float* hi, const float* alpha, 
                           int Thi, int K, int stride, int pad, float* lo_rowsum, void* stream);
 int sat_conv_wgrad_bf16x3_nsplit(int B, int M, int N, int Tlo, int K, int stride);
 
+/* The whole backward of a ResidualUnit's 1x1 conv (autoencoders.py:58-83: y = x + conv1(snake2(h))) in ONE pass over dy and h
+ * (csrc/ru_k1_bwd.hip; C == 128, T % 32 == 0 — sat_ru_k1_bwd_nsplit returns -1 otherwise and the caller keeps
+ * sat_conv_wgrad_bf16x3 + sat_conv1d_bf16x3_emit + sat_rowsum): replaces the autograd of F.conv1d(k = 1) + snake_beta for that conv.
+ *   dh (B, C, T)               = (W2^T dy) * dsnake2(h)        [+ em_hi / em_lo: dh as the k7 data-gradient's activation planes
+ *                                                                 [B][C/8][em_rows][8], row 32 + t; NULL: not written]
+ *   dw_partial [nsplit][C][C]  : slabs of dW2 (torch layout (Cout, Cin, 1)); sum with sat_reduce_splits
+ *   part [4][C][nsplit]        : per-split sums of d log-alpha2, d log-beta2, dh (= bias gradient of the k7 conv), dy (= bias
+ *                                gradient of the 1x1 conv); sum the last axis (sat_rowsum)
+ * wt_hi / wt_lo: W2^T as bf16 hi / lo planes [ci][co] (sat_ru_k1_pack of the (C, C) weight).  All pointers 16-byte aligned. */
+int sat_ru_k1_bwd_nsplit(int B, int C, int T);
+int sat_ru_k1_pack(const float* w, short* hi, short* lo, int C, void* stream);
+int sat_ru_k1_bwd(const float* dy, const float* h, const short* wt_hi, const short* wt_lo, const float* alpha2, const float* beta2,
+                  float* dh, short* em_hi, short* em_lo, int em_rows, float* dw_partial, float* part, int B, int C, int T,
+                  void* stream);
+
 /* out[i] (+)= scale * sum_z partial[z*count + i]   (deterministic split reduction) */
 int sat_reduce_splits(const float* partial, float* out, long long count, int nsplit, float scale, int accumulate,
                       void* stream);

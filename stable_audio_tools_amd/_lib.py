@@ -63,6 +63,9 @@ SIGNATURES = {
     "sat_conv_wgrad": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _L] + [_I] * 9 + [_P]),
     "sat_conv_wgrad_nsplit": (_I, [_I] * 7),
     "sat_reduce_splits": (_I, [_P, _P, _L, _I, _F, _I, _P]),
+    "sat_ru_k1_bwd_nsplit": (_I, [_I] * 3),
+    "sat_ru_k1_pack": (_I, [_P, _P, _P, _I, _P]),
+    "sat_ru_k1_bwd": (_I, [_P] * 9 + [_I, _P, _P, _I, _I, _I, _P]),
     "sat_rowsum": (_I, [_P, _P, _I, _I, _I, _P]),
     "sat_rowsum_nsplit": (_I, [_I]),
     # elementwise.hip

@@ -22,6 +22,8 @@
 #define SAT_FFT_MAX 2048
 #define SAT_STFT_NG 8  // frame groups per workgroup (consecutive frames share the LDS overlap-add buffer)
 #define SAT_STFT_OBUF (7 * 512 + 2048)
+#define SAT_STFT_SMALL 512             // n <= 512: fb * n == 512
+#define SAT_STFT_OBUF_SMALL 1408       // (8 fb - 1) hop + n at hop = n / 4 for n <= 512 (largest at n = 512)
 
 #if defined(SAT_HIPEMU)
 static inline unsigned sat_brev(unsigned v) {
@@ -218,8 +220,11 @@ SAT_DEVICE void sat_unpack_bins(const SatFftLds& L, int n, int fi, int k, float*
     *yi = -0.5f * (ar - br);
 }
 
+// NMAX: the largest fb * n this instance holds (2048, or 512 for the five resolutions n <= 512: a quarter of the LDS, so that eight
+// workgroups share a CU instead of two or three — these kernels are latency-bound: every phase is a dependent round trip)
+template <int NMAX>
 __global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
-    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
+    __shared__ float re[NMAX], im[NMAX], twr[NMAX / 2], twi[NMAX / 2];
     __shared__ float red[3][4];
     const SatFftLds L{re, im, twr, twi};
     const int n = p.n, nb = (n >> 1) + 1;
@@ -267,9 +272,10 @@ __global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
 // One workgroup handles its SAT_STFT_NG frame groups for ALL views (sum / difference / left / right): the per-view
 // time-domain gradients are overlap-added straight into two per-CHANNEL LDS buffers (weights va, vb of the view), so the
 // global scatter is one atomic per sample and channel instead of one per sample, channel and view.
+template <int NMAX, int OBUF>
 __global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
-    __shared__ float re[SAT_FFT_MAX], im[SAT_FFT_MAX], twr[SAT_FFT_MAX / 2], twi[SAT_FFT_MAX / 2];
-    __shared__ float obuf_a[SAT_STFT_OBUF], obuf_b[SAT_STFT_OBUF];
+    __shared__ float re[NMAX], im[NMAX], twr[NMAX / 2], twi[NMAX / 2];
+    __shared__ float obuf_a[OBUF], obuf_b[OBUF];
     const SatFftLds L{re, im, twr, twi};
     const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
     const int item = blockIdx.y;
@@ -418,7 +424,8 @@ extern "C" int sat_stft_fwd(const float* x, const float* y, const float* views, 
     p.x = x; p.y = y; p.views = views; p.partial = partial; p.coef = nullptr; p.dy = nullptr;
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = 0;
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
-    SAT_LAUNCH(sat_stft_fwd_kernel, grid, dim3(256), stream, p);
+    if (p.fb * p.n <= SAT_STFT_SMALL) SAT_LAUNCH(sat_stft_fwd_kernel<SAT_STFT_SMALL>, grid, dim3(256), stream, p);
+    else SAT_LAUNCH(sat_stft_fwd_kernel<SAT_FFT_MAX>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_fwd");
 }
 
@@ -430,7 +437,9 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     p.x = x; p.y = y; p.views = views; p.partial = nullptr; p.coef = coef; p.dy = dy;
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = wrt_x;
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, 1);       // the views are looped inside the workgroup
-    SAT_LAUNCH(sat_stft_bwd_kernel, grid, dim3(256), stream, p);
+    const int olen = (SAT_STFT_NG * p.fb - 1) * p.hop + p.n;
+    if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }
 

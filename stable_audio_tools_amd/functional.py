@@ -290,11 +290,17 @@ class ResidualUnitFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.recompute:
             h = _conv_fwd(ops, x, w1, 1, dil, pad1, bias=bias1, snake=(a1, b1))
-        dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
         # the k1 data-gradient also writes dh as the planes its consumer — the k7 data-gradient two launches below — reads
-        emit = {"snake": None} if (ops.emit_ok(w1.shape[0], k2, 1, t, dil) and ops.k7q_applicable(w1.shape[0], k1, 1, dil, pad1, c)) else None
-        dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit=emit)
-        dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
+        want_emit = ops.emit_ok(w1.shape[0], k2, 1, t, dil) and ops.k7q_applicable(w1.shape[0], k1, 1, dil, pad1, c)
+        if k2 == 1 and w2.shape[0] == c and w1.shape[0] == c and ops.ru_k1_bwd_ok(dy.shape[0], c, t):
+            # C == 128 (the widest levels): weight gradient, data gradient, both bias gradients and the snake gradients of the 1x1 conv in ONE pass
+            # over dy and h (csrc/ru_k1_bwd.hip) instead of three kernels that each stream them from HBM
+            dh, da2, db2, dw2, dbias2, dbias1 = ops.ru_k1_bwd(dy, h, w2, (a2, b2), emit=want_emit)
+            dw1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=False)
+        else:
+            dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
+            dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit={"snake": None} if want_emit else None)
+            dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
         return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None, None
 

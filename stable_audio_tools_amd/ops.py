@@ -465,6 +465,47 @@ class SatOps:
             return dw
         return dw, (self._sum_last(rs) if rs is not None else self.rowsum(lo))
 
+    # ---- fused backward of a ResidualUnit's 1x1 conv (csrc/ru_k1_bwd.hip): one pass over dy and h ----
+    ru_k1_fused = True
+
+    def ru_k1_bwd_ok(self, b, c, t):
+        return self.ru_k1_fused and self.use_bf16x3 and self.lib.sat_ru_k1_bwd_nsplit(b, c, t) > 0
+
+    def ru_k1_pack(self, w2):
+        """(C, C, 1) fp32 -> W2^T as bf16 hi / lo planes [ci][co] (sat_ru_k1_pack)."""
+        self._f32(w2)
+        c = w2.shape[0]
+        planes = torch.empty(2, c * c, dtype=torch.int16, device=w2.device)
+        self._chk(self.lib.sat_ru_k1_pack(_ptr(w2), _ptr(planes[0]), _ptr(planes[1]), c, self._stream(w2)))
+        return planes[0], planes[1]
+
+    def ru_k1_bwd(self, dy, h, w2, snake2, emit=False, wt=None):
+        """Backward of y = x + conv1x1(snake2(h)) w.r.t. everything but x, in one launch: returns (dh, dlog_alpha2, dlog_beta2, dW2 (C, C, 1),
+        dbias2 (C,), dbias1 (C,) = sum dh).  emit=True also writes dh as the activation planes of the k7 data-gradient that consumes it
+        next (as conv1d_bf16x3(emit={"snake": None}))."""
+        b, c, t = dy.shape
+        a2, b2 = snake2
+        self._f32(dy, h, w2, a2, b2)
+        ns = self.lib.sat_ru_k1_bwd_nsplit(b, c, t)
+        if ns <= 0:
+            raise RuntimeError("ru_k1_bwd: shape not served by the fused kernel (ru_k1_bwd_ok)")
+        st = self._stream(dy)
+        wt_hi, wt_lo = wt if wt is not None else self.ru_k1_pack(w2)
+        dh = torch.empty_like(dy)
+        slabs = torch.empty(ns, c * c, dtype=torch.float32, device=dy.device)
+        part = torch.empty(4 * c, ns, dtype=torch.float32, device=dy.device)
+        ehi = elo = None
+        erows = 0
+        if emit:
+            ehi, elo, erows = self._emit_planes(b, c, t, dy.device, st)
+        self._chk(self.lib.sat_ru_k1_bwd(_ptr(dy), _ptr(h), _ptr(wt_hi), _ptr(wt_lo), _ptr(a2), _ptr(b2), _ptr(dh), _ptr(ehi), _ptr(elo), erows,
+                                         _ptr(slabs), _ptr(part), b, c, t, st))
+        if emit:
+            self._note_emitted(dh, None, ehi, elo, erows)
+        dw2 = self._reduce_rows(slabs, ns, c * c).view(c, c, 1)
+        sums = self._sum_last(part)
+        return dh, sums[:c], sums[c:2 * c], dw2, sums[3 * c:], sums[2 * c:3 * c]
+
     def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):
         return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9)
 

@@ -212,6 +212,46 @@ def _run_ru(ops, dev, cases):
         ops.lib.sat_residual_unit_fwd = orig
 
 
+def _ru_k1_bwd_case(ops, dev, B, C, T, seed):
+    """csrc/ru_k1_bwd.hip (the whole backward of a unit's 1x1 conv in one pass over dy and h) against float64 autograd of
+    conv1d(snake(h), W2) + b2, and its emitted planes against the planes pre-pass of the same dh."""
+    gen = torch.Generator().manual_seed(seed)
+    dy = torch.randn(B, C, T, generator=gen).to(dev)
+    h = torch.randn(B, C, T, generator=gen).to(dev)
+    w2 = (torch.randn(C, C, 1, generator=gen) * (.5 / math.sqrt(C / 8))).to(dev)
+    a2, b2 = (torch.randn(C, generator=gen) * .3).to(dev), (torch.randn(C, generator=gen) * .3).to(dev)
+    assert ops.ru_k1_bwd_ok(B, C, T)
+    dh, da, db, dw, dbias2, dbias1 = ops.ru_k1_bwd(dy, h, w2, (a2, b2), emit=True)
+    em = ops._take_emitted(dh, None)
+    assert em is not None
+    hd, wd, ad, bd = (t.detach().double().cpu().requires_grad_(True) for t in (h, w2, a2, b2))
+    bias = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(snake(hd, ad, bd), wd, bias)
+    y.backward(dy.double().cpu())
+    for got, ref, name in ((dh, hd.grad, "dh"), (da, ad.grad, "dalpha"), (db, bd.grad, "dbeta"), (dw, wd.grad, "dW2"), (dbias2, bias.grad, "dbias2"),
+                           (dbias1, hd.grad.sum(dim=(0, 2)), "dbias1")):
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1e-3) + 1e-6 * math.sqrt(B * T), (name, (B, C, T), err, ref.abs().max().item())
+    # the emitted planes hold dh (hi + lo) at rows 32 + t of every 8-channel group
+    rows = em["rows"]
+    hi = em["hi"].view(B, C // 8, rows, 8)[:, :, 32:32 + T].permute(0, 1, 3, 2).reshape(B, C, T)
+    lo = em["lo"].view(B, C // 8, rows, 8)[:, :, 32:32 + T].permute(0, 1, 3, 2).reshape(B, C, T)
+    rec = (hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float()).cpu()
+    assert (rec - dh.cpu()).abs().max().item() <= 2.0 ** -15 * dh.abs().max().item()
+
+
+def test_ru_k1_bwd_sim(emu):
+    _ru_k1_bwd_case(emu, "cpu", 2, 128, 96, 41)          # two items, three tiles each
+    assert not emu.ru_k1_bwd_ok(1, 256, 64) and not emu.ru_k1_bwd_ok(1, 128, 48)      # other widths / ragged lengths: the separate kernels
+
+
+@pytest.mark.gpu
+def test_ru_k1_bwd_gpu(hip):
+    _ru_k1_bwd_case(hip, "cuda", 2, 128, 96, 41)
+    _ru_k1_bwd_case(hip, "cuda", 1, 128, 65536, 43)      # 2048 tiles: eight per workgroup, every workgroup of the grid busy
+    _ru_k1_bwd_case(hip, "cuda", 3, 128, 8224, 44)       # 771 tiles on 256 workgroups: ranges cross the batch boundaries, the last one is short
+
+
 def test_residual_unit_fused_sim(emu):
     _run_ru(emu, "cpu", [(1, 16, 300, 1), (2, 24, 520, 3), (1, 72, 260, 9), (1, 128, 256, 3)])
 
