@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--ddp-comm-dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--ops-set", action="append", default=[], metavar="ATTR=VALUE",
                     help="A/B knob: set an attribute of the SatOps object before the run (e.g. ru_k1_fused=0); recorded in config.ops_set")
+    ap.add_argument("--no-grad-steal", action="store_true",
+                    help="A/B knob: gradients accumulate into the flat views through autograd's per-parameter adds (rounds 1-4) instead of "
+                         "being adopted and gathered in one launch (training.FlatParameters.steal)")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launches only (skip the HIP-graph replay of the train step)")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="also try the HIP-graph step when a process group is active (the RCCL collectives are then captured too)")
@@ -782,7 +785,7 @@ def pmc_traffic(kernel, args):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     try:
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 doc = json.load(open(path))
@@ -795,16 +798,18 @@ def pmc_traffic(kernel, args):
 
 def hbm_roofline(args, ms_per_step):
     """The north-star's HBM view of the whole step (BASELINE.json: >= 60 % of the HBM roofline on the conv stack): HBM bytes per step
-    summed over every kernel of the committed rocprofv3 --pmc passes of this same command (profiles/r04_pmc_traffic.json: 2 x
+    summed over every kernel of the committed rocprofv3 --pmc passes of this same command (profiles/r05_pmc_traffic.json, else the previous round's: 2 x
     FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction; the passes profile `--steps 1 --warmup 1` = 2 steps) against the
     algorithmic bytes of SURVEY.md 8(d)'s fusion-unit convention (16.4 GB per direction per sample forward; x3 for forward +
     backward) and the 8 TB/s peak, at this run's step time."""
     if args.sample_size != 2097152 or args.batch != 1:
         return None
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(path):
+    path = None
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):      # the newest committed profile
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            path = os.path.join(ROOT, "profiles", name)
+            break
+    if path is None:
         return None
     try:
         doc = json.load(open(path))
@@ -817,7 +822,8 @@ def hbm_roofline(args, ms_per_step):
     return {"counter_bytes_per_step": counter, "algorithmic_bytes_per_step": algorithmic, "peak_bytes_per_s": 8.0e12,
             "counter_rate_frac_of_8TBs": counter / t / 8.0e12, "frac_of_8TBs": algorithmic / t / 8.0e12,
             "traffic_over_algorithmic": counter / algorithmic,
-            "note": "counter bytes: every sat_* kernel of the committed --pmc passes (profiles/r04_pmc_traffic.json); algorithmic: 3 x (16.4 + 16.4) GB "
+            "source": os.path.basename(path),
+            "note": "counter bytes: every sat_* kernel of the committed --pmc passes (`source`); algorithmic: 3 x (16.4 + 16.4) GB "
                     "(fusion-unit convention, forward + backward); frac_of_8TBs = algorithmic bytes / this run's step time / 8 TB/s — the "
                     "step is matrix-pipe-bound (roofline.bound), this is the north-star's second view of it"}
 
@@ -1194,6 +1200,10 @@ def main():
     stepper = AutoencoderTrainStep(model, cfg, use_discriminator=(world == 1 and not args.no_real_step), ddp_mode=args.ddp_mode,
                                    ddp_comm_dtype=torch.bfloat16 if args.ddp_comm_dtype == "bf16" else None,
                                    ddp_single_rank=True if args.ddp_single_rank else None)
+    if args.no_grad_steal:
+        stepper.flat.steal = False
+        if getattr(stepper, "flat_d", None) is not None:
+            stepper.flat_d.steal = False
     stepper.comm.timing = stepper.comm.active      # exchange timeline of the last timed step (config.ddp.timeline)
     stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
     ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
@@ -1300,7 +1310,7 @@ def main():
                                  "launches; peak: fp32-MFMA dense 157.3 for the fp32 kernels, dense bf16 MFMA / 3 = 833 for the "
                                  "bf16x3 split kernels (three MFMAs per fp32-accurate product); traffic = HBM bytes per launch "
                                  "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc passes of this "
-                                 "same command (profiles/r04_pmc_traffic.json; null for a non-default workload size)",
+                                 "same command (the newest profiles/r0N_pmc_traffic.json that has this kernel; null for a non-default workload size)",
                          "k7_family": k7_family(allk),
                          "hbm": hbm_roofline(args, 1e3 * elapsed / args.steps),
                          "all_conv_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in allk]},

@@ -275,6 +275,13 @@ int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int sat_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
                        float eps, float weight_decay, float* ema, void* stream);
 
+/* Many small fp32 device-to-device copies in one launch — the gather of the per-parameter gradients autograd produced into the flat
+ * gradient buffer (what torch's AccumulateGrad does with one `add` launch per parameter for the reference's optimizers,
+ * training/autoencoders.py:507-515).  table: DEVICE array of nent entries {const float* src; float* dst; long long numel; long long
+ * first_block} (32 bytes each), first_block = running sum of sat_multi_copy_blocks(numel); nblocks = the total. */
+long long sat_multi_copy_blocks(long long numel);
+int sat_multi_copy(const void* table, int nent, long long nblocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Data-parallel gradient exchange — what Lightning's `ddp` strategy does for the reference (train.py:138, :148-164): the SUM of
  * the flat gradient buffer over the ranks, RCCL over xGMI, one communicator per process, enqueued on the caller's stream.

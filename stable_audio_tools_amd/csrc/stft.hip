@@ -24,6 +24,8 @@
 #define SAT_STFT_OBUF (7 * 512 + 2048)
 #define SAT_STFT_SMALL 512             // n <= 512: fb * n == 512
 #define SAT_STFT_OBUF_SMALL 1408       // (8 fb - 1) hop + n at hop = n / 4 for n <= 512 (largest at n = 512)
+#define SAT_STFT_MID 1024              // n == 1024
+#define SAT_STFT_OBUF_MID 2816         // 7 * 256 + 1024
 
 #if defined(SAT_HIPEMU)
 static inline unsigned sat_brev(unsigned v) {
@@ -425,6 +427,7 @@ extern "C" int sat_stft_fwd(const float* x, const float* y, const float* views, 
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = 0;
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
     if (p.fb * p.n <= SAT_STFT_SMALL) SAT_LAUNCH(sat_stft_fwd_kernel<SAT_STFT_SMALL>, grid, dim3(256), stream, p);
+    else if (p.fb * p.n <= SAT_STFT_MID) SAT_LAUNCH(sat_stft_fwd_kernel<SAT_STFT_MID>, grid, dim3(256), stream, p);
     else SAT_LAUNCH(sat_stft_fwd_kernel<SAT_FFT_MAX>, grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_fwd");
 }
@@ -439,6 +442,7 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, 1);       // the views are looped inside the workgroup
     const int olen = (SAT_STFT_NG * p.fb - 1) * p.hop + p.n;
     if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL>), grid, dim3(256), stream, p);
+    else if (p.fb * p.n <= SAT_STFT_MID && olen <= SAT_STFT_OBUF_MID) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_MID, SAT_STFT_OBUF_MID>), grid, dim3(256), stream, p);
     else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }

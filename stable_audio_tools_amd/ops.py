@@ -1308,6 +1308,41 @@ class SatOps:
     def allreduce_finalize(self, comm):
         self._chk(self.lib.sat_allreduce_finalize(comm))
 
+    def multi_copy_plan(self, dsts):
+        """Static half of a sat_multi_copy table for the destination views `dsts` (fp32, contiguous): (host int64 array (n, 4) with dst /
+        numel / first block filled in, total blocks).  The source pointers (column 0) are filled per call: multi_copy()."""
+        import numpy as np
+        tab = np.zeros((len(dsts), 4), dtype=np.int64)
+        blk = 0
+        for i, d in enumerate(dsts):
+            self._f32(d)
+            tab[i, 1], tab[i, 2], tab[i, 3] = d.data_ptr(), d.numel(), blk
+            blk += self.lib.sat_multi_copy_blocks(d.numel())
+        return tab, blk
+
+    def multi_copy(self, srcs, plan, rows, device):
+        """dst[i] <- srcs[k] for the plan rows `rows` (parallel lists) in ONE launch.  The table travels host -> device through a pinned
+        staging buffer owned by this call's caller-visible cache (one per plan)."""
+        import numpy as np
+        tab, _ = plan
+        n = len(rows)
+        if n == 0:
+            return
+        sub = tab[rows].copy()
+        blk = 0
+        for k, (src, r) in enumerate(zip(srcs, rows)):
+            if src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != tab[r, 2]:
+                raise ValueError("multi_copy: sources must be contiguous fp32 tensors of the destinations' sizes")
+            sub[k, 0] = src.data_ptr()
+            sub[k, 3] = blk
+            blk += int(self.lib.sat_multi_copy_blocks(int(tab[r, 2])))
+        host = torch.from_numpy(sub.reshape(-1))
+        if device.type == "cuda":
+            dev = host.pin_memory().to(device, non_blocking=True)      # (torch's host allocator keeps the pinned block until the copy ran)
+        else:
+            dev = host
+        self._chk(self.lib.sat_multi_copy(_ptr(dev), n, blk, self._stream(srcs[0])))
+
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)
         self._chk(self.lib.sat_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,

@@ -48,20 +48,47 @@ class FlatParameters:
             self._views.append(gv)
             off += n
 
+    # steal=True (round 5): zero_grad() leaves `.grad = None`, so autograd's AccumulateGrad adopts each incoming gradient tensor as it is
+    # (no kernel) instead of adding it into the flat view (one 5-us `add` launch per parameter: 379 per VAE generator step, 2.0 ms;
+    # ~1 000 read-modify-write passes over 4.2 GB for the DiT), and gather_grads() moves them all into the flat buffer in ONE launch
+    # (csrc/elementwise.hip sat_multi_copy).  Parameters touched by several backward passes between two zero_grad() calls still
+    # accumulate (the second pass adds into the adopted tensor).
+    steal = True
+
     def zero_grad(self):
         self.grad.zero_()
         for p, gv in zip(self.params, self._views):
-            p.grad = gv
+            p.grad = None if self.steal else gv
 
-    def gather_grads(self):
-        """Autograd normally accumulates in place into our views; if it replaced a .grad tensor
-        (e.g. first-touch semantics), fold it back."""
-        for p, gv in zip(self.params, self._views):
-            if p.grad is None:
-                continue
-            if p.grad.data_ptr() != gv.data_ptr():
+    def gather_grads(self, ops=None):
+        """Every gradient autograd left outside the flat buffer (adopted tensors: steal mode; replaced `.grad`s otherwise) is copied
+        into its view and `.grad` re-pointed at the view.  One sat_multi_copy launch on the GPU; per-parameter copies while a HIP graph
+        is being captured (the table's source pointers would be frozen into a host buffer the next eager step rewrites) and when
+        no kernel library serves the device."""
+        todo = [i for i, (p, gv) in enumerate(zip(self.params, self._views)) if p.grad is not None and p.grad.data_ptr() != gv.data_ptr()]
+        batched = False
+        if len(todo) > 1 and not (self.grad.is_cuda and torch.cuda.is_current_stream_capturing()):
+            srcs = [self.params[i].grad for i in todo]
+            if all(g.dtype == torch.float32 and g.is_contiguous() and g.device == self.grad.device for g in srcs):
+                try:
+                    o = _fn._ops(ops)
+                except Exception:      # noqa: BLE001 — no kernel library for this device (plain CPU use of the step objects)
+                    o = None
+                if o is not None and (self.grad.is_cuda or o.simulator):
+                    if self._mc_plan is None:
+                        self._mc_plan = o.multi_copy_plan(self._views)
+                    o.multi_copy(srcs, self._mc_plan, todo, self.grad.device)
+                    batched = True
+        for i in todo:
+            p, gv = self.params[i], self._views[i]
+            if not batched:
                 gv.copy_(p.grad)
+            p.grad = gv
+        for p, gv in zip(self.params, self._views):      # parameters without a gradient this step read the zeroed view
+            if p.grad is None:
                 p.grad = gv
+
+    _mc_plan = None
 
 
 class GradAllReduce:
@@ -127,6 +154,17 @@ class GradAllReduce:
             s_ = max(0, e - per)
             self.buckets.append((s_, e))
             e = s_
+        # the bucket at the START of the buffer completes with the last kernel of the backward pass: its exchange cannot overlap
+        # anything (profiles/r05_bench_ddp_single_rank_*.json: every other bucket is ready tens of milliseconds earlier) — cut it into
+        # quarters so that only a quarter-size collective is exposed behind the backward
+        if len(self.buckets) > 1:
+            s0, e0 = self.buckets.pop()
+            q = max(self.world, ((e0 - s0 + 3) // 4 // self.world) * self.world)
+            e = e0
+            while e > s0:
+                s_ = max(s0, e - q)
+                self.buckets.append((s_, e))
+                e = s_
         # ONE exchange path by default (round 5): torch.distributed's RCCL communicator.  native=True (explicit argument only — no
         # environment switch) sends the same buckets through the C-ABI's own RCCL communicator instead (csrc/comm.hip sat_allreduce_*:
         # SURVEY.md §8b; executed on the MI355X in round 5 — tests/test_train_step.py::test_native_exchange_gpu, and
@@ -570,7 +608,7 @@ class AutoencoderTrainStep:
             dis_i, _, _ = self.discriminator.scale_losses(i, reals_t, decoded, need_fm=False)
             dis_i.backward()
             loss_dis = loss_dis + dis_i.detach()
-        self.flat_d.gather_grads()
+        self.flat_d.gather_grads(self.ops)
         self.comm_d()
         if self.clip_grad_norm > 0.0:
             clip_flat_grads(self.flat_d, self.clip_grad_norm, self.comm_d.grad_scale, self.ops)
@@ -648,7 +686,7 @@ class AutoencoderTrainStep:
             self.comm.mark_backward_start()
             loss.backward()
         self.comm.mark_backward_end()
-        self.flat.gather_grads()
+        self.flat.gather_grads(self.ops)
         self.comm()
         if self.clip_grad_norm > 0.0:
             clip_flat_grads(self.flat, self.clip_grad_norm, self.comm.grad_scale, self.ops)
@@ -847,7 +885,7 @@ class DiTTrainStep:
         self.comm.mark_backward_start()
         loss.backward()
         self.comm.mark_backward_end()
-        self.flat.gather_grads()
+        self.flat.gather_grads(self.opt._ops)
         self.comm()
         self.opt.step(grad_scale=self.comm.grad_scale)
         self.global_step += 1

@@ -5,8 +5,7 @@
 #   vae_launches_by_grid.txt              the conv-stack kernels' launches grouped by grid shape
 #   pmc_{FETCH,WRITE}_SIZE.txt + pmc_traffic.json   per-kernel HBM counters of the same bench command (separate passes)
 #   bench_*.json                          the bench lines themselves (the default line with cpu_baseline, parity, real step, secondary ...)
-# Round 4: one call of ~12 GPU-minutes; the kernel micro-benchmarks of tools/*_bench.py are collected by the experiment scripts
-# (tools/r04_*.sh) into profiles/r04_experiments/.
+# One call of ~15 GPU-minutes; A/B experiments live with their run scripts under profiles/r05_experiments/.
 set -u
 R=$(pwd)
 OUT=$R/gpurun_out/final
@@ -23,13 +22,13 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 for w in vae real dit_sample long_context; do python tools/rocpd_stats.py $(ls $OUT/$w/*/*.db | head -1) $OUT/${w}_stats.csv; done
-for k in wgrad_small wgrad7 conv1d_bf16x3_kernel k7q stft; do echo "=== $k"; python tools/rocpd_launches.py $(ls $OUT/vae/*/*.db | head -1) $k; done > $OUT/vae_launches_by_grid.txt 2>&1
+for k in wgrad_small wgrad7 conv1d_bf16x3_kernel k7q ru_k1_bwd stft; do echo "=== $k"; python tools/rocpd_launches.py $(ls $OUT/vae/*/*.db | head -1) $k; done > $OUT/vae_launches_by_grid.txt 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do python tools/pmc_summary.py $OUT/pmc_$ctr sat_ > $OUT/pmc_$ctr.txt 2>&1; done
 python tools/pmc_traffic_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 $GEN --no-graph, MI355X (tools/collect_profiles.sh)" > $OUT/pmc_traffic.log 2>&1
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/real $OUT/dit_sample $OUT/long_context
-cp $OUT/pmc_traffic.json $R/profiles/r04_pmc_traffic.json      # bench.py reads it for roofline.traffic / roofline.hbm
+cp $OUT/pmc_traffic.json $R/profiles/r05_pmc_traffic.json      # bench.py reads it for roofline.traffic / roofline.hbm
 timeout 900 python bench.py > $OUT/bench_vae_train.json 2> $OUT/bench_vae_train.err
 timeout 300 python bench.py --workload dit_train --no-cpu-baseline > $OUT/bench_dit_train.json 2> /dev/null
 tail -8 $OUT/gpu_tests.log
