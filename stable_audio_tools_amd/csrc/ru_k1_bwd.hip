@@ -111,6 +111,12 @@ __global__ void __launch_bounds__(512) sat_ru_k1_bwd_kernel(SatRuK1BwdParams p) 
 
     // this thread's slots of a tile: channels (tid >> 3) + 64 j, steps 4 (tid & 7) .. + 3
     const int srow = tid >> 3, st4 = (tid & 7) * 4;
+    // Transposed images [t][channel]: the 16-byte channel groups of row t are stored at group ^ ((t >> 3) & 3).  A wave's 2-byte
+    // transposed stores go to rows 0, 4, .. 28 of the same channel: at a row stride of 272 bytes those are two banks without the
+    // swizzle (4-way conflicts on every one of the 32 stores per thread and tile — the first versions of this kernel spent a third of
+    // their time there) and eight with it; the 16-byte reads (fragments, plane emission) apply the same XOR.
+    const int swz_w = ((st4 >> 3) & 3) << 3;      // writer: rows st4 .. st4 + 3 share (t >> 3)
+    const int swz_f = ((l31 >> 3) & 3) << 3;      // fragment reader: row l31
     float sa[NJ], sb[NJ], sib[NJ];               // snake2 constants of the thread's h channels
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -185,14 +191,15 @@ __global__ void __launch_bounds__(512) sat_ru_k1_bwd_kernel(SatRuK1BwdParams p) 
             sat_split2_pk(dyv[2], dyv[3], &h1, &l1);
             *reinterpret_cast<sat_u32x2*>(dyN + ch * ROWN + st4) = sat_u32x2{h0, h1};
             *reinterpret_cast<sat_u32x2*>(dyN + C * ROWN + ch * ROWN + st4) = sat_u32x2{l0, l1};
-            dyT[(st4 + 0) * ROWT + ch] = (short)(h0 & 0xffffu);
-            dyT[(st4 + 1) * ROWT + ch] = (short)(h0 >> 16);
-            dyT[(st4 + 2) * ROWT + ch] = (short)(h1 & 0xffffu);
-            dyT[(st4 + 3) * ROWT + ch] = (short)(h1 >> 16);
-            dyT[TT * ROWT + (st4 + 0) * ROWT + ch] = (short)(l0 & 0xffffu);
-            dyT[TT * ROWT + (st4 + 1) * ROWT + ch] = (short)(l0 >> 16);
-            dyT[TT * ROWT + (st4 + 2) * ROWT + ch] = (short)(l1 & 0xffffu);
-            dyT[TT * ROWT + (st4 + 3) * ROWT + ch] = (short)(l1 >> 16);
+            const int cs = ch ^ swz_w;
+            dyT[(st4 + 0) * ROWT + cs] = (short)(h0 & 0xffffu);
+            dyT[(st4 + 1) * ROWT + cs] = (short)(h0 >> 16);
+            dyT[(st4 + 2) * ROWT + cs] = (short)(h1 & 0xffffu);
+            dyT[(st4 + 3) * ROWT + cs] = (short)(h1 >> 16);
+            dyT[TT * ROWT + (st4 + 0) * ROWT + cs] = (short)(l0 & 0xffffu);
+            dyT[TT * ROWT + (st4 + 1) * ROWT + cs] = (short)(l0 >> 16);
+            dyT[TT * ROWT + (st4 + 2) * ROWT + cs] = (short)(l1 & 0xffffu);
+            dyT[TT * ROWT + (st4 + 3) * ROWT + cs] = (short)(l1 >> 16);
             sum_dy[j] += (dyv[0] + dyv[1]) + (dyv[2] + dyv[3]);
             float v[4];
 #pragma unroll
@@ -210,11 +217,12 @@ __global__ void __launch_bounds__(512) sat_ru_k1_bwd_kernel(SatRuK1BwdParams p) 
             f32x16 accd;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
-            const short* brow = dyT + l31 * ROWT + 8 * hi;
+            const short* brow = dyT + l31 * ROWT;
 #pragma unroll
             for (int s = 0; s < C / 16; ++s) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow + 16 * s);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + TT * ROWT + 16 * s);
+                const int col = (16 * s + 8 * hi) ^ swz_f;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(brow + col);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(brow + TT * ROWT + col);
                 const bf16x8 wh = sat_rk_frag(big[s >> 2], s & 3), wl = sat_rk_frag(big[2 + (s >> 2)], s & 3);
                 accd = sat_mfma_32x32x16_bf16(wh, bh, accd);
                 accd = sat_mfma_32x32x16_bf16(wh, bl, accd);
@@ -273,14 +281,15 @@ __global__ void __launch_bounds__(512) sat_ru_k1_bwd_kernel(SatRuK1BwdParams p) 
                 uint32_t h0, l0, h1, l1;
                 sat_split2_pk(out[0], out[1], &h0, &l0);
                 sat_split2_pk(out[2], out[3], &h1, &l1);
-                dhT[(st4 + 0) * ROWT + ch] = (short)(h0 & 0xffffu);
-                dhT[(st4 + 1) * ROWT + ch] = (short)(h0 >> 16);
-                dhT[(st4 + 2) * ROWT + ch] = (short)(h1 & 0xffffu);
-                dhT[(st4 + 3) * ROWT + ch] = (short)(h1 >> 16);
-                dhT[TT * ROWT + (st4 + 0) * ROWT + ch] = (short)(l0 & 0xffffu);
-                dhT[TT * ROWT + (st4 + 1) * ROWT + ch] = (short)(l0 >> 16);
-                dhT[TT * ROWT + (st4 + 2) * ROWT + ch] = (short)(l1 & 0xffffu);
-                dhT[TT * ROWT + (st4 + 3) * ROWT + ch] = (short)(l1 >> 16);
+                const int cs = ch ^ swz_w;
+                dhT[(st4 + 0) * ROWT + cs] = (short)(h0 & 0xffffu);
+                dhT[(st4 + 1) * ROWT + cs] = (short)(h0 >> 16);
+                dhT[(st4 + 2) * ROWT + cs] = (short)(h1 & 0xffffu);
+                dhT[(st4 + 3) * ROWT + cs] = (short)(h1 >> 16);
+                dhT[TT * ROWT + (st4 + 0) * ROWT + cs] = (short)(l0 & 0xffffu);
+                dhT[TT * ROWT + (st4 + 1) * ROWT + cs] = (short)(l0 >> 16);
+                dhT[TT * ROWT + (st4 + 2) * ROWT + cs] = (short)(l1 & 0xffffu);
+                dhT[TT * ROWT + (st4 + 3) * ROWT + cs] = (short)(l1 >> 16);
             }
         }
         SAT_WAIT_LGKM0();
@@ -290,8 +299,9 @@ __global__ void __launch_bounds__(512) sat_ru_k1_bwd_kernel(SatRuK1BwdParams p) 
         if (p.em_hi) {
             const int t = tid & 31, g = tid >> 5;                              // g: 8-channel group (0..15)
             const size_t o = (((size_t)b * (C / 8) + g) * p.em_rows + SAT_RK_LEAD + t0 + t) * 8;
-            *reinterpret_cast<u32x4*>(p.em_hi + o) = *reinterpret_cast<const u32x4*>(dhT + t * ROWT + 8 * g);
-            *reinterpret_cast<u32x4*>(p.em_lo + o) = *reinterpret_cast<const u32x4*>(dhT + TT * ROWT + t * ROWT + 8 * g);
+            const int gs = (8 * g) ^ (((t >> 3) & 3) << 3);
+            *reinterpret_cast<u32x4*>(p.em_hi + o) = *reinterpret_cast<const u32x4*>(dhT + t * ROWT + gs);
+            *reinterpret_cast<u32x4*>(p.em_lo + o) = *reinterpret_cast<const u32x4*>(dhT + TT * ROWT + t * ROWT + gs);
             SAT_WAIT_LGKM0();
             SAT_RAW_BARRIER();                    // the transposed image aliases the next tile's transposed dy image
         }
