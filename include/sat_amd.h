@@ -158,9 +158,6 @@ int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
 int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
 long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);
 int sat_snake_consts(const float* alpha, const float* beta, float* a, float* ib, int C, void* stream);
-/* sat_snake_consts for many activations in ONE launch.  table: DEVICE array of nent entries {const float* alpha; const float* beta;
- * float* a; float* ib; long long n; long long first_block} (48 bytes), first_block = running sum of ceil(n / 256); nblocks = the total. */
-int sat_snake_consts_multi(const void* table, int nent, long long nblocks, void* stream);
 
 /* Transposed conv, K == 2*stride (the Oobleck resampler, autoencoders.py:266-268), polyphase form.
  * Also the data-gradient of the strided down-conv (:245-247).  w_packed: [r][j][Cin][Cout]

@@ -50,7 +50,6 @@ SIGNATURES = {
     "sat_pack_weights_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_pack_weights_bf16x3_size": (_L, [_I, _I, _I, _I, _I]),
     "sat_snake_consts": (_I, [_P, _P, _P, _P, _I, _P]),
-    "sat_snake_consts_multi": (_I, [_P, _I, _L, _P]),
     # conv_wgrad_bf16x3.hip
     "sat_conv_wgrad7_bf16x3": (_I, [_P] * 5 + [_L] * 3 + [_I] * 6 + [_P, _P]),
     "sat_conv_wgrad7_bf16x3_nsplit": (_I, [_I] * 4),

@@ -537,33 +537,6 @@ extern "C" int sat_snake_consts(const float* alpha, const float* beta, float* a,
     return sat_check_launch("sat_snake_consts");
 }
 
-// The same for MANY activations in one launch (round 5: a generator step asked for ~96 of these 4-us launches; each costs the step more
-// than its own time, profiles/r05_experiments/grad_gather/).  table (device): nent entries {alpha, beta, a, ib, n, first block},
-// first block = running sum of ceil(n / 256).
-struct SatSnakeMultiEntry { const float* alpha; const float* beta; float* a; float* ib; long long n; long long block0; };
-struct SatSnakeMultiParams { const SatSnakeMultiEntry* table; int nent; };
-__global__ void __launch_bounds__(256) sat_snake_consts_multi_kernel(SatSnakeMultiParams p) {
-    const long long b = blockIdx.x;
-    int lo = 0, hi = p.nent - 1;
-    while (lo < hi) {                                         // largest e with block0[e] <= b
-        const int mid = (lo + hi + 1) >> 1;
-        if (p.table[mid].block0 <= b) lo = mid;
-        else hi = mid - 1;
-    }
-    const SatSnakeMultiEntry e = p.table[lo];
-    const long long i = (b - e.block0) * 256 + threadIdx.x;
-    if (i >= e.n) return;
-    e.a[i] = expf(e.alpha[i]);
-    e.ib[i] = 1.0f / (expf(e.beta[i]) + 1e-9f);
-}
-extern "C" int sat_snake_consts_multi(const void* table, int nent, long long nblocks, void* stream) {
-    if (nent <= 0 || nblocks <= 0) return 0;
-    if (!table || nblocks > 0x7fffffffLL) { sat_set_error("sat_snake_consts_multi: bad arguments"); return 1; }
-    SatSnakeMultiParams p{(const SatSnakeMultiEntry*)table, nent};
-    SAT_LAUNCH(sat_snake_consts_multi_kernel, dim3((unsigned)nblocks), dim3(256), stream, p);
-    return sat_check_launch("sat_snake_consts_multi");
-}
-
 #include "conv1d_bf16x3_k7.h"     // the pipelined kernel of the (8, 1) plan
 #include "conv1d_planes.h"        // activation planes [B][Cin/8][rows][8] (pre-pass kernel; layout constants)
 #include "conv1d_bf16x3_k7q.h"    // planes, 16-channel chunks (one tap per MFMA k-step), two wave rows one barrier apart

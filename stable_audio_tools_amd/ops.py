@@ -177,91 +177,12 @@ class SatOps:
         self._chk(self.lib.sat_pack_weights_bf16x3(_ptr(w), _ptr(hi), _ptr(lo), d0, d1, k, stride, mode, self._stream(w)))
         return hi, lo
 
-    snake_batch = True          # snake_prefill(): one launch per step for every activation's constants (False: one launch per pair)
-
-    def _sc_key(self, alpha, beta):
-        return (alpha.data_ptr(), beta.data_ptr(), alpha.device)
-
-    def _sc_stamp(self, alpha, beta):
-        return (_caches.version_of(alpha), _caches.version_of(beta), alpha.numel()) + _caches.epoch_of(alpha, beta)
-
-    def _sc_hit(self, memo, key, alpha, beta):
-        """The memoised (a, ib) of `key` or None.  The memo lives on the ops object, not on a module, so an entry also holds weak
-        references to the tensors it was computed from and is valid only while those are alive AND still start at the key's addresses:
-        a freed model's addresses are recycled by the allocator, and the next model's parameters can land there with equal stamps."""
-        hit = memo.get(key)
-        if hit is None or hit[0] != self._sc_stamp(alpha, beta):
-            return None
-        ra, rb = hit[3](), hit[4]()
-        if ra is None or rb is None or ra.data_ptr() != key[0] or rb.data_ptr() != key[1]:
-            return None
-        return hit
-
-    @staticmethod
-    def _sc_entry(stamp, a, ib, alpha, beta):
-        import weakref
-        return (stamp, a, ib, weakref.ref(alpha), weakref.ref(beta))
-
     def snake_consts(self, alpha, beta):
-        """(a, ib) = (e^alpha, 1 / (e^beta + 1e-9)).  Memoised per (storage, version, invalidation epoch) of the two parameters: the forward
-        conv, the producer that emits planes for it and every later call of the same optimisation step share one evaluation, and
-        snake_prefill() computes a whole model's constants in ONE launch (round 5: ~96 launches of 4 us per generator step before)."""
         self._f32(alpha, beta)
-        memo = self.__dict__.setdefault("_snake_memo", {})
-        track = _caches.trackable(alpha, beta)
-        if track:
-            key, stamp = self._sc_key(alpha, beta), self._sc_stamp(alpha, beta)
-            hit = self._sc_hit(memo, key, alpha, beta)
-            if hit is not None:
-                return hit[1], hit[2]
         a = torch.empty_like(alpha)
         ib = torch.empty_like(beta)
         self._chk(self.lib.sat_snake_consts(_ptr(alpha), _ptr(beta), _ptr(a), _ptr(ib), alpha.numel(), self._stream(alpha)))
-        if track:
-            memo[key] = self._sc_entry(stamp, a, ib, alpha, beta)
         return a, ib
-
-    def snake_prefill(self, pairs):
-        """Compute the constants of every (log-alpha, log-beta) pair of `pairs` that the memo does not hold at the parameters' current
-        version in ONE launch (sat_snake_consts_multi) and memoise them.  The table (pointers: static while the parameters stay where
-        they are) is uploaded once per distinct set of stale pairs."""
-        import numpy as np
-        if not self.snake_batch:
-            return 0
-        memo = self.__dict__.setdefault("_snake_memo", {})
-        todo = []
-        for alpha, beta in pairs:
-            if alpha.dtype != torch.float32 or beta.dtype != torch.float32 or not _caches.trackable(alpha, beta):
-                continue
-            key = self._sc_key(alpha, beta)
-            if self._sc_hit(memo, key, alpha, beta) is None:
-                todo.append((key, alpha, beta))
-        if len(memo) > 4 * len(todo) + 1024:                 # entries of models that are gone
-            for k in [k for k, v in memo.items() if v[3]() is None or v[4]() is None]:
-                del memo[k]
-        if not todo:
-            return 0
-        dev = todo[0][1].device
-        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            return 0        # (the table's host staging buffer would be frozen into the graph: the per-pair launches are captured instead)
-        total = sum(t[1].numel() for t in todo)
-        out = torch.empty(2, total, dtype=torch.float32, device=dev)
-        tab = np.zeros((len(todo), 6), dtype=np.int64)
-        off = blk = 0
-        views = []
-        for i, (key, alpha, beta) in enumerate(todo):
-            n = alpha.numel()
-            a, ib = out[0, off:off + n].view(alpha.shape), out[1, off:off + n].view(beta.shape)
-            tab[i] = (alpha.data_ptr(), beta.data_ptr(), a.data_ptr(), ib.data_ptr(), n, blk)
-            views.append((key, alpha, beta, a, ib))
-            off += n
-            blk += (n + 255) // 256
-        host = torch.from_numpy(tab.reshape(-1))
-        dtab = host.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else host
-        self._chk(self.lib.sat_snake_consts_multi(_ptr(dtab), len(todo), blk, self._stream(out)))
-        for key, alpha, beta, a, ib in views:
-            memo[key] = self._sc_entry(self._sc_stamp(alpha, beta), a, ib, alpha, beta)
-        return len(todo)
 
     def _conv_out(self, out, b, cout, tout, device):
         """The conv output tensor: a fresh one, or the caller's `out` (B, Cout, Tout) fp32 in dense layout — it may be a view at a

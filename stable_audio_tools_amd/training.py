@@ -593,24 +593,10 @@ class AutoencoderTrainStep:
         """True when a value baked into the launches changes from step to step (loss-weight decay): GraphedTrainStep stays eager then."""
         return self.spectral_decay != 1.0 or (self.time_decay != 1.0 and (self.w_l1 > 0.0 or self.w_l2 > 0.0))
 
-    def _prefill_snake(self):
-        """The SnakeBeta constants (e^alpha, 1 / (e^beta + 1e-9)) of every activation of the autoencoder in ONE launch per parameter
-        version (ops.snake_prefill): the convs' prologues and the plane emissions of this step then find them memoised."""
-        pairs = self.__dict__.get("_snake_pairs")
-        if pairs is None:
-            from .autoencoders import SnakeBeta
-            mods = [mod for mod in self.model.modules() if isinstance(mod, SnakeBeta)]
-            if self.teacher is not None:
-                mods += [mod for mod in self.teacher.modules() if isinstance(mod, SnakeBeta)]
-            pairs = self._snake_pairs = [(mod.alpha, mod.beta) for mod in mods if mod.alpha.dtype == torch.float32]
-        if pairs:
-            _fn._ops(self.ops).snake_prefill(pairs)
-
     def _disc_body(self, reals, kw):
         """Discriminator update (:484-497): everything that runs on the device, nothing that counts steps."""
         m = self.model
         self.flat_d.zero_grad()
-        self._prefill_snake()
         with torch.no_grad():
             latents = m.encode(self._encoder_input(reals), **self._encode_kw(kw))
             latents = self._mask_latents(latents, kw)
@@ -633,7 +619,6 @@ class AutoencoderTrainStep:
         """Generator update (:498-515)."""
         m = self.model
         self.flat.zero_grad()
-        self._prefill_snake()
         enc_in = self._encoder_input(reals)
         if self.warmed_up and self.encoder_freeze_on_warmup:
             with torch.no_grad():

@@ -345,48 +345,3 @@ def test_wgrad7_bias_gradient_sim(emu):
 @pytest.mark.gpu
 def test_wgrad7_bias_gradient_gpu(hip):
     _wgrad7_bias_case(hip, "cuda")
-
-
-def _snake_memo_case(ops, dev):
-    """ops.snake_consts / snake_prefill memoise (e^alpha, 1 / (e^beta + 1e-9)) per parameter version on the OPS object: one batched launch
-    fills every stale pair, in-place updates are seen through torch's version counter, and an entry does not outlive the tensors it was
-    computed from (a new model's parameters at recycled addresses with equal version counters must not hit it)."""
-    gen = torch.Generator().manual_seed(5)
-    buf = torch.randn(3, 2, 40, generator=gen).to(dev)
-    pairs = [(buf[i, 0], buf[i, 1]) for i in range(3)]
-
-    def ref(al, be):
-        return torch.exp(al), 1.0 / (torch.exp(be) + 1e-9)
-
-    assert ops.snake_prefill(pairs) == 3 and ops.snake_prefill(pairs) == 0
-    for al, be in pairs:
-        a, ib = ops.snake_consts(al, be)
-        ra, rib = ref(al, be)
-        assert torch.allclose(a, ra, rtol=1e-6, atol=0) and torch.allclose(ib, rib, rtol=1e-6, atol=0)
-    pairs[1][0].mul_(0.5)                                       # in place: version counter of the shared storage moves
-    assert ops.snake_prefill(pairs) == 3
-    a, _ = ops.snake_consts(*pairs[1])
-    assert torch.allclose(a, torch.exp(pairs[1][0]), rtol=1e-6, atol=0)
-    # same addresses, same version counters, other tensors and other values (what a freed model's recycled addresses look like)
-    ver = buf._version
-    pairs = None
-    fresh = torch.randn(3, 2, 40, generator=gen).to(dev)
-    import ctypes
-    ctypes.memmove(buf.data_ptr(), fresh.data_ptr(), buf.numel() * 4) if dev == "cpu" else torch.cuda.current_stream().synchronize()
-    if dev != "cpu":
-        return
-    assert buf._version == ver
-    again = [(buf[i, 0], buf[i, 1]) for i in range(3)]
-    for al, be in again:
-        a, ib = ops.snake_consts(al, be)
-        ra, rib = ref(al, be)
-        assert torch.allclose(a, ra, rtol=1e-6, atol=0) and torch.allclose(ib, rib, rtol=1e-6, atol=0)
-
-
-def test_snake_constants_memo_sim(emu):
-    _snake_memo_case(emu, "cpu")
-
-
-@pytest.mark.gpu
-def test_snake_constants_memo_gpu(hip):
-    _snake_memo_case(hip, "cuda")

@@ -10,15 +10,17 @@ set -u
 R=$(pwd)
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
+# a box whose GPU faults on everything (round 5, call 7) must not eat the budget: one smoke() first, stop if it fails
+if ! timeout 300 python __graft_entry__.py smoke > $OUT/smoke_first.log 2>&1; then tail -5 $OUT/smoke_first.log; echo "smoke failed on this box: stopping"; exit 1; fi
 ( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25; timeout 200 python __graft_entry__.py smoke 2>&1 | tail -3 ) > $OUT/gpu_tests.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 GEN="--no-cpu-baseline --no-real-step --no-secondary --no-parity --no-long-context --no-batch-sweep"
-rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 $GEN > $OUT/vae_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-long-context --no-batch-sweep --no-graph > $OUT/real_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/dit_sample -- python $R/bench.py --workload dit_sample --steps 10 --warmup 2 --no-cpu-baseline > $OUT/dit_sample_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/long_context -- python $R/bench.py --workload long_context --steps 4 --warmup 1 --no-cpu-baseline > $OUT/long_context_prof.log 2>&1
+timeout -k 20 400 rocprofv3 --kernel-trace --stats -d $OUT/vae -- python $R/bench.py --steps 3 --warmup 1 $GEN > $OUT/vae_prof.log 2>&1
+timeout -k 20 400 rocprofv3 --kernel-trace --stats -d $OUT/real -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-long-context --no-batch-sweep --no-graph > $OUT/real_prof.log 2>&1
+timeout -k 20 400 rocprofv3 --kernel-trace --stats -d $OUT/dit_sample -- python $R/bench.py --workload dit_sample --steps 10 --warmup 2 --no-cpu-baseline > $OUT/dit_sample_prof.log 2>&1
+timeout -k 20 400 rocprofv3 --kernel-trace --stats -d $OUT/long_context -- python $R/bench.py --workload long_context --steps 4 --warmup 1 --no-cpu-baseline > $OUT/long_context_prof.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python $R/bench.py --steps 1 --warmup 1 $GEN --no-graph > /dev/null 2>&1
+  timeout -k 20 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python $R/bench.py --steps 1 --warmup 1 $GEN --no-graph > /dev/null 2>&1
 done
 cd $R
 for w in vae real dit_sample long_context; do python tools/rocpd_stats.py $(ls $OUT/$w/*/*.db | head -1) $OUT/${w}_stats.csv; done

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for kind in conv7 conv7q disc9; do
   for ctr in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_WAVES"; do
     d=$OUT/${kind}_$(echo $ctr | tr ' ' '+' | cut -c1-30)
-    timeout 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $d -- python $R/tools/pmc_conv.py $kind 128 2097152 > /dev/null 2>&1
+    timeout -k 20 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $d -- python $R/tools/pmc_conv.py $kind 128 2097152 > /dev/null 2>&1
     echo "== $kind (C = 128, T = 2097152; disc9: 64 -> 64, 3 x 9, 8189 frames x 513 bins) :: $ctr"; python $R/tools/pmc_summary.py $d sat_conv1d sat_disc_conv
   done
 done > $OUT/summary.txt 2>&1

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for kind in calib conv7 dgrad7 conv1 wgrad7; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/${kind}_$ctr -- python $R/tools/pmc_conv.py $kind > /dev/null 2>&1
+    timeout -k 20 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/${kind}_$ctr -- python $R/tools/pmc_conv.py $kind > /dev/null 2>&1
   done
 done
 cd $R
