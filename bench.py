@@ -231,7 +231,7 @@ class AttnProfiler:
             nb, msb, flb = self.summary(which)
             if nb:
                 achb = flb / (msb * 1e-3) / 1e12
-                bwd[which] = {"kernels": "sat_attn_bwd_dq_kernel + sat_attn_bwd_dkv_kernel", "launches": nb, "avg_launch_ms": msb / nb,
+                bwd[which] = {"kernels": "sat_attn_bwd_dq_bf16_kernel + sat_attn_bwd_dkv_bf16_kernel (fp32 mode: the general sat_attn_bwd_{dq,dkv}_kernel)", "launches": nb, "avg_launch_ms": msb / nb,
                               "achieved": round(achb, 1), "frac": round(achb / peak, 4)}
         extra = {"backward": bwd} if bwd else {}
         return {**extra, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,

@@ -228,6 +228,12 @@ int sat_rowsum_nsplit(int T);
 int sat_wn_fold(const float* v, const float* g, float* w, float* norm, int D0, int R, void* stream);
 int sat_wn_grad(const float* v, const float* g, const float* norm, const float* dw, float* dv, float* dg, int D0,
                 int R, void* stream);
+/* The same gradient taken straight from a weight-gradient kernel's split slabs (sat_conv_wgrad*, sat_ru_k1_bwd): element (d, n, k) of
+ * dW = sum over z < nsplit of partial[z * count + d * so_m + n * so_n + k * so_k]; v / dv (D0, N, K) in torch layout.  Replaces
+ * sat_reduce_splits (+ layout permute) + sat_wn_grad for a weight-normed conv (reference: torch.nn.utils.weight_norm's backward through
+ * the convs of models/autoencoders.py:23-27). */
+int sat_wn_grad_splits(const float* partial, int nsplit, long long count, long long so_m, long long so_n, long long so_k,
+                       const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K, void* stream);
 /* torch weight w[D0][D1][K] -> GEMM-side layout.  mode 0: [D1][k][D0]; 1: [D0][K-1-k][D1]; 2: [r][j][D0][D1], k=r+j*S */
 int sat_pack_weights(const float* w, float* out, int D0, int D1, int K, int S, int mode, void* stream);
 
@@ -275,12 +281,11 @@ int sat_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int sat_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
                        float eps, float weight_decay, float* ema, void* stream);
 
-/* Many small fp32 device-to-device copies in one launch — the gather of the per-parameter gradients autograd produced into the flat
- * gradient buffer (what torch's AccumulateGrad does with one `add` launch per parameter for the reference's optimizers,
- * training/autoencoders.py:507-515).  table: DEVICE array of nent entries {const float* src; float* dst; long long numel; long long
- * first_block} (32 bytes each), first_block = running sum of sat_multi_copy_blocks(numel); nblocks = the total. */
-long long sat_multi_copy_blocks(long long numel);
-int sat_multi_copy(const void* table, int nent, long long nblocks, void* stream);
+/* Many small fp32 device-to-device copies in a few launches — the gather of the per-parameter gradients autograd produced into the
+ * flat gradient buffer (what torch's AccumulateGrad does with one `add` launch per parameter for the reference's optimizers,
+ * training/autoencoders.py:507-515).  entries: HOST array of nent {const float* src; float* dst; long long numel} (24 bytes each; read
+ * during the call: the table rides in the kernel arguments, 160 entries per launch, so a HIP-graph capture records it with the launch). */
+int sat_multi_copy(const void* entries, int nent, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data-parallel gradient exchange — what Lightning's `ddp` strategy does for the reference (train.py:138, :148-164): the SUM of

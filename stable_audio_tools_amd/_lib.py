@@ -71,12 +71,12 @@ SIGNATURES = {
     # elementwise.hip
     "sat_wn_fold": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "sat_wn_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sat_wn_grad_splits": (_I, [_P, _I, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sat_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_vae_nblocks": (_I, [_L]),
     "sat_vae_sample_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sat_vae_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "sat_multi_copy_blocks": (_L, [_L]),
-    "sat_multi_copy": (_I, [_P, _I, _L, _P]),
+    "sat_multi_copy": (_I, [_P, _I, _P]),
     "sat_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P]),
     "sat_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
     # comm.hip

@@ -175,6 +175,15 @@ class _WNConvBase(nn.Module):
             return self._derived.get("folded", (v, g), lambda: Fn.WeightNormFn.apply(v.detach(), g.detach()))
         return Fn.WeightNormFn.apply(v, g)
 
+    def weight_args(self):
+        """(w, g) for the conv's autograd unit: (weight_v, weight_g) when the pass trains them — the unit folds and un-folds the weight
+        norm itself (functional._wn_forward: one launch for dv / dg from the weight-gradient slabs) — else (folded weight, None)."""
+        if not self.is_folded:
+            v, g = self.p32("weight_v", self.weight_v), self.p32("weight_g", self.weight_g)
+            if not _inference_pass(v, g):
+                return v, g
+        return self.folded_weight(), None
+
     def derived_cache(self, *others):
         """The layer's DerivedCache when this call trains nothing of the layer (nor `others`: the SnakeBeta in front of it)."""
         ps = list(self._parameters.values()) + list(others)
@@ -187,8 +196,9 @@ class WNConv1d(_WNConvBase):
         a, b = (self.p32("alpha", snake.alpha), self.p32("beta", snake.beta)) if snake is not None else (None, None)
         if next_snake is not None and next_snake[0].dtype != torch.float32:
             next_snake = (self.p32("next_alpha", next_snake[0]), self.p32("next_beta", next_snake[1]), next_snake[2])
-        return Fn.SnakeConv1dFn.apply(x, a, b, self.folded_weight(), self.bias32(), res, self.stride, self.dilation,
-                                      self.padding, tanh_out, None, self.derived_cache(a, b), next_snake)
+        w, g = self.weight_args()
+        return Fn.SnakeConv1dFn.apply(x, a, b, w, self.bias32(), res, self.stride, self.dilation,
+                                      self.padding, tanh_out, None, self.derived_cache(a, b), next_snake, g)
 
 
 class WNConvTranspose1d(_WNConvBase):
@@ -196,8 +206,9 @@ class WNConvTranspose1d(_WNConvBase):
 
     def forward(self, x, snake=None):
         a, b = (self.p32("alpha", snake.alpha), self.p32("beta", snake.beta)) if snake is not None else (None, None)
-        return Fn.SnakeConvTr1dFn.apply(x, a, b, self.folded_weight(), self.bias32(), self.stride, self.padding, None,
-                                        self.derived_cache(a, b))
+        w, g = self.weight_args()
+        return Fn.SnakeConvTr1dFn.apply(x, a, b, w, self.bias32(), self.stride, self.padding, None,
+                                        self.derived_cache(a, b), g)
 
 
 def _require_snake(use_snake, antialias_activation=False):
@@ -241,10 +252,12 @@ class ResidualUnit(nn.Module):
         ca, cb = c1.derived_cache(s1.alpha, s1.beta), c2.derived_cache(s2.alpha, s2.beta)
         if next_snake is not None and next_snake[0].dtype != torch.float32:
             next_snake = (c2.p32("next_alpha", next_snake[0]), c2.p32("next_beta", next_snake[1]), next_snake[2])
-        return Fn.ResidualUnitFn.apply(x, c1.p32("alpha", s1.alpha), c1.p32("beta", s1.beta), c1.folded_weight(), c1.bias32(),
-                                       c2.p32("alpha", s2.alpha), c2.p32("beta", s2.beta), c2.folded_weight(), c2.bias32(), self.dilation, None,
+        (w1, g1), (w2, g2) = c1.weight_args(), c2.weight_args()
+        return Fn.ResidualUnitFn.apply(x, c1.p32("alpha", s1.alpha), c1.p32("beta", s1.beta), w1, c1.bias32(),
+                                       c2.p32("alpha", s2.alpha), c2.p32("beta", s2.beta), w2, c2.bias32(), self.dilation, None,
                                        self.checkpointing and torch.is_grad_enabled(), (ca, cb) if ca is not None and cb is not None else None,
-                                       next_snake, self.fuse if self.fuse is not None else ("nokeep" if not torch.is_grad_enabled() else False))
+                                       next_snake, self.fuse if self.fuse is not None else ("nokeep" if not torch.is_grad_enabled() else False),
+                                       g1, g2)
 
 
 class EncoderBlock(nn.Module):

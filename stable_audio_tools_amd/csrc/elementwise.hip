@@ -86,6 +86,88 @@ __global__ void __launch_bounds__(256) sat_wn_grad_kernel(SatWnParams p) {
     if (threadIdx.x == 0) p.dg[d] = dgv;
 }
 
+// Weight-norm gradient straight from the weight-gradient kernels' split slabs (round 5): dW[d][n][k] = sum_z partial[z * count +
+// d * so_m + n * so_n + k * so_k] is summed here, row by row, instead of by sat_reduce_splits (+ a torch permute for the tap-major
+// slabs of the k = 7 kernels) in front of sat_wn_grad — one launch per conv instead of two or three, and dW itself never touches HBM.
+// One workgroup per row d of v (D0, R = N * K, torch layout r = n * K + k).  The row of dW is staged in LDS (R <= SAT_WN_ROW_CAP
+// floats; longer rows are summed twice), walked in the slabs' own order so that the slab reads stay contiguous: tap-major slabs
+// (so_n == 1) as (k, n), everything else as (n, k).  Slabs are added in index order: deterministic.
+#define SAT_WN_ROW_CAP 16384
+struct SatWnSplitParams {
+    const float* partial;
+    const float* v;
+    const float* g;
+    const float* norm;
+    float* dv;
+    float* dg;
+    long long count, so_m, so_n, so_k;
+    int nsplit, D0, N, K;
+};
+SAT_DEVICE float sat_wn_slab_sum(const float* base, long long count, int nsplit) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {
+        s0 += base[(size_t)(z + 0) * count];
+        s1 += base[(size_t)(z + 1) * count];
+        s2 += base[(size_t)(z + 2) * count];
+        s3 += base[(size_t)(z + 3) * count];
+    }
+    for (; z < nsplit; ++z) s0 += base[(size_t)z * count];
+    return (s0 + s1) + (s2 + s3);
+}
+__global__ void __launch_bounds__(256) sat_wn_grad_splits_kernel(SatWnSplitParams p) {
+    __shared__ float row[SAT_WN_ROW_CAP];
+    __shared__ float red[4];
+    const int d = blockIdx.x;
+    const int R = p.N * p.K;
+    const float* base = p.partial + (size_t)d * p.so_m;
+    const float* v = p.v + (size_t)d * R;
+    const bool staged = R <= SAT_WN_ROW_CAP;
+    const bool tap_major = p.so_n == 1 && p.K > 1;
+    float s = 0.f;
+    if (staged) {
+        for (int i = threadIdx.x; i < R; i += 256) {
+            int n, k;
+            if (tap_major) { k = i / p.N; n = i - k * p.N; }
+            else           { n = i / p.K; k = i - n * p.K; }
+            row[n * p.K + k] = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += 256) s += v[r] * row[r];
+    } else {
+        for (int r = threadIdx.x; r < R; r += 256) {
+            const int n = r / p.K, k = r - n * p.K;
+            s += v[r] * sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+        }
+    }
+    s = sat_block_sum_256(s, red);
+    const float nrm = p.norm[d];
+    const float g = p.g[d];
+    const float c1 = g / nrm, c2 = g * s / (nrm * nrm * nrm);
+    float* dv = p.dv + (size_t)d * R;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        float dw;
+        if (staged) dw = row[r];
+        else {
+            const int n = r / p.K, k = r - n * p.K;
+            dw = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+        }
+        dv[r] = c1 * dw - c2 * v[r];
+    }
+    if (threadIdx.x == 0) p.dg[d] = s / nrm;
+}
+extern "C" int sat_wn_grad_splits(const float* partial, int nsplit, long long count, long long so_m, long long so_n, long long so_k,
+                                  const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K,
+                                  void* stream) {
+    if (D0 <= 0 || N <= 0 || K <= 0 || nsplit <= 0 || count < (long long)D0 * N * K) {
+        sat_set_error("sat_wn_grad_splits: bad shape");
+        return 1;
+    }
+    SatWnSplitParams p{partial, v, g, norm, dv, dg, count, so_m, so_n, so_k, nsplit, D0, N, K};
+    SAT_LAUNCH(sat_wn_grad_splits_kernel, dim3(D0), dim3(256), stream, p);
+    return sat_check_launch("sat_wn_grad_splits");
+}
+
 extern "C" int sat_wn_fold(const float* v, const float* g, float* w, float* norm, int D0, int R, void* stream) {
     if (D0 <= 0 || R <= 0) { sat_set_error("sat_wn_fold: empty shape"); return 1; }
     SatWnParams p{v, g, nullptr, w, norm, nullptr, D0, R};
@@ -462,38 +544,49 @@ extern "C" int sat_adamw_step(float* p, const float* g, float* m, float* v, long
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// sat_multi_copy — many small device-to-device copies in ONE launch: the gradients autograd produced for the ~380 parameters of the
-// Oobleck VAE (1 000+ of the DiT) gathered into the flat gradient buffer (training.FlatParameters.gather_grads).  Until round 5 every
-// parameter's gradient cost its own 5-us `add` launch of torch's AccumulateGrad (379 launches, 2.0 ms of the 148-ms generator step).
-// table (device): n entries {src, dst, numel, first block}; `first block` = prefix sum of ceil(numel / 16384) — a block finds its
-// entry by binary search.  fp32 only; 16-byte accesses when both pointers of an entry allow them.
+// sat_multi_copy — many small device-to-device copies in a few launches: the gradients autograd produced for the ~380 parameters of
+// the Oobleck VAE (1 000+ of the DiT) gathered into the flat gradient buffer (training.FlatParameters.gather_grads).  Until round 5
+// every parameter's gradient cost its own 5-us `add` launch of torch's AccumulateGrad (379 launches, 2.0 ms of the 148-ms generator step).
+// The table travels IN THE KERNEL ARGUMENTS (up to SAT_MC_ARGS entries of 24 bytes per launch: under the 4-KiB argument limit), not
+// through a device buffer: no pinned staging, no host-to-device copy in front of the launch, and a HIP-graph capture simply records
+// the entries with the launch (the gradients of a captured step live at fixed addresses of the graph's pool).  Entries: {src, dst,
+// numel, first block}, `first block` = prefix sum of ceil(numel / 16384) — a block finds its entry by binary search (uniform: scalar
+// loads from the argument segment).  fp32 only; 16-byte accesses when both pointers of an entry allow them.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SatCopyEntry {
+struct SatCopyEntry {          // host table of sat_multi_copy (C-ABI)
     const float* src;
     float* dst;
     long long n;
-    long long block0;
 };
+struct SatMcArg {
+    const float* src;
+    float* dst;
+    unsigned n;
+    unsigned block0;
+};
+#define SAT_MC_ARGS 160
 struct SatMultiCopyParams {
-    const SatCopyEntry* table;
+    SatMcArg e[SAT_MC_ARGS];
     int nent;
 };
+static_assert(sizeof(SatMultiCopyParams) <= 4096, "kernel arguments are limited to 4 KiB");
 #define SAT_MC_CHUNK 16384
 __global__ void __launch_bounds__(256) sat_multi_copy_kernel(SatMultiCopyParams p) {
-    const SatCopyEntry* table = p.table;
-    const long long b = blockIdx.x;
+    const unsigned b = blockIdx.x;
     int lo = 0, hi = p.nent - 1;
     while (lo < hi) {                                         // largest e with block0[e] <= b
         const int mid = (lo + hi + 1) >> 1;
-        if (table[mid].block0 <= b) lo = mid;
+        if (p.e[mid].block0 <= b) lo = mid;
         else hi = mid - 1;
     }
-    const SatCopyEntry e = table[lo];
-    const long long beg = (b - e.block0) * SAT_MC_CHUNK;
+    const float* src = p.e[lo].src;
+    float* dst = p.e[lo].dst;
+    const long long n = p.e[lo].n;
+    const long long beg = (long long)(b - p.e[lo].block0) * SAT_MC_CHUNK;
     long long end = beg + SAT_MC_CHUNK;
-    if (end > e.n) end = e.n;
-    const float* s = e.src + beg;
-    float* d = e.dst + beg;
+    if (end > n) end = n;
+    const float* s = src + beg;
+    float* d = dst + beg;
     const long long cnt = end - beg;
     if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
         const long long n4 = cnt >> 2;
@@ -503,11 +596,28 @@ __global__ void __launch_bounds__(256) sat_multi_copy_kernel(SatMultiCopyParams 
         for (long long i = threadIdx.x; i < cnt; i += 256) d[i] = s[i];
     }
 }
-extern "C" long long sat_multi_copy_blocks(long long numel) { return numel <= 0 ? 0 : (numel + SAT_MC_CHUNK - 1) / SAT_MC_CHUNK; }
-extern "C" int sat_multi_copy(const void* table, int nent, long long nblocks, void* stream) {
-    if (nent <= 0 || nblocks <= 0) return 0;
-    if (!table || nblocks > 0x7fffffffLL) { sat_set_error("sat_multi_copy: bad arguments"); return 1; }
-    SatMultiCopyParams p{(const SatCopyEntry*)table, nent};
-    SAT_LAUNCH(sat_multi_copy_kernel, dim3((unsigned)nblocks), dim3(256), stream, p);
-    return sat_check_launch("sat_multi_copy");
+extern "C" int sat_multi_copy(const void* entries, int nent, void* stream) {
+    if (nent <= 0) return 0;
+    if (!entries) { sat_set_error("sat_multi_copy: no table"); return 1; }
+    const SatCopyEntry* tab = (const SatCopyEntry*)entries;
+    for (int base = 0; base < nent; base += SAT_MC_ARGS) {
+        SatMultiCopyParams p;
+        const int cnt = nent - base < SAT_MC_ARGS ? nent - base : SAT_MC_ARGS;
+        unsigned blocks = 0;
+        int used = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const SatCopyEntry& e = tab[base + i];
+            if (e.n <= 0) continue;
+            if (!e.src || !e.dst || e.n > 0x7fffffffLL) { sat_set_error("sat_multi_copy: bad entry"); return 1; }
+            p.e[used] = SatMcArg{e.src, e.dst, (unsigned)e.n, blocks};
+            blocks += (unsigned)((e.n + SAT_MC_CHUNK - 1) / SAT_MC_CHUNK);
+            ++used;
+        }
+        if (!used) continue;
+        for (int i = used; i < SAT_MC_ARGS; ++i) p.e[i] = SatMcArg{nullptr, nullptr, 0u, 0u};
+        p.nent = used;
+        SAT_LAUNCH(sat_multi_copy_kernel, dim3(blocks), dim3(256), stream, p);
+        if (int rc = sat_check_launch("sat_multi_copy")) return rc;
+    }
+    return 0;
 }

@@ -116,13 +116,31 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out
     return ops.convtr1d(dy, wpb, cin, k, stride, pad, tout=tin, dsnake=dsnake, res=res)
 
 
-def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False):
+def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False, raw=False):
     """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 (dilation 1/3/9) -> the 7-tap bf16x3 kernels; k1 and K = 2*stride ->
     the short-kernel bf16x3 wgrad (chosen inside ops.conv_wgrad); anything else -> the fp32-MFMA kernel.
-    bias_grad=True returns (dW, dbias): the bf16x3 kernels sum the dy rows they stream anyway."""
+    bias_grad=True returns (dW, dbias): the bf16x3 kernels sum the dy rows they stream anyway.
+    raw=True: dW stays the kernel's split slabs (ops.WgradSlabs) — what _wn_backward takes."""
     if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
-        return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake, dy_rowsum=bias_grad)
-    return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad)
+        return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake, dy_rowsum=bias_grad, raw=raw)
+    return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad, raw=raw)
+
+
+def _wn_forward(ops, v, g):
+    """Weight norm INSIDE a conv's autograd unit (round 5): the unit takes (weight_v, weight_g) in place of the folded weight, folds in
+    its forward (sat_wn_fold) and, in its backward, turns the weight-gradient kernel's split slabs straight into (dv, dg)
+    (sat_wn_grad_splits) — no separate WeightNormFn node, no sat_reduce_splits / permute / sat_wn_grad launches, no dW in HBM.
+    Returns (w, (v, g_flat, norm))."""
+    v = v.contiguous()
+    gf = g.contiguous().view(-1)
+    w, norm = ops.wn_fold(v, gf)
+    return w, (v, gf, norm)
+
+
+def _wn_backward(ops, slabs, saved, g_shape):
+    v, gf, norm = saved
+    dv, dg = ops.wn_grad_splits(slabs, v, gf, norm)
+    return dv, dg.view(g_shape)
 
 
 def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None, cache=None, emit=None):
@@ -155,11 +173,15 @@ class SnakeConv1dFn(torch.autograd.Function):
     """y = tanh?( conv1d(snake(x; alpha, beta), w, bias, stride, dil, pad) + res )."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None, cache=None, next_snake=None):
+    def forward(ctx, x, alpha, beta, w, bias, res, stride, dil, pad, tanh_out, ops=None, cache=None, next_snake=None, g=None):
         """next_snake = (log-alpha, log-beta, dilation) of the ResidualUnit that reads y next (its k7 conv): the conv also emits
-        snake(y) as that conv's activation planes (no autograd through them: the consumer's own backward recomputes from y)."""
+        snake(y) as that conv's activation planes (no autograd through them: the consumer's own backward recomputes from y).
+        g: weight-norm magnitudes — `w` is then weight_v and the unit folds / un-folds itself (_wn_forward)."""
         ops = _ops(ops)
         x = x.contiguous()
+        wn = ()
+        if g is not None:
+            w, wn = _wn_forward(ops, w, g)
         w = w.contiguous()
         cout, cin, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
@@ -172,25 +194,29 @@ class SnakeConv1dFn(torch.autograd.Function):
                       res=res.contiguous() if res is not None else None, tanh_out=tanh_out, cache=cache, emit=emit)
         ctx.ops = ops
         ctx.cfg = (stride, dil, pad, tanh_out, bias is not None, res is not None, alpha is not None)
-        ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None)
+        ctx.g_shape = g.shape if g is not None else None
+        ctx.save_for_backward(x, alpha, beta, w, y if tanh_out else None, *wn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ops = ctx.ops
         stride, dil, pad, tanh_out, has_bias, has_res, has_snake = ctx.cfg
-        x, alpha, beta, w, y = ctx.saved_tensors
+        x, alpha, beta, w, y = ctx.saved_tensors[:5]
+        wn = ctx.saved_tensors[5:]
         cout, cin, k = w.shape
         dy = dy.contiguous()
         if tanh_out:
             dy = dy * (1.0 - y * y)
         snake = (alpha, beta) if has_snake else None
         dres = dy if has_res else None
-        dw = dbias = None
-        if ctx.needs_input_grad[3]:
-            dw = _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=has_bias)
+        dw = dbias = dg = None
+        if ctx.needs_input_grad[3] or (wn and ctx.needs_input_grad[13]):
+            dw = _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=has_bias, raw=bool(wn))
             if has_bias:
                 dw, dbias = dw
+            if wn:
+                dw, dg = _wn_backward(ops, dw, wn, ctx.g_shape)
         elif has_bias:
             dbias = ops.rowsum(dy)
         dx = da = db = None
@@ -198,42 +224,50 @@ class SnakeConv1dFn(torch.autograd.Function):
             dx, da, db = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], (x, alpha, beta))
         elif ctx.needs_input_grad[0]:
             dx = _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, x.shape[2], None)
-        return dx, da, db, dw, dbias, dres, None, None, None, None, None, None, None
+        return dx, da, db, dw, dbias, dres, None, None, None, None, None, None, None, dg
 
 
 class SnakeConvTr1dFn(torch.autograd.Function):
     """y = conv_transpose1d(snake(x), w (Cin, Cout, K=2*stride), bias, stride, pad)."""
 
     @staticmethod
-    def forward(ctx, x, alpha, beta, w, bias, stride, pad, ops=None, cache=None):
+    def forward(ctx, x, alpha, beta, w, bias, stride, pad, ops=None, cache=None, g=None):
         ops = _ops(ops)
         x = x.contiguous()
+        wn = ()
+        if g is not None:           # w is weight_v: fold here, un-fold in the backward (_wn_forward)
+            w, wn = _wn_forward(ops, w, g)
         w = w.contiguous()
         cin, cout, k = w.shape
         snake = (alpha.contiguous(), beta.contiguous()) if alpha is not None else None
         y = _convtr_fwd(ops, x, w, stride, pad, bias=bias, snake=snake, cache=cache)
         ctx.ops = ops
         ctx.cfg = (stride, pad, bias is not None, alpha is not None)
-        ctx.save_for_backward(x, alpha, beta, w)
+        ctx.g_shape = g.shape if g is not None else None
+        ctx.save_for_backward(x, alpha, beta, w, *wn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ops = ctx.ops
         stride, pad, has_bias, has_snake = ctx.cfg
-        x, alpha, beta, w = ctx.saved_tensors
+        x, alpha, beta, w = ctx.saved_tensors[:4]
+        wn = ctx.saved_tensors[4:]
         cin, cout, k = w.shape
         dy = dy.contiguous()
         snake = (alpha, beta) if has_snake else None
         dbias = ops.rowsum(dy) if has_bias else None
-        dw = ops.conv_wgrad(x, dy, k, stride, 1, pad, snake=snake, snake_on=1)
+        dw = ops.conv_wgrad(x, dy, k, stride, 1, pad, snake=snake, snake_on=1, raw=bool(wn))
+        dg = None
+        if wn:
+            dw, dg = _wn_backward(ops, dw, wn, ctx.g_shape)
         # dgrad of a transposed conv is the strided conv with in=Cout, out=Cin: w (Cin, Cout, K) is its [out][in][K] weight
         dx = da = db = None
         if has_snake:
             dx, da, db = _conv_fwd(ops, dy, w, stride, 1, pad, dsnake=(x, alpha, beta), tout=x.shape[2])
         elif ctx.needs_input_grad[0]:
             dx = _conv_fwd(ops, dy, w, stride, 1, pad, tout=x.shape[2])
-        return dx, da, db, dw, dbias, None, None, None, None
+        return dx, da, db, dw, dbias, None, None, None, None, dg
 
 
 class ResidualUnitFn(torch.autograd.Function):
@@ -243,14 +277,21 @@ class ResidualUnitFn(torch.autograd.Function):
     +1/3 of its forward flops.  caches = (DerivedCache of the k7 conv, of the k1 conv) or None."""
 
     @staticmethod
-    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None, next_snake=None, fuse=False):
+    def forward(ctx, x, a1, b1, w1, bias1, a2, b2, w2, bias2, dil, ops=None, recompute=False, caches=None, next_snake=None, fuse=False,
+                g1=None, g2=None):
         """next_snake = (log-alpha, log-beta, dilation) of the ResidualUnit that follows: the k1 conv's epilogue then also writes
         snake(y) as that unit's k7 activation planes (its sat_conv1d_k7_planes pre-pass disappears).
         fuse: run the unit as ONE launch where the kernel allows (C <= 128).  The caller asks for it when no backward will follow
         (inference: h is not kept and never touches HBM — 2.30 vs 2.65 ms at C = 128, T = 2 097 152); with h kept the fused launch
-        is slower than the two launches (3.06 ms: its extra 1-GB store burst is not overlapped, profiles/EXPERIMENTS.md)."""
+        is slower than the two launches (3.06 ms: its extra 1-GB store burst is not overlapped, profiles/EXPERIMENTS.md).
+        g1 / g2: weight-norm magnitudes of the two convs — w1 / w2 are then their weight_v (_wn_forward)."""
         ops = _ops(ops)
         x = x.contiguous()
+        wn1 = wn2 = ()
+        if g1 is not None:
+            w1, wn1 = _wn_forward(ops, w1, g1)
+        if g2 is not None:
+            w2, wn2 = _wn_forward(ops, w2, g2)
         w1 = w1.contiguous()
         w2 = w2.contiguous()
         c = x.shape[1]
@@ -275,13 +316,18 @@ class ResidualUnitFn(torch.autograd.Function):
         ctx.ops = ops
         ctx.dil = dil
         ctx.recompute = bool(recompute)
-        ctx.save_for_backward(x, None if recompute else h, a1, b1, w1, a2, b2, w2, bias1 if recompute else None)
+        ctx.g_shapes = (g1.shape if g1 is not None else None, g2.shape if g2 is not None else None)
+        ctx.save_for_backward(x, None if recompute else h, a1, b1, w1, a2, b2, w2, bias1 if recompute else None, *wn1, *wn2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ops = ctx.ops
-        x, h, a1, b1, w1, a2, b2, w2, bias1 = ctx.saved_tensors
+        x, h, a1, b1, w1, a2, b2, w2, bias1 = ctx.saved_tensors[:9]
+        gs1, gs2 = ctx.g_shapes
+        rest = ctx.saved_tensors[9:]
+        wn1 = rest[:3] if gs1 is not None else ()
+        wn2 = rest[len(wn1):] if gs2 is not None else ()
         dil = ctx.dil
         c = x.shape[1]
         k1, k2 = w1.shape[2], w2.shape[2]
@@ -295,14 +341,19 @@ class ResidualUnitFn(torch.autograd.Function):
         if k2 == 1 and w2.shape[0] == c and w1.shape[0] == c and ops.ru_k1_bwd_ok(dy.shape[0], c, t):
             # C == 128 (the widest levels): weight gradient, data gradient, both bias gradients and the snake gradients of the 1x1 conv in ONE pass
             # over dy and h (csrc/ru_k1_bwd.hip) instead of three kernels that each stream them from HBM
-            dh, da2, db2, dw2, dbias2, dbias1 = ops.ru_k1_bwd(dy, h, w2, (a2, b2), emit=want_emit)
-            dw1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=False)
+            dh, da2, db2, dw2, dbias2, dbias1 = ops.ru_k1_bwd(dy, h, w2, (a2, b2), emit=want_emit, raw=bool(wn2))
+            dw1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=False, raw=bool(wn1))
         else:
-            dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True)
+            dw2, dbias2 = ops.conv_wgrad(dy, h, k2, 1, 1, 0, snake=(a2, b2), snake_on=2, lo_rowsum=True, raw=bool(wn2))
             dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit={"snake": None} if want_emit else None)
-            dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True)
+            dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True, raw=bool(wn1))
+        dg1 = dg2 = None
+        if wn1:
+            dw1, dg1 = _wn_backward(ops, dw1, wn1, gs1)
+        if wn2:
+            dw2, dg2 = _wn_backward(ops, dw2, wn2, gs2)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
-        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None, None
+        return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None, None, dg1, dg2
 
 
 class VaeSampleFn(torch.autograd.Function):

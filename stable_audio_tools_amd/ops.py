@@ -33,6 +33,29 @@ def _keep_empty(shape, dtype, device):
         return torch.empty(shape, dtype=dtype, device=device)
 
 
+class WgradSlabs:
+    """A weight gradient as its kernel left it: `nsplit` slabs of `count` floats, element (m, n, k) of slab z at
+    partial[z, m * so_m + n * so_n + k * so_k] (tap-major [K][M][N] for the k = 7 kernels, torch order for the others).  reduce() sums
+    them into the torch-layout tensor (M, N, K); a weight-normed conv hands the slabs to SatOps.wn_grad_splits instead."""
+    __slots__ = ("partial", "nsplit", "dims", "strides")
+
+    def __init__(self, partial, nsplit, dims, strides):
+        self.partial, self.nsplit, self.dims, self.strides = partial, int(nsplit), tuple(int(d) for d in dims), tuple(int(x) for x in strides)
+
+    @property
+    def count(self):
+        return self.partial.shape[1]
+
+    def reduce(self, ops):
+        m, n, k = self.dims
+        flat = ops._reduce_rows(self.partial, self.nsplit, m * n * k)
+        if self.strides == (n * k, k, 1):
+            return flat.view(m, n, k)
+        if self.strides == (n, 1, m * n):
+            return flat.view(k, m, n).permute(1, 2, 0).contiguous()
+        raise ValueError("WgradSlabs.reduce: unknown slab layout %s" % (self.strides,))
+
+
 class SatOps:
     def __init__(self, cdll):
         self.lib = cdll
@@ -77,6 +100,20 @@ class SatOps:
         dv = torch.empty_like(v)
         dg = torch.empty_like(g)
         self._chk(self.lib.sat_wn_grad(_ptr(v), _ptr(g), _ptr(norm), _ptr(dw), _ptr(dv), _ptr(dg), d0, r, self._stream(v)))
+        return dv, dg
+
+    def wn_grad_splits(self, slabs, v, g, norm):
+        """(dv, dg) of w = g * v / ||v|| from a weight-gradient kernel's split slabs (WgradSlabs) in ONE launch: the sum over the slabs,
+        the layout change and the weight-norm gradient (csrc/elementwise.hip sat_wn_grad_splits) — dW never exists in HBM."""
+        self._f32(v, g, norm, slabs.partial)
+        m, n, k = slabs.dims
+        if tuple(v.shape) != (m, n, k):
+            raise ValueError("wn_grad_splits: slabs of a %s weight gradient for a %s weight" % ((m, n, k), tuple(v.shape)))
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        so_m, so_n, so_k = slabs.strides
+        self._chk(self.lib.sat_wn_grad_splits(_ptr(slabs.partial), slabs.nsplit, slabs.count, so_m, so_n, so_k, _ptr(v), _ptr(g), _ptr(norm),
+                                              _ptr(dv), _ptr(dg), m, n, k, self._stream(v)))
         return dv, dg
 
     def pack(self, w, mode, stride=1):
@@ -427,10 +464,10 @@ class SatOps:
             return (y, *self._sum_pair(pda, pdb))
         return y
 
-    def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, transposed_out=False, lo_rowsum=False):
-        """dW[m][n][k] = sum_{b,t} actA(lo[b,m,t]) * actB(hi[b,n,t*s + k*d - pad]).
-        Returns (M, N, K); with transposed_out=True returns it laid out as (N, M, K).
-        lo_rowsum=True also returns sum_{b,t} lo[b,m,t] (the bias gradient when lo = dy): (dW, (M,))."""
+    def conv_wgrad(self, lo, hi, k, stride=1, dil=1, pad=0, snake=None, snake_on=0, lo_rowsum=False, raw=False):
+        """dW[m][n][k] = sum_{b,t} actA(lo[b,m,t]) * actB(hi[b,n,t*s + k*d - pad]), (M, N, K).
+        lo_rowsum=True also returns sum_{b,t} lo[b,m,t] (the bias gradient when lo = dy): (dW, (M,)).
+        raw=True: dW as the kernel's un-summed slabs (WgradSlabs) for wn_grad_splits."""
         bsz, m, tlo = lo.shape
         _, n, thi = hi.shape
         alpha, beta = snake if snake is not None else (None, None)
@@ -443,12 +480,7 @@ class SatOps:
         if nsplit < 0:
             raise RuntimeError("sat_conv_wgrad: receptive field too large")
         partial = torch.empty(nsplit, m * n * k, dtype=torch.float32, device=lo.device)
-        if transposed_out:
-            so_m, so_n, so_k = k, m * k, 1
-            shape = (n, m, k)
-        else:
-            so_m, so_n, so_k = n * k, k, 1
-            shape = (m, n, k)
+        so_m, so_n, so_k = n * k, k, 1
         rs = None
         if x3:
             fused = lo_rowsum and not (snake is not None and snake_on == 1)     # the kernel sums the rows it stages anyway
@@ -460,7 +492,8 @@ class SatOps:
             self._chk(self.lib.sat_conv_wgrad(_ptr(lo), _ptr(hi), _ptr(alpha), _ptr(beta), snake_on if snake is not None else 0,
                                               _ptr(partial), so_m, so_n, so_k, bsz, m, n, tlo, thi, k, stride, dil, pad,
                                               self._stream(lo)))
-        dw = self._reduce_rows(partial, nsplit, m * n * k).view(shape)
+        slabs = WgradSlabs(partial, nsplit, (m, n, k), (so_m, so_n, so_k))
+        dw = slabs if raw else slabs.reduce(self)
         if not lo_rowsum:
             return dw
         return dw, (self._sum_last(rs) if rs is not None else self.rowsum(lo))
@@ -479,10 +512,10 @@ class SatOps:
         self._chk(self.lib.sat_ru_k1_pack(_ptr(w2), _ptr(planes[0]), _ptr(planes[1]), c, self._stream(w2)))
         return planes[0], planes[1]
 
-    def ru_k1_bwd(self, dy, h, w2, snake2, emit=False, wt=None):
+    def ru_k1_bwd(self, dy, h, w2, snake2, emit=False, wt=None, raw=False):
         """Backward of y = x + conv1x1(snake2(h)) w.r.t. everything but x, in one launch: returns (dh, dlog_alpha2, dlog_beta2, dW2 (C, C, 1),
         dbias2 (C,), dbias1 (C,) = sum dh).  emit=True also writes dh as the activation planes of the k7 data-gradient that consumes it
-        next (as conv1d_bf16x3(emit={"snake": None}))."""
+        next (as conv1d_bf16x3(emit={"snake": None})).  raw=True: dW2 as WgradSlabs (for wn_grad_splits)."""
         b, c, t = dy.shape
         a2, b2 = snake2
         self._f32(dy, h, w2, a2, b2)
@@ -502,16 +535,19 @@ class SatOps:
                                          _ptr(slabs), _ptr(part), b, c, t, st))
         if emit:
             self._note_emitted(dh, None, ehi, elo, erows)
-        dw2 = self._reduce_rows(slabs, ns, c * c).view(c, c, 1)
+        dw2 = WgradSlabs(slabs, ns, (c, c, 1), (c, 1, 1))
+        if not raw:
+            dw2 = dw2.reduce(self)
         sums = self._sum_last(part)
         return dh, sums[:c], sums[c:2 * c], dw2, sums[3 * c:], sums[2 * c:3 * c]
 
     def wgrad7_bf16x3_ok(self, n_in, k, stride, dil):
         return self.use_bf16x3 and stride == 1 and k == 7 and dil in (1, 3, 9)
 
-    def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None, dy_rowsum=False):
+    def conv_wgrad7_bf16x3(self, dy, x, dil, pad, snake=None, dy_rowsum=False, raw=False):
         """dW (Cout, Cin, 7) of a k7 stride-1 conv: dy (B, Cout, T), x (B, Cin, T) pre-activation, snake = (log-alpha, log-beta).
-        dy_rowsum=True also returns the bias gradient sum_{b,t} dy (fused into the kernel): (dW, (Cout,))."""
+        dy_rowsum=True also returns the bias gradient sum_{b,t} dy (fused into the kernel): (dW, (Cout,)).
+        raw=True: dW as the kernel's un-summed slabs (WgradSlabs) for wn_grad_splits."""
         b, m, t = dy.shape
         n = x.shape[1]
         alpha, beta = snake if snake is not None else (None, None)
@@ -524,7 +560,8 @@ class SatOps:
         rs = torch.empty(m, nsplit, dtype=torch.float32, device=dy.device) if fused else None
         self._chk(self.lib.sat_conv_wgrad7_bf16x3(_ptr(dy), _ptr(x), _ptr(alpha), _ptr(beta), _ptr(partial), n, 1, m * n,
                                                   b, m, n, t, dil, pad, _ptr(rs), self._stream(dy)))
-        dw = self._reduce_rows(partial, nsplit, m * n * 7).view(7, m, n).permute(1, 2, 0).contiguous()
+        slabs = WgradSlabs(partial, nsplit, (m, n, 7), (n, 1, m * n))
+        dw = slabs if raw else slabs.reduce(self)
         if not dy_rowsum:
             return dw
         return dw, (self._sum_last(rs) if fused else self.rowsum(dy))
@@ -1308,40 +1345,20 @@ class SatOps:
     def allreduce_finalize(self, comm):
         self._chk(self.lib.sat_allreduce_finalize(comm))
 
-    def multi_copy_plan(self, dsts):
-        """Static half of a sat_multi_copy table for the destination views `dsts` (fp32, contiguous): (host int64 array (n, 4) with dst /
-        numel / first block filled in, total blocks).  The source pointers (column 0) are filled per call: multi_copy()."""
+    def multi_copy(self, srcs, dsts):
+        """dsts[i] <- srcs[i] (contiguous fp32 tensors of equal sizes, pairwise) in ceil(n / 160) launches (sat_multi_copy: the table
+        rides in the kernel arguments — nothing to stage, capturable in a HIP graph)."""
         import numpy as np
-        tab = np.zeros((len(dsts), 4), dtype=np.int64)
-        blk = 0
-        for i, d in enumerate(dsts):
-            self._f32(d)
-            tab[i, 1], tab[i, 2], tab[i, 3] = d.data_ptr(), d.numel(), blk
-            blk += self.lib.sat_multi_copy_blocks(d.numel())
-        return tab, blk
-
-    def multi_copy(self, srcs, plan, rows, device):
-        """dst[i] <- srcs[k] for the plan rows `rows` (parallel lists) in ONE launch.  The table travels host -> device through a pinned
-        staging buffer owned by this call's caller-visible cache (one per plan)."""
-        import numpy as np
-        tab, _ = plan
-        n = len(rows)
+        n = len(srcs)
         if n == 0:
             return
-        sub = tab[rows].copy()
-        blk = 0
-        for k, (src, r) in enumerate(zip(srcs, rows)):
-            if src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != tab[r, 2]:
-                raise ValueError("multi_copy: sources must be contiguous fp32 tensors of the destinations' sizes")
-            sub[k, 0] = src.data_ptr()
-            sub[k, 3] = blk
-            blk += int(self.lib.sat_multi_copy_blocks(int(tab[r, 2])))
-        host = torch.from_numpy(sub.reshape(-1))
-        if device.type == "cuda":
-            dev = host.pin_memory().to(device, non_blocking=True)      # (torch's host allocator keeps the pinned block until the copy ran)
-        else:
-            dev = host
-        self._chk(self.lib.sat_multi_copy(_ptr(dev), n, blk, self._stream(srcs[0])))
+        tab = np.empty((n, 3), dtype=np.int64)
+        for i, (src, dst) in enumerate(zip(srcs, dsts)):
+            if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous() \
+                    or src.numel() != dst.numel() or src.device != dst.device:
+                raise ValueError("multi_copy: sources and destinations must be contiguous fp32 tensors of equal sizes on one device")
+            tab[i] = (src.data_ptr(), dst.data_ptr(), src.numel())
+        self._chk(self.lib.sat_multi_copy(tab.ctypes.data, n, self._stream(srcs[0])))
 
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, ema=None, ema_decay=0.0):
         self._f32(p, g, m, v, ema)

@@ -62,12 +62,11 @@ class FlatParameters:
 
     def gather_grads(self, ops=None):
         """Every gradient autograd left outside the flat buffer (adopted tensors: steal mode; replaced `.grad`s otherwise) is copied
-        into its view and `.grad` re-pointed at the view.  One sat_multi_copy launch on the GPU; per-parameter copies while a HIP graph
-        is being captured (the table's source pointers would be frozen into a host buffer the next eager step rewrites) and when
-        no kernel library serves the device."""
+        into its view and `.grad` re-pointed at the view.  A few sat_multi_copy launches on the GPU (160 parameters each; the table is
+        part of the launch, so a HIP-graph capture records it too); per-parameter copies when no kernel library serves the device."""
         todo = [i for i, (p, gv) in enumerate(zip(self.params, self._views)) if p.grad is not None and p.grad.data_ptr() != gv.data_ptr()]
         batched = False
-        if len(todo) > 1 and not (self.grad.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(todo) > 1:
             srcs = [self.params[i].grad for i in todo]
             if all(g.dtype == torch.float32 and g.is_contiguous() and g.device == self.grad.device for g in srcs):
                 try:
@@ -75,9 +74,7 @@ class FlatParameters:
                 except Exception:      # noqa: BLE001 — no kernel library for this device (plain CPU use of the step objects)
                     o = None
                 if o is not None and (self.grad.is_cuda or o.simulator):
-                    if self._mc_plan is None:
-                        self._mc_plan = o.multi_copy_plan(self._views)
-                    o.multi_copy(srcs, self._mc_plan, todo, self.grad.device)
+                    o.multi_copy(srcs, [self._views[i] for i in todo])
                     batched = True
         for i in todo:
             p, gv = self.params[i], self._views[i]
@@ -87,8 +84,6 @@ class FlatParameters:
         for p, gv in zip(self.params, self._views):      # parameters without a gradient this step read the zeroed view
             if p.grad is None:
                 p.grad = gv
-
-    _mc_plan = None
 
 
 class GradAllReduce:

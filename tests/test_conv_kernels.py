@@ -345,3 +345,39 @@ def test_wgrad7_bias_gradient_sim(emu):
 @pytest.mark.gpu
 def test_wgrad7_bias_gradient_gpu(hip):
     _wgrad7_bias_case(hip, "cuda")
+
+
+def _wn_splits_case(ops, dev):
+    """sat_wn_grad_splits (weight-norm gradient straight from a weight-gradient kernel's split slabs) against sat_reduce_splits + layout
+    change + sat_wn_grad, and against autograd of g * v / ||v|| in float64: both slab layouts (torch order, tap-major), one and many
+    slabs, a row longer than the LDS staging buffer (summed twice instead)."""
+    from stable_audio_tools_amd.ops import WgradSlabs
+    gen = torch.Generator().manual_seed(11)
+    for (m, n, k, ns, tap_major) in ((5, 12, 7, 3, True), (130, 64, 7, 1, True), (3, 9, 1, 6, False), (40, 24, 16, 5, False),
+                                     (2, 2400, 7, 2, True), (2, 2400, 7, 3, False)):
+        v = torch.randn(m, n, k, generator=gen).to(dev)
+        g = (torch.rand(m, 1, 1, generator=gen) + .5).to(dev)
+        pad = 8                                                           # slabs may be longer than M * N * K
+        partial = torch.randn(ns, m * n * k + pad, generator=gen).to(dev)
+        strides = (n, 1, m * n) if tap_major else (n * k, k, 1)
+        slabs = WgradSlabs(partial, ns, (m, n, k), strides)
+        summed = partial[:, :m * n * k].sum(0)
+        dw = summed.view(k, m, n).permute(1, 2, 0).contiguous() if tap_major else summed.view(m, n, k)
+        w, norm = ops.wn_fold(v, g.view(-1))
+        dv, dg = ops.wn_grad_splits(slabs, v, g.view(-1), norm)
+        dv0, dg0 = ops.wn_grad(v, g.view(-1), norm, dw)
+        vd, gd = v.double().cpu().requires_grad_(True), g.double().cpu().requires_grad_(True)
+        (gd * vd / vd.flatten(1).norm(dim=1).view(-1, 1, 1) * dw.double().cpu()).sum().backward()
+        for got, ref in ((dv, vd.grad), (dg, gd.grad.view(-1)), (dv0, vd.grad), (dg0, gd.grad.view(-1))):
+            assert (got.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (m, n, k, ns, tap_major)
+    with pytest.raises(ValueError):
+        ops.wn_grad_splits(slabs, v[:, :5], g.view(-1), norm)
+
+
+def test_wn_grad_from_slabs_sim(emu):
+    _wn_splits_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_wn_grad_from_slabs_gpu(hip):
+    _wn_splits_case(hip, "cuda")

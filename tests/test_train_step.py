@@ -866,3 +866,32 @@ def test_teacher_distillation_gpu(hip):
 @pytest.mark.gpu
 def test_wrapper_options_gpu(hip):
     _wrapper_options("cuda")
+
+
+def _multi_copy_case(ops, dev):
+    """sat_multi_copy (the gradient gather of FlatParameters.gather_grads): 401 pairs — three launches of <= 160 entries riding in the
+    kernel arguments — of sizes around the 16-byte vector width and the 16384-element block, at aligned and odd offsets."""
+    gen = torch.Generator().manual_seed(3)
+    sizes = [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 255, 1000, 16383, 16384, 16385, 40000] * 25 + [123457]
+    big = torch.zeros(sum(sizes) + len(sizes), device=dev)
+    srcs, dsts, off = [], [], 0
+    for i, n in enumerate(sizes):
+        srcs.append(torch.randn(n + 1, generator=gen).to(dev)[i % 2:][:n])         # every other source starts 4 bytes off alignment
+        dsts.append(big[off:off + n])
+        off += n + 1                                                                # one guard element between destinations
+    ops.multi_copy(srcs, dsts)
+    off = 0
+    for s, n in zip(srcs, sizes):
+        assert torch.equal(big[off:off + n], s) and float(big[off + n]) == 0.0
+        off += n + 1
+    with pytest.raises(ValueError):
+        ops.multi_copy([srcs[0]], [dsts[1]])
+
+
+def test_multi_copy_sim(emu):
+    _multi_copy_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_multi_copy_gpu(hip):
+    _multi_copy_case(hip, "cuda")
