@@ -231,9 +231,11 @@ int sat_wn_grad(const float* v, const float* g, const float* norm, const float* 
 /* The same gradient taken straight from a weight-gradient kernel's split slabs (sat_conv_wgrad*, sat_ru_k1_bwd): element (d, n, k) of
  * dW = sum over z < nsplit of partial[z * count + d * so_m + n * so_n + k * so_k]; v / dv (D0, N, K) in torch layout.  Replaces
  * sat_reduce_splits (+ layout permute) + sat_wn_grad for a weight-normed conv (reference: torch.nn.utils.weight_norm's backward through
- * the convs of models/autoencoders.py:23-27). */
+ * the convs of models/autoencoders.py:23-27).  bias_partial (D0, bias_cols) | NULL: per-split sums of dy (a weight-gradient kernel's
+ * row sums, or sat_rowsum's first pass); dbias[d] = their sum — the conv's bias gradient finishes in the same launch. */
 int sat_wn_grad_splits(const float* partial, int nsplit, long long count, long long so_m, long long so_n, long long so_k,
-                       const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K, void* stream);
+                       const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K,
+                       const float* bias_partial, int bias_cols, float* dbias, void* stream);
 /* torch weight w[D0][D1][K] -> GEMM-side layout.  mode 0: [D1][k][D0]; 1: [D0][K-1-k][D1]; 2: [r][j][D0][D1], k=r+j*S */
 int sat_pack_weights(const float* w, float* out, int D0, int D1, int K, int S, int mode, void* stream);
 

@@ -71,7 +71,7 @@ SIGNATURES = {
     # elementwise.hip
     "sat_wn_fold": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "sat_wn_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "sat_wn_grad_splits": (_I, [_P, _I, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sat_wn_grad_splits": (_I, [_P, _I, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "sat_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sat_vae_nblocks": (_I, [_L]),
     "sat_vae_sample_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

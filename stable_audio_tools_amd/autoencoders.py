@@ -178,7 +178,7 @@ class _WNConvBase(nn.Module):
     def weight_args(self):
         """(w, g) for the conv's autograd unit: (weight_v, weight_g) when the pass trains them — the unit folds and un-folds the weight
         norm itself (functional._wn_forward: one launch for dv / dg from the weight-gradient slabs) — else (folded weight, None)."""
-        if not self.is_folded:
+        if not self.is_folded and Fn._ops(None).wn_fused:
             v, g = self.p32("weight_v", self.weight_v), self.p32("weight_g", self.weight_g)
             if not _inference_pass(v, g):
                 return v, g

@@ -102,6 +102,9 @@ struct SatWnSplitParams {
     float* dg;
     long long count, so_m, so_n, so_k;
     int nsplit, D0, N, K;
+    const float* bias_partial;      // (D0, bias_cols) per-split sums of dy (the weight-gradient kernel's, or sat_rowsum's first pass) | NULL
+    float* dbias;                   // (D0): their sums — the bias gradient's last reduction rides along
+    int bias_cols;
 };
 SAT_DEVICE float sat_wn_slab_sum(const float* base, long long count, int nsplit) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -155,15 +158,22 @@ __global__ void __launch_bounds__(256) sat_wn_grad_splits_kernel(SatWnSplitParam
         dv[r] = c1 * dw - c2 * v[r];
     }
     if (threadIdx.x == 0) p.dg[d] = s / nrm;
+    if (p.bias_partial) {
+        const float* bp = p.bias_partial + (size_t)d * p.bias_cols;
+        float b = 0.f;
+        for (int i = threadIdx.x; i < p.bias_cols; i += 256) b += bp[i];
+        b = sat_block_sum_256(b, red);
+        if (threadIdx.x == 0) p.dbias[d] = b;
+    }
 }
 extern "C" int sat_wn_grad_splits(const float* partial, int nsplit, long long count, long long so_m, long long so_n, long long so_k,
                                   const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K,
-                                  void* stream) {
-    if (D0 <= 0 || N <= 0 || K <= 0 || nsplit <= 0 || count < (long long)D0 * N * K) {
+                                  const float* bias_partial, int bias_cols, float* dbias, void* stream) {
+    if (D0 <= 0 || N <= 0 || K <= 0 || nsplit <= 0 || count < (long long)D0 * N * K || (bias_partial && (bias_cols <= 0 || !dbias))) {
         sat_set_error("sat_wn_grad_splits: bad shape");
         return 1;
     }
-    SatWnSplitParams p{partial, v, g, norm, dv, dg, count, so_m, so_n, so_k, nsplit, D0, N, K};
+    SatWnSplitParams p{partial, v, g, norm, dv, dg, count, so_m, so_n, so_k, nsplit, D0, N, K, bias_partial, dbias, bias_cols};
     SAT_LAUNCH(sat_wn_grad_splits_kernel, dim3(D0), dim3(256), stream, p);
     return sat_check_launch("sat_wn_grad_splits");
 }

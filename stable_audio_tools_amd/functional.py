@@ -120,7 +120,8 @@ def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False, raw=Fal
     """dL/dW (Cout, Cin, K) of conv1d(snake(x)): k7 (dilation 1/3/9) -> the 7-tap bf16x3 kernels; k1 and K = 2*stride ->
     the short-kernel bf16x3 wgrad (chosen inside ops.conv_wgrad); anything else -> the fp32-MFMA kernel.
     bias_grad=True returns (dW, dbias): the bf16x3 kernels sum the dy rows they stream anyway.
-    raw=True: dW stays the kernel's split slabs (ops.WgradSlabs) — what _wn_backward takes."""
+    raw=True: dW stays the kernel's split slabs (ops.WgradSlabs), and dbias the per-split sums (C, R) one reduction short of the
+    gradient — what _wn_backward takes."""
     if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
         return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake, dy_rowsum=bias_grad, raw=raw)
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad, raw=raw)
@@ -137,10 +138,11 @@ def _wn_forward(ops, v, g):
     return w, (v, gf, norm)
 
 
-def _wn_backward(ops, slabs, saved, g_shape):
+def _wn_backward(ops, slabs, saved, g_shape, bias_partial=None):
+    """(dv, dg[, dbias]) from the slabs (+ the per-split sums of dy a raw _conv_wgrad(bias_grad=True) returned beside them)."""
     v, gf, norm = saved
-    dv, dg = ops.wn_grad_splits(slabs, v, gf, norm)
-    return dv, dg.view(g_shape)
+    out = ops.wn_grad_splits(slabs, v, gf, norm, bias_partial=bias_partial)
+    return (out[0], out[1].view(g_shape)) + tuple(out[2:])
 
 
 def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh_out=False, dsnake=None, tout=None, cache=None, emit=None):
@@ -216,7 +218,9 @@ class SnakeConv1dFn(torch.autograd.Function):
             if has_bias:
                 dw, dbias = dw
             if wn:
-                dw, dg = _wn_backward(ops, dw, wn, ctx.g_shape)
+                dw, dg, *rest = _wn_backward(ops, dw, wn, ctx.g_shape, bias_partial=dbias)
+                if has_bias:
+                    dbias = rest[0]
         elif has_bias:
             dbias = ops.rowsum(dy)
         dx = da = db = None
@@ -348,10 +352,16 @@ class ResidualUnitFn(torch.autograd.Function):
             dh, da2, db2 = _conv_dgrad(ops, dy, w2, k2, 1, 1, 0, c, t, (h, a2, b2), emit={"snake": None} if want_emit else None)
             dw1, dbias1 = _conv_wgrad(ops, dh, x, k1, 1, dil, pad1, (a1, b1), bias_grad=True, raw=bool(wn1))
         dg1 = dg2 = None
-        if wn1:
-            dw1, dg1 = _wn_backward(ops, dw1, wn1, gs1)
+        if wn1:         # a raw weight gradient brings its bias gradient as per-split sums (C, R): finished in the same launch
+            if dbias1.dim() == 2:
+                dw1, dg1, dbias1 = _wn_backward(ops, dw1, wn1, gs1, bias_partial=dbias1)
+            else:
+                dw1, dg1 = _wn_backward(ops, dw1, wn1, gs1)
         if wn2:
-            dw2, dg2 = _wn_backward(ops, dw2, wn2, gs2)
+            if dbias2.dim() == 2:
+                dw2, dg2, dbias2 = _wn_backward(ops, dw2, wn2, gs2, bias_partial=dbias2)
+            else:
+                dw2, dg2 = _wn_backward(ops, dw2, wn2, gs2)
         dx, da1, db1 = _conv_dgrad(ops, dh, w1, k1, 1, dil, pad1, c, t, (x, a1, b1), res=dy)
         return dx, da1, db1, dw1, dbias1, da2, db2, dw2, dbias2, None, None, None, None, None, None, dg1, dg2
 

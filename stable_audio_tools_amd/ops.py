@@ -102,19 +102,29 @@ class SatOps:
         self._chk(self.lib.sat_wn_grad(_ptr(v), _ptr(g), _ptr(norm), _ptr(dw), _ptr(dv), _ptr(dg), d0, r, self._stream(v)))
         return dv, dg
 
-    def wn_grad_splits(self, slabs, v, g, norm):
+    wn_fused = True     # weight norm inside the conv autograd units (functional._wn_forward); False: separate WeightNormFn nodes (A/B)
+
+    def wn_grad_splits(self, slabs, v, g, norm, bias_partial=None):
         """(dv, dg) of w = g * v / ||v|| from a weight-gradient kernel's split slabs (WgradSlabs) in ONE launch: the sum over the slabs,
-        the layout change and the weight-norm gradient (csrc/elementwise.hip sat_wn_grad_splits) — dW never exists in HBM."""
-        self._f32(v, g, norm, slabs.partial)
+        the layout change and the weight-norm gradient (csrc/elementwise.hip sat_wn_grad_splits) — dW never exists in HBM.
+        bias_partial (D0, R): per-split sums of dy (rowsum(..., partial=True) or a weight-gradient kernel's fused row sums); their sum,
+        the conv's bias gradient, is then a third result of the same launch: (dv, dg, dbias)."""
+        self._f32(v, g, norm, slabs.partial, bias_partial)
         m, n, k = slabs.dims
         if tuple(v.shape) != (m, n, k):
             raise ValueError("wn_grad_splits: slabs of a %s weight gradient for a %s weight" % ((m, n, k), tuple(v.shape)))
         dv = torch.empty_like(v)
         dg = torch.empty_like(g)
+        dbias, cols = None, 0
+        if bias_partial is not None:
+            if bias_partial.dim() != 2 or bias_partial.shape[0] != m:
+                raise ValueError("wn_grad_splits: bias_partial must be (D0, R)")
+            cols = bias_partial.shape[1]
+            dbias = torch.empty(m, dtype=torch.float32, device=v.device)
         so_m, so_n, so_k = slabs.strides
         self._chk(self.lib.sat_wn_grad_splits(_ptr(slabs.partial), slabs.nsplit, slabs.count, so_m, so_n, so_k, _ptr(v), _ptr(g), _ptr(norm),
-                                              _ptr(dv), _ptr(dg), m, n, k, self._stream(v)))
-        return dv, dg
+                                              _ptr(dv), _ptr(dg), m, n, k, _ptr(bias_partial), cols, _ptr(dbias), self._stream(v)))
+        return (dv, dg) if bias_partial is None else (dv, dg, dbias)
 
     def pack(self, w, mode, stride=1):
         self._f32(w)
@@ -496,6 +506,8 @@ class SatOps:
         dw = slabs if raw else slabs.reduce(self)
         if not lo_rowsum:
             return dw
+        if raw:
+            return dw, (rs if rs is not None else self.rowsum(lo, partial=True))
         return dw, (self._sum_last(rs) if rs is not None else self.rowsum(lo))
 
     # ---- fused backward of a ResidualUnit's 1x1 conv (csrc/ru_k1_bwd.hip): one pass over dy and h ----
@@ -564,20 +576,25 @@ class SatOps:
         dw = slabs if raw else slabs.reduce(self)
         if not dy_rowsum:
             return dw
+        if raw:         # the bias gradient one reduction short of done: wn_grad_splits finishes it
+            return dw, (rs if fused else self.rowsum(dy, partial=True))
         return dw, (self._sum_last(rs) if fused else self.rowsum(dy))
 
-    def rowsum(self, x):
+    def rowsum(self, x, partial=False):
         """(B, C, T) -> (C,) sum over batch and time: per-(channel, time split) partial sums laid out [C][nsplit], summed
-        by a second pass of the same kernel (deterministic, no atomics)."""
+        by a second pass of the same kernel (deterministic, no atomics).  partial=True: the first pass only, (C, nsplit) — for a
+        consumer that finishes the sum itself (wn_grad_splits)."""
         self._f32(x)
         b, c, t = x.shape
         while True:
             ns = self.lib.sat_rowsum_nsplit(t)
-            partial = torch.empty(c, ns, dtype=torch.float32, device=x.device)
-            self._chk(self.lib.sat_rowsum(_ptr(x), _ptr(partial), b, c, t, self._stream(x)))
+            part = torch.empty(c, ns, dtype=torch.float32, device=x.device)
+            self._chk(self.lib.sat_rowsum(_ptr(x), _ptr(part), b, c, t, self._stream(x)))
+            if partial:
+                return part
             if ns == 1:
-                return partial.view(c)
-            x, b, t = partial, 1, ns
+                return part.view(c)
+            x, b, t = part, 1, ns
 
     def sum_all(self, x):
         """Sum of EVERY element of a tensor as a 0-d fp32 tensor: passes of sat_rowsum over (1, 1, N) until one partial is left —

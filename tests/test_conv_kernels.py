@@ -364,7 +364,11 @@ def _wn_splits_case(ops, dev):
         summed = partial[:, :m * n * k].sum(0)
         dw = summed.view(k, m, n).permute(1, 2, 0).contiguous() if tap_major else summed.view(m, n, k)
         w, norm = ops.wn_fold(v, g.view(-1))
-        dv, dg = ops.wn_grad_splits(slabs, v, g.view(-1), norm)
+        bp = torch.randn(m, 1 + 37 * ns, generator=gen).to(dev)             # per-split sums of dy: the bias gradient rides along
+        dv, dg, dbias = ops.wn_grad_splits(slabs, v, g.view(-1), norm, bias_partial=bp)
+        assert (dbias.double().cpu() - bp.double().cpu().sum(1)).abs().max().item() <= 1e-5 * bp.abs().sum(1).max().item()
+        dv1, dg1 = ops.wn_grad_splits(slabs, v, g.view(-1), norm)
+        assert torch.equal(dv, dv1) and torch.equal(dg, dg1)
         dv0, dg0 = ops.wn_grad(v, g.view(-1), norm, dw)
         vd, gd = v.double().cpu().requires_grad_(True), g.double().cpu().requires_grad_(True)
         (gd * vd / vd.flatten(1).norm(dim=1).view(-1, 1, 1) * dw.double().cpu()).sum().backward()
