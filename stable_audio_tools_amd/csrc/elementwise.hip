@@ -106,54 +106,112 @@ struct SatWnSplitParams {
     float* dbias;                   // (D0): their sums — the bias gradient's last reduction rides along
     int bias_cols;
 };
-SAT_DEVICE float sat_wn_slab_sum(const float* base, long long count, int nsplit) {
+#define SAT_WN_THREADS 1024
+// sum over the slabs z = z0, z0 + zstep, ... of one element / of four consecutive elements
+SAT_DEVICE float sat_wn_slab_sum(const float* base, long long count, int z0, int zstep, int nsplit) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 4 <= nsplit; z += 4) {
-        s0 += base[(size_t)(z + 0) * count];
-        s1 += base[(size_t)(z + 1) * count];
-        s2 += base[(size_t)(z + 2) * count];
-        s3 += base[(size_t)(z + 3) * count];
+    int z = z0;
+    for (; z + 3 * zstep < nsplit; z += 4 * zstep) {
+        s0 += base[(size_t)z * count];
+        s1 += base[(size_t)(z + zstep) * count];
+        s2 += base[(size_t)(z + 2 * zstep) * count];
+        s3 += base[(size_t)(z + 3 * zstep) * count];
     }
-    for (; z < nsplit; ++z) s0 += base[(size_t)z * count];
+    for (; z < nsplit; z += zstep) s0 += base[(size_t)z * count];
     return (s0 + s1) + (s2 + s3);
 }
-__global__ void __launch_bounds__(256) sat_wn_grad_splits_kernel(SatWnSplitParams p) {
+SAT_DEVICE f32x4 sat_wn_slab_sum4(const float* base, long long count, int z0, int zstep, int nsplit) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s[8] = {zero, zero, zero, zero, zero, zero, zero, zero};        // eight 16-byte loads in flight per thread
+    int z = z0;
+    for (; z + 7 * zstep < nsplit; z += 8 * zstep) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += *reinterpret_cast<const f32x4*>(base + (size_t)(z + u * zstep) * count);
+    }
+    for (; z < nsplit; z += zstep) s[0] += *reinterpret_cast<const f32x4*>(base + (size_t)z * count);
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+SAT_DEVICE float sat_block_sum_1024(float s, float* red) {
+    s = sat_wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SAT_WN_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+// 16 waves per row: the narrow levels have few rows (128) and MANY slabs (256), so a row's workgroup must keep enough loads in flight
+// by itself.  The slab sum is spread over the threads as (z part, item): `nparts` groups of threads each add every nparts-th slab of
+// all the row's items (item = 4 consecutive elements when the layout allows 16-byte loads), park their partial rows in LDS
+// [part][R], and the parts are added in index order — deterministic.
+__global__ void __launch_bounds__(SAT_WN_THREADS) sat_wn_grad_splits_kernel(SatWnSplitParams p) {
     __shared__ float row[SAT_WN_ROW_CAP];
-    __shared__ float red[4];
+    __shared__ float red[SAT_WN_THREADS / 64];
     const int d = blockIdx.x;
     const int R = p.N * p.K;
     const float* base = p.partial + (size_t)d * p.so_m;
     const float* v = p.v + (size_t)d * R;
     const bool staged = R <= SAT_WN_ROW_CAP;
     const bool tap_major = p.so_n == 1 && p.K > 1;
+    const bool torch_order = p.so_k == 1 && p.so_n == p.K;
+    const bool vec = ((p.count | p.so_m) & 3) == 0 && (((uintptr_t)p.partial) & 15) == 0 &&
+                     (tap_major ? ((p.N | p.so_k) & 3) == 0 : (torch_order && (R & 3) == 0));
     float s = 0.f;
     if (staged) {
-        for (int i = threadIdx.x; i < R; i += 256) {
-            int n, k;
-            if (tap_major) { k = i / p.N; n = i - k * p.N; }
-            else           { n = i / p.K; k = i - n * p.K; }
-            row[n * p.K + k] = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+        const int items = vec ? (R >> 2) : R;
+        int nparts = SAT_WN_THREADS / items;
+        if (nparts > 8) nparts = 8;
+        if (nparts > p.nsplit) nparts = p.nsplit;
+        if (nparts < 1) nparts = 1;
+        while (nparts > 1 && (long long)nparts * R > SAT_WN_ROW_CAP) --nparts;
+        for (int idx = threadIdx.x; idx < items * nparts; idx += SAT_WN_THREADS) {
+            const int zp = idx / items, it = idx - zp * items;
+            float* dst = row + (size_t)zp * R;
+            if (vec) {
+                if (tap_major) {                                   // four consecutive n of one tap
+                    const int nq = p.N >> 2;
+                    const int k = it / nq, n = (it - k * nq) << 2;
+                    const f32x4 a = sat_wn_slab_sum4(base + (size_t)k * p.so_k + n, p.count, zp, nparts, p.nsplit);
+                    dst[(n + 0) * p.K + k] = a[0];
+                    dst[(n + 1) * p.K + k] = a[1];
+                    dst[(n + 2) * p.K + k] = a[2];
+                    dst[(n + 3) * p.K + k] = a[3];
+                } else {                                           // torch order: four consecutive r
+                    const f32x4 a = sat_wn_slab_sum4(base + 4 * it, p.count, zp, nparts, p.nsplit);
+                    *reinterpret_cast<f32x4*>(dst + 4 * it) = a;
+                }
+            } else {
+                int n, k;
+                if (tap_major) { k = it / p.N; n = it - k * p.N; }
+                else           { n = it / p.K; k = it - n * p.K; }
+                dst[n * p.K + k] = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, zp, nparts, p.nsplit);
+            }
         }
         __syncthreads();
-        for (int r = threadIdx.x; r < R; r += 256) s += v[r] * row[r];
+        for (int r = threadIdx.x; r < R; r += SAT_WN_THREADS) {
+            float a = row[r];
+            for (int zp = 1; zp < nparts; ++zp) a += row[(size_t)zp * R + r];
+            row[r] = a;                                            // (every thread touches its own r of every part only)
+            s += v[r] * a;
+        }
     } else {
-        for (int r = threadIdx.x; r < R; r += 256) {
+        for (int r = threadIdx.x; r < R; r += SAT_WN_THREADS) {
             const int n = r / p.K, k = r - n * p.K;
-            s += v[r] * sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+            s += v[r] * sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, 0, 1, p.nsplit);
         }
     }
-    s = sat_block_sum_256(s, red);
+    s = sat_block_sum_1024(s, red);
     const float nrm = p.norm[d];
     const float g = p.g[d];
     const float c1 = g / nrm, c2 = g * s / (nrm * nrm * nrm);
     float* dv = p.dv + (size_t)d * R;
-    for (int r = threadIdx.x; r < R; r += 256) {
+    for (int r = threadIdx.x; r < R; r += SAT_WN_THREADS) {
         float dw;
         if (staged) dw = row[r];
         else {
             const int n = r / p.K, k = r - n * p.K;
-            dw = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, p.nsplit);
+            dw = sat_wn_slab_sum(base + (size_t)n * p.so_n + (size_t)k * p.so_k, p.count, 0, 1, p.nsplit);
         }
         dv[r] = c1 * dw - c2 * v[r];
     }
@@ -161,8 +219,8 @@ __global__ void __launch_bounds__(256) sat_wn_grad_splits_kernel(SatWnSplitParam
     if (p.bias_partial) {
         const float* bp = p.bias_partial + (size_t)d * p.bias_cols;
         float b = 0.f;
-        for (int i = threadIdx.x; i < p.bias_cols; i += 256) b += bp[i];
-        b = sat_block_sum_256(b, red);
+        for (int i = threadIdx.x; i < p.bias_cols; i += SAT_WN_THREADS) b += bp[i];
+        b = sat_block_sum_1024(b, red);
         if (threadIdx.x == 0) p.dbias[d] = b;
     }
 }
@@ -174,7 +232,7 @@ extern "C" int sat_wn_grad_splits(const float* partial, int nsplit, long long co
         return 1;
     }
     SatWnSplitParams p{partial, v, g, norm, dv, dg, count, so_m, so_n, so_k, nsplit, D0, N, K, bias_partial, dbias, bias_cols};
-    SAT_LAUNCH(sat_wn_grad_splits_kernel, dim3(D0), dim3(256), stream, p);
+    SAT_LAUNCH(sat_wn_grad_splits_kernel, dim3(D0), dim3(SAT_WN_THREADS), stream, p);
     return sat_check_launch("sat_wn_grad_splits");
 }
 

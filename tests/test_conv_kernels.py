@@ -353,11 +353,12 @@ def _wn_splits_case(ops, dev):
     slabs, a row longer than the LDS staging buffer (summed twice instead)."""
     from stable_audio_tools_amd.ops import WgradSlabs
     gen = torch.Generator().manual_seed(11)
-    for (m, n, k, ns, tap_major) in ((5, 12, 7, 3, True), (130, 64, 7, 1, True), (3, 9, 1, 6, False), (40, 24, 16, 5, False),
-                                     (2, 2400, 7, 2, True), (2, 2400, 7, 3, False)):
+    for (m, n, k, ns, tap_major, pad) in ((5, 12, 7, 3, True, 8), (130, 64, 7, 1, True, 0), (3, 9, 1, 6, False, 8), (40, 24, 16, 5, False, 8),
+                                          (4, 6, 7, 9, True, 8), (6, 12, 7, 20, True, 7), (16, 32, 4, 11, False, 3), (128, 128, 7, 37, True, 0),
+                                          (2, 2400, 7, 2, True, 8), (2, 2400, 7, 3, False, 8)):
+        # (16-byte loads need aligned slabs: the odd paddings take the 4-byte path; 2400 x 7 > the LDS staging buffer: summed twice)
         v = torch.randn(m, n, k, generator=gen).to(dev)
         g = (torch.rand(m, 1, 1, generator=gen) + .5).to(dev)
-        pad = 8                                                           # slabs may be longer than M * N * K
         partial = torch.randn(ns, m * n * k + pad, generator=gen).to(dev)
         strides = (n, 1, m * n) if tap_major else (n * k, k, 1)
         slabs = WgradSlabs(partial, ns, (m, n, k), strides)
