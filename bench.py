@@ -243,6 +243,26 @@ class AttnProfiler:
                         "peak = dense bf16 MFMA (fp32 mode: /3 for the bf16x3 split); cross-attention (GQA, M=130 keys) apart"}
 
 
+
+_REF_DIT = {}
+
+
+def _ref_dit(dcfg, train=False):
+    """The reference's DiffusionTransformer (fp32, host) for `dcfg`, built ONCE per configuration and shared by every CPU leg of the line
+    (sampler baseline, the two parity evaluations, the training baseline): its default initialisation alone takes ~8 s of host time.
+    Callers load the weights they compare against; the training leg's gradients are dropped by the next call."""
+    import contextlib
+    import refimport
+    key = json.dumps(dcfg, sort_keys=True)
+    ref = _REF_DIT.get(key)
+    if ref is None:
+        with contextlib.redirect_stdout(sys.stderr):
+            refimport.import_reference()
+            from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
+            ref = _REF_DIT[key] = RefDiT(**dcfg).float()
+    ref.zero_grad(set_to_none=True)
+    return ref.train(train)
+
 def dit_cpu_baseline(dcfg, latent_len, ctx_len):
     """One sampler step's model evaluation (fp32, CFG batch of 2) on this box's host cores: the reference's own
     DiffusionTransformer when /root/reference is importable (kind "reference"), the oracle port otherwise.  Thread count =
@@ -258,12 +278,7 @@ def dit_cpu_baseline(dcfg, latent_len, ctx_len):
     t = torch.tensor([0.5])
     kind = "port"
     if _reference_importable():
-        import contextlib
-        import refimport
-        with contextlib.redirect_stdout(sys.stderr):
-            refimport.import_reference()
-        from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
-        ref = RefDiT(**dcfg).float().train(False)
+        ref = _ref_dit(dcfg)
         kind = "reference"
 
         def step():
@@ -307,16 +322,12 @@ def dit_train_cpu_baseline(dcfg, latent_len, ctx_len):
     target = torch.randn(1, dcfg["io_channels"], latent_len, generator=g)
     t = torch.tensor([0.5])
     if _reference_importable():
-        import contextlib
-        import refimport
-        with contextlib.redirect_stdout(sys.stderr):
-            refimport.import_reference()
-            from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
-            ref = RefDiT(**dcfg).float().train(True)
+        ref = _ref_dit(dcfg, train=True)
         t0 = time.perf_counter()
         out = ref(x, t, cross_attn_cond=cross, global_embed=glob, cfg_dropout_prob=0.1)
         (out - target).square().mean().backward()
         dt = time.perf_counter() - t0
+        ref.zero_grad(set_to_none=True)
         return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
                 "sample": f"1 sample: the reference's DiffusionTransformer forward (per-layer checkpointing as it trains) + autograd backward "
                           f"(fp32, N={latent_len + 1}, no optimizer step), single evaluation = {dt:.2f} s at {cores} threads"}
@@ -542,12 +553,7 @@ def dit_eval_parity(model, dcfg, x, cross, glob, kw, bound=4e-2):
     torch.set_num_threads(cores)
     want = {}
     if _reference_importable():
-        import contextlib
-        import refimport
-        with contextlib.redirect_stdout(sys.stderr):
-            refimport.import_reference()
-            from stable_audio_tools.models.dit import DiffusionTransformer as RefDiT
-            ref = RefDiT(**dcfg).float().train(False)
+        ref = _ref_dit(dcfg)
         ref.load_state_dict(sd, strict=False)
         kind = "reference"
         rbox, rundo = _capture_halves(ref)
