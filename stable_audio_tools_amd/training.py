@@ -60,11 +60,12 @@ class FlatParameters:
         for p, gv in zip(self.params, self._views):
             p.grad = None if self.steal else gv
 
-    def gather_grads(self, ops=None):
-        """Every gradient autograd left outside the flat buffer (adopted tensors: steal mode; replaced `.grad`s otherwise) is copied
-        into its view and `.grad` re-pointed at the view.  A few sat_multi_copy launches on the GPU (160 parameters each; the table is
-        part of the launch, so a HIP-graph capture records it too); per-parameter copies when no kernel library serves the device."""
-        todo = [i for i, (p, gv) in enumerate(zip(self.params, self._views)) if p.grad is not None and p.grad.data_ptr() != gv.data_ptr()]
+    def fold_grads(self, indices, ops=None):
+        """The gradients of parameters `indices` that autograd left outside the flat buffer (adopted tensors: steal mode; replaced
+        `.grad`s otherwise) are copied into their views and `.grad` re-pointed at the view.  A few sat_multi_copy launches on the GPU
+        (160 parameters each; the table is part of the launch, so a HIP-graph capture records it too); per-parameter copies when no
+        kernel library serves the device."""
+        todo = [i for i in indices if self.params[i].grad is not None and self.params[i].grad.data_ptr() != self._views[i].data_ptr()]
         batched = False
         if len(todo) > 1:
             srcs = [self.params[i].grad for i in todo]
@@ -81,7 +82,12 @@ class FlatParameters:
             if not batched:
                 gv.copy_(p.grad)
             p.grad = gv
-        for p, gv in zip(self.params, self._views):      # parameters without a gradient this step read the zeroed view
+
+    def gather_grads(self, ops=None):
+        """fold_grads over every parameter (what an overlapped exchange has not folded bucket by bucket already); parameters without a
+        gradient this step read the zeroed view."""
+        self.fold_grads(range(len(self.params)), ops)
+        for p, gv in zip(self.params, self._views):
             if p.grad is None:
                 p.grad = gv
 
@@ -185,6 +191,8 @@ class GradAllReduce:
         self._done = [None] * len(self.buckets)          # per-bucket completion events (side stream)
         self.launch_log = []                             # (bucket index, launched from a hook?) of the current step — read by the tests
         self._in_hook = False
+        self._pending = []                               # parameters whose final gradient is not in the flat buffer yet (hooks)
+        self._fold_ops = ops                             # SatOps handle for the folds (None: the product singleton, as everywhere)
         # timing=True (bench.py --ddp-single-rank / --gpus N): the per-bucket events are created with timing enabled and kept, together
         # with the events mark_backward_start() / mark_backward_end() record, until timeline() reads them — evidence of the overlap
         # (when each bucket's exchange was enqueued and when it completed, relative to the backward pass that produced it)
@@ -209,10 +217,11 @@ class GradAllReduce:
 
     def _make_hook(self, i):
         def hook(param):
-            gv = self.flat._views[i]
-            if param.grad is not None and param.grad.data_ptr() != gv.data_ptr():      # autograd replaced the view: fold it back
-                gv.copy_(param.grad)
-                param.grad = gv
+            # the gradient is final (post-accumulate) but may live outside the flat buffer (adopted tensors: FlatParameters.steal): it is
+            # folded in together with every other pending one when a bucket completes — ONE sat_multi_copy launch per bucket instead of a
+            # copy launch per parameter between the backward's kernels (each such launch costs the step 10-18 us)
+            self._pending.append(i)
+            complete = []
             for bi in self._of_param[i]:
                 self._left[bi] -= 1
                 if self._left[bi] < 0:
@@ -220,12 +229,21 @@ class GradAllReduce:
                                        "exchange supports ONE backward pass per step (use overlap=False for gradient accumulation "
                                        "or several backward() calls into the same parameters)")
                 if self._left[bi] == 0:
-                    self._in_hook = True
-                    try:
+                    complete.append(bi)
+            if complete:
+                self._flush_pending()
+                self._in_hook = True
+                try:
+                    for bi in complete:
                         self._launch(bi)
-                    finally:
-                        self._in_hook = False
+                finally:
+                    self._in_hook = False
         return hook
+
+    def _flush_pending(self):
+        if self._pending:
+            idx, self._pending = self._pending, []
+            self.flat.fold_grads(idx, self._fold_ops)
 
     def _exchange(self, chunk):
         buf = chunk if self.comm_dtype is None else chunk.to(self.comm_dtype)
@@ -278,6 +296,7 @@ class GradAllReduce:
         """All buckets exchanged and visible to the compute stream; re-arms the hooks' counters for the next step."""
         if not self.active:
             return
+        self._flush_pending()
         for bi in range(len(self.buckets)):
             self._launch(bi)
         for bi in range(len(self.buckets)):
@@ -321,6 +340,7 @@ class GradAllReduce:
         for bi in range(len(self.buckets)):
             self.wait_bucket(bi)
         self.launch_log = []
+        self._pending = []
         self._fired = [False] * len(self.buckets)
         self._done = [None] * len(self.buckets)
         if self.overlap:
@@ -840,7 +860,7 @@ class DiTTrainStep:
         self.flat = FlatParameters(list(model.parameters()), pad_to=max(world, 1))
         self.opt = FusedAdamW(self.flat, lr, betas=betas, weight_decay=weight_decay, ops=ops, use_ema=use_ema)
         self.comm = GradAllReduce(self.flat, bucket_bytes=bucket_bytes, mode=ddp_mode, overlap=ddp_overlap, comm_dtype=ddp_comm_dtype,
-                                  single_rank_exchange=ddp_single_rank)
+                                  single_rank_exchange=ddp_single_rank, ops=ops)
         self.cfg_dropout_prob = cfg_dropout_prob
         self.timestep_sampler = timestep_sampler
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
