@@ -143,8 +143,12 @@ def _ddp_worker(rank, world, port, q, ddp_mode="all_reduce", overlap=True, comm_
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    from emu_util import use_emu_ops
+    from emu_util import emu_ops, use_emu_ops
     use_emu_ops()
+    sim = emu_ops()
+    folds = []                                   # sizes of the gradient folds (one sat_multi_copy call each)
+    plain_multi_copy = sim.multi_copy
+    sim.multi_copy = lambda srcs, dsts: (folds.append(len(srcs)), plain_multi_copy(srcs, dsts))[1]
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -154,6 +158,11 @@ def _ddp_worker(rank, world, port, q, ddp_mode="all_reduce", overlap=True, comm_
                                       bucket_bytes=4096,          # tiny buckets: many of them fire from the hooks mid-backward
                                       ddp_comm_dtype={None: None, "bf16": torch.bfloat16}[comm_dtype])
         assert len(stepper.comm.buckets) > 4
+        # adopted gradients reach the flat buffer in batches: at most one fold per bucket (+ the final gather) when the hooks exchange,
+        # ONE gather otherwise — never a copy per parameter — and every parameter's gradient ends up as its flat view
+        nparams = len(stepper.flat.params)
+        assert 1 <= len(folds) <= (len(stepper.comm.buckets) + 1 if overlap else 1) and sum(folds) <= nparams, (folds, nparams)
+        assert max(folds) > 1 and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(stepper.flat.params, stepper.flat._views))
         log = stepper.comm.last_launch_log
         assert sorted(b for b, _ in log) == list(range(len(stepper.comm.buckets)))                 # every bucket exactly once
         assert (sum(h for _, h in log) >= len(log) - 1) if overlap else not any(h for _, h in log)   # ... from the hooks when overlapped
