@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the script of round 5, call 1 — the SAT_*_LEAN switches it sets were removed from the tree in the commit that followed this call)
 # Round-5 opener: every arm written blind at the end of round 4 (lean attention fwd/bwd, lean GEMM K loops bf16 + fp8, two-row LayerNorm,
 # the native RCCL exchange behind the C-ABI) executed on gfx950 and timed against the product kernels, in ONE call.
 # Output: gpurun_out/r05_lean/.  A trimmed version of tools/r05_attn_lean_ab.sh (GPU-minute budget).
