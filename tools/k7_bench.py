@@ -1,5 +1,6 @@
 """k = 7 conv (ResidualUnit) forward / data-gradient at the Oobleck level shapes: microseconds and fp32-equivalent TFLOP/s,
-direct kernel (conv1d_bf16x3_k7.h) vs planes kernel (conv1d_bf16x3_k7p.h: pre-pass + conv).  MI355X only."""
+direct kernel (conv1d_bf16x3_k7.h) vs the planes kernel every C >= 64 level takes (conv1d_bf16x3_k7q.h: pre-pass + conv; in the model the
+producer's epilogue writes the planes instead of the pre-pass).  MI355X only."""
 import json, sys
 import torch
 sys.path.insert(0, '.')
@@ -27,13 +28,13 @@ for (c, t, dil) in shapes:
     row = {"C": c, "T": t, "dil": dil}
     flops = 2.0 * c * c * 7 * t
     wq = o.pack_bf16x3(w, 0, 1, q=True)
-    for name, flag, wts in (("direct", False, wp), ("planes", True, wp), ("q", True, wq)):
-        o.k7_planes = flag
-        o.k7_planes_min_cin = 1
+    for name, flag, wts in (("direct", False, wp), ("q", True, wq)):
+        o.k7q = flag
+        o.k7q_min_cin = o.k7q_min_cout = 1
         us = timeit(lambda: o.conv1d_bf16x3(x, wts, c, 7, 1, dil, pad, bias=bias, snake=(la, lb)))
         usb = timeit(lambda: o.conv1d_bf16x3(x, wts, c, 7, 1, dil, pad, dsnake=(x2, la, lb)))
         row[name] = {"fwd_us": round(us, 1), "fwd_tf": round(flops / us * 1e-6, 1), "dgrad_us": round(usb, 1), "dgrad_tf": round(flops / usb * 1e-6, 1)}
-    # the planes pre-pass alone (SnakeBeta + split of the input), included in the "planes" and "q" rows above
+    # the planes pre-pass alone (SnakeBeta + split of the input), included in the "q" row above
     import ctypes
     rows = o.lib.sat_conv1d_k7_plane_rows(t, t, pad)
     hi = torch.empty(((c + 7) // 8) * rows * 8, dtype=torch.int16, device='cuda'); lo = torch.empty_like(hi)
