@@ -1,5 +1,5 @@
 """Run ONE conv configuration a few times (for rocprofv3 --pmc runs).  usage: pmc_conv.py <kind> [C] [T]
-kind: conv7 | conv7q | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | wgrads2 | wgrads8 | disc9 | calib"""
+kind: conv7 | conv7q | conv7ns | dgrad7 | conv1 | wgrad7 | wgrad1 | wgrads2 | wgrads8 | ruk1 | disc9 | calib"""
 import os
 import sys
 
@@ -25,8 +25,8 @@ if kind == "conv7":
     pl = ops.pack_bf16x3(w7)
     fn = lambda: ops.conv1d_bf16x3(x, pl, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
 elif kind == "conv7q":      # conv1d_bf16x3_k7q.h (the shipped kernel: planes pre-pass + q-packed weights)
-    ops.k7_planes = True
-    ops.k7_planes_min_cin = 1
+    ops.k7q = True
+    ops.k7q_min_cin = ops.k7q_min_cout = 1
     pl = ops.pack_bf16x3(w7, 0, 1, q=True)
     fn = lambda: ops.conv1d_bf16x3(x, pl, C, 7, 1, 9, 27, bias=bias, snake=(la, lb))
 elif kind == "disc9":       # csrc/disc_conv.hip: the discriminator's 64 -> 64 (3 x 9) layer at the n_fft = 1024 scale of a 2 097 152-sample item
@@ -63,6 +63,9 @@ elif kind in ("wgrads2", "wgrads8"):
     la2 = torch.randn(ci, device=dev) * 0.1
     lb2 = torch.randn(ci, device=dev) * 0.1
     fn = lambda: ops.conv_wgrad(dyl, xh, 2 * s_, s_, 1, (s_ + 1) // 2, snake=(la2, lb2), snake_on=2, lo_rowsum=True)
+elif kind == "ruk1":         # csrc/ru_k1_bwd.hip: the whole backward of a unit's 1 x 1 conv (C = 128) in one pass over dy and h
+    wt = ops.ru_k1_pack(w1)
+    fn = lambda: ops.ru_k1_bwd(dy, x, w1, (la, lb), emit=True, wt=wt, raw=True)
 elif kind == "calib":
     # known-traffic calibration launches: sat_rowsum reads C*T*4 bytes with 16-byte loads; the torch copy reads and
     # writes C*T*4 bytes
