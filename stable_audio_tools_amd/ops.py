@@ -48,7 +48,8 @@ class WgradSlabs:
 
     def reduce(self, ops):
         m, n, k = self.dims
-        flat = ops._reduce_rows(self.partial, self.nsplit, m * n * k)
+        part = self.partial if self.count == m * n * k else self.partial[:, :m * n * k].contiguous()      # (slabs longer than the gradient)
+        flat = ops._reduce_rows(part, self.nsplit, m * n * k)
         if self.strides == (n * k, k, 1):
             return flat.view(m, n, k)
         if self.strides == (n, 1, m * n):

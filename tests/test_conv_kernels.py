@@ -386,3 +386,31 @@ def test_wn_grad_from_slabs_sim(emu):
 @pytest.mark.gpu
 def test_wn_grad_from_slabs_gpu(hip):
     _wn_splits_case(hip, "cuda")
+
+
+def test_wn_grad_from_slabs_random_shapes_sim(emu):
+    """Randomised shapes through sat_wn_grad_splits on the simulator: degenerate dims (one row, one input channel, one tap, one slab),
+    every combination of layout, slab alignment and z-part count the kernel's dispatch distinguishes, against the separate kernels."""
+    import random
+    from stable_audio_tools_amd.ops import WgradSlabs
+    rnd = random.Random(5)
+    gen = torch.Generator().manual_seed(5)
+    for case in range(40):
+        m, n = rnd.randint(1, 9), rnd.choice([1, 2, 3, 4, 8, 12, 17, 40, 64])
+        k, ns = rnd.choice([1, 2, 3, 4, 7, 16]), rnd.choice([1, 2, 3, 5, 8, 12, 33])
+        tap_major, pad = rnd.random() < 0.5, rnd.choice([0, 1, 4, 8])
+        v = torch.randn(m, n, k, generator=gen)
+        g = torch.rand(m, generator=gen) + .5
+        partial = torch.randn(ns, m * n * k + pad, generator=gen)
+        slabs = WgradSlabs(partial, ns, (m, n, k), (n, 1, m * n) if tap_major else (n * k, k, 1))
+        summed = partial[:, :m * n * k].double().sum(0).float()
+        dw = summed.view(k, m, n).permute(1, 2, 0).contiguous() if tap_major else summed.view(m, n, k)
+        _, norm = emu.wn_fold(v, g)
+        bp = torch.randn(m, rnd.choice([1, 3, 64, 300]), generator=gen)
+        dv, dg, dbias = emu.wn_grad_splits(slabs, v, g, norm, bias_partial=bp)
+        dv0, dg0 = emu.wn_grad(v, g, norm, dw)
+        scale = max(dw.abs().max().item(), 1e-6)
+        assert (dv - dv0).abs().max().item() <= 2e-5 * max(dv0.abs().max().item(), scale), (case, m, n, k, ns, tap_major, pad)
+        assert (dg - dg0).abs().max().item() <= 2e-5 * max(dg0.abs().max().item(), scale), (case, m, n, k, ns, tap_major, pad)
+        assert (dbias - bp.sum(1)).abs().max().item() <= 1e-5 * max(bp.abs().sum(1).max().item(), 1e-6)
+        assert torch.equal(slabs.reduce(emu), dw) or (slabs.reduce(emu) - dw).abs().max().item() <= 1e-5 * scale
