@@ -791,7 +791,7 @@ def pmc_traffic(kernel, args):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     try:
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01g_pmc_traffic.json"):        # the newest committed profile that has this kernel
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 doc = json.load(open(path))
@@ -811,7 +811,7 @@ def hbm_roofline(args, ms_per_step):
     if args.sample_size != 2097152 or args.batch != 1:
         return None
     path = None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):      # the newest committed profile
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):      # the newest committed profile
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             path = os.path.join(ROOT, "profiles", name)
             break
