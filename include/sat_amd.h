@@ -334,6 +334,20 @@ int sat_attention_rowdot(const void* dout, const void* out, float* dsum, int B, 
 int sat_attention_bwd(const short* const* planes, const float* lse, const float* dsum, void* dq, void* dk, void* dv,
                       int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim, float scale, int dtype,
                       void* stream);
+/* Attention against a SHORT key sequence — the DiT's cross-attention (transformer.py:351-357, :459-472; kv heads repeated per
+ * :408-411; 130 conditioning tokens): bf16 planes, head dim 64, Nk <= 256.  All keys of a (batch item, kv head) are staged into LDS
+ * once per workgroup and serve every query head of the GQA group; exact one-pass softmax (csrc/attention_cross.h).
+ * sat_attention_cross_ok: 1 when the shape is served (the callers fall back to sat_attention_fwd / _bwd otherwise). */
+int sat_attention_cross_ok(int H, int Hkv, int Nk, int head_dim, int dtype);
+int sat_attention_cross_fwd(const short* q_rm, const short* k_rm, const short* v_tr, void* o, float* lse, int B, int H, int Hkv,
+                            int Nq, int Nk, int Nqp, int Nkp, int head_dim, float scale, void* stream);
+/* bytes of caller-owned workspace for sat_attention_cross_bwd (fp32 dK / dV slabs of the query ranges; -1: bad shape) */
+long long sat_attention_cross_bwd_ws(int B, int H, int Hkv, int Nq, int Nk);
+/* backward: planes[16] as sat_attention_bwd (only the hi planes are read); three launches — dQ, dK / dV partial sums per query
+ * range into ws, their sum in index order (no atomics).  dq: (B,H,Nq,64), dk / dv: (B,Hkv,Nk,64) bf16. */
+int sat_attention_cross_bwd(const short* const* planes, const float* lse, const float* dsum, void* dq, void* dk, void* dv,
+                            void* ws, long long ws_bytes, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim,
+                            float scale, void* stream);
 
 /* LayerNorm.forward (transformer.py:236-241: gamma, beta buffer, eps) fused with the adaLN modulation
  * y = LN(x) * (1 + scale[b]) + shift[b] (TransformerBlock.forward :682, :697).  x, y: (rows, D); gamma/beta fp32;
@@ -442,14 +456,16 @@ int sat_splitk_epilogue(const float* slabs, int S, const float* bias, const void
  * as sat_gemm_bf16 / sat_gemm_qkv_bf16 with A (M, K), B (N, K) in fp8 bytes (K, lda, ldb multiples of 16) on
  * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; alpha = device scalar (dequant scale of A x that of B).
  * row_alpha (M floats, or NULL): per-row factor applied with alpha — A quantised row by row (sat_quant_fp8_rows; alpha = B's scale).
+ * col_alpha (N floats, 16-byte aligned, or NULL): per-column factor — B's rows (the weight's output channels) quantised one by one
+ * (sat_quant_fp8_rows on the weight); alpha may be NULL when col_alpha is given.
  * tile: 0 = 128x128 (4 waves), 4 = 256x256, 7 = 160x256, 8 = 128x128 (eight-wave kernels, as sat_gemm_bf16). */
 int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                  const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
-                 long long ldp, const void* zeros, const float* alpha, const float* row_alpha, int M, int N, int K, int epilogue,
-                 int out_f32, int tile, void* stream);
+                 long long ldp, const void* zeros, const float* alpha, const float* row_alpha, const float* col_alpha, int M, int N,
+                 int K, int epilogue, int out_f32, int tile, void* stream);
 int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
-                     void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha, int nb,
-                     int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream);
+                     void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha,
+                     const float* col_alpha, int nb, int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream);
 /* dst (R, C) fp8 e4m3 = saturate_448(src * qscale[0]), round to nearest even; src fp32 | bf16; qscale a DEVICE scalar. */
 /* Dynamic per-tensor scale of the fp8 quantisation in one launch (last-arriving block reduces the per-block maxima): scales[0] =
  * 448 / max|src| (what sat_quant_fp8 takes as qscale), scales[1] = max|src| / 448 (the GEMM's de-quantisation factor).  work: >= 1 +

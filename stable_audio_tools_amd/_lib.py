@@ -98,11 +98,15 @@ SIGNATURES = {
     "sat_attention_fwd": (_I, [_P] * 8 + [_I] * 8 + [_F, _I, _P]),
     "sat_attention_rowdot": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_attention_bwd": (_I, [_P] * 6 + [_I] * 8 + [_F, _I, _P]),
+    "sat_attention_cross_ok": (_I, [_I] * 5),
+    "sat_attention_cross_fwd": (_I, [_P] * 5 + [_I] * 8 + [_F, _P]),
+    "sat_attention_cross_bwd_ws": (_L, [_I] * 5),
+    "sat_attention_cross_bwd": (_I, [_P] * 7 + [_L] + [_I] * 8 + [_F, _P]),
     # gemm.hip
     "sat_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P] + [_I] * 7 + [_P]),
     "sat_gemm_qkv_bf16": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P] + [_I] * 8 + [_P]),
-    "sat_gemm_fp8": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P, _P, _P] + [_I] * 6 + [_P]),
-    "sat_gemm_qkv_fp8": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "sat_gemm_fp8": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _P, _L, _P, _P, _P, _P] + [_I] * 6 + [_P]),
+    "sat_gemm_qkv_fp8": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "sat_quant_fp8": (_I, [_P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "sat_quant_fp8_rows": (_I, [_P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "sat_absmax_scale": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),

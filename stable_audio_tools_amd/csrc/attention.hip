@@ -1296,3 +1296,5 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
     }
     return sat_check_launch("sat_attention_bwd");
 }
+
+#include "attention_cross.h"

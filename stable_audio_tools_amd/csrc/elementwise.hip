@@ -23,6 +23,23 @@ int sat_check_launch(const char* what) {
     return 0;
 }
 extern "C" const char* sat_last_error() { return g_sat_err; }
+// compute units of the current device, queried once per thread (persistent kernels launch one workgroup per CU); 256 on the simulator
+int sat_cu_count() {
+#if defined(SAT_HIPEMU)
+    return 256;
+#else
+    static thread_local int dev_cached = -1, cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != dev_cached) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+        dev_cached = dev;
+    }
+    return cus;
+#endif
+}
 
 extern "C" int sat_abi_version() { return 1; }
 extern "C" int sat_is_simulator() {

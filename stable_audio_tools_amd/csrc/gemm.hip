@@ -36,6 +36,8 @@ struct SatGemmParams {
     const short* zeros;   // >= 16 bytes of zeros: source of the k-chunks past K
     const float* alpha;   // device scalar multiplied into the accumulators before the epilogue (fp8 de-quantisation), or null
     const float* row_alpha; // (M) per-row factor applied with it (fp8 activations quantised per row: sat_quant_fp8_rows), or null
+    const float* col_alpha; // (N) per-COLUMN factor = per-output-channel de-quantisation scale of B's rows (fp8 weights quantised row by
+                            // row, round 6: one scale per output channel instead of one per tensor), or null
     long long lda, ldb, ldc, ldr, ldg, ldp;
     int M, N, K;
     int rows_per_gate;
@@ -161,6 +163,11 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
 #pragma unroll
                     for (int e = 0; e < 4; ++e) of[e] *= p.row_alpha[mrow0 + re[e] < p.M ? mrow0 + re[e] : p.M - 1];
                 }
+                if (p.col_alpha) {
+                    const float ca = p.col_alpha[nwin + d];      // (the window is inside N: sat_gemm_window_is_v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) of[e] *= ca;
+                }
                 const uint32_t q01 = sat_cvt2_pk(of[0], of[1]), q23 = sat_cvt2_pk(of[2], of[3]);     // packed RNE converts
                 o[0] = (short)(q01 & 0xffffu); o[1] = (short)(q01 >> 16); o[2] = (short)(q23 & 0xffffu); o[3] = (short)(q23 >> 16);
                 int b = wb0, t = wt0 + tq;                // (batch item, token) of row m: no per-lane division (window-level wb0 / wt0)
@@ -210,6 +217,10 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                     xv *= ra;
                     gv *= ra;
                 }
+                if (p.col_alpha) {
+                    xv *= *(const f32x4*)(p.col_alpha + n);
+                    gv *= *(const f32x4*)(p.col_alpha + glu_f + n);
+                }
                 if (p.bias) {
                     xv += *(const f32x4*)(p.bias + n);
                     gv += *(const f32x4*)(p.bias + glu_f + n);
@@ -239,6 +250,7 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
             f32x4 v = *(const f32x4*)(ep + rr * 64 + cc);
             if (m < p.M && n < p.N) {
                 if (p.row_alpha) v *= p.row_alpha[m];
+                if (p.col_alpha) v *= *(const f32x4*)(p.col_alpha + n);
                 if (p.bias) v += *(const f32x4*)(p.bias + n);
                 if constexpr (EPI == SAT_EPI_GATE_RES) {
                     const f32x4 g = sat_load4<F32OUT>(p.gate, (long long)(m / p.rows_per_gate) * p.ldg + n);
@@ -260,6 +272,7 @@ SAT_DEVICE void sat_gemm_epilogue_window(const SatGemmParams& p, const float* ep
                         f32x4 o;
                         f32x4 pv = *(const f32x4*)(ep + rr * 64 + (cc ^ 16));
                         if (p.row_alpha) pv *= p.row_alpha[m];     // (the partner column comes straight from the window: same row factor)
+                        if (p.col_alpha) pv *= *(const f32x4*)(p.col_alpha + (n ^ 16));      // ... its own column factors (nwin is a multiple of 64)
                         // (cos, sin) of the lane's four dims: 8 consecutive floats, 32-byte aligned ((d & 15) is a multiple of 4)
                         const float* cs = p.rope_cs + ((long long)(t + p.rope_off) * 16 + (d & 15)) * 2;
                         const f32x4 cs0 = *(const f32x4*)cs, cs1 = *(const f32x4*)(cs + 4);
@@ -1177,15 +1190,18 @@ extern "C" int sat_splitk_epilogue(const float* slabs, int S, const float* bias,
 // (BASELINE.json configs[4]): A (M, K) and B (N, K) are fp8 bytes, K a multiple of 16, lda / ldb in elements (multiples of 16);
 // products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate, half the operand bytes);
 // alpha: device scalar = (de-quantisation scale of A) x (of B), multiplied into the fp32 accumulators before the epilogue; row_alpha
-// (M floats, or NULL): a per-ROW factor applied with it — A quantised row by row (sat_quant_fp8_rows; alpha is then B's scale alone).
+// (M floats, or NULL): a per-ROW factor applied with it — A quantised row by row (sat_quant_fp8_rows; alpha is then B's scale alone);
+// col_alpha (N floats, 16-byte aligned, or NULL): a per-COLUMN factor — B's rows (output channels) quantised one by one with
+// sat_quant_fp8_rows (round 6: the weight's scale is per output channel; alpha may then be NULL).
 // Everything else (epilogues, output types, tile: 0 / 4 / 7 / 8) as sat_gemm_bf16 / sat_gemm_qkv_bf16; no split-K.
 extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, const float* bias,
                             const void* res, long long ldr, const void* gate, long long ldg, int rows_per_gate, void* pre,
-                            long long ldp, const void* zeros, const float* alpha, const float* row_alpha, int M, int N, int K, int epilogue,
-                            int out_f32, int tile, void* stream) {
+                            long long ldp, const void* zeros, const float* alpha, const float* row_alpha, const float* col_alpha, int M, int N,
+                            int K, int epilogue, int out_f32, int tile, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) { sat_set_error("sat_gemm_fp8: empty shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15) || (N & 7) || (ldc & 3)) { sat_set_error("sat_gemm_fp8: K, lda, ldb must be multiples of 16, N of 8"); return 1; }
-    if (!zeros || !alpha) { sat_set_error("sat_gemm_fp8: zeros page and alpha required"); return 1; }
+    if (!zeros || (!alpha && !col_alpha)) { sat_set_error("sat_gemm_fp8: zeros page and alpha (or col_alpha) required"); return 1; }
+    if (col_alpha && ((uintptr_t)col_alpha & 15)) { sat_set_error("sat_gemm_fp8: col_alpha must be 16-byte aligned"); return 1; }
     if (epilogue < 0 || epilogue > 3) { sat_set_error("sat_gemm_fp8: bad epilogue"); return 1; }
     if ((epilogue == SAT_EPI_RES || epilogue == SAT_EPI_GATE_RES) && !res) { sat_set_error("sat_gemm_fp8: residual missing"); return 1; }
     if (epilogue == SAT_EPI_GATE_RES && (!gate || rows_per_gate <= 0)) { sat_set_error("sat_gemm_fp8: gate missing"); return 1; }
@@ -1193,20 +1209,21 @@ extern "C" int sat_gemm_fp8(const void* A, long long lda, const void* B, long lo
     SatGemmParams p{};
     // two fp8 elements = one "short" of the staging code: the kernel sees (M, K/2) x (N, K/2) 16-bit matrices
     p.A = (const short*)A; p.B = (const short*)B; p.C = C; p.bias = bias; p.res = res; p.gate = gate; p.pre = pre;
-    p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha;
+    p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha; p.col_alpha = col_alpha;
     p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc; p.ldr = ldr; p.ldg = ldg; p.ldp = ldp;
     p.M = M; p.N = N; p.K = K / 2; p.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
     p.klen = sat_cdiv(p.K, 64) * 64;
     return sat_gemm_dispatch_fp8(p, epilogue, out_f32, tile, stream);
 }
 extern "C" int sat_gemm_qkv_fp8(const void* A, long long lda, const void* B, long long ldb, const float* rope_cs, int rope_off,
-                                void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha, int nb,
-                                int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream) {
+                                void* q_rm, void* k_rm, void* v_tr, const void* zeros, const float* alpha, const float* row_alpha,
+                                const float* col_alpha, int nb, int ntok, int npad, int heads, int K, int sec0, int nsec, int tile, void* stream) {
     if (nb <= 0 || ntok <= 0 || heads <= 0 || K <= 0 || npad < ntok) { sat_set_error("sat_gemm_qkv_fp8: bad shape"); return 1; }
     if ((K & 15) || (lda & 15) || (ldb & 15)) { sat_set_error("sat_gemm_qkv_fp8: K, lda, ldb must be multiples of 16"); return 1; }
-    if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3 || !alpha) { sat_set_error("sat_gemm_qkv_fp8: bad section range / alpha"); return 1; }
+    if (sec0 < 0 || nsec < 1 || sec0 + nsec > 3 || (!alpha && !col_alpha)) { sat_set_error("sat_gemm_qkv_fp8: bad section range / alpha"); return 1; }
+    if (col_alpha && ((uintptr_t)col_alpha & 15)) { sat_set_error("sat_gemm_qkv_fp8: col_alpha must be 16-byte aligned"); return 1; }
     SatGemmParams p{};
-    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha;
+    p.A = (const short*)A; p.B = (const short*)B; p.zeros = (const short*)zeros; p.alpha = alpha; p.row_alpha = row_alpha; p.col_alpha = col_alpha;
     p.lda = lda / 2; p.ldb = ldb / 2;
     p.M = nb * ntok; p.N = nsec * heads * 64; p.K = K / 2; p.rows_per_gate = 1;
     p.klen = sat_cdiv(p.K, 64) * 64;

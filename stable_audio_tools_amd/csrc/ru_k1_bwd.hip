@@ -347,7 +347,7 @@ static int sat_ru_k1_plan(int B, int C, int T, int* nsplit, int* tiles_per_split
                                                                                 // W2^T fragments do not fit the register file — not served)
     const long long nt = (long long)B * (T / SAT_RK_TT);
     if (nt > 0x7fffffff) return 1;
-    int want = 256;                              // one eight-wave workgroup per CU
+    int want = sat_cu_count();                   // one eight-wave workgroup per CU
     if (want > nt) want = (int)nt;
     const int per = (int)((nt + want - 1) / want);
     *tiles_per_split = per;

@@ -362,6 +362,7 @@ SAT_DEVICE bool sat_wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 
 // ---------------------------------------------------------------------------------------------
 void sat_set_error(const char* msg);
 int sat_check_launch(const char* what);
+int sat_cu_count();      // compute units of the current device (elementwise.hip)
 
 #if defined(SAT_HIPEMU)
 #define SAT_LAUNCH(kernel, grid, block, stream, params) \

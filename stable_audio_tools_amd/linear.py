@@ -78,16 +78,41 @@ class Fp8Rows:
         self.is_cuda = q.is_cuda
 
 
+# weights quantised per OUTPUT CHANNEL (round 6: one dynamic scale per weight row — `col_alpha` of the fp8 GEMM epilogues — instead of
+# one per tensor: a channel's largest weight no longer sets every other channel's step size); False (A/B scripts): round 3's per-tensor scale
+fp8_channel_scales = True
+
+
+def _quant_weight_fp8(ops, w):
+    """(uint8 e4m3 weight rows padded to a multiple of 8, de-quantisation scale): a (rows,) vector with fp8_channel_scales (the K <= 8192
+    shapes sat_quant_fp8_rows takes), else a 0-dim per-tensor scale."""
+    wb = _pad_rows8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))
+    if fp8_channel_scales and wb.shape[1] % 8 == 0 and wb.stride(0) % 8 == 0 and wb.shape[1] <= 8192:
+        return ops.quant_fp8_rows(wb)
+    return ops.quant_fp8(wb)
+
+
+def fp8_scales(sa, sb):
+    """(alpha, col_alpha) of an fp8 GEMM from the activation's per-tensor scale `sa` (None when it is quantised per row: row_alpha) and
+    the weight's scale `sb` (0-dim: per tensor; 1-dim: per output channel)."""
+    if sb.dim() == 0:
+        return (sb if sa is None else sa * sb), None
+    return sa, sb
+
+
 def _fp8_operands(ops, x2, w, cache):
-    """(A, B, alpha, row_alpha) in fp8 e4m3 with dynamic scales: weights per tensor, once per version; activations per call and per ROW
-    (one pass, a token's outliers do not set the other tokens' step size) — or per tensor with `fp8_row_scales = False`."""
+    """(A, B, alpha, row_alpha, col_alpha) in fp8 e4m3 with dynamic scales: weights per output channel (or per tensor), once per version;
+    activations per call and per ROW (one pass, a token's outliers do not set the other tokens' step size) — or per tensor with
+    `fp8_row_scales = False`."""
     xb = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2)
-    b, sb = cache.get(w, "fp8", lambda: ops.quant_fp8(_pad_rows8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
+    b, sb = cache.get(w, "fp8", lambda: _quant_weight_fp8(ops, w))
     if fp8_row_scales and xb.shape[1] % 8 == 0 and xb.stride(0) % 8 == 0 and xb.shape[1] <= 8192:
         a, ra = ops.quant_fp8_rows(xb)
-        return a, b, sb, ra
+        alpha, ca = fp8_scales(None, sb)
+        return a, b, alpha, ra, ca
     a, sa = ops.quant_fp8(xb)
-    return a, b, sa * sb, None
+    alpha, ca = fp8_scales(sa, sb)
+    return a, b, alpha, None, ca
 
 
 def _operands(ops, x2, w, cache, lowp):
@@ -122,7 +147,7 @@ class LinearFn(torch.autograd.Function):
         out_dtype = torch.bfloat16 if lowp else torch.float32
         fp8 = bool(fp8) and lowp and k % 16 == 0
         if fp8:
-            a, b, alpha, ralpha = _fp8_operands(ops, x2, weight, cache)
+            a, b, alpha, ralpha, calpha = _fp8_operands(ops, x2, weight, cache)
         else:
             a, b = _operands(ops, x2, weight, cache, lowp)
         bias32 = None
@@ -147,14 +172,15 @@ class LinearFn(torch.autograd.Function):
             if n % 16:
                 raise ValueError("SwiGLU projection needs 2F output rows with F % 8 == 0")
             if fp8:
-                y = ops.gemm_fp8(a, b, alpha, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2, row_alpha=ralpha)
+                y = ops.gemm_fp8(a, b, alpha, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2, row_alpha=ralpha,
+                                 col_alpha=calpha)
             else:
                 y = ops.gemm_bf16(a, b, bias=bias32, epilogue=ops.EPI_SWIGLU, out_dtype=out_dtype, want_pre=need_grad, out=out2)
             if need_grad:
                 y, pre = y
         elif fp8:
             y = ops.gemm_fp8(a, b, alpha, bias=bias32, res=r2, epilogue=ops.EPI_RES if mode == "res" else ops.EPI_STORE, out_dtype=out_dtype,
-                             out=out2, row_alpha=ralpha)
+                             out=out2, row_alpha=ralpha, col_alpha=calpha)
         elif lowp and out2 is not None and ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]) > 1:
             y = ops.gemm_bf16_splitk(a, b, ops.splitk_for(a.shape[0], b.shape[0], a.shape[1]), bias=bias32, res=r2, out_dtype=out_dtype, out=out2)
         else:
@@ -291,20 +317,23 @@ class Linear(nn.Module):
             if r2.stride(1) != 1:
                 r2 = r2.contiguous()
         epi = ops.EPI_SWIGLU if mode == "swiglu" else (ops.EPI_RES if mode == "res" else ops.EPI_STORE)
-        ops.gemm_fp8(xq.q, b, sb, bias=bias32, res=r2, epilogue=epi, out_dtype=torch.bfloat16, out=y.view(-1, nout), row_alpha=xq.scale)
+        alpha, calpha = fp8_scales(None, sb)
+        ops.gemm_fp8(xq.q, b, alpha, bias=bias32, res=r2, epilogue=epi, out_dtype=torch.bfloat16, out=y.view(-1, nout), row_alpha=xq.scale,
+                     col_alpha=calpha)
         return y
 
     def fp8_weight(self):
-        """(uint8 e4m3 weight, dequant scale) cached per weight version, or None when K % 16 != 0."""
+        """(uint8 e4m3 weight, dequant scale: per output channel (rows,) or 0-dim per tensor — fp8_scales) cached per weight version, or
+        None when K % 16 != 0."""
         if self.in_features % 16:
             return None
         w = self.weight
-        return self._cache.get(w, "fp8", lambda: _ops().quant_fp8(_pad_rows8(w.detach() if w.dtype == torch.bfloat16 else _ops().cast_bf16(w.detach()))))
+        return self._cache.get(w, "fp8", lambda: _quant_weight_fp8(_ops(), w))
 
 
 def set_fp8(module, enabled=True, min_features=256):
     """Switch the forward GEMMs of every native Linear under `module` with in/out features >= min_features to fp8 e4m3
-    (per-tensor dynamic scaling, MX MFMA at twice the bf16 rate).  The tiny conditioning MLPs stay bf16."""
+    (dynamic scales per activation row and per weight output channel, MX MFMA at twice the bf16 rate).  The tiny conditioning MLPs stay bf16."""
     n = 0
     for m in module.modules():
         if isinstance(m, Linear) and min(m.in_features, m.out_features) >= min_features and m.in_features % 16 == 0:

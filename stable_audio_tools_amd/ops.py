@@ -893,9 +893,13 @@ class SatOps:
         vp = self.attn_planes(v, row_major=return_planes, transposed=True)
         o = torch.empty(b, nq, h * d, dtype=q.dtype, device=q.device)
         lse = torch.empty(b, h, nq, dtype=torch.float32, device=q.device) if (need_lse or return_planes) else None
-        self._chk(self.lib.sat_attention_fwd(_ptr(qp["rm"][0]), _ptr(qp["rm"][1]), _ptr(kp["rm"][0]), _ptr(kp["rm"][1]),
-                                             _ptr(vp["tr"][0]), _ptr(vp["tr"][1]), _ptr(o), _ptr(lse), b, h, hk, nq, nk,
-                                             qp["np"], kp["np"], d, float(scale), dt, self._stream(q)))
+        if self.cross_ok(h, hk, nk, d, dt):      # short key sequence (the DiT's cross-attention): all keys resident, one-pass softmax
+            self._chk(self.lib.sat_attention_cross_fwd(_ptr(qp["rm"][0]), _ptr(kp["rm"][0]), _ptr(vp["tr"][0]), _ptr(o), _ptr(lse), b, h, hk,
+                                                       nq, nk, qp["np"], kp["np"], d, float(scale), self._stream(q)))
+        else:
+            self._chk(self.lib.sat_attention_fwd(_ptr(qp["rm"][0]), _ptr(qp["rm"][1]), _ptr(kp["rm"][0]), _ptr(kp["rm"][1]),
+                                                 _ptr(vp["tr"][0]), _ptr(vp["tr"][1]), _ptr(o), _ptr(lse), b, h, hk, nq, nk,
+                                                 qp["np"], kp["np"], d, float(scale), dt, self._stream(q)))
         out = (o,)
         if need_lse or return_planes:
             out += (lse,)
@@ -918,9 +922,22 @@ class SatOps:
         dq = torch.empty(b, h, nq, 64, dtype=o.dtype, device=o.device)
         dk = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
         dv = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
-        self._chk(self.lib.sat_attention_bwd(arr, _ptr(lse), _ptr(dsum), _ptr(dq), _ptr(dk), _ptr(dv), b, h, hkv, nq, nk,
-                                             qp["np"], kp["np"], 64, float(scale), dt, self._stream(o)))
+        if self.cross_ok(h, hkv, nk, 64, dt):
+            nbytes = int(self.lib.sat_attention_cross_bwd_ws(b, h, hkv, nq, nk))
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=o.device)      # fp32 dK / dV slabs of the query ranges
+            self._chk(self.lib.sat_attention_cross_bwd(arr, _ptr(lse), _ptr(dsum), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), nbytes, b, h, hkv,
+                                                       nq, nk, qp["np"], kp["np"], 64, float(scale), self._stream(o)))
+        else:
+            self._chk(self.lib.sat_attention_bwd(arr, _ptr(lse), _ptr(dsum), _ptr(dq), _ptr(dk), _ptr(dv), b, h, hkv, nq, nk,
+                                                 qp["np"], kp["np"], 64, float(scale), dt, self._stream(o)))
         return dq, dk, dv
+
+    # the short-key attention kernels (csrc/attention_cross.h) serve bf16 planes with Nk <= 256; False sends every shape to the general
+    # flash-style kernels (A/B runs: bench.py --ops-set cross_kernels=0, and the kernel tests' second implementation)
+    cross_kernels = True
+
+    def cross_ok(self, h, hkv, nk, d, dt):
+        return bool(self.cross_kernels) and bool(self.lib.sat_attention_cross_ok(h, hkv, nk, d, dt))
 
     def layernorm(self, x, gamma, beta=None, scale=None, shift=None, eps=1e-5, save_stats=False):
         """x: (B, N, D) contiguous; gamma/beta fp32 (D,); scale/shift: (B, D) views (last dim contiguous) for adaLN."""
@@ -1220,8 +1237,12 @@ class SatOps:
         o = torch.empty(b, nq, h * d, dtype=out_dtype, device=q_rm.device)
         if out_dtype != torch.bfloat16:
             raise TypeError("attention_planes produces bf16")
-        self._chk(self.lib.sat_attention_fwd(_ptr(q_rm), None, _ptr(k_rm), None, _ptr(v_tr), None, _ptr(o), None, b, h, hk, nq, nk,
-                                             npq, npk, d, float(scale), 1, self._stream(q_rm)))
+        if self.cross_ok(h, hk, nk, d, 1):
+            self._chk(self.lib.sat_attention_cross_fwd(_ptr(q_rm), _ptr(k_rm), _ptr(v_tr), _ptr(o), None, b, h, hk, nq, nk, npq, npk, d,
+                                                       float(scale), self._stream(q_rm)))
+        else:
+            self._chk(self.lib.sat_attention_fwd(_ptr(q_rm), None, _ptr(k_rm), None, _ptr(v_tr), None, _ptr(o), None, b, h, hk, nq, nk,
+                                                 npq, npk, d, float(scale), 1, self._stream(q_rm)))
         return o
 
     # ---- fp8 (e4m3) forward projections: per-tensor dynamic scaling, MX MFMA with unit block scales ----
@@ -1264,9 +1285,10 @@ class SatOps:
         return min(self._TILE_MODEL, key=lambda t: (self._tile_cost(t, m, n, (k + 1) // 2), t))
 
     def gemm_fp8(self, a, b, alpha, bias=None, res=None, gate=None, rows_per_gate=0, epilogue=0, out_dtype=torch.bfloat16, want_pre=False,
-                 out=None, row_alpha=None):
+                 out=None, row_alpha=None, col_alpha=None):
         """gemm_bf16 on fp8 operands: a (M, K), b (N, K) uint8 (quant_fp8), alpha = 0-dim fp32 device tensor (scale_a * scale_b);
-        row_alpha (M,) fp32: a was quantised row by row (quant_fp8_rows) — alpha is then b's scale alone."""
+        row_alpha (M,) fp32: a was quantised row by row (quant_fp8_rows) — alpha is then b's scale alone; col_alpha (N,) fp32: b was
+        quantised row by row (one scale per output channel) — alpha is then a's per-tensor scale, or None with row_alpha."""
         if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[1] != b.shape[1]:
             raise TypeError("gemm_fp8 takes (rows, K) uint8 operands")
         m, k = a.shape
@@ -1277,27 +1299,37 @@ class SatOps:
         nout = n // 2 if epilogue == self.EPI_SWIGLU else n
         c = out if out is not None else torch.empty(m, nout, dtype=out_dtype, device=a.device)
         pre = torch.empty(m, n, dtype=out_dtype, device=a.device) if (want_pre and epilogue == self.EPI_SWIGLU) else None
-        alpha = alpha.float().reshape(1).contiguous()
+        alpha, col_alpha = self._fp8_alphas(alpha, col_alpha, n)
         if row_alpha is not None and (row_alpha.dtype != torch.float32 or row_alpha.numel() != m or not row_alpha.is_contiguous()):
             raise TypeError("gemm_fp8: row_alpha is (M,) fp32")
         self._chk(self.lib.sat_gemm_fp8(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), nout, _ptr(bias),
                                         _ptr(res), res.stride(0) if res is not None else 0, _ptr(gate), gate.stride(0) if gate is not None else 0,
-                                        rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), _ptr(row_alpha), m, n, k, epilogue, int(f32),
-                                        self._pick_tile_fp8(m, n, k), self._stream(a)))
+                                        rows_per_gate, _ptr(pre), n, _ptr(self._zeros_page(a.device)), _ptr(alpha), _ptr(row_alpha), _ptr(col_alpha),
+                                        m, n, k, epilogue, int(f32), self._pick_tile_fp8(m, n, k), self._stream(a)))
         return (c, pre) if want_pre and epilogue == self.EPI_SWIGLU else c
 
-    def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None, row_alpha=None):
-        """gemm_heads_bf16 on fp8 operands (planes come out in bf16); row_alpha as gemm_fp8."""
+    @staticmethod
+    def _fp8_alphas(alpha, col_alpha, n):
+        if alpha is None and col_alpha is None:
+            raise TypeError("fp8 GEMM: alpha (per-tensor de-quantisation scale) or col_alpha (per output channel) is required")
+        if alpha is not None:
+            alpha = alpha.float().reshape(1).contiguous()
+        if col_alpha is not None and (col_alpha.dtype != torch.float32 or col_alpha.numel() != n or not col_alpha.is_contiguous()):
+            raise TypeError("fp8 GEMM: col_alpha is (N,) fp32, one factor per row of b")
+        return alpha, col_alpha
+
+    def gemm_heads_fp8(self, x, w, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=None, row_alpha=None, col_alpha=None):
+        """gemm_heads_bf16 on fp8 operands (planes come out in bf16); row_alpha / col_alpha as gemm_fp8."""
         npad = (ntok + 63) // 64 * 64
         out = {"n": ntok, "np": npad}
         for i, (name, shape) in enumerate((("q", (nb, heads, npad, 64)), ("k", (nb, heads, npad, 64)), ("v_tr", (nb, heads, 64, npad)))):
             if sec0 <= i < sec0 + nsec:
                 out[name] = (self._plane_cache((reuse, name, shape), shape, x.device) if reuse is not None
                              else torch.zeros(shape, dtype=torch.int16, device=x.device))
-        alpha = alpha.float().reshape(1).contiguous()
+        alpha, col_alpha = self._fp8_alphas(alpha, col_alpha, w.shape[0])
         self._chk(self.lib.sat_gemm_qkv_fp8(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(cs), (cs.shape[0] - ntok) if cs is not None else 0,
                                             _ptr(out.get("q")), _ptr(out.get("k")), _ptr(out.get("v_tr")), _ptr(self._zeros_page(x.device)),
-                                            _ptr(alpha), _ptr(row_alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec,
+                                            _ptr(alpha), _ptr(row_alpha), _ptr(col_alpha), nb, ntok, npad, heads, x.shape[1], sec0, nsec,
                                             self._pick_tile_fp8(nb * ntok, nsec * heads * 64, x.shape[1]), self._stream(x)))
         return out
 

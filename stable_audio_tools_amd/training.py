@@ -69,7 +69,7 @@ class FlatParameters:
         batched = False
         if len(todo) > 1:
             srcs = [self.params[i].grad for i in todo]
-            if all(g.dtype == torch.float32 and g.is_contiguous() and g.device == self.grad.device for g in srcs):
+            if all(g.dtype == torch.float32 and g.is_contiguous() and g.device == self.grad.device and g.numel() <= 0x7fffffff for g in srcs):      # sat_multi_copy: < 2^31 elements per entry
                 try:
                     o = _fn._ops(ops)
                 except Exception:      # noqa: BLE001 — no kernel library for this device (plain CPU use of the step objects)
@@ -160,7 +160,9 @@ class GradAllReduce:
         # quarters so that only a quarter-size collective is exposed behind the backward
         if len(self.buckets) > 1:
             s0, e0 = self.buckets.pop()
-            q = max(self.world, ((e0 - s0 + 3) // 4 // self.world) * self.world)
+            # rounded UP to a multiple of world: at most four pieces, every one but the last (the one at the very start of the buffer, which
+            # takes what is left) world-aligned — rounding down left a fifth, unaligned remainder bucket (36 elements, world 8: 8,8,8,8,4)
+            q = max(self.world, -(-(-(-(e0 - s0) // 4)) // self.world) * self.world)
             e = e0
             while e > s0:
                 s_ = max(s0, e - q)
@@ -272,15 +274,17 @@ class GradAllReduce:
         if chunk.is_cuda and self.overlap:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=chunk.device)
-            ev = torch.cuda.Event(enable_timing=self.timing)
+            # timing events cannot be recorded inside a stream capture: a captured step is exchanged without a timeline
+            timing = self.timing and not torch.cuda.is_current_stream_capturing()
+            ev = torch.cuda.Event(enable_timing=timing)
             ev.record(torch.cuda.current_stream(chunk.device))      # the bucket's gradients are complete at this point
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 self._exchange(chunk)
-                done = torch.cuda.Event(enable_timing=self.timing)
+                done = torch.cuda.Event(enable_timing=timing)
                 done.record(self._side)
             self._done[bi] = done
-            if self.timing:
+            if timing:
                 self._timeline.append((bi, self._in_hook, ev, done, (e_ - s_) * 4))
         else:
             self._exchange(chunk)
@@ -336,9 +340,14 @@ class GradAllReduce:
 
     def rearm(self):
         """Forget what the hooks of an ABORTED backward already did (a failed HIP-graph capture, an exception inside the step): the next
-        backward starts from fresh counters.  Collectives already enqueued on the side stream are joined first."""
+        backward starts from fresh counters.  Collectives already enqueued on the side stream are joined first — best effort: an event
+        recorded inside an invalidated capture cannot be waited for, and that failure must neither replace the error that brought us
+        here nor leave the counters half reset."""
         for bi in range(len(self.buckets)):
-            self.wait_bucket(bi)
+            try:
+                self.wait_bucket(bi)
+            except RuntimeError:
+                pass
         self.launch_log = []
         self._pending = []
         self._fired = [False] * len(self.buckets)

@@ -272,14 +272,17 @@ class Attention(nn.Module):
         """Input projection straight into attention operand planes (bf16, or fp8 operands when the layer is switched to fp8)."""
         if isinstance(x2, _linear.Fp8Rows):
             qw, sw = lin.fp8_weight()
-            return ops.gemm_heads_fp8(x2.q, qw, sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=x2.scale)
+            alpha, calpha = _linear.fp8_scales(None, sw)
+            return ops.gemm_heads_fp8(x2.q, qw, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=x2.scale, col_alpha=calpha)
         if lin.fp8 and lin.fp8_weight() is not None:
             qw, sw = lin.fp8_weight()
             if _linear.fp8_row_scales and x2.shape[1] % 8 == 0 and x2.stride(0) % 8 == 0 and x2.shape[1] <= 8192:
                 qx, rs = ops.quant_fp8_rows(x2)
-                return ops.gemm_heads_fp8(qx, qw, sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=rs)
+                alpha, calpha = _linear.fp8_scales(None, sw)
+                return ops.gemm_heads_fp8(qx, qw, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=tag, row_alpha=rs, col_alpha=calpha)
             qx, sx = ops.quant_fp8(x2)
-            return ops.gemm_heads_fp8(qx, qw, sx * sw, cs, heads, nb, ntok, sec0, nsec, reuse=tag)
+            alpha, calpha = _linear.fp8_scales(sx, sw)
+            return ops.gemm_heads_fp8(qx, qw, alpha, cs, heads, nb, ntok, sec0, nsec, reuse=tag, col_alpha=calpha)
         return ops.gemm_heads_bf16(x2, lin.lowp_weight(), cs, heads, nb, ntok, sec0, nsec, reuse=tag)
 
     def forward(self, x, context=None, rotary_pos_emb=None, causal=None, res=None, **unsupported):

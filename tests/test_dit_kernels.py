@@ -100,10 +100,24 @@ def test_layernorm_fp8_gpu(hip):
 # ---------------------------------------------------------------------------------------------------------------------
 ATT_CASES = [  # (B, H, Hkv, Nq, Nk)
     (1, 2, 2, 64, 64), (2, 2, 2, 65, 65), (1, 4, 2, 130, 37), (1, 2, 1, 37, 200), (1, 2, 2, 193, 193), (1, 4, 4, 1, 70),
+    (1, 4, 2, 100, 130), (1, 2, 2, 40, 256), (1, 2, 1, 70, 257),      # the DiT's 130 context tokens on a GQA pair; the short-key kernels' limit and one past it
 ]
 
 
-def _attn_case(ops, dev, dtype, case, seed, spikes=()):
+def _attn_case(ops, dev, dtype, case, seed, spikes=(), cross=True):
+    """cross: bf16 shapes with Nk <= 256 run on the short-key kernels (csrc/attention_cross.h) when True, on the general flash-style
+    kernels when False — both implementations are held to the same SDPA reference."""
+    b, h, hkv, nq, nk = case
+    saved = ops.cross_kernels
+    ops.cross_kernels = cross
+    try:
+        assert ops.cross_ok(h, hkv, nk, 64, 1) == (cross and nk <= 256)
+        _attn_case_body(ops, dev, dtype, case, seed, spikes)
+    finally:
+        ops.cross_kernels = saved
+
+
+def _attn_case_body(ops, dev, dtype, case, seed, spikes):
     b, h, hkv, nq, nk = case
     gen = torch.Generator().manual_seed(seed)
     q = torch.randn(b, h, nq, 64, generator=gen)
@@ -136,6 +150,8 @@ def _attn_case(ops, dev, dtype, case, seed, spikes=()):
 @pytest.mark.parametrize("case", ATT_CASES)
 def test_attention_sim(emu, case, dtype):
     _attn_case(emu, "cpu", dtype, case, seed=21)
+    if dtype == torch.bfloat16 and case[4] <= 256:
+        _attn_case(emu, "cpu", dtype, case, seed=21, cross=False)
 
 
 # The forward moves its running max only when a row outgrows it by more than 2^4 (deferred rescale): rows whose max jumps far past the
@@ -145,22 +161,26 @@ SPIKES = [(5, 150, 6.0), (7, 100, 0.3), (40, 190, 0.5), (41, 70, 3.0), (64, 192,
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_deferred_max_sim(emu, dtype):
-    _attn_case(emu, "cpu", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES)
-    _attn_case(emu, "cpu", dtype, (1, 4, 2, 70, 200), seed=24, spikes=SPIKES[:4])
+    for cross in ((True, False) if dtype == torch.bfloat16 else (True,)):      # the one-pass softmax of the short-key kernels sees the same spikes
+        _attn_case(emu, "cpu", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES, cross=cross)
+        _attn_case(emu, "cpu", dtype, (1, 4, 2, 70, 200), seed=24, spikes=SPIKES[:4], cross=cross)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_deferred_max_gpu(hip, dtype):
-    _attn_case(hip, "cuda", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES)
+    for cross in ((True, False) if dtype == torch.bfloat16 else (True,)):
+        _attn_case(hip, "cuda", dtype, (1, 2, 2, 130, 193), seed=23, spikes=SPIKES, cross=cross)
     _attn_case(hip, "cuda", dtype, (2, 24, 24, 1025, 1025), seed=25, spikes=SPIKES + [(1000, 1024, 5.0), (1024, 3, 4.0)])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_gpu(hip, dtype):
-    for case in ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130), (1, 4, 4, 300, 6145)]:
+    for case in ATT_CASES + [(2, 24, 24, 1025, 1025), (2, 24, 12, 1025, 130), (4, 24, 12, 1025, 130), (16, 24, 12, 1025, 130), (1, 4, 4, 300, 6145)]:
         _attn_case(hip, "cuda", dtype, case, seed=22)
+        if dtype == torch.bfloat16 and case[4] <= 256:
+            _attn_case(hip, "cuda", dtype, case, seed=22, cross=False)
 
 
 def _cfg_step_case(ops, dev):

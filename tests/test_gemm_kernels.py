@@ -210,6 +210,32 @@ def _fp8_case(ops, dev, tiles=(None, 0, 4, 7, 8), shapes=((130, 144, 144), (330,
                 ops.gemm_fp8_tile = None
         full32 = xb @ w.bfloat16().float().cpu().t()
         assert float((ref - full32).norm() / full32.norm()) < 8e-2
+        # per-OUTPUT-CHANNEL weight scales (round 6: the weight's rows quantised one by one, col_alpha of the epilogues) with per-row
+        # activation scales (alpha None) and with a per-tensor activation scale (alpha = the activation's); the weight rows are given
+        # very different magnitudes, which is where one scale per tensor loses: the per-channel product is closer to the fp32 one
+        wv = (w * (torch.rand(n, 1) * 8 + 0.05).to(dev)).bfloat16()
+        qwc, swc = ops.quant_fp8_rows(wv)
+        qwt, swt = ops.quant_fp8(wv)
+        wdc = qwc.cpu().view(torch.float8_e4m3fn).float() * swc.cpu()[:, None]
+        refc = xd @ wdc.t()
+        fullc = refc + bias.cpu()
+        qxt, sxt = ops.quant_fp8(x.bfloat16())
+        reft = (qxt.cpu().view(torch.float8_e4m3fn).float() * sxt.cpu()) @ wdc.t()
+        for tile in (None, 0, 4, 7, 8):
+            ops.gemm_fp8_tile = tile
+            try:
+                assert rel_err(ops.gemm_fp8(qx, qwc, None, out_dtype=torch.float32, row_alpha=rs, col_alpha=swc), refc) < 1e-4
+                assert rel_err(ops.gemm_fp8(qxt, qwc, sxt, out_dtype=torch.float32, col_alpha=swc), reft) < 1e-4
+                assert rel_err(ops.gemm_fp8(qx, qwc, None, bias=bias, res=res, epilogue=ops.EPI_RES, out_dtype=torch.float32, row_alpha=rs, col_alpha=swc),
+                               refc + bias.cpu() + res.cpu()) < 1e-4
+                c = ops.gemm_fp8(qx, qwc, None, bias=bias, epilogue=ops.EPI_SWIGLU, out_dtype=torch.float32, row_alpha=rs, col_alpha=swc)
+                assert rel_err(c, fullc[:, :n // 2] * torch.nn.functional.silu(fullc[:, n // 2:])) < 1e-4
+            finally:
+                ops.gemm_fp8_tile = None
+        exact = xd @ wv.float().cpu().t()
+        e_chan = float((refc - exact).norm() / exact.norm())
+        e_tens = float((xd @ (qwt.cpu().view(torch.float8_e4m3fn).float() * swt.cpu()).t() - exact).norm() / exact.norm())
+        assert e_chan < e_tens, (e_chan, e_tens)
     # the head-split / plane-layout epilogue on fp8 operands (no rotary: the cross-attention to_q; with: to_qkv), every fp8 tile
     nb, ntok, heads, k = 2, 71, 3, 80
     x = torch.randn(nb * ntok, k).to(dev)
@@ -242,6 +268,18 @@ def _fp8_case(ops, dev, tiles=(None, 0, 4, 7, 8), shapes=((130, 144, 144), (330,
             qp, kp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k")]
             assert rel_err(qp[:, :, :ntok], dit_oracle.apply_rotary(qr_, freqs)) < 6e-3
             assert rel_err(kp[:, :, :ntok], dit_oracle.apply_rotary(kr_, freqs)) < 6e-3
+            # ... and per-output-channel weight scales through the same epilogues (transposed V: one factor per head dim; rotary: the
+            # partner column has its own factor)
+            wvar = (w * (torch.rand(w.shape[0], 1) * 8 + 0.05).to(dev)).bfloat16()
+            qwc, swc = ops.quant_fp8_rows(wvar)
+            wdc = qwc.cpu().view(torch.float8_e4m3fn).float() * swc.cpu()[:, None]
+            qkv_c = ((qxr.cpu().view(torch.float8_e4m3fn).float() * rsr.cpu()[:, None]) @ wdc.t()).view(nb, ntok, 3, heads, 64)
+            qc_, kc_, vc_ = [qkv_c[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+            pl = ops.gemm_heads_fp8(qxr, qwc, None, cs, heads, nb, ntok, 0, 3, row_alpha=rsr, col_alpha=swc)
+            qp, kp, vp = [pl[nm].view(torch.bfloat16).float().cpu() for nm in ("q", "k", "v_tr")]
+            assert rel_err(qp[:, :, :ntok], dit_oracle.apply_rotary(qc_, freqs)) < 6e-3
+            assert rel_err(kp[:, :, :ntok], dit_oracle.apply_rotary(kc_, freqs)) < 6e-3
+            assert rel_err(vp[:, :, :, :ntok], vc_.transpose(2, 3)) < 6e-3
         finally:
             ops.gemm_fp8_tile = None
 

@@ -7,6 +7,9 @@ widths by tests/test_full_width.py) executed on the host cores of the GPU box in
          gradient dL/d(decoded) at the oracle's decoded audio.  That gradient is ill-conditioned in the reference's own float32
          arithmetic (A-weighted log-magnitudes at the 1e-4 clamp, auraloss.py:385-387 — see tests/test_full_width.py), so the
          truth is the float64 oracle and the bar is max(1e-3, 3 x the float32 oracle's own distance to it), measured here.
+  B = 1, backward: EVERY parameter gradient of a linear functional of the decoded audio (+ 0.1 KL) against the oracle's autograd at
+         this size (round 6: the conv-stack backward — data gradients, split-K weight gradients over 8192 time tiles, weight-norm,
+         SnakeBeta and bias sums — held to the 1e-3 bar at T = 2 097 152 itself, not on a crop; +~1.5 CPU-minutes, +41 GiB of host memory).
   B = 2: items [other, same] — the second item starts 2^31 bytes into the C = 128 activations (B*C*T*4 = 2^31 exactly), the
          case 32-bit byte offsets get wrong.  Item 1 is compared with the SAME oracle results (no extra CPU time), item 0 with
          the native B = 1 run of that item; the batch-mean loss and the per-item gradient follow from the per-item values.
@@ -56,10 +59,18 @@ def headline(hip):
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, os.cpu_count() or 1))      # torch's CPU convs degrade when oversubscribed on the 256-thread host
     try:
-        with torch.no_grad():
-            z, kl, pre = vae_oracle.autoencoder_encode(sd, cfg["model"], audio, noise)
-            dec = vae_oracle.autoencoder_decode(sd, cfg["model"], z)
-        out = {"pre": pre, "z": z, "kl": kl, "dec": dec}
+        # forward WITH the autograd graph: the same pass gives the forward quantities and the parameter gradients of a linear functional
+        # (well conditioned — tests/test_full_width.py explains why the composite MR-STFT gradient is not)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        z, kl, pre = vae_oracle.autoencoder_encode(sdg, cfg["model"], audio, noise)
+        dec = vae_oracle.autoencoder_decode(sdg, cfg["model"], z)
+        proj = torch.from_numpy(seeded.seeded_array((1, 2, T), SEED + 78))
+        loss_lin = (dec * proj).sum() / proj.numel() ** 0.5 + 0.1 * kl
+        names = list(sdg.keys())
+        g_lin = dict(zip(names, torch.autograd.grad(loss_lin, [sdg[n] for n in names])))
+        z, kl, pre, dec, loss_lin = z.detach(), kl.detach(), pre.detach(), dec.detach(), loss_lin.detach()
+        del sdg
+        out = {"pre": pre, "z": z, "kl": kl, "dec": dec, "proj": proj, "loss_lin": float(loss_lin), "g_lin": g_lin}
         for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
             d = dec.to(dt).requires_grad_(True)
             loss = stft_oracle.autoencoder_spectral_loss(audio.to(dt), d, seeded.STFT_CFG, 44100)
@@ -99,6 +110,29 @@ def test_headline_forward_and_loss_match_oracle(headline):
     for k in ("pre", "z", "kl", "decoded", "loss", "loss_at_oracle_decoded"):
         assert errs[k] < TOL, (k, errs)
     assert errs["gdec"] < max(TOL, 3.0 * h["gdec_refdist"]), errs
+
+
+def test_headline_parameter_gradients_match_oracle(headline):
+    """The conv stack's backward AT the headline size against the oracle's autograd: every parameter of the 156 M-parameter autoencoder."""
+    h = headline
+    model, audio, noise = h["model"], h["audio"].cuda(), h["noise"].cuda()
+    z, info = model.encode(audio, return_info=True, noise=noise)
+    dec = model.decode(z)
+    proj = h["proj"].cuda()
+    loss = (dec * proj).sum() / proj.numel() ** 0.5 + 0.1 * info["kl"]
+    assert abs(float(loss) - h["loss_lin"]) < TOL * max(abs(h["loss_lin"]), 1.0)
+    names = [n for n, _ in model.named_parameters()]
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    assert set(names) == set(h["g_lin"])
+    worst, bad = ("", 0.0), []
+    for n, g in zip(names, grads):
+        e = rel_err(g, h["g_lin"][n])
+        if e > worst[1]:
+            worst = (n, e)
+        if not e < TOL:
+            bad.append((n, float(f"{e:.3g}")))
+    print(f"headline parameter gradients (T={T}, full width, {len(names)} parameters): worst {worst[0]} {worst[1]:.2e}")
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:12]
 
 
 def test_headline_batch2_offsets(headline):
