@@ -455,7 +455,23 @@ def dit_train_object(batches=(4, 16), steps=5, warmup=2, with_cpu_baseline=True)
     return obj
 
 
+def apply_ops_set(args, ops=None):
+    """--ops-set NAME=VALUE: attributes of the SatOps object for A/B runs (every workload; recorded in config.ops_set)."""
+    if not args.ops_set:
+        return
+    if ops is None:
+        from stable_audio_tools_amd import ops as O
+        ops = O.get_ops()
+    for kv in args.ops_set:
+        name, val = kv.split("=", 1)
+        if not hasattr(ops, name):
+            raise SystemExit(f"--ops-set: SatOps has no attribute {name!r}")
+        cur = getattr(type(ops), name)
+        setattr(ops, name, (type(cur)(int(val)) if isinstance(cur, (bool, int)) else (bool(int(val)) if cur is None else val)))
+
+
 def run_dit_sample(args):
+    apply_ops_set(args)
     line = dit_sample_line(args.dit_dtype, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
     emit(line)
 
@@ -1156,6 +1172,7 @@ def run_dit_train(args):
     dev = torch.device("cuda", local_rank)
     from stable_audio_tools_amd.dit import DiffusionTransformer
     from stable_audio_tools_amd.training import DiTTrainStep
+    apply_ops_set(args)
     cfg = json.load(open(os.path.join(ROOT, "stable_audio_tools_amd", "configs", "stable_audio_open_dit.json")))
     dcfg = cfg["diffusion"]["config"]
     torch.manual_seed(1234)
@@ -1276,6 +1293,7 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (there is no CPU path for the product kernels)")
         torch.cuda.set_device(0)
+        apply_ops_set(args)
         lc = long_context_line(args.steps, args.warmup, not args.no_cpu_baseline)
         emit(({"metric": "DiT sampling steps/sec", "value": lc["value"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": lc["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -1325,11 +1343,7 @@ def main():
     stepper.comm.timing = stepper.comm.active      # exchange timeline of the last timed step (config.ddp.timeline)
     stepper.use_disc = False        # the headline `value` is the generator step (comparable across rounds); the real alternating
     ops = O.get_ops()               # discriminator / generator step is timed separately below -> config.real_step
-    for kv in args.ops_set:
-        name, val = kv.split("=", 1)
-        if not hasattr(ops, name):
-            raise SystemExit(f"--ops-set: SatOps has no attribute {name!r}")
-        setattr(ops, name, type(getattr(type(ops), name))(int(val)) if isinstance(getattr(type(ops), name), (bool, int)) else val)
+    apply_ops_set(args, ops)
     prof = ConvProfiler(ops)
 
     g = torch.Generator().manual_seed(rank)     # per-rank data (train.py:30-33 seeds ranks differently)

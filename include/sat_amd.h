@@ -322,7 +322,8 @@ int sat_allreduce_finalize(void* comm);
 int sat_attn_prepare(const void* src, long long sb, long long sh, long long sn, short* rm_hi, short* rm_lo,
                      short* tr_hi, short* tr_lo, int B, int H, int N, int Np, int dtype, void* stream);
 /* forward: q_* row-major planes (B,H,Nqp,64), k_* row-major (B,Hkv,Nkp,64), vt_* TRANSPOSED (B,Hkv,64,Nkp);
- * o: (B, Nq, H*64) in the model dtype — heads merged; lse: (B, H, Nq) fp32 or NULL. */
+ * o: (B, Nq, H*64) in the model dtype — heads merged; lse: (B, H, Nq) fp32 or NULL.  dtype 1 (bf16): a wave owns 64 queries when
+ * 256-query workgroups still put two on every CU (long context, training batches), else 32; dtype 2 / 3 force 32 / 64 (A/B, tests). */
 int sat_attention_fwd(const short* q_hi, const short* q_lo, const short* k_hi, const short* k_lo, const short* vt_hi,
                       const short* vt_lo, void* o, float* lse, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp,
                       int head_dim, float scale, int dtype, void* stream);

@@ -557,6 +557,251 @@ sat_attn_fwd_kernel(SatAttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, 64 queries per wave (round 6; bf16 planes only).  The 32-query kernel above is ISSUE-bound (profiles/r04_pmc_attn_summary.txt:
+// ~135 issued instructions per 16 MFMAs); a wave that owns TWO 32-query blocks reads every K / V^T fragment once for both (the 16
+// ds_read_b128 per 64-key tile, the staging loads / stores and the scalar work are shared: ~185 issue slots per 32 MFMAs instead of
+// 270), at two waves per SIMD (~210 registers) instead of three.  The tile is walked one 32-KEY block at a time — QK^T (4 MFMAs per
+// query block), exp2 / pack / row sum, P V (4 MFMAs per query block) — so only 2 x 16 score registers are live; the stale-max check
+// (the deferred rescale of the kernel above) is per key block: 16 scores per lane, limit 16 x 2^SAT_ATT_DEFER.
+// Used where the grid still fills the chip (sat_attention_fwd: >= 2 workgroups of 256 queries per CU — the long context, training
+// batches); the sampler's small launch stays on the 32-query kernel.
+// ---------------------------------------------------------------------------------------------
+#define SAT_ATT_SUMLIM_KB 256.0f
+
+template <int NQB, int KB, bool MASK, bool FIRST>
+SAT_DEVICE void sat_attn_fwd_kb(short (*k_lds)[SAT_ATT_ROW], short (*v_lds)[SAT_ATT_ROW], const bf16x8 (&qf)[NQB][4], f32x16 (&oacc)[NQB][2],
+                                f32x16 (&negm)[NQB], float (&mb)[NQB], float (&l_run)[NQB], int l31, int hi, int kperm, int nvalid) {
+    f32x16 sacc[NQB];
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto qk = [&]() {
+        SAT_SETPRIO(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = sat_att_frag_rm(k_lds, KB * 32 + kperm, 16 * s + 8 * hi);      // ONE fragment read for both query blocks
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) sacc[qb] = sat_mfma_32x32x16_bf16(ka, qf[qb][s], s == 0 ? (FIRST ? zero : negm[qb]) : sacc[qb]);
+        }
+        SAT_SETPRIO(0);
+    };
+    auto rowmax = [&](int qb) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 7) + 8 * hi + 16 * (r >> 3);
+            if (!MASK || key < nvalid) tmax = fmaxf(tmax, sacc[qb][r]);
+        }
+        return sat_att_halfmax(tmax);
+    };
+    bf16x8 pbs[NQB][2];
+    float ps[NQB];
+    auto expsum = [&](int qb) {
+        float ps0 = 0.0f, ps1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = sat_exp2(sacc[qb][r]);
+            if (MASK) {
+                if ((r & 7) + 8 * hi + 16 * (r >> 3) >= nvalid) a = 0.0f;
+            }
+            sacc[qb][r] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 one[1];
+            sat_att_pack<1>(sacc[qb], u, one);
+            pbs[qb][u] = one[0];
+            const u32x4 w = __builtin_bit_cast(u32x4, one[0]);
+            ps0 = sat_att_sum2(w[0], ps0);
+            ps1 = sat_att_sum2(w[1], ps1);
+            ps0 = sat_att_sum2(w[2], ps0);
+            ps1 = sat_att_sum2(w[3], ps1);
+        }
+        ps[qb] = ps0 + ps1;
+    };
+    qk();
+    if (FIRST) {
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const float tmax = rowmax(qb);
+            mb[qb] = tmax;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[qb][r] -= tmax;
+                negm[qb][r] = -tmax;
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) expsum(qb);
+    if (!FIRST) {
+        bool stale = false;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) stale = stale || !(ps[qb] <= SAT_ATT_SUMLIM_KB);
+        if (sat_wave_any(stale)) {      // a row of the wave outgrew its running max (rare): redo this key block with the true one
+            qk();
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                const float d = fmaxf(rowmax(qb), 0.0f), alpha = sat_exp2(-d);
+                mb[qb] += d;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qb][t][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[qb][r] -= d;
+                    negm[qb][r] = -mb[qb];
+                }
+                expsum(qb);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += ps[qb];
+    SAT_SETPRIO(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 va = sat_att_frag_rm(v_lds, t * 32 + l31, KB * 32 + 16 * u + 8 * hi);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) oacc[qb][t] = sat_mfma_32x32x16_bf16(va, pbs[qb][u], oacc[qb][t]);
+        }
+    SAT_SETPRIO(0);
+}
+
+template <int NQB>
+__global__ void __launch_bounds__(256)
+#if !defined(SAT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sat_attn_fwd_q_kernel(SatAttnParams p) {
+    __shared__ __attribute__((aligned(16))) short k_lds2[2][SAT_ATT_T][SAT_ATT_ROW];   // [buffer][key][d]
+    __shared__ __attribute__((aligned(16))) short v_lds2[2][SAT_ATT_D][SAT_ATT_ROW];   // [buffer][d][key]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kperm = sat_att_kperm(l31);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const int qrow0 = blockIdx.x * (128 * NQB) + wave * (32 * NQB);      // the wave's first query; its blocks: qrow0 + 32 qb + l31
+    const bool w_ok = qrow0 < p.Nq;                                      // wave-uniform: this wave owns a valid query
+    const size_t qplane = ((size_t)b * p.H + h) * (size_t)p.Nqp * SAT_ATT_D;
+    const size_t kplane = ((size_t)b * p.Hkv + hk) * (size_t)p.Nkp * SAT_ATT_D;
+    const float sl2 = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[NQB][4];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int qrow = qrow0 + qb * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 w = u32x4{0u, 0u, 0u, 0u};
+            if (qrow < p.Nqp) w = *reinterpret_cast<const u32x4*>(p.q_rm[0] + qplane + (size_t)qrow * SAT_ATT_D + 16 * s + 8 * hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e0 = __builtin_bit_cast(float, w[j] << 16), e1 = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+                w[j] = sat_cvt2_pk(e0 * sl2, e1 * sl2);
+            }
+            qf[qb][s] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    f32x16 oacc[NQB][2], negm[NQB];
+    float mb[NQB], l_run[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        mb[qb] = 0.0f;
+        l_run[qb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oacc[qb][0][r] = 0.0f;
+            oacc[qb][1][r] = 0.0f;
+            negm[qb][r] = 0.0f;
+        }
+    }
+
+    int srow[2], spart[2];
+    unsigned kob[2], vob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        srow[j] = c >> 3;
+        spart[j] = c & 7;
+        kob[j] = (unsigned)(srow[j] * SAT_ATT_D + spart[j] * 8) * 2u;
+        vob[j] = ((unsigned)srow[j] * (unsigned)p.Nkp + (unsigned)spart[j] * 8u) * 2u;
+    }
+    const SatBuf kbuf = sat_buf_make(p.k_rm[0] + kplane), vbuf = sat_buf_make(p.v_tr[0] + kplane);
+    bf16x8 kreg[2], vreg[2];
+    auto tile_load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            kreg[j] = sat_buf_load16(kbuf, kob[j], (unsigned)k0 * (SAT_ATT_D * 2));
+            vreg[j] = sat_buf_load16(vbuf, vob[j], (unsigned)k0 * 2u);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x8*>(&k_lds2[buf][srow[j]][spart[j] * 8]) = kreg[j];
+            *reinterpret_cast<bf16x8*>(&v_lds2[buf][srow[j]][spart[j] * 8]) = vreg[j];
+        }
+    };
+    tile_load(0);
+    tile_store(0);
+    if (SAT_ATT_T < p.Nk) tile_load(SAT_ATT_T);
+    __syncthreads();
+    int buf = 0, k0 = 0;
+    if (p.Nk >= SAT_ATT_T) {      // the first full tile, peeled: its first key block establishes the running max
+        if (SAT_ATT_T < p.Nk) {
+            tile_store(1);
+            if (2 * SAT_ATT_T < p.Nk) tile_load(2 * SAT_ATT_T);
+        }
+        if (w_ok) {
+            sat_attn_fwd_kb<NQB, 0, false, true>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, 32);
+            sat_attn_fwd_kb<NQB, 1, false, false>(k_lds2[0], v_lds2[0], qf, oacc, negm, mb, l_run, l31, hi, kperm, 32);
+        }
+        __syncthreads();
+        k0 = SAT_ATT_T;
+        buf = 1;
+    }
+    for (; k0 + SAT_ATT_T <= p.Nk; k0 += SAT_ATT_T, buf ^= 1) {
+        if (k0 + SAT_ATT_T < p.Nk) {
+            tile_store(buf ^ 1);
+            if (k0 + 2 * SAT_ATT_T < p.Nk) tile_load(k0 + 2 * SAT_ATT_T);
+        }
+        if (w_ok) {
+            sat_attn_fwd_kb<NQB, 0, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, 32);
+            sat_attn_fwd_kb<NQB, 1, false, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, 32);
+        }
+        __syncthreads();
+    }
+    if (k0 < p.Nk && w_ok) {      // the ragged last tile (also the first when Nk < 64)
+        const int rem = p.Nk - k0;
+        const int n0 = rem < 32 ? rem : 32;
+        if (k0 == 0) sat_attn_fwd_kb<NQB, 0, true, true>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, n0);
+        else sat_attn_fwd_kb<NQB, 0, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, n0);
+        if (rem > 32) sat_attn_fwd_kb<NQB, 1, true, false>(k_lds2[buf], v_lds2[buf], qf, oacc, negm, mb, l_run, l31, hi, kperm, rem - 32);
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int qrow = qrow0 + qb * 32 + l31;
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow < p.Nq) {
+            const long long obase = ((long long)b * p.Nq + qrow) * ((long long)p.H * SAT_ATT_D) + (long long)h * SAT_ATT_D;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const long long idx = obase + t * 32 + 8 * g + 4 * hi;
+                    *(u32x2*)((short*)p.o + idx) = u32x2{sat_cvt2_pk(oacc[qb][t][4 * g] * inv_l, oacc[qb][t][4 * g + 1] * inv_l),
+                                                         sat_cvt2_pk(oacc[qb][t][4 * g + 2] * inv_l, oacc[qb][t][4 * g + 3] * inv_l)};
+                }
+            if (p.lse && hi == 0) p.lse[((long long)b * p.H + h) * p.Nq + qrow] = (mb[qb] + log2f(l_tot)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, part 1: dQ.  Same roles as the forward (wave owns 32 queries, loop over key tiles).
 //   S^T = K Q^T ; P^T = exp(S^T*scale - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) scale ; dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------
@@ -1245,7 +1490,7 @@ static int sat_attn_check(int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nk
     if (head_dim != SAT_ATT_D) { sat_set_error("attention: only head_dim == 64 (the Stable Audio DiT) is implemented"); return 1; }
     if (H % Hkv != 0) { sat_set_error("attention: H must be a multiple of Hkv"); return 1; }
     if (Nqp < Nq || Nkp < Nk || Nqp % SAT_ATT_T || Nkp % SAT_ATT_T) { sat_set_error("attention: padded lengths must be multiples of 64 and cover N"); return 1; }
-    if (dtype != 0 && dtype != 1) { sat_set_error("attention: dtype must be 0 (f32, split planes) or 1 (bf16)"); return 1; }
+    if (dtype < 0 || dtype > 3) { sat_set_error("attention: dtype must be 0 (f32, split planes) or 1 (bf16; forward only: 2 / 3 = bf16 with 32 / 64 queries per wave forced)"); return 1; }
     // tile loads go through buffer descriptors with 32-bit byte offsets: 64 rows of a transposed plane, and a kv group's query heads
     if (Nkp >= (1 << 24) || (long long)Nqp * (H / Hkv) >= (1 << 24)) { sat_set_error("attention: sequences of 2^24 tokens or more are not supported"); return 1; }
     return 0;
@@ -1259,8 +1504,16 @@ extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const sho
     p.q_rm[0] = q_hi; p.q_rm[1] = q_lo; p.k_rm[0] = k_hi; p.k_rm[1] = k_lo; p.v_tr[0] = vt_hi; p.v_tr[1] = vt_lo;
     p.o = o; p.lse = lse; p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.Nqp = Nqp; p.Nkp = Nkp; p.scale = scale;
     dim3 grid(sat_cdiv(Nq, 128), H, B);
-    if (dtype == 0) SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
-    else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
+    if (dtype == 0) {
+        SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
+    } else {
+        // bf16: 64 queries per wave (sat_attn_fwd_q_kernel<2>) where 256-query workgroups still put >= 2 on every CU, else 32;
+        // dtype 2 / 3 force the 32- / 64-query kernel (A/B runs and the tests' second implementation)
+        const long long wg64 = (long long)sat_cdiv(Nq, 256) * H * B;
+        const bool q64 = dtype == 3 || (dtype == 1 && wg64 >= 2LL * sat_cu_count());
+        if (q64) SAT_LAUNCH((sat_attn_fwd_q_kernel<2>), dim3(sat_cdiv(Nq, 256), H, B), dim3(256), stream, p);
+        else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
+    }
     return sat_check_launch("sat_attention_fwd");
 }
 
@@ -1279,6 +1532,7 @@ extern "C" int sat_attention_bwd(const short* const* planes, const float* lse, c
                                  void* dv, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp, int head_dim,
                                  float scale, int dtype, void* stream) {
     if (sat_attn_check(B, H, Hkv, Nq, Nk, Nqp, Nkp, head_dim, dtype, "sat_attention_bwd: empty shape")) return 1;
+    if (dtype > 1) { sat_set_error("sat_attention_bwd: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
     SatAttnParams p{};
     for (int i = 0; i < 2; ++i) {
         p.q_rm[i] = planes[0 + i]; p.k_rm[i] = planes[2 + i]; p.v_rm[i] = planes[4 + i]; p.k_tr[i] = planes[6 + i];

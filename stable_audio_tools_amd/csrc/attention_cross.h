@@ -36,14 +36,42 @@ struct SatXAttnParams {
     float scale;
 };
 
-// stage ROWS x (COLS bf16) of a plane into padded LDS rows with NT threads, 16 bytes per piece
-template <int NT, int LROW>
-SAT_DEVICE void sat_xatt_stage(short (*dst)[LROW], const short* src, size_t rstride, int rows, int cols) {
-    const int parts = cols >> 3;
-    for (int c = threadIdx.x; c < rows * parts; c += NT) {
+// stage a plane tile into padded LDS rows with 256 threads, 16 bytes per piece.  NPT = pieces per thread (compile time): ALL loads are
+// issued before the first LDS store — a rolled copy loop waits for each load in turn (the first version of these kernels staged
+// 2 x 5 pieces per thread behind ten serial L2 / HBM latencies).  `parts` = 16-byte pieces per row; rows * parts == 256 * NPT.
+template <int NPT, int LROW>
+SAT_DEVICE void sat_xatt_stage(short (*dst)[LROW], const short* src, size_t rstride, int parts) {
+    bf16x8 reg[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int c = threadIdx.x + j * 256;
         const int r = c / parts, part = c - r * parts;
-        *reinterpret_cast<bf16x8*>(&dst[r][part * 8]) = *reinterpret_cast<const bf16x8*>(src + (size_t)r * rstride + part * 8);
+        reg[j] = *reinterpret_cast<const bf16x8*>(src + (size_t)r * rstride + part * 8);
     }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const int r = c / parts, part = c - r * parts;
+        *reinterpret_cast<bf16x8*>(&dst[r][part * 8]) = reg[j];
+    }
+}
+// max(a, b, c) as ONE v_max3_f32.  fmaxf on MFMA results makes hipcc emit a canonicalising v_max_f32 v, v, v per operand first
+// (cdna_hip_programming.md, "fused attention prefill": 75 of them for the 80 scores of a query row here); the asm form takes the
+// accumulator registers as they are.  NaN scores propagate differently from fmaxf — a NaN row is NaN either way.
+SAT_DEVICE float sat_xatt_max3(float a, float b, float c) {
+#if defined(SAT_HIPEMU)
+    return fmaxf(fmaxf(a, b), c);
+#else
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+// max of the 16 accumulator registers as a tree of eight v_max3 (a serial fmaxf chain over 80 scores is 80 dependent VALU latencies)
+SAT_DEVICE float sat_xatt_max16(const f32x16& v) {
+    const float a0 = sat_xatt_max3(v[0], v[1], v[2]), a1 = sat_xatt_max3(v[3], v[4], v[5]), a2 = sat_xatt_max3(v[6], v[7], v[8]);
+    const float a3 = sat_xatt_max3(v[9], v[10], v[11]), a4 = sat_xatt_max3(v[12], v[13], v[14]);
+    return sat_xatt_max3(sat_xatt_max3(a0, a1, a2), sat_xatt_max3(a3, a4, v[15]), v[15]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -80,8 +108,8 @@ sat_attn_cross_fwd_kernel(SatXAttnParams p) {
     };
     int wb = wb0 + wave;
     if (wb < wb1) load_q(wb);
-    sat_xatt_stage<256, SAT_ATT_ROW>(k_lds, p.k_rm + kplane, SAT_ATT_D, NKEY, SAT_ATT_D);
-    sat_xatt_stage<256, VROW>(v_lds, p.v_tr + kplane, (size_t)p.Nkp, SAT_ATT_D, NKEY);
+    sat_xatt_stage<NKB, SAT_ATT_ROW>(k_lds, p.k_rm + kplane, SAT_ATT_D, 8);                 // NKEY rows x 8 pieces
+    sat_xatt_stage<NKB, VROW>(v_lds, p.v_tr + kplane, (size_t)p.Nkp, NKEY / 8);             // 64 rows x NKEY / 8 pieces
     __syncthreads();
 
     for (; wb < wb1; wb += 4) {
@@ -103,14 +131,12 @@ sat_attn_cross_fwd_kernel(SatXAttnParams p) {
 
         f32x16 sacc[NKB];
         SAT_SETPRIO(1);
+        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int s = 0; s < 4; ++s)            // k-step outside: the NKB accumulator chains interleave (a dependent MFMA waits 64 cycles)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                sacc[kb] = sat_mfma_32x32x16_bf16(sat_att_frag_rm(k_lds, kb * 32 + kperm, 16 * s + 8 * hi), qf[s], sacc[kb]);
-        }
+            for (int kb = 0; kb < NKB; ++kb)
+                sacc[kb] = sat_mfma_32x32x16_bf16(sat_att_frag_rm(k_lds, kb * 32 + kperm, 16 * s + 8 * hi), qf[s], s == 0 ? zero : sacc[kb]);
         SAT_SETPRIO(0);
         // register r of block kb is key kb * 32 + (r & 7) + 8 hi + 16 (r >> 3); only the last block holds padded keys
         if (nvalid < 32) {
@@ -118,11 +144,12 @@ sat_attn_cross_fwd_kernel(SatXAttnParams p) {
             for (int r = 0; r < 16; ++r)
                 if ((r & 7) + 8 * hi + 16 * (r >> 3) >= nvalid) sacc[NKB - 1][r] = -INFINITY;
         }
-        float tmax = -INFINITY;
+        float tmax = sat_xatt_max16(sacc[0]);
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
+        for (int kb = 1; kb < NKB; ++kb) {
+            const float m = sat_xatt_max16(sacc[kb]);
+            tmax = sat_xatt_max3(tmax, m, m);
+        }
         const float mb = sat_att_halfmax(tmax);      // finite: key 0 is always valid
         f32x16 oacc[2];
 #pragma unroll
@@ -213,9 +240,9 @@ sat_attn_cross_dq_kernel(SatXAttnParams p) {
     };
     int wb = wb0 + wave;
     if (wb < wb1) load_q(wb);
-    sat_xatt_stage<256, SAT_ATT_ROW>(k_lds, p.k_rm + kplane, SAT_ATT_D, NKEY, SAT_ATT_D);
-    sat_xatt_stage<256, SAT_ATT_ROW>(v_lds, p.v_rm + kplane, SAT_ATT_D, NKEY, SAT_ATT_D);
-    sat_xatt_stage<256, VROW>(kt_lds, p.k_tr + kplane, (size_t)p.Nkp, SAT_ATT_D, NKEY);
+    sat_xatt_stage<NKB, SAT_ATT_ROW>(k_lds, p.k_rm + kplane, SAT_ATT_D, 8);
+    sat_xatt_stage<NKB, SAT_ATT_ROW>(v_lds, p.v_rm + kplane, SAT_ATT_D, 8);
+    sat_xatt_stage<NKB, VROW>(kt_lds, p.k_tr + kplane, (size_t)p.Nkp, NKEY / 8);
     __syncthreads();
 
     for (; wb < wb1; wb += 4) {
@@ -483,10 +510,10 @@ extern "C" int sat_attention_cross_ok(int H, int Hkv, int Nk, int head_dim, int 
     return (dtype == 1 && head_dim == SAT_ATT_D && Hkv > 0 && H % Hkv == 0 && Nk > 0 && Nk <= SAT_XATT_MAXK) ? 1 : 0;
 }
 
-// wave blocks per workgroup: enough workgroups to put ~2 on every CU while a workgroup's one-time K / V staging is shared by at
-// least four wave blocks (one per wave)
+// wave blocks per workgroup: enough workgroups to put ~4 on every CU (three are co-resident at 160 keys; a finer grain keeps the last
+// round's imbalance small) while a workgroup's one-time K / V staging is shared by at least four wave blocks (one per wave)
 static int sat_xatt_per_wg(int units_bhk, int nwb) {
-    const int target = 2 * sat_cu_count();
+    const int target = 4 * sat_cu_count();
     int nchunks = sat_cdiv(target, units_bhk);
     if (nchunks < 1) nchunks = 1;
     int per = sat_cdiv(nwb, nchunks);

@@ -899,7 +899,7 @@ class SatOps:
         else:
             self._chk(self.lib.sat_attention_fwd(_ptr(qp["rm"][0]), _ptr(qp["rm"][1]), _ptr(kp["rm"][0]), _ptr(kp["rm"][1]),
                                                  _ptr(vp["tr"][0]), _ptr(vp["tr"][1]), _ptr(o), _ptr(lse), b, h, hk, nq, nk,
-                                                 qp["np"], kp["np"], d, float(scale), dt, self._stream(q)))
+                                                 qp["np"], kp["np"], d, float(scale), self._fwd_dtype(dt), self._stream(q)))
         out = (o,)
         if need_lse or return_planes:
             out += (lse,)
@@ -935,6 +935,14 @@ class SatOps:
     # the short-key attention kernels (csrc/attention_cross.h) serve bf16 planes with Nk <= 256; False sends every shape to the general
     # flash-style kernels (A/B runs: bench.py --ops-set cross_kernels=0, and the kernel tests' second implementation)
     cross_kernels = True
+    # bf16 self-attention forward: None = the library picks 32 or 64 queries per wave by grid size (sat_attention_fwd), False / True force
+    # the 32- / 64-query kernel (A/B runs: bench.py --ops-set attn_q64=1; the kernel tests run both)
+    attn_q64 = None
+
+    def _fwd_dtype(self, dt):
+        if dt != 1 or self.attn_q64 is None:
+            return dt
+        return 3 if self.attn_q64 else 2
 
     def cross_ok(self, h, hkv, nk, d, dt):
         return bool(self.cross_kernels) and bool(self.lib.sat_attention_cross_ok(h, hkv, nk, d, dt))
@@ -1242,7 +1250,7 @@ class SatOps:
                                                        float(scale), self._stream(q_rm)))
         else:
             self._chk(self.lib.sat_attention_fwd(_ptr(q_rm), None, _ptr(k_rm), None, _ptr(v_tr), None, _ptr(o), None, b, h, hk, nq, nk,
-                                                 npq, npk, d, float(scale), 1, self._stream(q_rm)))
+                                                 npq, npk, d, float(scale), self._fwd_dtype(1), self._stream(q_rm)))
         return o
 
     # ---- fp8 (e4m3) forward projections: per-tensor dynamic scaling, MX MFMA with unit block scales ----

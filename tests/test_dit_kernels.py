@@ -108,13 +108,16 @@ def _attn_case(ops, dev, dtype, case, seed, spikes=(), cross=True):
     """cross: bf16 shapes with Nk <= 256 run on the short-key kernels (csrc/attention_cross.h) when True, on the general flash-style
     kernels when False — both implementations are held to the same SDPA reference."""
     b, h, hkv, nq, nk = case
-    saved = ops.cross_kernels
+    saved = ops.cross_kernels, ops.attn_q64
     ops.cross_kernels = cross
     try:
         assert ops.cross_ok(h, hkv, nk, 64, 1) == (cross and nk <= 256)
-        _attn_case_body(ops, dev, dtype, case, seed, spikes)
+        # the general bf16 forward has two kernel shapes (32 / 64 queries per wave, picked by grid size): both are held to the reference
+        for q64 in ((False, True) if (dtype == torch.bfloat16 and not ops.cross_ok(h, hkv, nk, 64, 1)) else (None,)):
+            ops.attn_q64 = q64
+            _attn_case_body(ops, dev, dtype, case, seed, spikes)
     finally:
-        ops.cross_kernels = saved
+        ops.cross_kernels, ops.attn_q64 = saved
 
 
 def _attn_case_body(ops, dev, dtype, case, seed, spikes):

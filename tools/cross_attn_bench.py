@@ -1,5 +1,5 @@
 """Cross-attention (130 keys, GQA 24:12) forward and backward, bf16 planes: the short-key kernels (csrc/attention_cross.h) against the
-general flash-style kernels on the same operands — microseconds per launch (HIP events over 100 launches after 10 warm-up), achieved
+general flash-style kernels on the same operands — microseconds per launch (HIP-graph replay of 20 launches: no host dispatch in the figure), achieved
 TFLOP/s (4 N M d per head forward, 10 N M d backward: the algorithmic count, recomputation not credited) and the error against SDPA.
     python tools/cross_attn_bench.py            one JSON line per (shape, implementation)"""
 import json
@@ -15,16 +15,31 @@ torch.manual_seed(0)
 
 
 def timeit(f, n=100):
-    for _ in range(10):
+    """microseconds per call of f: 20 calls captured into ONE HIP graph, the graph replayed n / 20 times — a launch of a few microseconds
+    is otherwise timed together with the host's ~10 us of Python / ctypes dispatch per call (the first version of this tool did)."""
+    for _ in range(3):
         f()
     torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        f()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(20):
+                f()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    reps = max(1, n // 20)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        f()
+    for _ in range(reps):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (20 * reps) * 1e3
 
 
 shapes = [(2, 24, 12, 1025, 130), (4, 24, 12, 1025, 130), (16, 24, 12, 1025, 130), (2, 24, 12, 6145, 130)]
