@@ -236,6 +236,30 @@ int sat_wn_grad(const float* v, const float* g, const float* norm, const float* 
 int sat_wn_grad_splits(const float* partial, int nsplit, long long count, long long so_m, long long so_n, long long so_k,
                        const float* v, const float* g, const float* norm, float* dv, float* dg, int D0, int N, int K,
                        const float* bias_partial, int bias_cols, float* dbias, void* stream);
+/* The two-channel ends of the Oobleck stack (csrc/edge_conv.hip, round 6): the encoder's first conv (models/autoencoders.py:303), the
+ * decoder's last conv (:355-356: Snake -> WNConv1d(channels, out_channels, 7, padding=3, bias=False)), its data-gradient and both
+ * weight gradients as fp32 FMA streams bound by the one pass over the 128-channel tensor (a 2-channel operand wastes 7/8 of an MFMA
+ * k-chunk / 63/64 of an output tile).  sat_edge_conv_ok: stride 1, dilation 1, odd K <= 7 with 2 * pad == K - 1, one of (cin, cout)
+ * <= 2 and the other >= 8. */
+int sat_edge_conv_ok(int cin, int cout, int k, int stride, int dil, int pad);
+/* rows of the data-gradient epilogue's partial sums: part_da / part_db are [Cout][rows] (sum the rows: sat_rowsum) */
+int sat_edge_conv_partial_rows(int B, int T);
+/* y (B, Cout, T) = conv1d(act(x), W) + bias.  w: the torch weight (Cout, Cin, K) with mode 0, or (Cin, Cout, K) with mode 1 (the
+ * data-gradient of that weight's conv: transposed, taps flipped).  alpha / beta: log parameters of the INPUT's SnakeBeta (Cout <= 2
+ * only) | NULL.  x2 / alpha2 / beta2 / part_da / part_db: y *= dsnake(x2) with the per-channel d log-alpha / d log-beta partial sums
+ * (Cin <= 2 only) | NULL.  em_hi / em_lo | NULL (Cin <= 2 only): plane emission as sat_conv1d_bf16x3_emit — act_next(y) as the bf16 hi / lo
+ * planes [B][ceil(Cout/8)][em_rows][8] (row 32 + t) of the k7 conv that reads y next; em_alpha / em_beta: its SnakeBeta's log parameters | NULL. */
+int sat_edge_conv(const float* x, const float* w, const float* bias, const float* alpha, const float* beta, float* y, const float* x2,
+                  const float* alpha2, const float* beta2, float* part_da, float* part_db, short* em_hi, short* em_lo,
+                  const float* em_alpha, const float* em_beta, int em_rows, int B, int Cin, int Cout, int T, int K, int pad, int mode,
+                  int tanh_out, void* stream);
+/* slabs sat_edge_conv_wgrad writes for this shape (-1: bad shape) */
+int sat_edge_conv_wgrad_nsplit(int B, int M, int N, int T);
+/* dW (M, N, K) of y = conv1d(act(x), W) as slabs partial[nsplit][M * N * K] in torch order (sat_wn_grad_splits / sat_reduce_splits);
+ * dy (B, M, T), x (B, N, T) pre-activation; alpha / beta: x's SnakeBeta (M <= 2 form only) | NULL; rowsum [M][nsplit] | NULL: per-slab
+ * row sums of dy = the bias gradient one reduction short (N <= 2 form only). */
+int sat_edge_conv_wgrad(const float* dy, const float* x, const float* alpha, const float* beta, float* partial, float* rowsum, int B,
+                        int M, int N, int T, int K, int pad, void* stream);
 /* torch weight w[D0][D1][K] -> GEMM-side layout.  mode 0: [D1][k][D0]; 1: [D0][K-1-k][D1]; 2: [r][j][D0][D1], k=r+j*S */
 int sat_pack_weights(const float* w, float* out, int D0, int D1, int K, int S, int mode, void* stream);
 
@@ -323,7 +347,7 @@ int sat_attn_prepare(const void* src, long long sb, long long sh, long long sn, 
                      short* tr_hi, short* tr_lo, int B, int H, int N, int Np, int dtype, void* stream);
 /* forward: q_* row-major planes (B,H,Nqp,64), k_* row-major (B,Hkv,Nkp,64), vt_* TRANSPOSED (B,Hkv,64,Nkp);
  * o: (B, Nq, H*64) in the model dtype — heads merged; lse: (B, H, Nq) fp32 or NULL.  dtype 1 (bf16): a wave owns 64 queries when
- * 256-query workgroups still put two on every CU (long context, training batches), else 32; dtype 2 / 3 force 32 / 64 (A/B, tests). */
+ * Nq >= 2048 and 256-query workgroups still put two on every CU (the long context), else 32; dtype 2 / 3 force 32 / 64 (A/B, tests). */
 int sat_attention_fwd(const short* q_hi, const short* q_lo, const short* k_hi, const short* k_lo, const short* vt_hi,
                       const short* vt_lo, void* o, float* lse, int B, int H, int Hkv, int Nq, int Nk, int Nqp, int Nkp,
                       int head_dim, float scale, int dtype, void* stream);

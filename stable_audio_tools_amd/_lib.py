@@ -98,6 +98,12 @@ SIGNATURES = {
     "sat_attention_fwd": (_I, [_P] * 8 + [_I] * 8 + [_F, _I, _P]),
     "sat_attention_rowdot": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_attention_bwd": (_I, [_P] * 6 + [_I] * 8 + [_F, _I, _P]),
+    # edge_conv.hip
+    "sat_edge_conv_ok": (_I, [_I] * 6),
+    "sat_edge_conv_partial_rows": (_I, [_I] * 2),
+    "sat_edge_conv": (_I, [_P] * 15 + [_I] * 9 + [_P]),
+    "sat_edge_conv_wgrad_nsplit": (_I, [_I] * 4),
+    "sat_edge_conv_wgrad": (_I, [_P] * 6 + [_I] * 6 + [_P]),
     "sat_attention_cross_ok": (_I, [_I] * 5),
     "sat_attention_cross_fwd": (_I, [_P] * 5 + [_I] * 8 + [_F, _P]),
     "sat_attention_cross_bwd_ws": (_L, [_I] * 5),

@@ -319,8 +319,9 @@ class OobleckEncoder(nn.Module):
 
     def forward(self, x):
         mods = list(self.layers)
-        x = mods[0](x)
         blocks = mods[1:-2]
+        # the first conv (two audio channels in: csrc/edge_conv.hip) writes the first ResidualUnit's k7 activation planes beside its output
+        x = mods[0](x, next_snake=blocks[0].layers[0].entry_snake() if blocks else None)
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1].layers[0].entry_snake() if i + 1 < len(blocks) else None
             x = blk(x, next_snake=nxt)

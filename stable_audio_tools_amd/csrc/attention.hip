@@ -563,8 +563,9 @@ sat_attn_fwd_kernel(SatAttnParams p) {
 // 270), at two waves per SIMD (~210 registers) instead of three.  The tile is walked one 32-KEY block at a time — QK^T (4 MFMAs per
 // query block), exp2 / pack / row sum, P V (4 MFMAs per query block) — so only 2 x 16 score registers are live; the stale-max check
 // (the deferred rescale of the kernel above) is per key block: 16 scores per lane, limit 16 x 2^SAT_ATT_DEFER.
-// Used where the grid still fills the chip (sat_attention_fwd: >= 2 workgroups of 256 queries per CU — the long context, training
-// batches); the sampler's small launch stays on the 32-query kernel.
+// Used for long sequences whose grid still fills the chip (sat_attention_fwd: Nq >= 2048 and >= 2 workgroups of 256 queries per CU);
+// measured gain: 2 % at N = 6145, none at N = 1025 — the kernel is bound by the softmax's VALU issue per score, which sharing
+// fragments does not touch (the experiment's answer to round 5's hypothesis).
 // ---------------------------------------------------------------------------------------------
 #define SAT_ATT_SUMLIM_KB 256.0f
 
@@ -1507,10 +1508,12 @@ extern "C" int sat_attention_fwd(const short* q_hi, const short* q_lo, const sho
     if (dtype == 0) {
         SAT_LAUNCH((sat_attn_fwd_kernel<float, 2>), grid, dim3(256), stream, p);
     } else {
-        // bf16: 64 queries per wave (sat_attn_fwd_q_kernel<2>) where 256-query workgroups still put >= 2 on every CU, else 32;
-        // dtype 2 / 3 force the 32- / 64-query kernel (A/B runs and the tests' second implementation)
+        // bf16: 64 queries per wave (sat_attn_fwd_q_kernel<2>) for LONG sequences whose 256-query workgroups still put >= 2 on every CU,
+        // else 32 — measured (profiles/r06_experiments/attn_q64/): N = 6145 520 vs 530 us (0.357 vs 0.350 of the bf16 peak), N = 1025
+        // 164.7 vs 157.3 us at B = 16 (the ragged 1025 = 4 x 256 + 1 costs a fifth workgroup per head and two waves per SIMD overlap the
+        // softmax less than three).  dtype 2 / 3 force the 32- / 64-query kernel (A/B runs and the tests' second implementation)
         const long long wg64 = (long long)sat_cdiv(Nq, 256) * H * B;
-        const bool q64 = dtype == 3 || (dtype == 1 && wg64 >= 2LL * sat_cu_count());
+        const bool q64 = dtype == 3 || (dtype == 1 && Nq >= 2048 && wg64 >= 2LL * sat_cu_count());
         if (q64) SAT_LAUNCH((sat_attn_fwd_q_kernel<2>), dim3(sat_cdiv(Nq, 256), H, B), dim3(256), stream, p);
         else SAT_LAUNCH((sat_attn_fwd_kernel<short, 1>), grid, dim3(256), stream, p);
     }

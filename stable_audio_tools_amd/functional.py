@@ -101,6 +101,10 @@ def _conv_dgrad(ops, dy, w, k, stride, dil, pad, cin, tin, dsnake, res=None, out
     the caller's tensor (it may alias `res`: accumulation in place).  emit: {"snake": None | (la, lb)} — also write the result as
     the activation planes of the k7 conv that consumes it next (ops.emit_ok decides)."""
     if stride == 1:
+        if (res is None and out is None and emit is None and ops.edge_ok(w.shape[0], cin, k, 1, dil, (k - 1) * dil - pad) and tin == dy.shape[2]
+                and (dsnake is None or w.shape[0] <= 2)):
+            # the data-gradient of a conv with a two-channel side = that side's edge conv on the transposed, tap-flipped weight
+            return ops.edge_conv(dy, w, (k - 1) * dil - pad, mode=1, dsnake=dsnake)
         if ops.bf16x3_ok(k, 1, dil):
             q = ops.k7q_applicable(w.shape[0], k, 1, dil, (k - 1) * dil - pad, cin)  # the data-gradient's input channels = Cout
             return ops.conv1d_bf16x3(dy, ops.pack_bf16x3(w, mode=1, q=q), cin, k, 1, dil, (k - 1) * dil - pad, tout=tin,
@@ -122,6 +126,8 @@ def _conv_wgrad(ops, dy, x, k, stride, dil, pad, snake, bias_grad=False, raw=Fal
     bias_grad=True returns (dW, dbias): the bf16x3 kernels sum the dy rows they stream anyway.
     raw=True: dW stays the kernel's split slabs (ops.WgradSlabs), and dbias the per-split sums (C, R) one reduction short of the
     gradient — what _wn_backward takes."""
+    if ops.edge_ok(x.shape[1], dy.shape[1], k, stride, dil, pad) and dy.shape[2] == x.shape[2] and (snake is None or dy.shape[1] <= 2):
+        return ops.edge_conv_wgrad(dy, x, k, pad, snake=snake, dy_rowsum=bias_grad, raw=raw)      # a two-channel side: fp32 FMA stream
     if ops.wgrad7_bf16x3_ok(x.shape[1], k, stride, dil):
         return ops.conv_wgrad7_bf16x3(dy, x, dil, pad, snake=snake, dy_rowsum=bias_grad, raw=raw)
     return ops.conv_wgrad(dy, x, k, stride, dil, pad, snake=snake, snake_on=2, lo_rowsum=bias_grad, raw=raw)
@@ -150,6 +156,10 @@ def _conv_fwd(ops, x, w, stride, dil, pad, bias=None, snake=None, res=None, tanh
     its shape rules allow, else the fp32-MFMA kernel (csrc/conv1d.hip).  cache: DerivedCache of the layer (no-grad / frozen
     passes only) for the packed planes and the SnakeBeta constants."""
     cout, cin, k = w.shape
+    if (res is None and ops.edge_ok(cin, cout, k, stride, dil, pad) and (tout is None or tout == x.shape[2])
+            and (snake is None or cout <= 2) and (dsnake is None or cin <= 2) and (emit is None or cin <= 2)):
+        # a two-channel end of the stack (the encoder's first conv, the decoder's last): fp32 FMA stream straight from the folded weight
+        return ops.edge_conv(x, w, pad, bias=bias, snake=snake, tanh_out=tanh_out, dsnake=dsnake, emit=emit)
     if ops.bf16x3_ok(k, stride, dil):
         q = ops.k7q_applicable(cin, k, stride, dil, pad, cout)
         planes = _cached(cache, "pack_fwd_q" if q else "pack_fwd", (w,), lambda: ops.pack_bf16x3(w, stride=stride, q=q))
@@ -190,7 +200,8 @@ class SnakeConv1dFn(torch.autograd.Function):
         emit = None
         if next_snake is not None and not tanh_out:
             tout_ = (x.shape[2] + 2 * pad - dil * (k - 1) - 1) // stride + 1
-            if ops.emit_ok(cout, k, stride, tout_, next_snake[2]) and ops.bf16x3_ok(k, stride, dil):
+            if ((ops.emit_ok(cout, k, stride, tout_, next_snake[2]) and ops.bf16x3_ok(k, stride, dil))
+                    or (res is None and snake is None and ops.edge_emit_ok(cin, cout, k, stride, dil, pad, next_snake[2]))):
                 emit = {"snake": (next_snake[0].detach(), next_snake[1].detach())}
         y = _conv_fwd(ops, x, w, stride, dil, pad, bias=bias, snake=snake,
                       res=res.contiguous() if res is not None else None, tanh_out=tanh_out, cache=cache, emit=emit)

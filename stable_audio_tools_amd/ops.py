@@ -179,6 +179,67 @@ class SatOps:
     #    down / up (transposed) convs with a power-of-two stride --
     use_bf16x3 = True   # fp32-accurate (hi/lo split, 3 MFMAs per product); set False to force the fp32-MFMA kernels
 
+    # the two-channel ends of the stack (csrc/edge_conv.hip): fp32 FMA streams instead of padded MFMA tiles; False (A/B, second
+    # implementation in the tests) sends them to the matrix kernels like every other conv
+    edge_convs = True
+
+    def edge_ok(self, cin, cout, k, stride, dil, pad):
+        return bool(self.edge_convs) and bool(self.lib.sat_edge_conv_ok(cin, cout, k, stride, dil, pad))
+
+    def edge_conv(self, x, w, pad, mode=0, bias=None, snake=None, tanh_out=False, dsnake=None, emit=None):
+        """conv1d(snake(x), W) + bias for a conv with <= 2 channels on one side (edge_ok).  w: the FOLDED torch weight — (Cout, Cin, K),
+        or with mode=1 the (Cin', Cout', K) weight whose conv's data-gradient this is.  snake = (log-alpha, log-beta) of the input
+        (Cout <= 2 form); dsnake = (x2, log-alpha2, log-beta2): returns (y * dsnake(x2), d log-alpha, d log-beta) (Cin <= 2 form)."""
+        b, cin, t = x.shape
+        k = w.shape[2]
+        cout = w.shape[0] if mode == 0 else w.shape[1]
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(x, w, bias, alpha, beta)
+        y = torch.empty(b, cout, t, dtype=torch.float32, device=x.device)
+        x2 = a2 = b2 = pda = pdb = None
+        if dsnake is not None:
+            x2, a2, b2 = dsnake
+            self._f32(x2, a2, b2)
+            rows = self.lib.sat_edge_conv_partial_rows(b, t)
+            pda, pdb = torch.empty(2, cout, rows, dtype=torch.float32, device=x.device).unbind(0)
+        ehi = elo = ela = elb = None
+        erows = 0
+        if emit is not None:      # emit = {"snake": (la, lb) | None}: act_next(y) as the planes of the k7 conv that reads y next (narrow-input form)
+            esnake = emit.get("snake")
+            if esnake is not None:
+                ela, elb = esnake
+                self._f32(ela, elb)
+            ehi, elo, erows = self._emit_planes(b, cout, t, x.device, self._stream(x))
+        self._chk(self.lib.sat_edge_conv(_ptr(x), _ptr(w), _ptr(bias), _ptr(alpha), _ptr(beta), _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2),
+                                         _ptr(pda), _ptr(pdb), _ptr(ehi), _ptr(elo), _ptr(ela), _ptr(elb), erows, b, cin, cout, t, k, pad, mode,
+                                         int(tanh_out), self._stream(x)))
+        if emit is not None:
+            self._note_emitted(y, emit.get("snake"), ehi, elo, erows)
+        if dsnake is not None:
+            return (y, *self._sum_pair(pda, pdb))
+        return y
+
+    def edge_conv_wgrad(self, dy, x, k, pad, snake=None, dy_rowsum=False, raw=False):
+        """dW (M, N, K) of conv1d(snake(x), W) with <= 2 channels on one side; contract of conv_wgrad7_bf16x3 (raw: WgradSlabs + the bias
+        gradient's per-slab partial sums)."""
+        b, m, t = dy.shape
+        n = x.shape[1]
+        alpha, beta = snake if snake is not None else (None, None)
+        self._f32(dy, x, alpha, beta)
+        nsplit = self.lib.sat_edge_conv_wgrad_nsplit(b, m, n, t)
+        partial = torch.empty(nsplit, m * n * k, dtype=torch.float32, device=dy.device)
+        fused = dy_rowsum and n <= 2                      # the kernel streams dy in that form and sums its rows on the way
+        rs = torch.empty(m, nsplit, dtype=torch.float32, device=dy.device) if fused else None
+        self._chk(self.lib.sat_edge_conv_wgrad(_ptr(dy), _ptr(x), _ptr(alpha), _ptr(beta), _ptr(partial), _ptr(rs), b, m, n, t, k, pad,
+                                               self._stream(dy)))
+        slabs = WgradSlabs(partial, nsplit, (m, n, k), (n * k, k, 1))
+        dw = slabs if raw else slabs.reduce(self)
+        if not dy_rowsum:
+            return dw
+        if raw:
+            return dw, (rs if fused else self.rowsum(dy, partial=True))
+        return dw, (self._sum_last(rs) if fused else self.rowsum(dy))
+
     def bf16x3_ok(self, k, stride, dil, transposed=False):
         if not self.use_bf16x3:
             return False
@@ -362,6 +423,11 @@ class SatOps:
             return False
         generic = (stride == 1 and k <= 4) or stride > 1          # the plans of csrc/conv1d_bf16x3.hip's generic kernel
         return generic and tout % 4 == 0
+
+    def edge_emit_ok(self, cin, cout, k, stride, dil, pad, consumer_dil):
+        """May the narrow-input edge conv (the encoder's first conv) emit the planes of the k7 conv (dilation consumer_dil) that reads it next?"""
+        return (self.k7_emit and self.use_bf16x3 and cin <= 2 and self.edge_ok(cin, cout, k, stride, dil, pad)
+                and self.k7q_applicable(cout, 7, 1, consumer_dil, 3 * consumer_dil, cout))
 
     def _emit_planes(self, b, c, t, device, st, alt=False):
         """Emission target for a (b, c, t) tensor: planes [b][ceil(c/8)][rows][8] with the rows around the sequence zero.  One pair

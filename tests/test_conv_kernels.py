@@ -108,6 +108,94 @@ def _run_nosnake_tanh(ops, dev):
     _compare([y1], [y2], [x, w], gen)
 
 
+# the two-channel ends of the stack (csrc/edge_conv.hip, round 6): encoder-first-conv form (Cin <= 2, no activation, bias), decoder-last-conv
+# form (SnakeBeta -> Cout <= 2, with and without bias / tanh), every gradient (the decoder form's data-gradient is the narrow-input
+# kernel with the dsnake epilogue on the flipped weight; both weight-gradient forms; the bias gradient fused into the narrow-input one);
+# lengths around the 1024-step tile and not multiples of 4 (the scalar edge paths); the same cases on the matrix kernels
+# (ops.edge_convs = False) — two implementations, one torch reference
+EDGE_CASES = [  # (B, Cin, Cout, T, K, snake, bias, tanh)
+    (1, 2, 24, 1500, 7, False, True, False), (2, 2, 40, 1024, 7, False, True, False), (1, 1, 16, 333, 7, False, True, False),
+    (1, 24, 2, 1500, 7, True, False, False), (2, 40, 2, 2050, 7, True, True, True), (1, 16, 1, 1027, 7, True, False, False),
+    (1, 2, 8, 4100, 5, False, True, False), (1, 12, 2, 700, 3, True, False, False), (1, 2, 130, 2048, 7, False, True, False),
+]
+
+
+def _run_edge(ops, dev, case, edge):
+    B, Cin, Cout, T, K, use_snake, use_bias, tanh_out = case
+    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    saved = ops.edge_convs
+    ops.edge_convs = edge
+    try:
+        pad = (K - 1) // 2
+        assert ops.edge_ok(Cin, Cout, K, 1, 1, pad) == edge
+        x = _leaf(gen, dev, B, Cin, T)
+        la, lb = (_leaf(gen, dev, Cin, s=.3), _leaf(gen, dev, Cin, s=.3)) if use_snake else (None, None)
+        w = _leaf(gen, dev, Cout, Cin, K, s=.2)
+        bias = _leaf(gen, dev, Cout) if use_bias else None
+        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, w, bias, None, 1, 1, pad, tanh_out, ops)
+        y2 = F.conv1d(snake(x, la, lb) if use_snake else x, w, bias, padding=pad)
+        if tanh_out:
+            y2 = torch.tanh(y2)
+        _compare([y1], [y2], [t for t in (x, la, lb, w, bias) if t is not None], gen)
+        # weight-normed form (what the model runs): the unit folds (v, g) itself and takes the edge kernels' slabs to sat_wn_grad_splits
+        v, g = _leaf(gen, dev, Cout, Cin, K, s=.2), _leaf(gen, dev, Cout, 1, 1)
+        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, v, bias, None, 1, 1, pad, tanh_out, ops, None, None, g)
+        wn = g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+        y2 = F.conv1d(snake(x, la, lb) if use_snake else x, wn, bias, padding=pad)
+        if tanh_out:
+            y2 = torch.tanh(y2)
+        _compare([y1], [y2], [t for t in (x, la, lb, v, g, bias) if t is not None], gen)
+    finally:
+        ops.edge_convs = saved
+
+
+def _edge_emit_case(ops, dev):
+    """Plane emission of the narrow-input edge conv (the encoder's first conv writes the first ResidualUnit's k7 planes): hi + lo of the
+    emitted planes == snake(y) to 2^-16, rows around the sequence zero, channels past Cout zero (Cout = 20: a partial group of 8)."""
+    gen = torch.Generator().manual_seed(11)
+    B, Cin, Cout, T = 2, 2, 20, 1300
+    x = (torch.randn(B, Cin, T, generator=gen)).to(dev)
+    w = (torch.randn(Cout, Cin, 7, generator=gen) * .3).to(dev)
+    bias = torch.randn(Cout, generator=gen).to(dev)
+    la, lb = (torch.randn(Cout, generator=gen) * .3).to(dev), (torch.randn(Cout, generator=gen) * .3).to(dev)
+    for esnake in ((la, lb), None):
+        y = ops.edge_conv(x, w, 3, bias=bias, emit={"snake": esnake})
+        ref = F.conv1d(x.cpu(), w.cpu(), bias.cpu(), padding=3)
+        assert (y.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+        em = ops._take_emitted(y, esnake)
+        assert em is not None
+        rows = em["rows"]
+        hi = em["hi"].view(torch.bfloat16).float().view(B, 3, rows, 8).cpu()
+        lo = em["lo"].view(torch.bfloat16).float().view(B, 3, rows, 8).cpu()
+        got = (hi + lo).permute(0, 1, 3, 2).reshape(B, 24, rows)           # (B, channel, plane row)
+        want = snake(ref, la.cpu(), lb.cpu()) if esnake is not None else ref
+        assert (got[:, :Cout, 32:32 + T] - want).abs().max() <= 2.0 ** -15 * want.abs().max()
+        assert got[:, Cout:, :].abs().max() == 0 and got[:, :, :32].abs().max() == 0 and got[:, :, 32 + T:].abs().max() == 0
+
+
+def test_edge_conv_emission_sim(emu):
+    _edge_emit_case(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_edge_conv_emission_gpu(hip):
+    _edge_emit_case(hip, "cuda")
+
+
+@pytest.mark.parametrize("case", EDGE_CASES)
+def test_edge_conv_sim(emu, case):
+    _run_edge(emu, "cpu", case, True)
+    if case[3] <= 1500:
+        _run_edge(emu, "cpu", case, False)
+
+
+@pytest.mark.gpu
+def test_edge_conv_gpu(hip):
+    for case in EDGE_CASES + [(1, 2, 128, 262144, 7, False, True, False), (1, 128, 2, 262144, 7, True, False, False)]:
+        _run_edge(hip, "cuda", case, True)
+        _run_edge(hip, "cuda", case, False)
+
+
 @pytest.mark.parametrize("case", S1_CASES)
 def test_conv_stride1_sim(emu, case):
     _run_s1(emu, "cpu", case, True)

@@ -112,6 +112,8 @@ def test_dit_block_long_context_gpu(hip):
 # residual stream, so they add in quadrature: 2e-2 * sqrt(24) = 0.098 expected, bound = 2 x that = 0.2 (bench.py FP8_DEPTH24_BOUND is the
 # same number).  The guided output before the rescale is held to the triangle inequality on the two measured half errors.
 FP8_DEPTH24 = 0.2
+# policy "ff" (round 6: fp8 on the feed-forward pair only): 2 of the 7 fp8 roundings per layer -> 0.2 * sqrt(2 / 7) = 0.107
+FP8_FF_DEPTH24 = 0.11
 
 
 @pytest.mark.gpu
@@ -147,6 +149,14 @@ def test_dit_depth24_fp8_long_context_final_output_gpu(hip):
           f"guided pre-rescale {eg:.2e} (triangle bound {gb:.2e})")
     assert ec < FP8_DEPTH24 and eu < FP8_DEPTH24, (ec, eu)
     assert eg <= gb, (eg, gb)
+    # the accuracy-first policy: feed-forward pair in fp8, attention projections in bf16 — same oracle results
+    with torch.no_grad():
+        assert linear.set_fp8(model, True, policy="ff") == 2 * 24
+        cf = model(xb, tb, **kw).float().cpu()
+        uf = model(xb, tb, cross_attn_cond=torch.zeros_like(kw["cross_attn_cond"]), global_embed=kw["global_embed"]).float().cpu()
+    ecf, euf = l2_err(cf, c_ref), l2_err(uf, u_ref)
+    print(f"   policy 'ff' (fp8 feed-forward only): conditioned {ecf:.2e} unconditioned {euf:.2e} (bound {FP8_FF_DEPTH24})")
+    assert ecf < FP8_FF_DEPTH24 and euf < FP8_FF_DEPTH24 and ecf < ec, (ecf, euf, ec)
 
 
 # Trajectory level (round 6).  10 v-DDIM steps with CFG 6 + rescale 0.75 at N = 6145 from one noise tensor; the final latents of the fp8 model
