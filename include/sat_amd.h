@@ -153,7 +153,7 @@ int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0, int D1, i
 int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo, const float* bias,
                              const float* res, float* y, const float* x2, const float* alpha2, const float* beta2, float* part_da,
                              float* part_db, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int tanh_out,
-                             void* stream);
+                             int flags, void* stream);      /* flags bit 0: one workgroup per tile instead of the persistent launch (A/B); bit 1: persistent at any size (tests) */
 int sat_convtr1d_bf16x3_partial_rows(int B, int Tout, int stride, int pad);
 int sat_pack_weights_bf16x3(const float* w, short* hi, short* lo, int D0, int D1, int K, int stride, int mode, void* stream);
 long long sat_pack_weights_bf16x3_size(int D0, int D1, int K, int stride, int mode);

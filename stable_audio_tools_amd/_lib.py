@@ -42,7 +42,7 @@ SIGNATURES = {
     "sat_disc_wgrad": (_I, [_P] * 3 + [_I] * 8 + [_P]),
     "sat_conv1d_k7_plane_rows": (_I, [_I] * 3),
     "sat_conv1d_k7_planes": (_I, [_P] * 5 + [_I] * 4 + [_P]),
-    "sat_conv1d_bf16x3_planesq": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 9 + [_P]),
+    "sat_conv1d_bf16x3_planesq": (_I, [_P, _P, _I] + [_P] * 10 + [_I] * 10 + [_P]),
     "sat_pack_weights_k7q": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sat_residual_unit_fwd": (_I, [_P, _P, _I] + [_P] * 11 + [_I] * 6 + [_P] * 4 + [_I, _P]),
     "sat_pack_weights_k7q_size": (_L, [_I, _I, _I, _I]),

@@ -40,6 +40,7 @@ struct SatConvBfLaunch {
     int xp_rows = 0, xp_c8 = 0;
     int wq = 0;            // conv1d_bf16x3_k7q.h: the weight planes are in sat_pack_weights_k7q layout ([chunk16][tap][group][co][8])
     int stagger = 0;       // conv1d_bf16x3_k7q.h: start delay units (x ~4 us x (0..7)) that de-phase the CUs' epilogue bursts
+    int persist = 0;       // conv1d_bf16x3_k7q.h: one workgroup per CU walks the tiles, the next tile's first chunk requested before the epilogue
     // plane EMISSION (generic kernel, 16-byte epilogue): besides y the kernel writes act(y) as the bf16 hi / lo planes the next k7
     // conv reads ([B][em_c8][em_rows][8], row = 32 + t; the zero rows around the sequence belong to the caller) — the consumer's
     // sat_k7_planes_kernel pre-pass (one read + one write of the tensor) disappears.  em_a / em_ib: pre-exponentiated SnakeBeta
@@ -645,7 +646,7 @@ extern "C" int sat_conv1d_k7_planes(const float* x, const float* snake_a, const 
 extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo, int rows, const short* w_hi, const short* w_lo,
                                          const float* bias, const float* res, float* y, const float* x2, const float* alpha2,
                                          const float* beta2, float* part_da, float* part_db, int B, int Cin, int Cout, int Tin, int Tout,
-                                         int K, int dil, int pad, int tanh_out, void* stream) {
+                                         int K, int dil, int pad, int tanh_out, int flags, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0) { sat_set_error("sat_conv1d_bf16x3_planesq: empty shape"); return 1; }
     if (K < 5 || K > SAT_K7Q_TAPS || dil < 1 || (K - 1) * dil > 62) {
         sat_set_error("sat_conv1d_bf16x3_planesq: needs stride 1, 5 <= K <= 7, (K-1)*dil <= 62");
@@ -671,6 +672,8 @@ extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo,
     a.xp_rows = rows;
     a.xp_c8 = sat_cdiv(Cin, 8);
     a.wq = 1;
+    a.persist = (flags & 1) ? 0 : ((flags & 2) ? 2 : 1);      // flags bit 0: one workgroup per tile (round 5's launch; A/B runs and the tests'
+                                                              // second arm); bit 1: persistent at any size (the tests: small shapes)
     SatBfPlan pl{8, 1, K};
     return sat_bf_launch("sat_conv1d_bf16x3_planesq", a, pl, stream);
 }

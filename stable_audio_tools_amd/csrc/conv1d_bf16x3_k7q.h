@@ -86,8 +86,13 @@ extern "C" int sat_pack_weights_k7q(const float* w, short* hi, short* lo, int D0
 // straight into registers) and finishes with the ordinary epilogue on the second accumulators (bias2, residual x, plane emission for
 // the next unit).  The k1 launch, its read of h and its separate activation pass disappear.
 typedef uint32_t u32x2_q __attribute__((ext_vector_type(2)));
-template <int VARIANT = 1, bool FUSED = false>
+// PERSIST (round 6): one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Every chunk of a tile lives in the stage of
+// the OPPOSITE parity (chunk 0 in stage 1) — the half of the LDS the epilogue's transposition windows (offset 0, 70 KB) do not touch: the
+// NEXT tile's chunk 0 is requested (76 LDS-DMA pieces, nothing in registers) right after the K loop and lands under the epilogue,
+// instead of a fresh workgroup's prologue waiting for it with an idle CU (~2-3 us of the ~51 us a C = 128 tile takes).
+template <int VARIANT = 1, bool FUSED = false, bool PERSIST = false>
 __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatConvBfLaunch a) {
+    static_assert(!(FUSED && PERSIST), "the fused unit is not persistent");
     // VARIANT 1 (shipped): the next chunk's LDS-DMA goes out longest latency first — phase 0 issues its activation pieces (HBM) and
     // taps 0, 1, phase 1 taps 2..6 (L2-resident weights) — with COUNTED waits: phase 1 leaves taps 4-6 in flight (vmcnt(3)), they are
     // retired by the next chunk's phase 0 (which leaves its own new pieces in flight: 5 for waves 0-3, 4 for waves 4-7) one phase
@@ -102,21 +107,27 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     float (*red_lds)[TW][CO_T] = reinterpret_cast<float (*)[TW][CO_T]>(lds + RED_OFF);
     float (*ep_lds)[CO_T] = reinterpret_cast<float (*)[CO_T]>(lds + EP_OFF);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = SAT_UNIFORM(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wr = wave / TW;
-    const int co_w = wr * 64, t_w = (wave % TW) * 64;
+    // (PERSIST re-derives the lane- / wave-dependent values per tile from laundered copies: as loop invariants of the tile loop they
+    // — and everything the epilogue computes from them — would stay live across the K loop and the epilogue alike: 171 spilled registers)
+    int tid = threadIdx.x;
+    int lane = tid & 63;
+    int wave = SAT_UNIFORM(tid >> 6);
+    int l31 = lane & 31, hi = lane >> 5;
+    int wr = wave / TW;
+    int co_w = wr * 64, t_w = (wave % TW) * 64;
     const int K = p.K, dil = p.dil;
     const int nchunks = (a.cin_v + 15) / 16;
     const int co_tiles = a.cout_pad / CO_T, t_tiles = (a.nq + T_T - 1) / T_T;
+    const int total_tiles = co_tiles * t_tiles * p.B;
+    int tile_id = (int)blockIdx.x;
     int co_tile, win;
-    sat_xcd_tile((int)blockIdx.x, co_tiles, t_tiles * p.B, &co_tile, &win);
-    const int b = win / t_tiles, t_tile = win - b * t_tiles;
-    const int co0 = co_tile * CO_T, t0 = t_tile * T_T;
-    const int row_in0 = SAT_K7P_LEAD + t0 - p.pad;        // plane row of the window's first input step (>= 0: pad <= LEAD)
+    sat_xcd_tile(tile_id, co_tiles, t_tiles * p.B, &co_tile, &win);
+    int b = win / t_tiles, t_tile = win - b * t_tiles;
+    int co0 = co_tile * CO_T, t0 = t_tile * T_T;
+    int row_in0 = SAT_K7P_LEAD + t0 - p.pad;              // plane row of the window's first input step (>= 0: pad <= LEAD)
+    constexpr int SPAR = PERSIST ? 1 : 0;                 // chunk c is staged in stage (c + SPAR) & 1
 
+    auto load_consts = [&]() {
     if (tid < CO_T) {
         const int m = co0 + tid;
         const bool ok = m < a.cout_v;
@@ -131,12 +142,14 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         ep_lds[3][tid] = (ok && a.em_a) ? a.em_a[m] : 0.0f;
         ep_lds[4][tid] = (ok && a.em_a) ? a.em_ib[m] : 0.0f;
     }
+    };
+    load_consts();
 
     // ---- LDS-DMA of a chunk: 56 weight pieces (per tap: 8 = plane x group x 64-row half, ONE per wave) + 20 activation pieces
     //      ((plane, group) x 5 x 64 rows: waves 0-7 twice, waves 0-3 a third).  Every source address is a WAVE-UNIFORM base
     //      (scalar registers) + lane * 16 bytes: no per-piece address registers to keep alive (a spilled address would be reloaded
     //      with a vmcnt(0) that drains the DMA queue) ----
-    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned lane16 = (unsigned)lane * 16u;
     const int w_pl = wave >> 2, w_g = (wave >> 1) & 1, w_half = wave & 1;
     const char* w_src0 = (const char*)(w_pl ? a.w_lo : a.w_hi) + ((size_t)w_g * a.cout_pad + co0 + w_half * 64) * 16;
     const size_t w_tap_stride = (size_t)a.cout_pad * 32;                      // bytes between taps: [tap][2 groups][cout_pad][16 B]
@@ -156,12 +169,15 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     };
 
     f32x16 acc[2][2];
+    auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
+    zero_acc();
 
     struct Frags { bf16x8 wa[2][2], xa[2][2]; };          // [mi | ni][plane]
     Frags fr[4];
@@ -191,7 +207,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = sat_mfma_32x32x16_bf16(f.wa[mi][1], f.xa[ni][0], acc[mi][ni]);
     };
 
-    const bool wave_on_co = (co0 + co_w) < a.cout_v;      // Cout <= 64 (one co half empty): that wave row multiplies nothing
+    bool wave_on_co = (co0 + co_w) < a.cout_v;            // Cout <= 64 (one co half empty): that wave row multiplies nothing
 #if !defined(SAT_HIPEMU)
     // De-phase the CUs: the first wave of workgroups starts everywhere at once and every tile takes the same time, so all 256 CUs
     // would reach their epilogues — 128 KiB of stores (+ two loads of the same size in a data-gradient) each — in the same few
@@ -202,24 +218,28 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    // prologue: chunk 0 complete in stage 0
+    // prologue: chunk 0 complete in its stage
+    auto issue_chunk0 = [&]() {
 #pragma unroll
-    for (int tap = 0; tap < SAT_K7Q_TAPS; ++tap) issue_w(0, 0, tap);
-    issue_a(0, 0, 0); issue_a(0, 0, 1); issue_a(0, 0, 2);
+        for (int tap = 0; tap < SAT_K7Q_TAPS; ++tap) issue_w(0, SPAR, tap);
+        issue_a(0, SPAR, 0); issue_a(0, SPAR, 1); issue_a(0, SPAR, 2);
+    };
+    issue_chunk0();
+  for (;;) {                                               // (one pass unless PERSIST)
     SAT_WAIT_VMCNT(0);
     SAT_RAW_BARRIER();
     if (wr == 1) SAT_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
 
     for (int c = 0; c < nchunks; ++c) {
-        const char* sb = lds + (c & 1) * SAT_K7Q_STAGE;
+        const char* sb = lds + ((c + SPAR) & 1) * SAT_K7Q_STAGE;
         const bool more = c + 1 < nchunks;
         // ---- phase 0: taps 0..3 ----
 #pragma unroll
         for (int u = 0; u < 4; ++u) load_frags(fr[u], sb, u);
         if constexpr (REORDER) {
             if (more) {
-                issue_a(c + 1, (c + 1) & 1, 0); issue_a(c + 1, (c + 1) & 1, 1); issue_a(c + 1, (c + 1) & 1, 2);
-                issue_w(c + 1, (c + 1) & 1, 0); issue_w(c + 1, (c + 1) & 1, 1);
+                issue_a(c + 1, (c + 1 + SPAR) & 1, 0); issue_a(c + 1, (c + 1 + SPAR) & 1, 1); issue_a(c + 1, (c + 1 + SPAR) & 1, 2);
+                issue_w(c + 1, (c + 1 + SPAR) & 1, 0); issue_w(c + 1, (c + 1 + SPAR) & 1, 1);
                 if (K != SAT_K7Q_TAPS) { SAT_WAIT_VMCNT(0); }
                 else if (wave < 4) { SAT_WAIT_VMCNT(5); }
                 else { SAT_WAIT_VMCNT(4); }
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         } else {
             if (more) {
 #pragma unroll
-                for (int tap = 0; tap < 5; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+                for (int tap = 0; tap < 5; ++tap) issue_w(c + 1, (c + 1 + SPAR) & 1, tap);
             }
         }
         SAT_WAIT_LGKM0();
@@ -250,12 +270,12 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         if constexpr (REORDER) {
             if (more) {
 #pragma unroll
-                for (int tap = 2; tap < SAT_K7Q_TAPS; ++tap) issue_w(c + 1, (c + 1) & 1, tap);
+                for (int tap = 2; tap < SAT_K7Q_TAPS; ++tap) issue_w(c + 1, (c + 1 + SPAR) & 1, tap);
                 if (K == SAT_K7Q_TAPS) { SAT_WAIT_VMCNT(3); } else { SAT_WAIT_VMCNT(0); }
             }
         } else if (more) {
-            issue_w(c + 1, (c + 1) & 1, 5); issue_w(c + 1, (c + 1) & 1, 6);
-            issue_a(c + 1, (c + 1) & 1, 0); issue_a(c + 1, (c + 1) & 1, 1); issue_a(c + 1, (c + 1) & 1, 2);
+            issue_w(c + 1, (c + 1 + SPAR) & 1, 5); issue_w(c + 1, (c + 1 + SPAR) & 1, 6);
+            issue_a(c + 1, (c + 1 + SPAR) & 1, 0); issue_a(c + 1, (c + 1 + SPAR) & 1, 1); issue_a(c + 1, (c + 1 + SPAR) & 1, 2);
             SAT_WAIT_VMCNT(0);                             // chunk c+1 has landed (this wave's pieces; the barriers publish the others')
         }
         SAT_WAIT_LGKM0();
@@ -273,21 +293,52 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     }
     if (wr == 0) SAT_RAW_BARRIER();                        // pairs with the second wave row's last barrier
     __syncthreads();                                       // every wave is done with the stages: their memory serves the epilogue
+    // this tile's coordinates for the epilogue; PERSIST: the next tile's become current for the DMA lambdas
+    const int e_b = b, e_t_tile = t_tile, e_co0 = co0, e_t0 = t0;
+    bool have_next = false;
+    if constexpr (PERSIST) {
+        tile_id += (int)gridDim.x;
+        have_next = tile_id < total_tiles;                 // block-uniform
+        if (have_next) {
+            const int prev_co0 = co0;
+            sat_xcd_tile(tile_id, co_tiles, t_tiles * p.B, &co_tile, &win);
+            b = win / t_tiles;
+            t_tile = win - b * t_tiles;
+            co0 = co_tile * CO_T;
+            t0 = t_tile * T_T;
+            row_in0 = SAT_K7P_LEAD + t0 - p.pad;
+            w_src0 += (long long)(co0 - prev_co0) * 16;
+            issue_chunk0();                                // into stage 1: lands under the epilogue below (which uses offsets < 70 KB)
+        }
+    }
 
     // the epilogue of one accumulator set: bias (ep_lds row 0), dsnake + its sums (data-gradients), residual, tanh, stores, plane emission
+    // PERSIST: the epilogue reads its launch arguments through a pointer to the kernarg segment that is laundered once per tile — loads
+    // through it cannot be hoisted out of the tile loop, where ~40 scalar registers of epilogue-only arguments would stay live across
+    // the K loop (the first build of this variant spilled 112 SGPRs and, through their v_writelane homes, 171 VGPRs)
+#if defined(SAT_HIPEMU)
+    const SatConvBfLaunch& ea = a;
+#else
+    typedef const __attribute__((address_space(4))) SatConvBfLaunch* sat_kargs_t;
+    sat_kargs_t eap = (sat_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (PERSIST) asm volatile("" : "+s"(eap));
+    const auto& ea = *eap;
+#endif
+    const auto& ep = ea.p;
     auto epilogue = [&](float* y_out, const float* res_in, bool emit_on) __attribute__((always_inline)) {
-    short* em_hi_ = emit_on ? a.em_hi : nullptr;
-    short* em_lo_ = emit_on ? a.em_lo : nullptr;
+    const int b = e_b, t_tile = e_t_tile, co0 = e_co0, t0 = e_t0;      // (shadow the DMA lambdas' — PERSIST: already the next tile's)
+    short* em_hi_ = emit_on ? ea.em_hi : nullptr;
+    short* em_lo_ = emit_on ? ea.em_lo : nullptr;
     // ------------------------------------ epilogue (as the generic kernel) ------------------------------------
-    const bool bwd = (p.x2 != nullptr);
-    const bool wave_on = (co0 + co_w) < a.cout_v;
-    const bool mi1_on = (co0 + co_w + 32) < a.cout_v;
+    const bool bwd = (ep.x2 != nullptr);
+    const bool wave_on = (co0 + co_w) < ea.cout_v;
+    const bool mi1_on = (co0 + co_w + 32) < ea.cout_v;
     if (bwd) {
         __syncthreads();
         for (int i = tid; i < 2 * TW * CO_T; i += NT) (&red_lds[0][0][0])[i] = 0.0f;
         __syncthreads();
     }
-    const bool vec4 = (p.Tout & 3) == 0 && (((uintptr_t)y_out | (uintptr_t)p.x2 | (uintptr_t)res_in) & 15) == 0;
+    const bool vec4 = (ep.Tout & 3) == 0 && (((uintptr_t)y_out | (uintptr_t)ep.x2 | (uintptr_t)res_in) & 15) == 0;
     if (vec4) {
         // 16-byte epilogue: each wave transposes its accumulators through LDS (the stage memory is free now) so that
         // a lane owns 4 consecutive time steps of a row; the x2 / res loads of a 32-row half are all issued before use.
@@ -312,9 +363,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                 for (int j = 0; j < 8; ++j) {
                     const int col = co_w + mi * 32 + j * 4 + lr;
                     const int co = co0 + col;
-                    const bool ok = co < a.cout_v && tg < p.Tout;
-                    const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? tg : 0);
-                    xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(p.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool ok = co < ea.cout_v && tg < ep.Tout;
+                    const size_t o = ((size_t)b * ep.Cout + (ok ? co : 0)) * ep.Tout + (ok ? tg : 0);
+                    xv[j] = (bwd && ok) ? *reinterpret_cast<const f32x4*>(ep.x2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
                     rv[j] = (res_in && ok) ? *reinterpret_cast<const f32x4*>(res_in + o) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -322,7 +373,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                     const int row = j * 4 + lr;
                     const int col = co_w + mi * 32 + row;
                     const int co = co0 + col;
-                    const bool ok = co < a.cout_v && tg < p.Tout;
+                    const bool ok = co < ea.cout_v && tg < ep.Tout;
                     const f32x4 av = *reinterpret_cast<const f32x4*>(&tile[row][t4]);
                     const float bias = ep_lds[0][col];
                     const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
@@ -338,15 +389,15 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                             v *= g.dx;
                         }
                         v += rv[j][e];
-                        if (p.tanh_out) v = tanhf(v);
+                        if (ep.tanh_out) v = tanhf(v);
                         ov[e] = v;
                     }
-                    if (ok) *reinterpret_cast<f32x4*>(y_out + ((size_t)b * p.Cout + co) * p.Tout + tg) = ov;
+                    if (ok) *reinterpret_cast<f32x4*>(y_out + ((size_t)b * ep.Cout + co) * ep.Tout + tg) = ov;
                     if (em_hi_) {
                         // plane emission (as conv1d_bf16x3.hip's generic kernel), step 1: the consumer's activation of the finished
                         // values goes back into this lane's own cell of the transposition tile (rows past Cout hold act(0) = 0)
                         f32x4 ev = ov;
-                        if (a.em_a) {
+                        if (ea.em_a) {
                             const float ea = ep_lds[3][col], eib = ep_lds[4][col];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) ev[e] = sat_snake(ov[e], ea, eib);
@@ -380,8 +431,8 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                         uint32_t eh[4], el[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) sat_split2_pk(v8[2 * e], v8[2 * e + 1], &eh[e], &el[e]);
-                        if (c8i < a.em_c8 && tq < p.Tout) {
-                            const size_t o = (((size_t)b * a.em_c8 + c8i) * a.em_rows + SAT_K7P_LEAD + tq) * 8;
+                        if (c8i < ea.em_c8 && tq < ep.Tout) {
+                            const size_t o = (((size_t)b * ea.em_c8 + c8i) * ea.em_rows + SAT_K7P_LEAD + tq) * 8;
                             *reinterpret_cast<u32x4*>(em_hi_ + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
                             *reinterpret_cast<u32x4*>(em_lo_ + o) = u32x4{el[0], el[1], el[2], el[3]};
                         }
@@ -398,24 +449,24 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
             for (int r = 0; r < 16; ++r) {
                 const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int co = co0 + col;
-                const bool co_ok = co < a.cout_v;
+                const bool co_ok = co < ea.cout_v;
                 const float bias = ep_lds[0][col];
                 const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
                 float pda = 0.f, pdb = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int t = t0 + t_w + ni * 32 + l31;
-                    if (co_ok && t < p.Tout) {
-                        const size_t o = ((size_t)b * p.Cout + co) * p.Tout + t;
+                    if (co_ok && t < ep.Tout) {
+                        const size_t o = ((size_t)b * ep.Cout + co) * ep.Tout + t;
                         float v = acc[mi][ni][r] + bias;
                         if (bwd) {
-                            const SatSnakeGrad g = sat_snake_grad(p.x2[o], a2, b2);
+                            const SatSnakeGrad g = sat_snake_grad(ep.x2[o], a2, b2);
                             pda += v * g.dla;
                             pdb += v * g.dlb;
                             v *= g.dx;
                         }
                         if (res_in) v += res_in[o];
-                        if (p.tanh_out) v = tanhf(v);
+                        if (ep.tanh_out) v = tanhf(v);
                         y_out[o] = v;
                     }
                 }
@@ -433,7 +484,7 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     if (bwd) {
         __syncthreads();
         const int m = co0 + tid;
-        if (tid < CO_T && m < a.cout_v) {
+        if (tid < CO_T && m < ea.cout_v) {
             float sa = 0.f, sb = 0.f;
 #pragma unroll
             for (int w = 0; w < TW; ++w) {
@@ -441,9 +492,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
                 sb += red_lds[1][w][tid];
             }
             const size_t row = (size_t)b * t_tiles + t_tile;
-            const size_t nrows_p = (size_t)p.B * t_tiles;
-            p.part_da[(size_t)m * nrows_p + row] = sa;
-            p.part_db[(size_t)m * nrows_p + row] = sb;
+            const size_t nrows_p = (size_t)ep.B * t_tiles;
+            ep.part_da[(size_t)m * nrows_p + row] = sa;
+            ep.part_db[(size_t)m * nrows_p + row] = sb;
         }
     }
     };
@@ -519,6 +570,29 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     }
 
     epilogue(p.y, p.res, true);
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (!have_next) break;
+        if (e_co0 != co0) {                                // a different channel tile: its bias / SnakeBeta constants
+            __syncthreads();
+            load_consts();
+        }
+        wave_on_co = (co0 + co_w) < a.cout_v;
+        zero_acc();
+#if !defined(SAT_HIPEMU)
+        asm volatile("" : "+v"(lane));                     // opaque per-tile copies: nothing derived from them is a tile-loop invariant
+        asm volatile("" : "+s"(wave));
+#endif
+        tid = wave * 64 + lane;
+        l31 = lane & 31;
+        hi = lane >> 5;
+        lane16 = (unsigned)lane * 16u;
+        wr = wave / TW;
+        co_w = wr * 64;
+        t_w = (wave % TW) * 64;
+    }
+  }
 }
 
 static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
@@ -526,5 +600,15 @@ static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     a.stagger = 1;                                         // measured: -1 % forward, -2.5 % data-gradient (tools/kq_ab.py); 2 and 4 lose
     if (total < 1024) a.stagger = 0;                       // few tiles per CU: the delay would not be paid back
     if (a.ru_w1_hi) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, true>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); return; }
+    const int cus = sat_cu_count();
+    if (a.persist == 2 && total >= 2) {                    // test hook (flags bit 1): persistent at ANY size, three tiles per workgroup
+        a.stagger = 0;
+        SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)sat_cdivll(total, 3)), dim3(SAT_K7_NT), stream, a);
+        return;
+    }
+    if (a.persist && total >= 2 * cus) {                   // PERSIST: one workgroup per CU walks total / cus tiles (>= 2 each)
+        SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)cus), dim3(SAT_K7_NT), stream, a);
+        return;
+    }
     SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a);
 }

@@ -81,87 +81,133 @@ SAT_DEVICE void sat_ec_store4(float* row, int t0, int T, bool vec, f32x4 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// narrow input: Cin = S <= 2
+// narrow input: Cin = S <= 2.  Everything that depends on the output channel only — the 7 x S taps (zero outside the conv's K), the
+// bias, the data-gradient's and the emission's SnakeBeta constants — is staged in LDS once per workgroup and read as broadcasts:
+// the first version read them per row with scalar / uniform global loads behind their own waits (14 dependent L2 latencies per row:
+// 0.8 ms forward, 1.56 ms data-gradient at T = 2 097 152 — profiles/r06_experiments/edge_convs/).  Rows are processed in groups of 8
+// in one basic block (no per-row early exits: the x2 loads of a group are all in flight before the first is used).
 // ---------------------------------------------------------------------------------------------
 template <int S>
 __global__ void __launch_bounds__(256) sat_edge_conv_in_kernel(SatEdgeParams p) {
+    __shared__ __attribute__((aligned(16))) float wl[SAT_EC_ROWS][16];      // [row][ci * 8 + (d + 3)], d = tap offset -3 .. 3
+    __shared__ float cl[5][SAT_EC_ROWS];                                    // bias, a2, b2, em_a, em_ib
     __shared__ float red[2][SAT_EC_ROWS][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, co0 = blockIdx.y * SAT_EC_ROWS;
     const int t0 = blockIdx.x * SAT_EC_TT + threadIdx.x * 4;
     const bool vec = (p.T & 3) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.x2)) & 15) == 0;
+    const int K = p.K, pad = p.pad;
+    const bool bwd = p.x2 != nullptr;
+    for (int i = threadIdx.x; i < SAT_EC_ROWS * 16; i += 256) {
+        const int j = i >> 4, ci = (i >> 3) & 1, d = (i & 7) - 3, k = d + pad;
+        const int co = co0 + j;
+        float v = 0.0f;
+        if (co < p.Cout && ci < S && d <= 3 && k >= 0 && k < K)
+            v = p.mode == 0 ? p.w[((size_t)co * S + ci) * K + k] : p.w[((size_t)ci * p.Cout + co) * K + (K - 1 - k)];
+        wl[j][i & 15] = v;
+    }
+    if (threadIdx.x < SAT_EC_ROWS) {
+        const int co = co0 + threadIdx.x;
+        const bool ok = co < p.Cout;
+        cl[0][threadIdx.x] = (ok && p.bias) ? p.bias[co] : 0.0f;
+        cl[1][threadIdx.x] = (ok && bwd) ? expf(p.alpha2[co]) : 1.0f;
+        cl[2][threadIdx.x] = (ok && bwd) ? expf(p.beta2[co]) : 1.0f;
+        cl[3][threadIdx.x] = (ok && p.em_alpha) ? expf(p.em_alpha[co]) : 0.0f;
+        cl[4][threadIdx.x] = (ok && p.em_alpha) ? 1.0f / (expf(p.em_beta[co]) + 1e-9f) : 0.0f;
+    }
     float win[S][12];
 #pragma unroll
     for (int ci = 0; ci < S; ++ci) sat_ec_window(p.x + ((size_t)b * S + ci) * p.T, t0, p.T, vec, win[ci]);
-    const int K = p.K, pad = p.pad;
-    const bool bwd = p.x2 != nullptr;
+    __syncthreads();
+    const int last = p.Cout - 1;
     for (int jg = 0; jg < SAT_EC_ROWS / 8; ++jg) {
         if (co0 + jg * 8 >= p.Cout) break;            // block-uniform
-        f32x4 evs[8];                                 // emission: the activated outputs of this group's 8 channels
+        f32x4 xv[8];
+        if (bwd) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int co = co0 + jg * 8 + jj;
+                xv[jj] = sat_ec_load4(p.x2 + ((size_t)b * p.Cout + (co < p.Cout ? co : last)) * p.T, t0, p.T, vec);
+            }
+        }
+        f32x4 out[8];
+        float pda[8], pdb[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = jg * 8 + jj;
-            const int co = co0 + j;                   // block-uniform
-            evs[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (co >= p.Cout) continue;
+            float wr[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&wl[j][4 * q]);      // broadcast reads
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wr[4 * q + e] = v[e];
+            }
             f32x4 acc;
-            const float bv = p.bias ? p.bias[co] : 0.0f;
+            const float bv = cl[0][j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = bv;
 #pragma unroll
             for (int ci = 0; ci < S; ++ci)
 #pragma unroll
-                for (int d = -3; d <= 3; ++d) {       // tap k = d + pad reads step t + d: window index 4 + e + d is a compile-time constant
-                    const int k = d + pad;
-                    if (k >= 0 && k < K) {
-                        const float wv = p.mode == 0 ? p.w[((size_t)co * S + ci) * K + k] : p.w[((size_t)ci * p.Cout + co) * K + (K - 1 - k)];
+                for (int d = -3; d <= 3; ++d)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, win[ci][4 + e + d], acc[e]);
-                    }
-                }
-            const size_t orow = ((size_t)b * p.Cout + co) * p.T;
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(wr[ci * 8 + d + 3], win[ci][4 + e + d], acc[e]);
+            pda[jj] = 0.0f;
+            pdb[jj] = 0.0f;
             if (bwd) {
-                const float a2 = expf(p.alpha2[co]), b2 = expf(p.beta2[co]);
-                const f32x4 xv = sat_ec_load4(p.x2 + orow, t0, p.T, vec);
-                float pda = 0.0f, pdb = 0.0f;
+                const float a2 = cl[1][j], b2 = cl[2][j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const SatSnakeGrad g = sat_snake_grad(xv[e], a2, b2);
+                    const SatSnakeGrad g = sat_snake_grad(xv[jj][e], a2, b2);
                     const bool ok = t0 + e < p.T;
-                    pda += ok ? acc[e] * g.dla : 0.0f;
-                    pdb += ok ? acc[e] * g.dlb : 0.0f;
+                    pda[jj] += ok ? acc[e] * g.dla : 0.0f;
+                    pdb[jj] += ok ? acc[e] * g.dlb : 0.0f;
                     acc[e] *= g.dx;
-                }
-                pda = sat_wave_sum(pda);
-                pdb = sat_wave_sum(pdb);
-                if (lane == 0) {
-                    red[0][j][wave] = pda;
-                    red[1][j][wave] = pdb;
                 }
             }
             if (p.tanh_out) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = tanhf(acc[e]);
             }
-            sat_ec_store4(p.y + orow, t0, p.T, vec, acc);
-            if (p.em_hi) {
-                evs[jj] = acc;
-                if (p.em_alpha) {
-                    const float ea = expf(p.em_alpha[co]), eib = 1.0f / (expf(p.em_beta[co]) + 1e-9f);
+            out[jj] = acc;
+        }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) evs[jj][e] = sat_snake(acc[e], ea, eib);
+        for (int jj = 0; jj < 8; ++jj) {
+            const int co = co0 + jg * 8 + jj;
+            if (co < p.Cout) sat_ec_store4(p.y + ((size_t)b * p.Cout + co) * p.T, t0, p.T, vec, out[jj]);
+        }
+        if (bwd) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {           // 16 independent reductions: their cross-lane steps overlap
+                pda[jj] = sat_wave_sum(pda[jj]);
+                pdb[jj] = sat_wave_sum(pdb[jj]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    red[0][jg * 8 + jj][wave] = pda[jj];
+                    red[1][jg * 8 + jj][wave] = pdb[jj];
                 }
             }
         }
         if (p.em_hi) {
-            // 8 consecutive channels of one time step = one 16-byte plane row; a lane's four steps are 64 contiguous bytes per plane
+            // act_next(y): 8 consecutive channels of one time step = one 16-byte plane row; a lane's four steps are 64 contiguous bytes per
+            // plane (channels past Cout: weights and bias were staged as 0, act(0) = 0)
+            if (p.em_alpha) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float ea = cl[3][jg * 8 + jj], eib = cl[4][jg * 8 + jj];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[jj][e] = sat_snake(out[jj][e], ea, eib);
+                }
+            }
             const int c8i = (co0 >> 3) + jg;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (t0 + e < p.T) {
                     uint32_t eh[4], el[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) sat_split2_pk(evs[2 * q][e], evs[2 * q + 1][e], &eh[q], &el[q]);
+                    for (int q = 0; q < 4; ++q) sat_split2_pk(out[2 * q][e], out[2 * q + 1][e], &eh[q], &el[q]);
                     const size_t o = (((size_t)b * p.em_c8 + c8i) * p.em_rows + SAT_EC_LEAD + t0 + e) * 8;
                     *reinterpret_cast<u32x4*>(p.em_hi + o) = u32x4{eh[0], eh[1], eh[2], eh[3]};
                     *reinterpret_cast<u32x4*>(p.em_lo + o) = u32x4{el[0], el[1], el[2], el[3]};
@@ -181,13 +227,15 @@ __global__ void __launch_bounds__(256) sat_edge_conv_in_kernel(SatEdgeParams p) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// narrow output: Cout = S <= 2, SnakeBeta prologue on the Cin-channel input
+// narrow output: Cout = S <= 2, SnakeBeta prologue on the Cin-channel input.  Batches of 8 input channels: their activated steps
+// (+ halo) and their 8 x S x 7 taps go through LDS; the NEXT batch's global loads are issued before the current batch's arithmetic.
 // ---------------------------------------------------------------------------------------------
 #define SAT_EC_CB 8                      // channels staged per barrier pair
 #define SAT_EC_LROW (SAT_EC_TT + 8)      // t0_tile - 4 .. t0_tile + 1028
 template <int S>
 __global__ void __launch_bounds__(256) sat_edge_conv_out_kernel(SatEdgeParams p) {
     __shared__ __attribute__((aligned(16))) float a_lds[SAT_EC_CB][SAT_EC_LROW];
+    __shared__ __attribute__((aligned(16))) float wl[SAT_EC_CB][16];         // [channel of the batch][co * 8 + (d + 3)]
     const int b = blockIdx.z;
     const int tile0 = blockIdx.x * SAT_EC_TT;
     const int t0 = tile0 + threadIdx.x * 4;
@@ -200,46 +248,57 @@ __global__ void __launch_bounds__(256) sat_edge_conv_out_kernel(SatEdgeParams p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[co][e] = bv;
     }
-    for (int c0 = 0; c0 < p.Cin; c0 += SAT_EC_CB) {
-        // stage act(x[c0 .. c0 + 8)[tile0 - 4 .. tile0 + 1028)): every thread its own four steps of each channel, threads 0-63 the halos
-        f32x4 mine[SAT_EC_CB];
+    // per-thread roles that do not change over the batches
+    const int hc = threadIdx.x >> 3, hh = threadIdx.x & 7;                   // halo element (threads 0-63): channel of the batch, slot
+    const int hidx = hh < 4 ? hh : SAT_EC_TT + hh;                           // LDS index 0..3 | 1028..1031
+    const int ht = tile0 - 4 + hidx;
+    const int wc = threadIdx.x >> 4, wi = threadIdx.x & 15;                  // weight element (threads 0-127): channel of the batch, slot
+    const int wco = wi >> 3, wd = (wi & 7) - 3, wk = wd + pad;
+    f32x4 mine[SAT_EC_CB];
+    float halo = 0.0f, wv = 0.0f, sa = 1.0f, sib = 0.0f;                     // sa / sib: this thread's halo channel's SnakeBeta constants
+    auto fetch = [&](int c0) {
 #pragma unroll
         for (int c = 0; c < SAT_EC_CB; ++c) {
-            const int ci = c0 + c;
-            mine[c] = ci < p.Cin ? sat_ec_load4(p.x + ((size_t)b * p.Cin + ci) * p.T, t0, p.T, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ci = c0 + c < p.Cin ? c0 + c : p.Cin - 1;
+            mine[c] = sat_ec_load4(p.x + ((size_t)b * p.Cin + ci) * p.T, t0, p.T, vec);
         }
-        float halo = 0.0f;
-        int hci = 0, hidx = 0;
+        halo = 0.0f;
+        wv = 0.0f;
         if (threadIdx.x < 8 * SAT_EC_CB) {
-            const int c = threadIdx.x >> 3, h = threadIdx.x & 7;
-            hci = c;
-            hidx = h < 4 ? h : SAT_EC_TT + h;                              // LDS index: 0..3 | 1028..1031
-            const int t = tile0 - 4 + hidx;
-            if (c0 + c < p.Cin && t >= 0 && t < p.T) halo = p.x[((size_t)b * p.Cin + c0 + c) * p.T + t];
+            const int ci = c0 + hc;
+            if (ci < p.Cin && ht >= 0 && ht < p.T) halo = p.x[((size_t)b * p.Cin + ci) * p.T + ht];
+            if (p.alpha && ci < p.Cin) {
+                sa = expf(p.alpha[ci]);
+                sib = 1.0f / (expf(p.beta[ci]) + 1e-9f);
+            }
         }
-        __syncthreads();                                                    // the previous batch's readers are done
+        if (threadIdx.x < 16 * SAT_EC_CB) {
+            const int ci = c0 + wc;
+            if (ci < p.Cin && wco < S && wd <= 3 && wk >= 0 && wk < K)
+                wv = p.mode == 0 ? p.w[((size_t)wco * p.Cin + ci) * K + wk] : p.w[((size_t)ci * S + wco) * K + (K - 1 - wk)];
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += SAT_EC_CB) {
+        __syncthreads();                                                     // the previous batch's readers are done
 #pragma unroll
         for (int c = 0; c < SAT_EC_CB; ++c) {
-            const int ci = c0 + c;
             f32x4 v = mine[c];
-            if (p.alpha && ci < p.Cin) {
-                const float a = expf(p.alpha[ci]), ib = 1.0f / (expf(p.beta[ci]) + 1e-9f);
+            if (p.alpha) {
+                const int ci = c0 + c < p.Cin ? c0 + c : p.Cin - 1;
+                const float a = expf(p.alpha[ci]), ib = 1.0f / (expf(p.beta[ci]) + 1e-9f);      // (block-uniform: scalar loads, batched)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = sat_snake(v[e], a, ib);
             }
-            *reinterpret_cast<f32x4*>(&a_lds[c][4 + threadIdx.x * 4]) = v;  // (steps past T were loaded as 0: act(0) = 0)
+            *reinterpret_cast<f32x4*>(&a_lds[c][4 + threadIdx.x * 4]) = v;   // (steps past T were loaded as 0: act(0) = 0)
         }
-        if (threadIdx.x < 8 * SAT_EC_CB) {
-            const int ci = c0 + hci;
-            if (p.alpha && ci < p.Cin) halo = sat_snake(halo, expf(p.alpha[ci]), 1.0f / (expf(p.beta[ci]) + 1e-9f));
-            a_lds[hci][hidx] = halo;
-        }
+        if (threadIdx.x < 8 * SAT_EC_CB) a_lds[hc][hidx] = p.alpha ? sat_snake(halo, sa, sib) : halo;
+        if (threadIdx.x < 16 * SAT_EC_CB) wl[wc][wi] = wv;                   // (channels past Cin: zero taps)
+        if (c0 + SAT_EC_CB < p.Cin) fetch(c0 + SAT_EC_CB);                   // next batch: in flight under this batch's arithmetic
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < SAT_EC_CB; ++c) {
-            const int ci = c0 + c;
-            if (ci >= p.Cin) break;
-            float win[12];
+            float win[12], wr[16];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(&a_lds[c][threadIdx.x * 4 + 4 * q]);
@@ -247,16 +306,17 @@ __global__ void __launch_bounds__(256) sat_edge_conv_out_kernel(SatEdgeParams p)
                 for (int e = 0; e < 4; ++e) win[4 * q + e] = v[e];
             }
 #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&wl[c][4 * q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wr[4 * q + e] = v[e];
+            }
+#pragma unroll
             for (int co = 0; co < S; ++co)
 #pragma unroll
-                for (int d = -3; d <= 3; ++d) {
-                    const int k = d + pad;
-                    if (k >= 0 && k < K) {
-                        const float wv = p.mode == 0 ? p.w[((size_t)co * p.Cin + ci) * K + k] : p.w[((size_t)ci * S + co) * K + (K - 1 - k)];
+                for (int d = -3; d <= 3; ++d)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(wv, win[4 + e + d], acc[co][e]);
-                    }
-                }
+                    for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(wr[co * 8 + d + 3], win[4 + e + d], acc[co][e]);
         }
     }
 #pragma unroll
@@ -271,8 +331,9 @@ __global__ void __launch_bounds__(256) sat_edge_conv_out_kernel(SatEdgeParams p)
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient with one narrow side.  wide (B, R, T) is streamed (optionally through SnakeBeta), narrow (B, S, T) windowed:
-//   acc[row][s][k] += sum_t wide[row][t] * narrow[s][t + k - pad]
+//   acc[row][s][d + 3] += sum_t wide[row][t] * narrow[s][t + d],   d = -3 .. 3   (tap k = d + pad)
 // wave w of workgroup (split, row group, b) owns rows rg * 32 + w * 8 .. + 7 over the split's time tiles; slab (b * nsplit_t + split).
+// The 8 row loads of a 256-step chunk are issued together (one basic block: rows past R re-read the last row and are not stored).
 // ---------------------------------------------------------------------------------------------
 template <int S>
 __global__ void __launch_bounds__(256) sat_edge_wgrad_kernel(SatEdgeParams p) {
@@ -293,41 +354,39 @@ __global__ void __launch_bounds__(256) sat_edge_wgrad_kernel(SatEdgeParams p) {
             for (int k = 0; k < 7; ++k) acc[j][s][k] = 0.0f;
     }
     float sa[8], sib[8];
+    const float* rowp[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int r = row0 + j;
-        sa[j] = (p.alpha && r < R) ? expf(p.alpha[r]) : 1.0f;
-        sib[j] = (p.alpha && r < R) ? 1.0f / (expf(p.beta[r]) + 1e-9f) : 0.0f;
+        const int r = row0 + j < R ? row0 + j : R - 1;
+        rowp[j] = p.x + ((size_t)b * R + r) * p.T;
+        sa[j] = p.alpha ? expf(p.alpha[r]) : 1.0f;
+        sib[j] = p.alpha ? 1.0f / (expf(p.beta[r]) + 1e-9f) : 0.0f;
     }
     const int ntiles = (p.T + SAT_EC_TT - 1) / SAT_EC_TT;
     const int tile_a = split * p.tiles_per_split;
     const int tile_b = tile_a + p.tiles_per_split < ntiles ? tile_a + p.tiles_per_split : ntiles;
-    for (int tile = tile_a; tile < tile_b; ++tile) {
-#pragma unroll 1
-        for (int ch = 0; ch < 4; ++ch) {                    // four 256-step chunks: a wave instruction covers 1 KiB of a row
-            const int t0 = tile * SAT_EC_TT + ch * 256 + lane * 4;
-            if (t0 >= p.T) continue;
-            float win[S][12];
+    const int t_end = tile_b * SAT_EC_TT < p.T ? tile_b * SAT_EC_TT : p.T;
+    for (int tc = tile_a * SAT_EC_TT; tc < t_end; tc += 256) {      // 256-step chunks: a wave instruction covers 1 KiB of a row
+        const int t0 = tc + lane * 4;
+        f32x4 v[8];
 #pragma unroll
-            for (int s = 0; s < S; ++s) sat_ec_window(p.w + ((size_t)b * S + s) * p.T, t0, p.T, vec, win[s]);
+        for (int j = 0; j < 8; ++j) v[j] = sat_ec_load4(rowp[j], t0, p.T, vec);       // (steps past T load as 0)
+        float win[S][12];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = row0 + j;                     // wave-uniform
-                if (r >= R) break;
-                f32x4 v = sat_ec_load4(p.x + ((size_t)b * R + r) * p.T, t0, p.T, vec);
-                if (p.alpha) {
+        for (int s = 0; s < S; ++s) sat_ec_window(p.w + ((size_t)b * S + s) * p.T, t0, p.T, vec, win[s]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sat_snake(v[e], sa[j], sib[j]);
-                }
-                rs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+        for (int j = 0; j < 8; ++j) {
+            if (p.alpha) {
 #pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int d = -3; d <= 3; ++d) {         // accumulator slot d + 3 <-> tap k = d + pad (K = 2 pad + 1: the host checks)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j][s][d + 3] = fmaf(v[e], win[s][4 + e + d], acc[j][s][d + 3]);
-                    }
+                for (int e = 0; e < 4; ++e) v[j][e] = sat_snake(v[j][e], sa[j], sib[j]);
             }
+            rs[j] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int d = -3; d <= 3; ++d)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][s][d + 3] = fmaf(v[j][e], win[s][4 + e + d], acc[j][s][d + 3]);
         }
     }
     const int M = p.flip ? S : R, N = p.flip ? R : S;      // dW is (M, N, K)
@@ -335,23 +394,23 @@ __global__ void __launch_bounds__(256) sat_edge_wgrad_kernel(SatEdgeParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = row0 + j;
-        if (r >= R) break;
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int d = -3; d <= 3; ++d) {
-                const int k = d + pad;
-                if (k >= 0 && k < K) {                     // (wave-uniform)
-                    const float v = sat_wave_sum(acc[j][s][d + 3]);
-                    if (lane == 0) {
-                        if (p.flip) slab[((size_t)s * N + r) * K + (K - 1 - k)] = v;
-                        else slab[((size_t)r * N + s) * K + k] = v;
+            for (int d = -3; d <= 3; ++d) acc[j][s][d + 3] = sat_wave_sum(acc[j][s][d + 3]);
+        rs[j] = sat_wave_sum(rs[j]);
+        if (lane == 0 && r < R) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int d = -3; d <= 3; ++d) {
+                    const int k = d + pad;
+                    if (k >= 0 && k < K) {
+                        if (p.flip) slab[((size_t)s * N + r) * K + (K - 1 - k)] = acc[j][s][d + 3];
+                        else slab[((size_t)r * N + s) * K + k] = acc[j][s][d + 3];
                     }
                 }
-            }
-        if (p.part_da) {
-            const float v = sat_wave_sum(rs[j]);
-            if (lane == 0) p.part_da[(size_t)r * ((size_t)p.B * p.nsplit_t) + (size_t)b * p.nsplit_t + split] = v;
+            if (p.part_da) p.part_da[(size_t)r * ((size_t)p.B * p.nsplit_t) + (size_t)b * p.nsplit_t + split] = rs[j];
         }
     }
 }

@@ -250,6 +250,8 @@ class SatOps:
     # the k7 kernel (csrc/conv1d_bf16x3_k7q.h): activation planes + 16-channel chunks + two wave rows one barrier apart.  Plain class
     # attributes (an A/B script sets them on the ops object; no environment switches: round 5)
     k7q = True
+    k7q_persist = True      # one workgroup per CU walks the tiles (round 6: launches of >= 2 tiles per CU); False: one workgroup per tile
+                            # (A/B: bench.py --ops-set k7q_persist=0); "force": persistent at any size (the tests' small shapes)
     k7q_min_cin = 64
     k7q_min_cout = 128
     k7q_wide_cin = 512      # from this many input channels on, fewer than k7q_min_cout output channels still take the planes kernel
@@ -502,7 +504,7 @@ class SatOps:
             pda, pdb = torch.empty(2, cout, prows, dtype=torch.float32, device=x.device).unbind(0)
         self._chk(self.lib.sat_conv1d_bf16x3_planesq(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
                                                      _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
-                                                     k, dil, pad, int(tanh_out), st))
+                                                     k, dil, pad, int(tanh_out), {True: 0, False: 1, "force": 2}[self.k7q_persist], st))
         if dsnake is not None:
             return (y, *self._sum_pair(pda, pdb))
         return y

@@ -120,6 +120,21 @@ EDGE_CASES = [  # (B, Cin, Cout, T, K, snake, bias, tanh)
 ]
 
 
+def _compare64(native, ref, inputs, gen, tol=TOL):
+    """native(*inputs) on the device against ref(*float64 CPU copies): outputs and every gradient.  The truth is float64: a same-device
+    torch conv is itself an fp32 kernel with its own summation order (MIOpen on the GPU: 2e-4 off on a one-channel weight-norm
+    magnitude summed over 1027 x 16 x 7 terms — as far from float64 as the kernels under test)."""
+    outs = native(*inputs)
+    in64 = [t.detach().double().cpu().requires_grad_(True) for t in inputs]
+    refs = ref(*in64)
+    gy = [torch.randn(r.shape, generator=gen, dtype=torch.float64) for r in refs]
+    g1 = torch.autograd.grad(outs, inputs, [g.float().to(o.device) for g, o in zip(gy, outs)], allow_unused=True)
+    g2 = torch.autograd.grad(refs, in64, gy, allow_unused=True)
+    for a, b in list(zip(outs, refs)) + [(a, b) for a, b in zip(g1, g2) if b is not None]:
+        err = (a.detach().double().cpu() - b.detach()).abs().max().item()
+        assert err <= tol * max(b.abs().max().item(), FLOOR[0]), (err, b.abs().max().item())
+
+
 def _run_edge(ops, dev, case, edge):
     B, Cin, Cout, T, K, use_snake, use_bias, tanh_out = case
     gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
@@ -132,19 +147,39 @@ def _run_edge(ops, dev, case, edge):
         la, lb = (_leaf(gen, dev, Cin, s=.3), _leaf(gen, dev, Cin, s=.3)) if use_snake else (None, None)
         w = _leaf(gen, dev, Cout, Cin, K, s=.2)
         bias = _leaf(gen, dev, Cout) if use_bias else None
-        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, w, bias, None, 1, 1, pad, tanh_out, ops)
-        y2 = F.conv1d(snake(x, la, lb) if use_snake else x, w, bias, padding=pad)
-        if tanh_out:
-            y2 = torch.tanh(y2)
-        _compare([y1], [y2], [t for t in (x, la, lb, w, bias) if t is not None], gen)
+        def unpack(ts):
+            it = iter(ts)
+            x_ = next(it)
+            la_, lb_ = (next(it), next(it)) if use_snake else (None, None)
+            return x_, la_, lb_, it
+
+        def ref_conv(x_, la_, lb_, w_, b_):
+            y = F.conv1d(snake(x_, la_, lb_) if use_snake else x_, w_, b_, padding=pad)
+            return [torch.tanh(y) if tanh_out else y]
+
+        def native_plain(*ts):
+            x_, la_, lb_, it = unpack(ts)
+            w_ = next(it)
+            return [Fn.SnakeConv1dFn.apply(x_, la_, lb_, w_, next(it, None), None, 1, 1, pad, tanh_out, ops)]
+
+        def ref_plain(*ts):
+            x_, la_, lb_, it = unpack(ts)
+            w_ = next(it)
+            return ref_conv(x_, la_, lb_, w_, next(it, None))
+        _compare64(native_plain, ref_plain, [t for t in (x, la, lb, w, bias) if t is not None], gen)
         # weight-normed form (what the model runs): the unit folds (v, g) itself and takes the edge kernels' slabs to sat_wn_grad_splits
         v, g = _leaf(gen, dev, Cout, Cin, K, s=.2), _leaf(gen, dev, Cout, 1, 1)
-        y1 = Fn.SnakeConv1dFn.apply(x, la, lb, v, bias, None, 1, 1, pad, tanh_out, ops, None, None, g)
-        wn = g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
-        y2 = F.conv1d(snake(x, la, lb) if use_snake else x, wn, bias, padding=pad)
-        if tanh_out:
-            y2 = torch.tanh(y2)
-        _compare([y1], [y2], [t for t in (x, la, lb, v, g, bias) if t is not None], gen)
+
+        def native_wn(*ts):
+            x_, la_, lb_, it = unpack(ts)
+            v_, g_ = next(it), next(it)
+            return [Fn.SnakeConv1dFn.apply(x_, la_, lb_, v_, next(it, None), None, 1, 1, pad, tanh_out, ops, None, None, g_)]
+
+        def ref_wn(*ts):
+            x_, la_, lb_, it = unpack(ts)
+            v_, g_ = next(it), next(it)
+            return ref_conv(x_, la_, lb_, g_ * v_ / v_.flatten(1).norm(dim=1).view(-1, 1, 1), next(it, None))
+        _compare64(native_wn, ref_wn, [t for t in (x, la, lb, v, g, bias) if t is not None], gen)
     finally:
         ops.edge_convs = saved
 
@@ -215,10 +250,15 @@ def _run_planes(ops, dev, cases):
     """The k = 7 convs fed from pre-split activation planes (conv1d_planes.h: sat_conv1d_k7_planes; conv1d_bf16x3_k7q.h:
     sat_conv1d_bf16x3_planesq) — the path every C >= 64 level takes — forced on for every channel count: forward and all gradients vs
     torch, and outputs equal to the direct kernel's up to the accumulation order (16-channel chunks, one tap per k-step)."""
-    keepq = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout)
+    keepq = (ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7q_persist)
     try:
         for case in cases:
             ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = True, 1, 1
+            # the PERSISTENT launch (round 6: a workgroup walks several tiles, the next tile's first chunk requested before the epilogue) forced on
+            # these small shapes (three tiles per workgroup: first / middle / last-and-partial), then the one-workgroup-per-tile launch
+            ops.k7q_persist = "force"
+            _run_s1(ops, dev, case, True)
+            ops.k7q_persist = False
             _run_s1(ops, dev, case, True)               # autograd units through the planes kernel
             B, Cin, Cout, T, K, dil = case
             gen = torch.Generator().manual_seed(7)
@@ -237,12 +277,17 @@ def _run_planes(ops, dev, cases):
                         *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
                 for a, b in zip(outq, direct):
                     assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), (case, (a - b).abs().max().item())
+                ops.k7q_persist = "force"
+                outp = (ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, snake=(la, lb)),
+                        *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
+                for a, b in zip(outp, outq):
+                    assert torch.equal(a, b), case        # same arithmetic in the same order: the persistent launch is bit-identical
     finally:
-        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout = keepq
+        ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7q_persist = keepq
 
 
 def test_conv_k7_planes_sim(emu):
-    _run_planes(emu, "cpu", [c for c in S1_CASES if c[4] == 7][:6] + [(1, 20, 5, 90, 5, 2), (2, 16, 130, 517, 7, 3)])
+    _run_planes(emu, "cpu", [c for c in S1_CASES if c[4] == 7][:6] + [(1, 20, 5, 90, 5, 2), (2, 16, 130, 517, 7, 3), (1, 16, 130, 1300, 7, 9)])
 
 
 def test_conv_k7_wide_input_few_outputs_sim(emu):
