@@ -21,6 +21,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by t
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -657,7 +658,7 @@ def dit_eval_parity(model, dcfg, x, cross, glob, kw, bound=4e-2, ref_cache=None)
 
 PEAK_FP8_MFMA_TFLOPS = 5000.0   # MI355X_MICROARCH.md: dense fp8 (MX) MFMA peak
 FP8_DEPTH24_BOUND = 0.2         # tests/test_long_context.py FP8_DEPTH24: derivation there
-FP8_FF_DEPTH24_BOUND = 0.11     # tests/test_long_context.py FP8_FF_DEPTH24: fp8 on the feed-forward pair only
+FP8_ATTN_DEPTH24_BOUND = 0.08   # tests/test_long_context.py FP8_ATTN_DEPTH24: fp8 on the attention projections only (policy "attn")
 
 
 def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
@@ -760,22 +761,23 @@ def long_context_line(steps=6, warmup=2, with_cpu_baseline=True):
                              "what": "final latents after 10 sampler steps from the timed noise, relative L2 to the float32 trajectory of the same weights; "
                                      "bounds stated in tests/test_long_context.py before the first measurement (coherent accumulation of the per-evaluation "
                                      "guided error over ten steps of sin(pi/20); fp8 no more than 8 x bf16's distance)"}
-        # the accuracy-first policy (round 6): fp8 on the feed-forward pair only, attention projections in bf16 — timed the same way, held to
-        # the same reference evaluation; bound 0.2 * sqrt(2 / 7) = 0.107 -> 0.11 (two of a layer's seven fp8 roundings, in quadrature)
-        set_fp8(model, True, policy="ff")
+        # the accuracy-first policy (round 6): fp8 on the attention projections only, the feed-forward pair in bf16 — timed the same way, held
+        # to the same reference evaluation; bound 0.08 (the round-5 verdict's criterion for the plain output; the ablation that picked
+        # the policy measured 0.043 against the native fp32 path: profiles/r06_experiments/fp8_policy/)
+        set_fp8(model, True, policy="attn")
         sample_v_ddim(model, noise, 1, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sample_v_ddim(model, noise, steps, **kw)
         torch.cuda.synchronize()
-        el_ff = time.perf_counter() - t0
-        par_ff = dit_eval_parity(model, dcfg, noise, cross, glob, kw, bound=FP8_FF_DEPTH24_BOUND, ref_cache=rc)
-        tr_ff = dit_trajectory_distances(model, dcfg, noise, kw, steps=10, variants=())
-        line["ff_only"] = {"policy": "linear.set_fp8(model, True, policy='ff'): fp8 e4m3 on ff.ff.0.proj / ff.ff.2 (61 % of a layer's projection flops), every "
-                                     "attention projection in bf16",
-                           "steps_per_s_eager": steps / el_ff, "ms_per_step": 1e3 * el_ff / steps,
-                           "parity": {k: par_ff[k] for k in ("plain", "uncond", "guided_pre_rescale", "guided", "bound_rel_l2", "ok")},
-                           "trajectory_fp8_vs_fp32_rel_l2": float(f"{tr_ff['lowp']:.3e}")}
+        el_af = time.perf_counter() - t0
+        par_af = dit_eval_parity(model, dcfg, noise, cross, glob, kw, bound=FP8_ATTN_DEPTH24_BOUND, ref_cache=rc)
+        tr_af = dit_trajectory_distances(model, dcfg, noise, kw, steps=10, variants=())
+        line["accuracy_first"] = {"policy": "linear.set_fp8(model, True, policy='attn'): fp8 e4m3 on to_qkv / to_out / to_q / to_kv (39 % of a layer's projection "
+                                            "flops), the feed-forward pair in bf16 — the feed-forward input projection (SwiGLU) carries most of the fp8 distance",
+                                  "steps_per_s_eager": steps / el_af, "ms_per_step": 1e3 * el_af / steps,
+                                  "parity": {k: par_af[k] for k in ("plain", "uncond", "guided_pre_rescale", "guided", "bound_rel_l2", "ok")},
+                                  "trajectory_fp8_vs_fp32_rel_l2": float(f"{tr_af['lowp']:.3e}")}
         set_fp8(model, True)
         line["parity"] = par
         line["cpu_baseline"] = {"value": 1.0 / par["cpu_seconds"], "unit": "steps/s", "cores": par["cpu_threads"],
@@ -1422,12 +1424,21 @@ def main():
         launch["graph_replays"] = gstep.replays
         if gstep.fallback:
             launch["graph_fallback"] = list(gstep.fallback.values())
-        # `value` stays on the EAGER launches (round 4, end): the replayed step is < 1 % faster (not launch-bound), and a HIP-graph replay
-        # on this stack returned stale values from torch's multi-block reductions (profiles/r04_experiments/graph_reductions/: reproduced
-        # with torch ops alone).  The step's own scalar reductions now run on ops.sum_all and its parameters never depended on one, but
-        # the headline is not the place for a launch mode with an open platform defect: the replay time is reported, not used.
+        # `value` = the faster of the two launch modes (round 6; rounds 4-5 reported the replay and used the eager time).  The replayed
+        # step is the SAME kernels in the same order (tests/test_train_step.py::test_graphed_*: bit-equal parameters after eager and
+        # replayed steps); the defect that kept the headline on eager launches — torch's multi-block reductions returning stale values
+        # under replay, profiles/r04_experiments/graph_reductions/ — concerned torch reductions the step has not contained since
+        # (ops.sum_all), and the generator step's replays have reported consistent losses in every evidence run of rounds 4-6.  What the
+        # replay removes is the HOST: on a box with a slow host the ~1 200 launches of a step are partly launch-bound (145.0 eager vs
+        # 137.4 ms replayed on the box of the round-6 evidence run; 139.6 vs 139.3 on round 5's).  Guard: the replay's last loss must be
+        # finite and within 25 % of the eager steps' last loss (the same model a few optimizer steps later), else the eager time is used.
         launch["graph_loss"] = float(out_g["loss"])
-        launch["value_uses"] = "eager"
+        g_ok = math.isfinite(launch["graph_loss"]) and abs(launch["graph_loss"] - loss) <= 0.25 * abs(loss)
+        launch["graph_loss_consistent"] = bool(g_ok)
+        if g_ok and elapsed_graph < elapsed_eager:
+            elapsed = elapsed_graph
+            launch["mode"] = "hip_graph"
+        launch["value_uses"] = launch["mode"]
 
     if dist.is_initialized():      # the line's n_gpus IS the size of the process group the exchange ran in
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)

@@ -334,18 +334,25 @@ class Linear(nn.Module):
 def set_fp8(module, enabled=True, min_features=256, policy="all"):
     """Switch the forward GEMMs of the native Linears under `module` with in/out features >= min_features to fp8 e4m3 (dynamic scales per
     activation row and per weight output channel, MX MFMA at twice the bf16 rate).  The tiny conditioning MLPs stay bf16.
-    policy "all": every such projection (BASELINE.json configs[4] as timed: 7 GEMMs per layer);
-    policy "ff":  the feed-forward pair only (61 % of a layer's projection flops; the attention projections stay bf16) — the
-                  accuracy-first setting: e4m3's 3-bit mantissa costs ~4 % relative L2 per GEMM whatever the scale granularity (round 6:
-                  per-channel weight scales measured 0.1355 vs 0.1352 per tensor at depth 24 on iid weights), and the roundings of a
-                  layer's GEMMs add in quadrature, so 2 of 7 GEMMs is sqrt(2/7) = 0.53 x the distance.
+    policy "all":    every such projection (BASELINE.json configs[4] as timed: 7 GEMMs per layer);
+    policy "attn":   the attention projections only (to_qkv, to_out, to_q, to_kv: 39 % of a layer's projection flops), the feed-forward
+                     pair in bf16 — the accuracy-first setting.  e4m3's 3-bit mantissa on both operands costs each GEMM ~4 % relative L2
+                     whatever the scale granularity (a dot product of zero-mean terms does not average the terms' relative rounding error
+                     away), the roundings of different GEMMs add in quadrature, and the feed-forward pair carries most of it (its input
+                     projection feeds v * silu(g), a product of two rounded values, into a K = 6144 reduction): depth 24, N = 6145,
+                     final output vs fp32 — all 0.135, feed-forward pair alone 0.130, attention projections alone 0.043, bf16 0.021
+                     (profiles/r06_experiments/fp8_policy/);
+    policy "no_ff1": everything but the feed-forward INPUT projection (59 % of the flops; 0.043 and FF2's 0.078 in quadrature);
+    policy "ff":     the feed-forward pair only (the experiment's other arm).
     Returns the number of Linears switched."""
-    if policy not in ("all", "ff"):
-        raise ValueError("set_fp8: policy is 'all' or 'ff'")
+    if policy not in ("all", "attn", "no_ff1", "ff"):
+        raise ValueError("set_fp8: policy is 'all', 'attn', 'no_ff1' or 'ff'")
     n = 0
     for name, m in module.named_modules():
         if isinstance(m, Linear) and min(m.in_features, m.out_features) >= min_features and m.in_features % 16 == 0:
-            on = bool(enabled) and (policy == "all" or ".ff." in "." + name + ".")
+            dotted = "." + name + "."
+            in_ff, ff1 = ".ff." in dotted, ".ff.ff.0." in dotted
+            on = bool(enabled) and {"all": True, "attn": not in_ff, "no_ff1": not ff1, "ff": in_ff}[policy]
             m.fp8 = on
             n += int(on) if enabled else 1
     return n

@@ -112,8 +112,10 @@ def test_dit_block_long_context_gpu(hip):
 # residual stream, so they add in quadrature: 2e-2 * sqrt(24) = 0.098 expected, bound = 2 x that = 0.2 (bench.py FP8_DEPTH24_BOUND is the
 # same number).  The guided output before the rescale is held to the triangle inequality on the two measured half errors.
 FP8_DEPTH24 = 0.2
-# policy "ff" (round 6: fp8 on the feed-forward pair only): 2 of the 7 fp8 roundings per layer -> 0.2 * sqrt(2 / 7) = 0.107
-FP8_FF_DEPTH24 = 0.11
+# policy "attn" (round 6: fp8 on the attention projections only, the accuracy-first setting): the round-5 verdict's criterion for the plain
+# output, 0.08; the ablation that picked the policy measured 0.043 on bench.py's weights (profiles/r06_experiments/fp8_policy/: the
+# feed-forward pair carries the distance — the round's first guess, fp8 on the feed-forward pair only, was the wrong way round)
+FP8_ATTN_DEPTH24 = 0.08
 
 
 @pytest.mark.gpu
@@ -149,14 +151,14 @@ def test_dit_depth24_fp8_long_context_final_output_gpu(hip):
           f"guided pre-rescale {eg:.2e} (triangle bound {gb:.2e})")
     assert ec < FP8_DEPTH24 and eu < FP8_DEPTH24, (ec, eu)
     assert eg <= gb, (eg, gb)
-    # the accuracy-first policy: feed-forward pair in fp8, attention projections in bf16 — same oracle results
+    # the accuracy-first policy: attention projections in fp8, the feed-forward pair in bf16 — same oracle results
     with torch.no_grad():
-        assert linear.set_fp8(model, True, policy="ff") == 2 * 24
-        cf = model(xb, tb, **kw).float().cpu()
-        uf = model(xb, tb, cross_attn_cond=torch.zeros_like(kw["cross_attn_cond"]), global_embed=kw["global_embed"]).float().cpu()
-    ecf, euf = l2_err(cf, c_ref), l2_err(uf, u_ref)
-    print(f"   policy 'ff' (fp8 feed-forward only): conditioned {ecf:.2e} unconditioned {euf:.2e} (bound {FP8_FF_DEPTH24})")
-    assert ecf < FP8_FF_DEPTH24 and euf < FP8_FF_DEPTH24 and ecf < ec, (ecf, euf, ec)
+        assert linear.set_fp8(model, True, policy="attn") == 5 * 24 + 6
+        ca = model(xb, tb, **kw).float().cpu()
+        ua = model(xb, tb, cross_attn_cond=torch.zeros_like(kw["cross_attn_cond"]), global_embed=kw["global_embed"]).float().cpu()
+    eca, eua = l2_err(ca, c_ref), l2_err(ua, u_ref)
+    print(f"   policy 'attn' (fp8 on the attention projections only): conditioned {eca:.2e} unconditioned {eua:.2e} (bound {FP8_ATTN_DEPTH24})")
+    assert eca < FP8_ATTN_DEPTH24 and eua < FP8_ATTN_DEPTH24 and eca < ec, (eca, eua, ec)
 
 
 # Trajectory level (round 6).  10 v-DDIM steps with CFG 6 + rescale 0.75 at N = 6145 from one noise tensor; the final latents of the fp8 model
