@@ -1138,7 +1138,7 @@ def headline_parity(model, cfg, stepper, audio, with_gradients=True):
         loss_lin_native = float(loss_lin)
         del zg, infog, decg, pr, loss_lin
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    cores = min(os.cpu_count() or 1, 16)
+    cores = min(os.cpu_count() or 1, 48 if with_gradients else 16)      # (not a timed baseline: the autograd pass over 2 M samples scales past 16 threads)
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
     grad_obj = "skipped (--no-parity-gradients)"
@@ -1431,9 +1431,13 @@ def main():
         # (ops.sum_all), and the generator step's replays have reported consistent losses in every evidence run of rounds 4-6.  What the
         # replay removes is the HOST: on a box with a slow host the ~1 200 launches of a step are partly launch-bound (145.0 eager vs
         # 137.4 ms replayed on the box of the round-6 evidence run; 139.6 vs 139.3 on round 5's).  Guard: the replay's last loss must be
-        # finite and within 25 % of the eager steps' last loss (the same model a few optimizer steps later), else the eager time is used.
+        # finite and within 25 % of the loss of the NEXT step run eagerly from the replays' state, else the eager time is used.
         launch["graph_loss"] = float(out_g["loss"])
-        g_ok = math.isfinite(launch["graph_loss"]) and abs(launch["graph_loss"] - loss) <= 0.25 * abs(loss)
+        out_e = stepper(batches[args.steps % 2])           # the NEXT step, eagerly, from the state the replays left (outside both timed regions)
+        sync()
+        launch["eager_loss_after_graph"] = float(out_e["loss"])
+        g_ok = (math.isfinite(launch["graph_loss"]) and math.isfinite(launch["eager_loss_after_graph"])
+                and abs(launch["graph_loss"] - launch["eager_loss_after_graph"]) <= 0.25 * abs(launch["eager_loss_after_graph"]))
         launch["graph_loss_consistent"] = bool(g_ok)
         if g_ok and elapsed_graph < elapsed_eager:
             elapsed = elapsed_graph

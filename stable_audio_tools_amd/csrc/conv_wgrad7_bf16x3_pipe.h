@@ -202,21 +202,16 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
     write_lds(I0{});
     issue_loads(clampc(1));
     __syncthreads();
-    int c = 0;
-    for (; c + 2 < nst; c += 2) {
-        phase(I0{}, I1{}, c + 2);                          // stage c out of buffer 0; stage c+1 -> buffer 1
+    // ONE loop body for every stage (round 6): the last stages run the same two phases with clamped (redundant) refills instead of a
+    // separate remainder — three more inlined copies of the MFMA phase, in which the register allocator spilled 34-172 registers
+    // (tools/check_resources.py allow-listed them: scratch outside the steady-state loop, but scratch)
+    for (int c = 0; c < nst; c += 2) {
+        phase(I0{}, I1{}, clampc(c + 2));                  // stage c out of buffer 0; stage c+1 -> buffer 1
         __syncthreads();
-        phase(I1{}, I0{}, clampc(c + 3));                  // stage c+1 out of buffer 1; stage c+2 -> buffer 0
-        __syncthreads();
-    }
-    if (c + 1 < nst) {                                     // stage c in buffer 0, stage c+1 in the registers
-        if (!mfma_first) write_lds(I1{});
-        mfma_phase(I0{});
-        if (mfma_first) write_lds(I1{});
-        __syncthreads();
-        mfma_phase(I1{});
-    } else {
-        mfma_phase(I0{});
+        if (c + 1 < nst) {                                 // (block-uniform)
+            phase(I1{}, I0{}, clampc(c + 3));              // stage c+1 out of buffer 1; stage c+2 -> buffer 0
+            __syncthreads();
+        }
     }
 
     if (m0 + m_w < p.M) {
