@@ -94,6 +94,12 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
     short (*a_lds)[CS][AROWS][8] = reinterpret_cast<short (*)[CS][AROWS][8]>(lds_pool + W_BYTES);           // [plane][sub-block][time row][8 ci]
     __shared__ float red_lds[2][2][SAT_CO_T];
     __shared__ float ep_lds[5][SAT_CO_T];
+    // the input's SnakeBeta constants (pre-exponentiated), ALL channels, staged once (round 6).  They used to be read per chunk inside
+    // write_lds: the channel is wave-uniform, but hipcc cannot prove the arrays unclobbered and emits sixteen VECTOR loads from a uniform
+    // address behind the chunk's barrier — an L2 round trip on the critical path of every chunk, and a vmcnt(0) that also drains whatever
+    // was prefetched further ahead.  (k = 1 plan: 1024 channels = 8 KB, still three workgroups per CU; the others 2048 = 16 KB, two.)
+    constexpr int SN_MAX = (NG == 4) ? 1024 : 2048;
+    __shared__ float sn_lds[2][SN_MAX];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -133,6 +139,14 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
         ep_lds[3][tid] = (ok && a.em_a) ? a.em_a[co] : 0.0f;
         ep_lds[4][tid] = (ok && a.em_a) ? a.em_ib[co] : 0.0f;
     }
+    if (has_snake) {
+        const int nsn = p.Cin < SN_MAX ? p.Cin : SN_MAX;
+        for (int i = tid; i < nsn; i += 256) {
+            sn_lds[0][i] = p.alpha[i];
+            sn_lds[1][i] = p.beta[i];
+        }
+    }
+    __syncthreads();                                       // (the first write_lds reads the table)
 
     const int nchunks = (a.cin_v + 8 * CS - 1) / (8 * CS);
     // Register-staged software pipeline: the global loads of chunk c+1 are issued right after the barrier that
@@ -144,37 +158,58 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
     const int nhalo = (CS > 1) ? (nrows - SAT_T_T) * 8 : 0;
     const bool halo_on = (CS > 1) && (wave % WPS) == 0 && lane < nhalo;
     const int h_row = SAT_T_T + (lane >> 3), h_e = lane & 7;
-    float av[NU][8];
-    float hv = 0.0f, h_a = 0.0f, h_ib = 0.0f;
-    bf16x8 wv[NG];
+    // DEEP (round 6, the strided / transposed plans <8, 4>): TWO staging register sets — chunk c + 2 is requested while chunk c multiplies and
+    // is converted after chunk c + 1's MFMA phase, two phases of latency cover instead of one (these launches sat at 0.22 matrix-busy and
+    // 0.8-1.1 TB/s: two workgroups of four waves per CU, each stalled on a single chunk of 4-byte loads per phase).  The k = 1 plan keeps one
+    // set (three workgroups per CU at 164 registers).
+    constexpr bool DEEP = (NG == 8 && CS == 4);
+    constexpr int NSET = DEEP ? 2 : 1;
+    float av[NSET][NU][8];
+    float hv[NSET];
+    bf16x8 wv[NG];                                        // the weight slab (L2-resident) stays one chunk ahead in ONE set
+#pragma unroll
+    for (int s_ = 0; s_ < NSET; ++s_) hv[s_] = 0.0f;
     // element (virtual channel v, time row) -> real input: channel v >> si at time ((q_in0 + row) << si) + (v & mask) - in_shift;
     // channels past the end are clamped (their weights are zero), times outside [0, Tin) read as 0 (= snake(0)).
-    auto load_elem = [&](int v, int row) -> float {
+    // The value comes back RAW (from a clamped address) with its in-range flag beside it: `ok ? val : 0` right behind the load makes hipcc wait
+    // for every load of a chunk before the MFMA phase they were issued in front of (round 6: the ISA of rounds 1-5 shows vmcnt(15) ... vmcnt(0)
+    // between the loads and the first MFMA — the "register-staged software pipeline" never overlapped anything).  The flags travel as one
+    // bit mask per staging set and are applied when the set is converted (write_lds).
+    auto load_elem = [&](int v, int row, bool* okp) -> float {
         int ch = v >> si;
         ch = ch < p.Cin ? ch : p.Cin - 1;
         const int tin = ((q_in0 + row) << si) + (v & smask_i) - (GATHER ? a.in_shift : 0);
         const bool ok = (unsigned)tin < (unsigned)p.Tin;
-        const float val = xb[(size_t)ch * p.Tin + (ok ? tin : 0)];
-        return ok ? val : 0.0f;
+        *okp = ok;
+        return xb[(size_t)ch * p.Tin + (ok ? tin : 0)];
     };
-    auto issue_loads = [&](int c) {
+    unsigned okm[NSET];
+#pragma unroll
+    for (int s_ = 0; s_ < NSET; ++s_) okm[s_] = 0u;
+    auto issue_loads = [&](int c, auto set_c) {
+        constexpr int ST = decltype(set_c)::value;
         const int v0 = (c * CS + cs_w) * 8;
+        unsigned m = 0u;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int row = row0 + u * 64 * WPS;
             if (CS == 1 && row >= nrows) continue;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[u][e] = load_elem(v0 + e, row);
-        }
-        if (CS > 1 && halo_on) {
-            hv = load_elem(v0 + h_e, h_row);
-            if (has_snake) {
-                int ch = (v0 + h_e) >> si;
-                ch = ch < p.Cin ? ch : p.Cin - 1;
-                h_a = p.alpha[ch];
-                h_ib = p.beta[ch];
+            for (int e = 0; e < 8; ++e) {
+                bool ok;
+                av[ST][u][e] = load_elem(v0 + e, row, &ok);
+                m |= ok ? (1u << (u * 8 + e)) : 0u;
             }
         }
+        static_assert(NU * 8 < 31, "the in-range flags of a staging set are one 32-bit mask (bit 31: the halo element)");
+        if (CS > 1 && halo_on) {
+            bool ok;
+            hv[ST] = load_elem(v0 + h_e, h_row, &ok);
+            m |= ok ? (1u << 31) : 0u;
+        }
+        okm[ST] = m;
+    };
+    auto issue_w = [&](int c) {
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int idx = tid + u * 256;                 // part = idx % NG, co = (idx / NG) & 127, plane = idx / (NG * 128)
@@ -183,16 +218,17 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             wv[u] = *reinterpret_cast<const bf16x8*>(src);
         }
     };
-    auto write_lds = [&](int c) {
+    auto write_lds = [&](int c, auto set_c) {
+        constexpr int ST = decltype(set_c)::value;
         const int v0 = (c * CS + cs_w) * 8;
         float sa[8], sib[8];
         if (has_snake) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {                  // wave-uniform channel -> scalar loads; pre-exponentiated constants
+            for (int e = 0; e < 8; ++e) {                  // wave-uniform channel: LDS broadcast reads of the staged (pre-exponentiated) constants
                 int ch = (v0 + e) >> si;
                 ch = ch < p.Cin ? ch : p.Cin - 1;
-                sa[e] = p.alpha[ch];
-                sib[e] = p.beta[ch];
+                sa[e] = sn_lds[0][ch];                     // (Cin <= SN_MAX: the host entry points check)
+                sib[e] = sn_lds[1][ch];
             }
         }
 #pragma unroll
@@ -202,7 +238,7 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             uint32_t ph[4], pl[4];
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                float o0 = av[u][e], o1 = av[u][e + 1];
+                float o0 = (okm[ST] >> (u * 8 + e)) & 1u ? av[ST][u][e] : 0.0f, o1 = (okm[ST] >> (u * 8 + e + 1)) & 1u ? av[ST][u][e + 1] : 0.0f;
                 if (has_snake) {
                     o0 = sat_snake(o0, sa[e], sib[e]);
                     o1 = sat_snake(o1, sa[e + 1], sib[e + 1]);
@@ -213,8 +249,12 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             *reinterpret_cast<u32x4*>(&a_lds[1][cs_w][row][0]) = u32x4{pl[0], pl[1], pl[2], pl[3]};
         }
         if (CS > 1 && halo_on) {
-            float o = hv;
-            if (has_snake) o = sat_snake(o, h_a, h_ib);
+            float o = (okm[ST] >> 31) & 1u ? hv[ST] : 0.0f;
+            if (has_snake) {
+                int ch = (v0 + h_e) >> si;
+                ch = ch < p.Cin ? ch : p.Cin - 1;
+                o = sat_snake(o, sn_lds[0][ch], sn_lds[1][ch]);
+            }
             short h, l;
             sat_split2(o, &h, &l);
             a_lds[0][cs_w][h_row][h_e] = h;
@@ -227,13 +267,7 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             *reinterpret_cast<bf16x8*>(&w_lds[pl][co][part * 8]) = wv[u];
         }
     };
-
-    issue_loads(0);
-    for (int c = 0; c < nchunks; ++c) {
-        write_lds(c);
-        __syncthreads();
-        if (c + 1 < nchunks) issue_loads(c + 1);
-
+    auto mfma_chunk = [&]() {
         if (wave_on) {
             SAT_MFMA_PRIO(1);
 #pragma unroll
@@ -263,7 +297,45 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             }
             SAT_MFMA_PRIO(0);
         }
-        __syncthreads();
+    };
+    using SatSet0 = std::integral_constant<int, 0>;
+    using SatSet1 = std::integral_constant<int, NSET - 1>;
+    issue_loads(0, SatSet0{});
+    issue_w(0);
+    if constexpr (DEEP) {
+        if (nchunks > 1) issue_loads(1, SatSet1{});
+        for (int c = 0; c < nchunks; c += 2) {
+            write_lds(c, SatSet0{});
+            __syncthreads();
+            // (oldest first: vmcnt retires in order — the weights of chunk c + 1 are needed one phase before the activations of c + 2)
+            if (c + 1 < nchunks) issue_w(c + 1);
+            SAT_SCHED_FENCE();                             // (the scheduler would otherwise mix the two groups: program order IS the retire order)
+            if (c + 2 < nchunks) issue_loads(c + 2, SatSet0{});
+            SAT_SCHED_FENCE();
+            mfma_chunk();
+            __syncthreads();
+            if (c + 1 < nchunks) {                         // (block-uniform)
+                write_lds(c + 1, SatSet1{});
+                __syncthreads();
+                if (c + 2 < nchunks) issue_w(c + 2);
+                SAT_SCHED_FENCE();
+                if (c + 3 < nchunks) issue_loads(c + 3, SatSet1{});
+                SAT_SCHED_FENCE();
+                mfma_chunk();
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            write_lds(c, SatSet0{});
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                issue_loads(c + 1, SatSet0{});
+                issue_w(c + 1);
+            }
+            mfma_chunk();
+            __syncthreads();
+        }
     }
 
     // ------------- epilogue (as conv1d.hip; virtual channel m = co*S + r lands on y[co][q*S + r - out_shift]) -------------
@@ -547,6 +619,12 @@ static int sat_bf_launch(const char* what, SatConvBfLaunch& a, const SatBfPlan& 
         if (a.xp_hi && a.wq) sat_bf_launch_k7q(a, stream);
         else sat_bf_launch_k7(a, stream);
         return sat_check_launch(what);
+    }
+    // the generic kernel stages the input's SnakeBeta constants of ALL channels in LDS: 1024 channels on the k = 1 plan (4, 4), 2048 on the others
+    // (every Oobleck level: channels 128 x c_mults <= 16)
+    if (a.p.alpha && a.p.Cin > ((pl.ng == 4) ? 1024 : 2048)) {
+        sat_set_error("conv1d_bf16x3: an activated input of more than 2048 channels (1024 for K <= 4 at stride 1) is not served by the bf16x3 kernels (ops.use_bf16x3 = False takes the fp32-MFMA ones)");
+        return 1;
     }
     dim3 grid(sat_cdiv(a.nq, SAT_T_T), a.cout_pad / SAT_CO_T, a.p.B);
     if (a.sin_log2 > 0) { SAT_LAUNCH((sat_conv1d_bf16x3_kernel<8, 4, true>), grid, dim3(256), stream, a); }     // strided: always plan (8, 4)
