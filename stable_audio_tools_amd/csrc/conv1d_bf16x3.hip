@@ -449,15 +449,112 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             }
         }
     } else
+    if (wave_on && so >= 1 && ((t0 << so) - a.out_shift) >= 0 && (((t0 + SAT_T_T - 1) << so) + smask_o - a.out_shift) < p.Tout) {
+        // depth-to-space epilogue of an INTERIOR tile (round 6): the four consecutive accumulator rows of a lane are four consecutive TIME steps
+        // of one real channel (S >= 4) or two pairs (S = 2): x2 / res / y move as 16- / 8-byte accesses at dword alignment, a quarter /
+        // half of the memory instructions of the element-wise path below (which keeps the first and the last tile of an item).
+        auto ep_vec = [&](auto lg_c) {
+            constexpr int GL = 1 << decltype(lg_c)::value, NGP = 4 / GL;      // group length, groups per accumulator quad
+            typedef float vecu __attribute__((ext_vector_type(GL), aligned(4)));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (mi == 1 && !mi1_on) break;
+                vecu xv[4][NGP][2], rv[4][NGP][2];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int gp = 0; gp < NGP; ++gp) {
+                        const int m = co0 + co_w + mi * 32 + 8 * rg + 4 * hi + gp * GL;
+                        const bool m_ok = m < a.cout_v;
+                        const int co = m_ok ? m >> so : 0;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int q = t0 + t_w + ni * 32 + l31;
+                            const size_t o = ((size_t)b * p.Cout + co) * p.Tout + ((q << so) + (m & smask_o) - a.out_shift);
+#pragma unroll
+                            for (int e = 0; e < GL; ++e) { xv[rg][gp][ni][e] = 0.0f; rv[rg][gp][ni][e] = 0.0f; }
+                            if (bwd) xv[rg][gp][ni] = *reinterpret_cast<const vecu*>(p.x2 + o);
+                            if (p.res) rv[rg][gp][ni] = *reinterpret_cast<const vecu*>(p.res + o);
+                        }
+                    }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int gp = 0; gp < NGP; ++gp) {
+                        const int col0 = co_w + mi * 32 + 8 * rg + 4 * hi + gp * GL;
+                        const int m = co0 + col0;
+                        const bool m_ok = m < a.cout_v;
+                        const int co = m_ok ? m >> so : 0;
+                        float pda[GL], pdb[GL];
+#pragma unroll
+                        for (int e = 0; e < GL; ++e) { pda[e] = 0.f; pdb[e] = 0.f; }
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int q = t0 + t_w + ni * 32 + l31;
+                            vecu ov;
+#pragma unroll
+                            for (int e = 0; e < GL; ++e) {
+                                const int col = col0 + e;
+                                float v = acc[mi][ni][rg * 4 + gp * GL + e] + ep_lds[0][col];
+                                if (bwd) {
+                                    const SatSnakeGrad g = sat_snake_grad(xv[rg][gp][ni][e], ep_lds[1][col], ep_lds[2][col]);
+                                    pda[e] += v * g.dla;
+                                    pdb[e] += v * g.dlb;
+                                    v *= g.dx;
+                                }
+                                v += rv[rg][gp][ni][e];
+                                if (p.tanh_out) v = tanhf(v);
+                                ov[e] = v;
+                            }
+                            if (m_ok) *reinterpret_cast<vecu*>(p.y + ((size_t)b * p.Cout + co) * p.Tout + ((q << so) + (m & smask_o) - a.out_shift)) = ov;
+                        }
+                        if (bwd) {
+#pragma unroll
+                            for (int e = 0; e < GL; ++e) {
+                                const float sa_ = sat_half_sum(m_ok ? pda[e] : 0.f), sb_ = sat_half_sum(m_ok ? pdb[e] : 0.f);
+                                if (l31 == 0) {
+                                    red_lds[0][wave & 1][col0 + e] = sa_;
+                                    red_lds[1][wave & 1][col0 + e] = sb_;
+                                }
+                            }
+                        }
+                    }
+            }
+        };
+        if (so >= 2) ep_vec(std::integral_constant<int, 2>{});
+        else ep_vec(std::integral_constant<int, 1>{});
+    } else
     if (wave_on) {
+        // 4-byte epilogue (depth-to-space outputs: transposed convs and the data-gradients of strided convs).  Round 6: the x2 / res loads of
+        // a 32-row half are ALL issued (from clamped addresses, no branch around them) before the first is used — they used to sit inside
+        // the per-element `if (in range)` block, one dependent load per element: 64 serialised HBM latencies per thread and tile in the
+        // strided convs' data-gradients.
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             if (mi == 1 && !mi1_on) break;
+            float xv[16][2], rv[16][2];
+            unsigned okb = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int m = co0 + col;
                 const bool m_ok = m < a.cout_v;
+                const int co = m >> so;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int q = t0 + t_w + ni * 32 + l31;
+                    const int t = (q << so) + (m & smask_o) - a.out_shift;
+                    const bool ok = m_ok && t >= 0 && t < p.Tout;
+                    okb |= ok ? (1u << (2 * r + ni)) : 0u;
+                    const size_t o = ((size_t)b * p.Cout + (ok ? co : 0)) * p.Tout + (ok ? t : 0);
+                    xv[r][ni] = bwd ? p.x2[o] : 0.0f;
+                    rv[r][ni] = p.res ? p.res[o] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = co_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = co0 + col;
                 const int co = m >> so;
                 const float bias = ep_lds[0][col];
                 const float a2 = ep_lds[1][col], b2 = ep_lds[2][col];
@@ -466,19 +563,17 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
                 for (int ni = 0; ni < 2; ++ni) {
                     const int q = t0 + t_w + ni * 32 + l31;
                     const int t = (q << so) + (m & smask_o) - a.out_shift;
-                    if (m_ok && t >= 0 && t < p.Tout) {
-                        const size_t o = ((size_t)b * p.Cout + co) * p.Tout + t;
-                        float v = acc[mi][ni][r] + bias;
-                        if (bwd) {
-                            const SatSnakeGrad g = sat_snake_grad(p.x2[o], a2, b2);
-                            pda += v * g.dla;
-                            pdb += v * g.dlb;
-                            v *= g.dx;
-                        }
-                        if (p.res) v += p.res[o];
-                        if (p.tanh_out) v = tanhf(v);
-                        p.y[o] = v;
+                    const bool ok = (okb >> (2 * r + ni)) & 1u;
+                    float v = acc[mi][ni][r] + bias;
+                    if (bwd) {
+                        const SatSnakeGrad g = sat_snake_grad(xv[r][ni], a2, b2);
+                        pda += ok ? v * g.dla : 0.0f;
+                        pdb += ok ? v * g.dlb : 0.0f;
+                        v *= g.dx;
                     }
+                    v += rv[r][ni];
+                    if (p.tanh_out) v = tanhf(v);
+                    if (ok) p.y[((size_t)b * p.Cout + co) * p.Tout + t] = v;
                 }
                 if (bwd) {
                     pda = sat_half_sum(pda);

@@ -44,9 +44,12 @@ S1_CASES = [(1, 8, 8, 300, 7, 1), (1, 16, 70, 280, 7, 3), (2, 24, 8, 200, 7, 9),
             (1, 64, 130, 152, 7, 1)]   # >= 64 in-channels: the pipelined wgrad kernel (two co tiles)
 DOWN_CASES = [(1, 8, 16, 256, 2), (2, 12, 20, 333, 4), (1, 6, 130, 1100, 8), (1, 40, 6, 300, 2), (1, 8, 8, 520, 4),
               # output lengths that are multiples of 4: the vector-staged weight-gradient path (round 4), S = 2 / 4 / 8, partial and second tiles
-              (2, 70, 6, 264, 2), (1, 40, 24, 1040, 4), (1, 20, 130, 2112, 8)]
+              (2, 70, 6, 264, 2), (1, 40, 24, 1040, 4), (1, 20, 130, 2112, 8),
+              # three and more time tiles: INTERIOR tiles take the vector staging loads (forward) / the vector depth-to-space epilogue (data-gradient)
+              (1, 12, 10, 800, 2), (1, 5, 9, 1560, 4)]
 UP_CASES = [(1, 16, 8, 40, 2), (2, 12, 20, 33, 4), (1, 6, 130, 70, 8), (1, 70, 6, 150, 2), (1, 48, 8, 131, 4),
-            (2, 6, 70, 260, 2), (1, 24, 40, 132, 4), (1, 130, 12, 68, 8)]
+            (2, 6, 70, 260, 2), (1, 24, 40, 132, 4), (1, 130, 12, 68, 8),
+            (1, 8, 12, 300, 4), (1, 10, 12, 300, 8), (1, 7, 5, 390, 2)]      # interior tiles (see DOWN_CASES), odd channel counts
 
 
 def _run_s1(ops, dev, case, use_x3):
