@@ -419,7 +419,15 @@ class AudioAutoencoder(nn.Module):
         y_size = total // r
         out = torch.zeros((audio.shape[0], self.latent_dim, y_size), device=audio.device, dtype=audio.dtype)
         half = overlap // 2
+        # noise= may be a list / tuple with one tensor per chunk (native extension: the reference draws each chunk's VAE noise from
+        # torch's global generator, autoencoders.py:646 -> bottleneck.py:109; an explicit list makes a chunked encode reproducible on
+        # any device); a single tensor is handed to every chunk as before
+        chunk_noise = kwargs.pop("noise", None)
+        if isinstance(chunk_noise, (list, tuple)) and len(chunk_noise) != len(starts):
+            raise ValueError(f"chunked encode: {len(starts)} chunks but {len(chunk_noise)} noise tensors")
         for i, s0 in enumerate(starts):
+            if chunk_noise is not None:
+                kwargs["noise"] = chunk_noise[i] if isinstance(chunk_noise, (list, tuple)) else chunk_noise
             y = self.encode(audio[:, :, s0:s0 + csz], **kwargs)
             last = i == len(starts) - 1
             t1 = y_size if last else i * hop // r + chunk_size

@@ -137,10 +137,16 @@ def _chunked(device):
         with torch.no_grad():
             enc = model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16)
         assert rel_err(enc, g["encoded_chunked"]) < TOL
-    else:
-        with torch.no_grad():
-            enc = model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16)
-        assert enc.shape == (1, cfg["model"]["latent_dim"], 44) and bool(torch.isfinite(enc).all())
+    # ... and on any device with the SAME draws injected chunk by chunk (noise= as a list, one tensor per chunk): the golden run's
+    # four draws are randn_like of a (1, latent, 16) CPU tensor after manual_seed(4242), i.e. the CPU generator's stream in chunk order
+    gen = torch.Generator().manual_seed(4242)
+    draws = [torch.randn(1, cfg["model"]["latent_dim"], 16, generator=gen).to(device) for _ in range(4)]
+    with torch.no_grad():
+        enc = model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16, noise=draws)
+    assert enc.shape == (1, cfg["model"]["latent_dim"], 44)
+    assert rel_err(enc, g["encoded_chunked"]) < TOL
+    with pytest.raises(ValueError):
+        model.encode_audio(audio, chunked=True, overlap=4, chunk_size=16, noise=draws[:3])
 
 
 def test_chunked_encode_decode_simulator(emu_modules):
