@@ -41,6 +41,7 @@ struct SatConvBfLaunch {
     int wq = 0;            // conv1d_bf16x3_k7q.h: the weight planes are in sat_pack_weights_k7q layout ([chunk16][tap][group][co][8])
     int stagger = 0;       // conv1d_bf16x3_k7q.h: start delay units (x ~4 us x (0..7)) that de-phase the CUs' epilogue bursts
     int persist = 0;       // conv1d_bf16x3_k7q.h: one workgroup per CU walks the tiles, the next tile's first chunk requested before the epilogue
+    int dma_in_mfma = 0;   // conv1d_bf16x3_k7q.h VARIANT 3: the next chunk's LDS-DMA issued inside the MFMA sections
     // plane EMISSION (generic kernel, 16-byte epilogue): besides y the kernel writes act(y) as the bf16 hi / lo planes the next k7
     // conv reads ([B][em_c8][em_rows][8], row = 32 + t; the zero rows around the sequence belong to the caller) — the consumer's
     // sat_k7_planes_kernel pre-pass (one read + one write of the tensor) disappears.  em_a / em_ib: pre-exponentiated SnakeBeta
@@ -845,6 +846,7 @@ extern "C" int sat_conv1d_bf16x3_planesq(const short* xp_hi, const short* xp_lo,
     a.xp_rows = rows;
     a.xp_c8 = sat_cdiv(Cin, 8);
     a.wq = 1;
+    a.dma_in_mfma = (flags & 4) ? 1 : 0;                     // flags bit 2: VARIANT 3 of the k7q kernel
     a.persist = (flags & 1) ? 0 : ((flags & 2) ? 2 : 1);      // flags bit 0: one workgroup per tile (round 5's launch; A/B runs and the tests'
                                                               // second arm); bit 1: persistent at any size (the tests: small shapes)
     SatBfPlan pl{8, 1, K};

@@ -98,6 +98,13 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
     // retired by the next chunk's phase 0 (which leaves its own new pieces in flight: 5 for waves 0-3, 4 for waves 4-7) one phase
     // before they are read.  VARIANT 0: weights first, vmcnt(0) once per chunk (3-4 % slower at C = 128 / 256, profiles/EXPERIMENTS.md).
     constexpr bool REORDER = (VARIANT & 1) != 0;
+    // VARIANT 3 (round 6): the next chunk's LDS-DMA is issued INSIDE the MFMA sections — a piece costs 100-185 cycles of issue in a read section that
+    // also carries 32 ds_read_b128 and ~60 between MFMAs (MI355X_MICROARCH.md), and an ablation put the DMA at 21-24 % of the launch
+    // (profiles/r06_experiments/k7q_ablation/).  Phase 0 issues [activations, taps 0-3] of chunk c+1 after its taps' MFMAs, phase 1 [taps 4-6];
+    // each read section then waits vmcnt(0) for what the PREVIOUS MFMA section issued: phase 1's wait retires [activations, taps 0-3] of c+1 (first
+    // read two barriers later by the first wave row, three by the second), phase 0's wait retires [taps 4-6] of its own chunk (first read
+    // after the phase's closing barrier).  Both wave rows' waits precede, by a barrier, every read of what they publish.
+    constexpr bool INMFMA = VARIANT == 3;
     constexpr int CO_T = SAT_K7_CO, T_T = SAT_K7_T, NT = SAT_K7_NT, AROWS = SAT_K7_AROWS;
     constexpr int TW = T_T / 64;                          // waves along time
     const SatConvParams& p = a.p;
@@ -236,7 +243,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         // ---- phase 0: taps 0..3 ----
 #pragma unroll
         for (int u = 0; u < 4; ++u) load_frags(fr[u], sb, u);
-        if constexpr (REORDER) {
+        if constexpr (INMFMA) {
+            SAT_WAIT_VMCNT(0);                             // taps 4 .. K-1 of THIS chunk (issued in the previous chunk's second MFMA section)
+        } else if constexpr (REORDER) {
             if (more) {
                 issue_a(c + 1, (c + 1 + SPAR) & 1, 0); issue_a(c + 1, (c + 1 + SPAR) & 1, 1); issue_a(c + 1, (c + 1 + SPAR) & 1, 2);
                 issue_w(c + 1, (c + 1 + SPAR) & 1, 0); issue_w(c + 1, (c + 1 + SPAR) & 1, 1);
@@ -256,6 +265,20 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         SAT_RAW_BARRIER();
         SAT_SCHED_FENCE();
         SAT_SETPRIO(1);
+        if constexpr (INMFMA) {
+            const int sn = (c + 1 + SPAR) & 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (wave_on_co) mfma_frags(fr[u]);
+                SAT_SCHED_FENCE();
+                if (more) {                                // (block-uniform) longest latency first: the activation pieces come from HBM
+                    // (early in the section: behind taps 0 and 1 — spread over all four taps the launch was 0.4 % slower, `k7q_dma_in_mfma/`)
+                    if (u == 0) { issue_a(c + 1, sn, 0); issue_a(c + 1, sn, 1); issue_a(c + 1, sn, 2); issue_w(c + 1, sn, 0); }
+                    if (u == 1) { issue_w(c + 1, sn, 1); issue_w(c + 1, sn, 2); issue_w(c + 1, sn, 3); }
+                }
+                SAT_SCHED_FENCE();
+            }
+        } else
         if (wave_on_co) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) mfma_frags(fr[u]);
@@ -267,7 +290,9 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
 #pragma unroll
         for (int u = 0; u < 3; ++u)
             if (4 + u < K) load_frags(fr[u], sb, 4 + u);
-        if constexpr (REORDER) {
+        if constexpr (INMFMA) {
+            SAT_WAIT_VMCNT(0);                             // activations and taps 0-3 of chunk c + 1 (issued in this chunk's first MFMA section)
+        } else if constexpr (REORDER) {
             if (more) {
 #pragma unroll
                 for (int tap = 2; tap < SAT_K7Q_TAPS; ++tap) issue_w(c + 1, (c + 1 + SPAR) & 1, tap);
@@ -282,6 +307,16 @@ __global__ void __launch_bounds__(SAT_K7_NT) sat_conv1d_bf16x3_k7q_kernel(SatCon
         SAT_RAW_BARRIER();
         SAT_SCHED_FENCE();
         SAT_SETPRIO(1);
+        if constexpr (INMFMA) {
+            const int sn = (c + 1 + SPAR) & 1;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (wave_on_co && 4 + u < K) mfma_frags(fr[u]);
+                SAT_SCHED_FENCE();
+                if (more) issue_w(c + 1, sn, 4 + u);       // (taps >= K: nothing)
+                SAT_SCHED_FENCE();
+            }
+        } else
         if (wave_on_co) {
 #pragma unroll
             for (int u = 0; u < 3; ++u)
@@ -603,12 +638,15 @@ static void sat_bf_launch_k7q(SatConvBfLaunch& a, void* stream) {
     const int cus = sat_cu_count();
     if (a.persist == 2 && total >= 2) {                    // test hook (flags bit 1): persistent at ANY size, three tiles per workgroup
         a.stagger = 0;
-        SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)sat_cdivll(total, 3)), dim3(SAT_K7_NT), stream, a);
+        if (a.dma_in_mfma) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<3, false, true>), dim3((unsigned)sat_cdivll(total, 3)), dim3(SAT_K7_NT), stream, a); }
+        else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)sat_cdivll(total, 3)), dim3(SAT_K7_NT), stream, a); }
         return;
     }
     if (a.persist && total >= 2 * cus) {                   // PERSIST: one workgroup per CU walks total / cus tiles (>= 2 each)
-        SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)cus), dim3(SAT_K7_NT), stream, a);
+        if (a.dma_in_mfma) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<3, false, true>), dim3((unsigned)cus), dim3(SAT_K7_NT), stream, a); }
+        else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1, false, true>), dim3((unsigned)cus), dim3(SAT_K7_NT), stream, a); }
         return;
     }
-    SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a);
+    if (a.dma_in_mfma) { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<3>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
+    else { SAT_LAUNCH((sat_conv1d_bf16x3_k7q_kernel<1>), dim3((unsigned)total), dim3(SAT_K7_NT), stream, a); }
 }

@@ -252,6 +252,8 @@ class SatOps:
     k7q = True
     k7q_persist = True      # one workgroup per CU walks the tiles (round 6: launches of >= 2 tiles per CU); False: one workgroup per tile
                             # (A/B: bench.py --ops-set k7q_persist=0); "force": persistent at any size (the tests' small shapes)
+    k7q_dma_in_mfma = True  # VARIANT 3 of the k7q kernel (round 6): the next chunk's LDS-DMA issued between the MFMAs instead of beside the fragment
+                            # reads (k7q 46.2 -> 44.9 ms per generator step; A/B: bench.py --ops-set k7q_dma_in_mfma=0)
     k7q_min_cin = 64
     k7q_min_cout = 128
     k7q_wide_cin = 512      # from this many input channels on, fewer than k7q_min_cout output channels still take the planes kernel
@@ -504,7 +506,7 @@ class SatOps:
             pda, pdb = torch.empty(2, cout, prows, dtype=torch.float32, device=x.device).unbind(0)
         self._chk(self.lib.sat_conv1d_bf16x3_planesq(_ptr(hi), _ptr(lo), rows, _ptr(w_planes[0]), _ptr(w_planes[1]), _ptr(bias), _ptr(res),
                                                      _ptr(y), _ptr(x2), _ptr(a2), _ptr(b2), _ptr(pda), _ptr(pdb), b, cin, cout, tin, tout,
-                                                     k, dil, pad, int(tanh_out), {True: 0, False: 1, "force": 2}[self.k7q_persist], st))
+                                                     k, dil, pad, int(tanh_out), {True: 0, False: 1, "force": 2}[self.k7q_persist] | (4 if self.k7q_dma_in_mfma else 0), st))
         if dsnake is not None:
             return (y, *self._sum_pair(pda, pdb))
         return y

@@ -285,6 +285,18 @@ def _run_planes(ops, dev, cases):
                         *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
                 for a, b in zip(outp, outq):
                     assert torch.equal(a, b), case        # same arithmetic in the same order: the persistent launch is bit-identical
+                # the kernel variant that issues the next chunk's LDS-DMA inside the MFMA sections (round 6): same arithmetic, other schedule
+                keepv = ops.k7q_dma_in_mfma
+                try:
+                    ops.k7q_dma_in_mfma = not keepv
+                    for mode in ("force", False, True):
+                        ops.k7q_persist = mode
+                        outv = (ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, snake=(la, lb)),
+                                *ops.conv1d_bf16x3(x, wq, Cout, K, 1, dil, pad, dsnake=(x2, a2, b2)))
+                        for a, b in zip(outv, outq):
+                            assert torch.equal(a, b), (case, mode)
+                finally:
+                    ops.k7q_dma_in_mfma = keepv
     finally:
         ops.k7q, ops.k7q_min_cin, ops.k7q_min_cout, ops.k7q_persist = keepq
 

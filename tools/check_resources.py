@@ -20,7 +20,10 @@ ALLOW = (
     "sat_gemm256_kernelILi3E", "sat_gemm256_kernelILi4E",
     # the fp32 (two-plane) dK / dV kernel: 4 registers spilled in the prologue and reloaded in the epilogue (no scratch instruction inside
     # the tile loop)
-    "sat_attn_bwd_dkv_kernelIfLi2ELi32E")
+    "sat_attn_bwd_dkv_kernelIfLi2ELi32E",
+    # the persistent k7q kernel with the LDS-DMA issued inside the MFMA sections (round 6): 67 scalar registers spilled to VGPR lanes (no scratch
+    # instruction in the ISA; 36 bytes reserved), 2 v_readlane per 16-channel chunk (one base pointer), the rest per tile
+    "sat_conv1d_bf16x3_k7q_kernelILi3ELb0ELb1E")
 # (round 6: sat_wgrad7_bf16x3_pipe_kernel left this list — its 34-172 spilled registers lived in a separate remainder after the stage
 # loop; the remainder is now the loop body itself with clamped refills: 210-230 VGPRs, no scratch)
 
