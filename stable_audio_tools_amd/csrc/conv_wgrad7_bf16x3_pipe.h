@@ -79,6 +79,36 @@ __global__ void __launch_bounds__(SAT_WP_NT) sat_wgrad7_bf16x3_pipe_kernel(SatWg
         const float* sdy = p.dy + (size_t)b * p.M * p.T;
         const int c4 = (tid & 15) * 4;
         const bool t_ok = tt0 + c4 < p.T;
+        // INTERIOR stages (every sample the stage reads lies inside the sequence — all but the first and the last of a batch item; block-uniform):
+        // unconditional loads from clamped rows, the activation pairs as 8-byte loads at dword alignment.  No select and no branch behind a
+        // load: rows past M / N and pairs past HP carry finite garbage that is never stored (write_lds skips pi >= HP; dW rows / columns
+        // past M / N are not written out).  Round 6: the ablation of this kernel put its global loads at 25 % of the launch — sixteen
+        // `s_cbranch_execz`-wrapped 4-byte loads per thread and stage (profiles/r06_experiments/wgrad7_ablation/).
+        if (tt0 - p.pad >= 0 && tt0 - p.pad + HSPAN <= p.T && tt0 + SAT_WB_TT <= p.T) {
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+            for (int u = 0; u < NDY; ++u) {
+                int m = m0 + (tid >> 4) + u * 32;
+                m = m < p.M ? m : p.M - 1;
+                dyv[st][u] = *reinterpret_cast<const float4*>(sdy + (size_t)m * p.T + tt0 + c4);
+            }
+            const float* sx = p.x + (size_t)b * p.N * p.T + (tt0 - p.pad);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                int n = n0 + (tid >> 4) + 32 * v;
+                n = n < p.N ? n : p.N - 1;
+                const float* s = sx + (size_t)n * p.T;
+#pragma unroll
+                for (int u = 0; u < NXU; ++u) {
+                    int pi = (tid & 15) + 16 * u;
+                    pi = pi < HP ? pi : HP - 1;
+                    const f2u q = *reinterpret_cast<const f2u*>(s + 2 * pi);
+                    xv[st][v * NXU + u][0] = q[0];
+                    xv[st][v * NXU + u][1] = q[1];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
             const int m = m0 + (tid >> 4) + u * 32;
