@@ -43,6 +43,8 @@ python tools/pmc_traffic_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pm
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vae $OUT/real $OUT/dit_sample $OUT/long_context $OUT/dit_train_b4 $OUT/dit_train_b16
+# (these copies live on the GPU box only — bench.py reads them there for roofline.traffic / mfma_utilisation; gpurun brings back gpurun_out/ alone, so
+#  after the call copy gpurun_out/final/{pmc_traffic,pmc_sq_*}.json over profiles/r06_pmc_{traffic,mfma_*}.json by hand, with the other files)
 cp $OUT/pmc_traffic.json $R/profiles/r06_pmc_traffic.json; cp $OUT/pmc_sq_vae.json $R/profiles/r06_pmc_mfma_vae.json; cp $OUT/pmc_sq_dit_train.json $R/profiles/r06_pmc_mfma_dit_train.json; cp $OUT/pmc_sq_dit_sample.json $R/profiles/r06_pmc_mfma_dit_sample.json; cp $OUT/pmc_sq_long_context.json $R/profiles/r06_pmc_mfma_long_context.json      # bench.py reads it for roofline.traffic / roofline.hbm
 timeout 900 python bench.py > $OUT/bench_vae_train.json 2> $OUT/bench_vae_train.err
 timeout 300 python bench.py --workload dit_train --no-cpu-baseline > $OUT/bench_dit_train.json 2> /dev/null
