@@ -367,6 +367,17 @@ sat_conv1d_bf16x3_kernel(SatConvBfLaunch a) {
             if (half_on) {
                 const int tg = t0 + t_w + t4;
                 f32x4 xv[8], rv[8];
+                if (co0 + SAT_CO_T <= p.Cout && t0 + SAT_T_T <= p.Tout) {
+                    // a tile fully inside the tensor (block-uniform): the loads go out back to back, none wrapped in its own branch
+                    const size_t o0 = ((size_t)b * p.Cout + co0 + co_w + mi * 32 + lr) * p.Tout + tg;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (bwd) xv[j] = *reinterpret_cast<const f32x4*>(p.x2 + o0 + (size_t)(j * 4) * p.Tout);
+                        if (p.res) rv[j] = *reinterpret_cast<const f32x4*>(p.res + o0 + (size_t)(j * 4) * p.Tout);
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int co = co0 + co_w + mi * 32 + j * 4 + lr;
