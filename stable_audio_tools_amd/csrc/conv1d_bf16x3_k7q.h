@@ -17,6 +17,8 @@
 //     is overwritten from the phase after the barrier that retired its last reads.
 //   * epilogue: as conv1d_bf16x3_k7.h (bias, dsnake + its per-channel sums, residual, tanh; 16-byte accesses through an LDS
 //     transposition that reuses the drained stage memory).
+//   * round 6 (VARIANT 3, the shipped K loop): the next chunk's LDS-DMA is issued INSIDE the MFMA sections, not beside the fragment reads
+//     (the item above describes VARIANT 1, kept as the A / B arm: SatConvBfLaunch::dma_in_mfma, ops.k7q_dma_in_mfma) — see INMFMA below.
 #pragma once
 
 #define SAT_K7Q_TAPS 7
