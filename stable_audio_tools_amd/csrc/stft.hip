@@ -184,34 +184,29 @@ SAT_DEVICE void sat_fft_run(const SatFftLds& L, int n, int log2n, int fb) {
     else if (log2n - s + 1 == 1) sat_fft_pass<1>(L, n, log2n, fb, s);
 }
 
-SAT_DEVICE void sat_stft_load_frames(const SatStftParams& p, const SatFftLds& L, int item, int view, int f0) {
+// frames f0 .. f0+fb-1 of ONE channel into the frame slots slot0 .. slot0+fb-1: x (first loss argument) in the real part,
+// y in the imaginary part, windowed, stored bit-reversed for the in-place DIT
+SAT_DEVICE void sat_stft_load_channel(const SatStftParams& p, const SatFftLds& L, int item, int ch, int f0, int slot0) {
     const int n = p.n, log2n = p.log2n;
-    const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
-    const float* x0 = p.x + (size_t)item * p.C * p.T;
-    const float* y0 = p.y + (size_t)item * p.C * p.T;
+    const float* x0 = p.x + ((size_t)item * p.C + ch) * p.T;
+    const float* y0 = p.y + ((size_t)item * p.C + ch) * p.T;
     for (int i = threadIdx.x; i < p.fb * n; i += 256) {
         const int fi = i >> log2n, j = i & (n - 1);
         const int f = f0 + fi;
         float xv = 0.f, yv = 0.f;
         if (f < p.nframes) {
             const int t = sat_reflect(f * p.hop + j - (n >> 1), p.T);
-            xv = va * x0[t];
-            yv = va * y0[t];
-            if (p.C > 1) {
-                xv += vb * x0[p.T + t];
-                yv += vb * y0[p.T + t];
-            }
             const float w = sat_hann(L, j, n);
-            xv *= w;
-            yv *= w;
+            xv = w * x0[t];
+            yv = w * y0[t];
         }
         const int jr = (int)(sat_brev((unsigned)j) >> (32 - log2n));
-        L.re[fi * n + jr] = xv;
-        L.im[fi * n + jr] = yv;
+        L.re[(slot0 + fi) * n + jr] = xv;
+        L.im[(slot0 + fi) * n + jr] = yv;
     }
 }
 
-// spectra of the two packed real signals at bin k of frame fi
+// spectra of the two packed real signals at bin k of frame slot fi
 SAT_DEVICE void sat_unpack_bins(const SatFftLds& L, int n, int fi, int k, float* xr, float* xi, float* yr, float* yi) {
     const int k2 = (n - k) & (n - 1);
     const float ar = L.re[fi * n + k], ai = L.im[fi * n + k];
@@ -222,61 +217,116 @@ SAT_DEVICE void sat_unpack_bins(const SatFftLds& L, int n, int fi, int k, float*
     *yi = -0.5f * (ar - br);
 }
 
-// NMAX: the largest fb * n this instance holds (2048, or 512 for the five resolutions n <= 512: a quarter of the LDS, so that eight
-// workgroups share a CU instead of two or three — these kernels are latency-bound: every phase is a dependent round trip)
-template <int NMAX>
-__global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
-    __shared__ float re[NMAX], im[NMAX], twr[NMAX / 2], twi[NMAX / 2];
-    __shared__ float red[3][4];
-    const SatFftLds L{re, im, twr, twi};
+// The DFT is linear and a view is a linear combination of an item's channels, so the kernels transform each CHANNEL once
+// (x and y of a channel packed in one complex FFT) and form every view's spectrum from the channels' bins in registers:
+// two transforms per frame group instead of one per view (round 6; four views = the sum / difference / left / right of
+// training/autoencoders.py:186-194).  Template parameters: NMAX = the largest fb * n an instance holds (2048, 1024, or 512 for
+// the five resolutions n <= 512: a fraction of the LDS, so that several workgroups share a CU — these kernels are chains of
+// dependent LDS round trips); U = bins a thread owns (fb * (n/2+1) <= 256 U); CC = channels transformed concurrently (2: both
+// channels of a stereo item go through the FFT passes side by side — twice the butterflies per barrier).
+//
+// Loads the channels' frames, transforms them and leaves each thread with the bins it owns: sx / sy [channel][u][re, im].
+// Ends with a barrier: the frame buffer may be overwritten afterwards.
+template <int U, int CC>
+SAT_DEVICE void sat_stft_channel_spectra(const SatStftParams& p, const SatFftLds& L, int item, int f0, float (&sx)[2][U][2], float (&sy)[2][U][2]) {
     const int n = p.n, nb = (n >> 1) + 1;
-    const int item = blockIdx.y, view = blockIdx.z;
-    sat_fft_init_twiddles(L, n);
-    __syncthreads();
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int g = 0; g < SAT_STFT_NG; ++g) {
-        const int f0 = (blockIdx.x * SAT_STFT_NG + g) * p.fb;
-        if (f0 >= p.nframes) break;  // block-uniform
-        sat_stft_load_frames(p, L, item, view, f0);
-        __syncthreads();
-        sat_fft_run(L, n, p.log2n, p.fb);
-        for (int i = threadIdx.x; i < p.fb * nb; i += 256) {
-            const int fi = i / nb, k = i - fi * nb;
-            if (f0 + fi < p.nframes) {
-                float xr, xi, yr, yi;
-                sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
-                const float xm = sqrtf(fmaxf(xr * xr + xi * xi, 1e-8f));
-                const float ym = sqrtf(fmaxf(yr * yr + yi * yi, 1e-8f));
-                const float d = ym - xm;
-                s1 += d * d;
-                s2 += ym * ym;
-                s3 += fabsf(logf(xm) - logf(ym));
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int u = 0; u < U; ++u) sx[c][u][0] = sx[c][u][1] = sy[c][u][0] = sy[c][u][1] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < 2; c0 += CC) {
+        if (c0 < p.C) {  // block-uniform
+            const int nc = (p.C - c0 < CC) ? p.C - c0 : CC;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+                if (cc < nc) sat_stft_load_channel(p, L, item, c0 + cc, f0, cc * p.fb);
+            __syncthreads();
+            sat_fft_run(L, n, p.log2n, nc * p.fb);
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                if (cc < nc) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = threadIdx.x + u * 256;
+                        if (i < p.fb * nb) {
+                            const int fi = i / nb, k = i - fi * nb;
+                            sat_unpack_bins(L, n, cc * p.fb + fi, k, &sx[c0 + cc][u][0], &sx[c0 + cc][u][1], &sy[c0 + cc][u][0], &sy[c0 + cc][u][1]);
+                        }
+                    }
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    s1 = sat_wave_sum(s1);
-    s2 = sat_wave_sum(s2);
-    s3 = sat_wave_sum(s3);
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = s1;
-        red[1][threadIdx.x >> 6] = s2;
-        red[2][threadIdx.x >> 6] = s3;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        // layout [(item, view, q)][tile]: reduced over tiles by sat_rowsum
-        float* o = p.partial + ((((size_t)item * p.NV + view) * 3 + threadIdx.x) * gridDim.x + blockIdx.x);
-        *o = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
     }
 }
 
-// One workgroup handles its SAT_STFT_NG frame groups for ALL views (sum / difference / left / right): the per-view
-// time-domain gradients are overlap-added straight into two per-CHANNEL LDS buffers (weights va, vb of the view), so the
-// global scatter is one atomic per sample and channel instead of one per sample, channel and view.
-template <int NMAX, int OBUF>
+#define SAT_STFT_VB 4  // views per forward workgroup (grid z walks chunks of views)
+template <int NMAX, int U, int CC>
+__global__ void __launch_bounds__(256) sat_stft_fwd_kernel(SatStftParams p) {
+    __shared__ float re[NMAX * CC], im[NMAX * CC], twr[NMAX / 2], twi[NMAX / 2];
+    __shared__ float red[SAT_STFT_VB][3][4];
+    const SatFftLds L{re, im, twr, twi};
+    const int n = p.n, nb = (n >> 1) + 1;
+    const int item = blockIdx.y, v0 = blockIdx.z * SAT_STFT_VB;
+    const int nv = (p.NV - v0 < SAT_STFT_VB) ? p.NV - v0 : SAT_STFT_VB;
+    sat_fft_init_twiddles(L, n);
+    float va[SAT_STFT_VB], vb[SAT_STFT_VB], s[SAT_STFT_VB][3];
+#pragma unroll
+    for (int v = 0; v < SAT_STFT_VB; ++v) {
+        va[v] = (v < nv) ? p.views[(v0 + v) * 2 + 0] : 0.f;
+        vb[v] = (v < nv && p.C > 1) ? p.views[(v0 + v) * 2 + 1] : 0.f;
+        s[v][0] = s[v][1] = s[v][2] = 0.f;
+    }
+    __syncthreads();
+    for (int g = 0; g < SAT_STFT_NG; ++g) {
+        const int f0 = (blockIdx.x * SAT_STFT_NG + g) * p.fb;
+        if (f0 >= p.nframes) break;  // block-uniform
+        float sx[2][U][2], sy[2][U][2];
+        sat_stft_channel_spectra<U, CC>(p, L, item, f0, sx, sy);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = threadIdx.x + u * 256;
+            if (i < p.fb * nb && f0 + i / nb < p.nframes) {
+#pragma unroll
+                for (int v = 0; v < SAT_STFT_VB; ++v) {
+                    if (v < nv) {
+                        const float xr = va[v] * sx[0][u][0] + vb[v] * sx[1][u][0], xi = va[v] * sx[0][u][1] + vb[v] * sx[1][u][1];
+                        const float yr = va[v] * sy[0][u][0] + vb[v] * sy[1][u][0], yi = va[v] * sy[0][u][1] + vb[v] * sy[1][u][1];
+                        const float xm = sqrtf(fmaxf(xr * xr + xi * xi, 1e-8f));
+                        const float ym = sqrtf(fmaxf(yr * yr + yi * yi, 1e-8f));
+                        const float d = ym - xm;
+                        s[v][0] += d * d;
+                        s[v][1] += ym * ym;
+                        s[v][2] += fabsf(logf(xm) - logf(ym));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < SAT_STFT_VB; ++v)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float t = sat_wave_sum(s[v][q]);
+            if ((threadIdx.x & 63) == 0) red[v][q][threadIdx.x >> 6] = t;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * nv) {
+        // layout [(item, view, q)][tile]: reduced over tiles by sat_rowsum
+        const int v = threadIdx.x / 3, q = threadIdx.x - 3 * v;
+        float* o = p.partial + ((((size_t)item * p.NV + v0 + v) * 3 + q) * gridDim.x + blockIdx.x);
+        *o = red[v][q][0] + red[v][q][1] + red[v][q][2] + red[v][q][3];
+    }
+}
+
+// One workgroup handles its SAT_STFT_NG frame groups for ALL views: the views' bin gradients are accumulated per CHANNEL in the
+// frequency domain (dL/dY_c = sum_v w_vc dL/dY_v), the two channels' half-spectra are extended to Hermitian ones and packed as
+// Z = H_a + i H_b, and ONE complex FFT per frame group returns both channels' time-domain gradients (real / imaginary part),
+// which are overlap-added into two per-channel LDS buffers.
+template <int NMAX, int OBUF, int U, int CC>
 __global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
-    __shared__ float re[NMAX], im[NMAX], twr[NMAX / 2], twi[NMAX / 2];
+    __shared__ float re[NMAX * CC], im[NMAX * CC], twr[NMAX / 2], twi[NMAX / 2];
     __shared__ float obuf_a[OBUF], obuf_b[OBUF];
     const SatFftLds L{re, im, twr, twi};
     const int n = p.n, nb = (n >> 1) + 1, log2n = p.log2n;
@@ -290,90 +340,99 @@ __global__ void __launch_bounds__(256) sat_stft_bwd_kernel(SatStftParams p) {
     }
     __syncthreads();
     const int fbase = blockIdx.x * fpb;
-    for (int view = 0; view < p.NV; ++view) {
-        const float c1 = p.coef[(item * p.NV + view) * 3 + 0];
-        const float c2 = p.coef[(item * p.NV + view) * 3 + 1];
-        const float c3 = p.coef[(item * p.NV + view) * 3 + 2];
-        const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
-        for (int g = 0; g < SAT_STFT_NG; ++g) {
-            const int f0 = fbase + g * p.fb;
-            if (f0 >= p.nframes) break;
-            sat_stft_load_frames(p, L, item, view, f0);
-            __syncthreads();
-            sat_fft_run(L, n, log2n, p.fb);
-            // dL/dY per bin, kept in registers while the LDS frame buffer is recycled
-            float gr[5], gi[5];
+    for (int g = 0; g < SAT_STFT_NG; ++g) {
+        const int f0 = fbase + g * p.fb;
+        if (f0 >= p.nframes) break;
+        float sx[2][U][2], sy[2][U][2];
+        sat_stft_channel_spectra<U, CC>(p, L, item, f0, sx, sy);
+        // dL/dY_a, dL/dY_b per owned bin (G = gr + i gi: the derivatives w.r.t. the real and the imaginary part)
+        float ga[U][2], gb[U][2];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                gr[u] = 0.f;
-                gi[u] = 0.f;
+        for (int u = 0; u < U; ++u) ga[u][0] = ga[u][1] = gb[u][0] = gb[u][1] = 0.f;
+        for (int view = 0; view < p.NV; ++view) {
+            const float c1 = p.coef[(item * p.NV + view) * 3 + 0];
+            const float c2 = p.coef[(item * p.NV + view) * 3 + 1];
+            const float c3 = p.coef[(item * p.NV + view) * 3 + 2];
+            const float va = p.views[view * 2 + 0], vb = (p.C > 1) ? p.views[view * 2 + 1] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 const int i = threadIdx.x + u * 256;
-                if (i < p.fb * nb) {
-                    const int fi = i / nb, k = i - fi * nb;
-                    if (f0 + fi < p.nframes) {
-                        float xr, xi, yr, yi;
-                        sat_unpack_bins(L, n, fi, k, &xr, &xi, &yr, &yi);
-                        const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
-                        const float xm = sqrtf(fmaxf(px, 1e-8f)), ym = sqrtf(fmaxf(py, 1e-8f));
-                        const float dl = logf(ym) - logf(xm);
-                        const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
-                        // clamp(min=eps) passes no gradient below eps (auraloss.py:385-387)
-                        if (!p.wrt_x) {
-                            if (py > 1e-8f) {
-                                const float gm = c1 * ((ym - xm) - c2 * ym) + c3 * sg / ym;
-                                gr[u] = gm * yr / ym;
-                                gi[u] = gm * yi / ym;
-                            }
-                        } else if (px > 1e-8f) {
-                            const float gm = -c1 * (ym - xm) - c3 * sg / xm;
-                            gr[u] = gm * xr / xm;
-                            gi[u] = gm * xi / xm;
+                if (i < p.fb * nb && f0 + i / nb < p.nframes) {
+                    const float xr = va * sx[0][u][0] + vb * sx[1][u][0], xi = va * sx[0][u][1] + vb * sx[1][u][1];
+                    const float yr = va * sy[0][u][0] + vb * sy[1][u][0], yi = va * sy[0][u][1] + vb * sy[1][u][1];
+                    const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
+                    const float xm = sqrtf(fmaxf(px, 1e-8f)), ym = sqrtf(fmaxf(py, 1e-8f));
+                    const float dl = logf(ym) - logf(xm);
+                    const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+                    float gr = 0.f, gi = 0.f;
+                    // clamp(min=eps) passes no gradient below eps (auraloss.py:385-387)
+                    if (!p.wrt_x) {
+                        if (py > 1e-8f) {
+                            const float gm = c1 * ((ym - xm) - c2 * ym) + c3 * sg / ym;
+                            gr = gm * yr / ym;
+                            gi = gm * yi / ym;
                         }
+                    } else if (px > 1e-8f) {
+                        const float gm = -c1 * (ym - xm) - c3 * sg / xm;
+                        gr = gm * xr / xm;
+                        gi = gm * xi / xm;
                     }
+                    ga[u][0] += va * gr;
+                    ga[u][1] += va * gi;
+                    gb[u][0] += vb * gr;
+                    gb[u][1] += vb * gi;
                 }
             }
-            __syncthreads();
-            for (int i = threadIdx.x; i < p.fb * n; i += 256) {
-                re[i] = 0.f;
-                im[i] = 0.f;
-            }
-            __syncthreads();
-            // adjoint DFT: Re(sum_k G[k] e^{+2 pi i jk/n}) = Re(DFT(conj G))[j]
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int i = threadIdx.x + u * 256;
-                if (i < p.fb * nb) {
-                    const int fi = i / nb, k = i - fi * nb;
-                    const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
-                    if (k < n) {  // k == n/2 < n always; guard keeps the index in range for n == 1 corner
-                        re[fi * n + kr] = gr[u];
-                        im[fi * n + kr] = -gi[u];
-                    }
-                }
-            }
-            __syncthreads();
-            sat_fft_run(L, n, log2n, p.fb);
-            // overlap-add of this group's fb frames into the per-channel LDS buffers, GATHERED: a thread owns output sample o and
-            // sums the (<= n/hop) frames that cover it in frame order — no LDS atomics, so the result does not depend on wave timing
-            {
-                const int gspan = (p.fb - 1) * p.hop + n;
-                const int obase = g * p.fb * p.hop;
-                for (int orel = threadIdx.x; orel < gspan; orel += 256) {
-                    int f_lo = (orel - n + p.hop) / p.hop;            // first frame with f*hop + n > orel  (ceil((orel - n + 1) / hop))
-                    if (orel - n + 1 <= 0) f_lo = 0;
-                    int f_hi = orel / p.hop;
-                    if (f_hi > p.fb - 1) f_hi = p.fb - 1;
-                    float v = 0.f;
-                    for (int fi = f_lo; fi <= f_hi; ++fi) {
-                        const int j = orel - fi * p.hop;
-                        if (f0 + fi < p.nframes) v += re[fi * n + j] * sat_hann(L, j, n);
-                    }
-                    obuf_a[obase + orel] += va * v;
-                    if (p.C > 1) obuf_b[obase + orel] += vb * v;
-                }
-            }
-            __syncthreads();
         }
+        // adjoint DFT of both channels in one transform: a_j = Re(sum_{k <= n/2} Ga_k e^{+2 pi i jk/n}) = sum_{k < n} Ha_k e^{+2 pi i jk/n}
+        // with Ha_k = Ga_k / 2, Ha_{n-k} = conj(Ga_k) / 2 (0 < k < n/2), Ha_0 = Re Ga_0, Ha_{n/2} = Re Ga_{n/2}; Z = Ha + i Hb;
+        // sum_k Z_k e^{+...jk} = forward DFT of W_m = Z_{(n-m) mod n}: real part a_j, imaginary part b_j.  Every position m is written
+        // by the owner of bin k = m or n - m (zeros for frames past the end), so the buffer needs no clearing.
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = threadIdx.x + u * 256;
+            if (i < p.fb * nb) {
+                const int fi = i / nb, k = i - fi * nb;
+                if (k == 0 || k == (n >> 1)) {
+                    const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
+                    re[fi * n + kr] = ga[u][0];
+                    im[fi * n + kr] = gb[u][0];
+                } else {
+                    const int kr = (int)(sat_brev((unsigned)k) >> (32 - log2n));
+                    const int mr = (int)(sat_brev((unsigned)(n - k)) >> (32 - log2n));
+                    re[fi * n + mr] = 0.5f * (ga[u][0] - gb[u][1]);   // W_{n-k} = Z_k
+                    im[fi * n + mr] = 0.5f * (ga[u][1] + gb[u][0]);
+                    re[fi * n + kr] = 0.5f * (ga[u][0] + gb[u][1]);   // W_k = Z_{n-k}
+                    im[fi * n + kr] = 0.5f * (gb[u][0] - ga[u][1]);
+                }
+            }
+        }
+        __syncthreads();
+        sat_fft_run(L, n, log2n, p.fb);
+        // overlap-add of this group's fb frames into the per-channel LDS buffers, GATHERED: a thread owns output sample o and
+        // sums the (<= n/hop) frames that cover it in frame order — no LDS atomics, so the result does not depend on wave timing
+        {
+            const int gspan = (p.fb - 1) * p.hop + n;
+            const int obase = g * p.fb * p.hop;
+            for (int orel = threadIdx.x; orel < gspan; orel += 256) {
+                int f_lo = (orel - n + p.hop) / p.hop;            // first frame with f*hop + n > orel  (ceil((orel - n + 1) / hop))
+                if (orel - n + 1 <= 0) f_lo = 0;
+                int f_hi = orel / p.hop;
+                if (f_hi > p.fb - 1) f_hi = p.fb - 1;
+                float v = 0.f, w = 0.f;
+                for (int fi = f_lo; fi <= f_hi; ++fi) {
+                    const int j = orel - fi * p.hop;
+                    if (f0 + fi < p.nframes) {
+                        const float h = sat_hann(L, j, n);
+                        v += re[fi * n + j] * h;
+                        w += im[fi * n + j] * h;
+                    }
+                }
+                obuf_a[obase + orel] += v;
+                if (p.C > 1) obuf_b[obase + orel] += w;
+            }
+        }
+        __syncthreads();
     }
     // write-out without atomics: obuf[i] belongs to padded-signal index fbase*hop + i -> sample (.. - n/2), reflected at the ends.
     // Consecutive workgroups overlap by n - hop < their own stride, so a sample is touched by at most two NEIGHBOURING workgroups:
@@ -425,10 +484,11 @@ extern "C" int sat_stft_fwd(const float* x, const float* y, const float* views, 
     if (sat_stft_plan(n_fft, hop, T, &p)) { sat_set_error("sat_stft_fwd: unsupported n_fft/hop/T (n_fft power of two in [8, 2048], hop <= n_fft, T > n_fft/2)"); return 1; }
     p.x = x; p.y = y; p.views = views; p.partial = partial; p.coef = nullptr; p.dy = nullptr;
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = 0;
-    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, NV);
-    if (p.fb * p.n <= SAT_STFT_SMALL) SAT_LAUNCH(sat_stft_fwd_kernel<SAT_STFT_SMALL>, grid, dim3(256), stream, p);
-    else if (p.fb * p.n <= SAT_STFT_MID) SAT_LAUNCH(sat_stft_fwd_kernel<SAT_STFT_MID>, grid, dim3(256), stream, p);
-    else SAT_LAUNCH(sat_stft_fwd_kernel<SAT_FFT_MAX>, grid, dim3(256), stream, p);
+    dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, sat_cdiv(NV, SAT_STFT_VB));
+    const int bins = p.fb * (p.n / 2 + 1);
+    if (p.fb * p.n <= SAT_STFT_SMALL && bins <= 2 * 256) SAT_LAUNCH((sat_stft_fwd_kernel<SAT_STFT_SMALL, 2, 2>), grid, dim3(256), stream, p);
+    else if (p.fb * p.n <= SAT_STFT_MID && bins <= 3 * 256) SAT_LAUNCH((sat_stft_fwd_kernel<SAT_STFT_MID, 3, 2>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_stft_fwd_kernel<SAT_FFT_MAX, 5, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_fwd");
 }
 
@@ -441,9 +501,10 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = wrt_x;
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, 1);       // the views are looped inside the workgroup
     const int olen = (SAT_STFT_NG * p.fb - 1) * p.hop + p.n;
-    if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL>), grid, dim3(256), stream, p);
-    else if (p.fb * p.n <= SAT_STFT_MID && olen <= SAT_STFT_OBUF_MID) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_MID, SAT_STFT_OBUF_MID>), grid, dim3(256), stream, p);
-    else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF>), grid, dim3(256), stream, p);
+    const int bins = p.fb * (p.n / 2 + 1);
+    if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL && bins <= 2 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL, 2, 2>), grid, dim3(256), stream, p);
+    else if (p.fb * p.n <= SAT_STFT_MID && olen <= SAT_STFT_OBUF_MID && bins <= 3 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_MID, SAT_STFT_OBUF_MID, 3, 2>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF, 5, 1>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }
 
