@@ -508,6 +508,11 @@ int sat_quant_fp8_rows(const void* src, long long lds, void* dst, long long ldd,
  * with columns R..Rpad-1 zero (reduction-dim padding of the weight-gradient GEMM). */
 int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int R, int C, int Rpad, int src_f32,
                   int transpose, void* stream);
+/* Both bf16 copies of a weight in one pass (nn.Linear under bf16 autocast, models/transformer.py:263,308,362,481: the forward GEMM reads
+ * W (R, C), the data-gradient GEMM its transpose): dst (R, C) row stride ldd and dst_t (C, Rpad) row stride ldd_t, columns R..Rpad-1
+ * zero.  All three tensors with 16-byte aligned rows, C % 8 == 0 (status 1 otherwise: the caller keeps two sat_cast_bf16 calls). */
+int sat_cast_bf16_dual(const void* src, long long lds, void* dst, long long ldd, void* dst_t, long long ldd_t, int R, int C, int Rpad,
+                       int src_f32, void* stream);
 
 /* fp32 (R, C) -> bf16 (R, 3C): side 0 (activations) [hi | hi | lo], side 1 (weights) [hi | lo | hi], so that
  * A' · B'^T = hi·hi + hi·lo + lo·hi  (|x - hi - lo| <= 2^-17 |x|). */

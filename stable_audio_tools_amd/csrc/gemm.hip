@@ -1424,6 +1424,8 @@ struct SatCastParams {
     short* dst;
     long long lds_, ldd;
     int R, Cc, Rpad, src_f32, transpose;
+    short* dst2;            // transpose launches only: optional second destination (R, ldd2) — the un-transposed cast of the same tile
+    long long ldd2;
 };
 // 8 consecutive source elements -> 8 bf16 (16 bytes); `vec` = the 16-byte path is legal for this launch
 SAT_DEVICE u32x4 sat_cast_load8(const SatCastParams& p, int r, int c, bool vec) {
@@ -1474,6 +1476,8 @@ __global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
         const u32x4 v = sat_cast_load8(p, r0 + rr, c0 + cc, vec);
         uint32_t* t = (uint32_t*)&tile[rr][cc];
         t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        if (p.dst2 && r0 + rr < p.R && c0 + cc < p.Cc)      // (dual launches are vec launches with C % 8 == 0: checked on the host)
+            *(u32x4*)(p.dst2 + (long long)(r0 + rr) * p.ldd2 + c0 + cc) = v;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 8; i += 256) {
@@ -1499,7 +1503,7 @@ extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long lon
     // 16-byte path: every row start 16-byte aligned on both sides
     const long long salign = src_f32 ? 4 : 8;
     const bool vec = ((unsigned long long)src % 16 == 0) && ((unsigned long long)dst % 16 == 0) && (lds % salign == 0) && (ldd % 8 == 0);
-    SatCastParams p{src, (short*)dst, lds, ldd, R, C, Rpad, src_f32, (transpose ? 1 : 0) | (vec ? 2 : 0)};
+    SatCastParams p{src, (short*)dst, lds, ldd, R, C, Rpad, src_f32, (transpose ? 1 : 0) | (vec ? 2 : 0), nullptr, 0};
     if (transpose) {
         SAT_LAUNCH(sat_cast_kernel, dim3(sat_cdiv(C, 64), sat_cdiv(Rpad, 64)), dim3(256), stream, p);
     } else {
@@ -1507,6 +1511,21 @@ extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long lon
         SAT_LAUNCH(sat_cast_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 8192 ? sat_cdivll(total, 256) : 8192)), dim3(256), stream, p);
     }
     return sat_check_launch("sat_cast_bf16");
+}
+
+// One pass over a weight for BOTH bf16 copies a training step needs (round 6): dst (R, ldd) = cast(src) for the forward GEMM, dst_t
+// (C, ldd_t) = its transpose (columns R..Rpad-1 zero) for the data-gradient GEMM — the source tile is read once.
+extern "C" int sat_cast_bf16_dual(const void* src, long long lds, void* dst, long long ldd, void* dst_t, long long ldd_t, int R, int C,
+                                  int Rpad, int src_f32, void* stream) {
+    if (R <= 0 || C <= 0 || !src || !dst || !dst_t) { sat_set_error("sat_cast_bf16_dual: bad arguments"); return 1; }
+    if (Rpad < R) Rpad = R;
+    const long long salign = src_f32 ? 4 : 8;
+    const bool vec = ((unsigned long long)src % 16 == 0) && ((unsigned long long)dst % 16 == 0) && ((unsigned long long)dst_t % 16 == 0) &&
+                     (lds % salign == 0) && (ldd % 8 == 0) && (ldd_t % 8 == 0) && (C % 8 == 0);
+    if (!vec) { sat_set_error("sat_cast_bf16_dual: needs 16-byte aligned rows on all three tensors and C % 8 == 0"); return 1; }
+    SatCastParams p{src, (short*)dst_t, lds, ldd_t, R, C, Rpad, src_f32, 3, (short*)dst, ldd};
+    SAT_LAUNCH(sat_cast_kernel, dim3(sat_cdiv(C, 64), sat_cdiv(Rpad, 64)), dim3(256), stream, p);
+    return sat_check_launch("sat_cast_bf16_dual");
 }
 
 // fp32 (R, C) -> bf16 (R, 3C) split planes along K for the fp32-accurate GEMM: side 0 (activations / A) = [hi | hi | lo],

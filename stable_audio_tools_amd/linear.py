@@ -62,6 +62,11 @@ class _WeightCache:
             self.items[name] = hit
         return hit[1]
 
+    def put(self, w, name, value):
+        """Store an entry made together with another one (the transposed weight copy that rides in the forward's cast launch)."""
+        if _caches.trackable(w):
+            self.items[name] = ((w.data_ptr(), _caches.version_of(w), w.dtype, w.device, _caches.epoch_of(w)), value)
+
 
 # activations quantised per ROW in one pass (round 4); False (set by an A/B script): round 3's per-tensor scale (absmax pass + quant pass)
 fp8_row_scales = True
@@ -115,16 +120,48 @@ def _fp8_operands(ops, x2, w, cache):
     return a, b, alpha, None, ca
 
 
-def _operands(ops, x2, w, cache, lowp):
-    """GEMM operands (A, B) for y = x2 · w^T in the chosen precision mode."""
+def _lowp_weight_pair(ops, w, cache):
+    """The bf16 weight of a training forward; its transposed copy for the data-gradient GEMM (LinearFn.backward's "bf16_t" entry) comes
+    out of the same launch when the shape allows (round 6: one pass over the fp32 master weight per optimizer step instead of two)."""
+    if w.dtype == torch.float32 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+        pair = ops.cast_bf16_dual(w.detach())
+        if pair is not None:
+            cache.put(w, "bf16_t", pair[1])
+            return pair[0]
+    return _pad_rows8(_pad8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach())))
+
+
+def _operands(ops, x2, w, cache, lowp, want_t=False):
+    """GEMM operands (A, B) for y = x2 · w^T in the chosen precision mode.  want_t: the caller's backward will ask for the transposed weight."""
     if lowp:
         a = x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2)
         a = _pad8(a)
-        b = cache.get(w, "bf16", lambda: _pad_rows8(_pad8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
+        if want_t and ops.train_fused_nodes:
+            b = cache.get(w, "bf16", lambda: _lowp_weight_pair(ops, w, cache))
+        else:
+            b = cache.get(w, "bf16", lambda: _pad_rows8(_pad8(w.detach() if w.dtype == torch.bfloat16 else ops.cast_bf16(w.detach()))))
         return a, b
     a = ops.split_bf16x3(_pad8(x2.float()).contiguous(), 0)
     b = cache.get(w, "x3", lambda: ops.split_bf16x3(_pad_rows8(_pad8(w.detach().float())).contiguous(), 1))
     return a, b
+
+
+_bias_operands = {}
+
+
+def _bias_operand(device, k, k8, mp, m):
+    """The (k8 + 8, Mp) transposed-activation operand of a weight-gradient GEMM that also yields the bias gradient (row k8 = ones over
+    the m tokens): rows k .. k8 + 7 never change, so the buffer is kept per shape and only rows [:k] are rewritten by each call's cast
+    (two fills per call before).  Reuse is stream-ordered: the GEMM that read the previous contents is enqueued before the next cast."""
+    key = (device, k, mp, m)
+    buf = _bias_operands.get(key)
+    if buf is None:
+        if len(_bias_operands) >= 16:
+            _bias_operands.clear()
+        buf = torch.zeros(k8 + 8, mp, dtype=torch.bfloat16, device=device)
+        buf[k8, :m] = 1.0
+        _bias_operands[key] = buf
+    return buf
 
 
 def _wgrad_splits(n, k, red):
@@ -149,7 +186,7 @@ class LinearFn(torch.autograd.Function):
         if fp8:
             a, b, alpha, ralpha, calpha = _fp8_operands(ops, x2, weight, cache)
         else:
-            a, b = _operands(ops, x2, weight, cache, lowp)
+            a, b = _operands(ops, x2, weight, cache, lowp, want_t=ctx.needs_input_grad[0])
         bias32 = None
         if bias is not None:
             bias32 = cache.get(bias, "bias32", lambda: torch.nn.functional.pad(bias.detach().float(), (0, (-n) % 8)).contiguous())
@@ -220,11 +257,15 @@ class LinearFn(torch.autograd.Function):
                 # the same GEMM: one extra "activation" row of ones makes column K of the result the column sum of dz.
                 dzt = _pad_rows8(ops.cast_bf16(dzb, transpose=True, row_pad=8))          # (N8, Mp)
                 k8 = (k + 7) // 8 * 8
-                xt = torch.empty(k8 + (8 if has_bias else 0), dzt.shape[1], dtype=torch.bfloat16, device=dzt.device)
-                ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
-                xt[k:].zero_()
-                if has_bias:
-                    xt[k8, :m] = 1.0
+                if has_bias and ops.train_fused_nodes:
+                    xt = _bias_operand(dzt.device, k, k8, dzt.shape[1], m)     # rows k.. (zero padding, the row of ones) already in place
+                    ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
+                else:
+                    xt = torch.empty(k8 + (8 if has_bias else 0), dzt.shape[1], dtype=torch.bfloat16, device=dzt.device)
+                    ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
+                    xt[k:].zero_()
+                    if has_bias:
+                        xt[k8, :m] = 1.0
                 dwb = ops.gemm_bf16(dzt, xt, out_dtype=torch.float32, splits=_wgrad_splits(n, k, m))
                 if ctx.needs_input_grad[1]:
                     dw = dwb[:n, :k]

@@ -977,8 +977,9 @@ class SatOps:
             out += ({"q": qp, "k": kp, "v": vp},)
         return out[0] if len(out) == 1 else out
 
-    def attention_bwd(self, planes, o, do, lse, scale, hkv, nk):
-        """Gradients (dq (B,H,Nq,64), dk, dv (B,Hkv,Nk,64)) in the dtype of `o`; `planes` from attention(return_planes=True)."""
+    def attention_bwd(self, planes, o, do, lse, scale, hkv, nk, out=None):
+        """Gradients (dq (B,H,Nq,64), dk, dv (B,Hkv,Nk,64)) in the dtype of `o`; `planes` from attention(return_planes=True).
+        out: optional (dq, dk, dv) contiguous tensors of those shapes to write into (e.g. slices of one buffer)."""
         dt = self._dt(o, do)
         b, nq, hd = o.shape
         h = hd // 64
@@ -989,9 +990,15 @@ class SatOps:
         qp, kp, vp = planes["q"], planes["k"], planes["v"]
         ptrs = [qp["rm"], kp["rm"], vp["rm"], kp["tr"], qp["tr"], gp["rm"], gp["tr"], (None, None)]
         arr = (ctypes.c_void_p * 16)(*[(x.data_ptr() if x is not None else None) for pair in ptrs for x in pair])
-        dq = torch.empty(b, h, nq, 64, dtype=o.dtype, device=o.device)
-        dk = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
-        dv = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
+        if out is not None:
+            dq, dk, dv = out
+            if (tuple(dq.shape), tuple(dk.shape), tuple(dv.shape)) != ((b, h, nq, 64), (b, hkv, nk, 64), (b, hkv, nk, 64)) \
+                    or not (dq.is_contiguous() and dk.is_contiguous() and dv.is_contiguous()) or {dq.dtype, dk.dtype, dv.dtype} != {o.dtype}:
+                raise ValueError("attention_bwd: out must be contiguous (B,H,Nq,64) / (B,Hkv,Nk,64) x 2 tensors in the dtype of o")
+        else:
+            dq = torch.empty(b, h, nq, 64, dtype=o.dtype, device=o.device)
+            dk = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
+            dv = torch.empty(b, hkv, nk, 64, dtype=o.dtype, device=o.device)
         if self.cross_ok(h, hkv, nk, 64, dt):
             nbytes = int(self.lib.sat_attention_cross_bwd_ws(b, h, hkv, nq, nk))
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=o.device)      # fp32 dK / dV slabs of the query ranges
@@ -1005,6 +1012,10 @@ class SatOps:
     # the short-key attention kernels (csrc/attention_cross.h) serve bf16 planes with Nk <= 256; False sends every shape to the general
     # flash-style kernels (A/B runs: bench.py --ops-set cross_kernels=0, and the kernel tests' second implementation)
     cross_kernels = True
+    # DiT training glue (round 6): rotary + head split + attention core as ONE autograd node (transformer._SelfAttnFn / _CrossAttnFn), both
+    # bf16 copies of a weight from one cast launch (sat_cast_bf16_dual), the bias row of the weight-gradient GEMM's operand kept in a cached
+    # buffer instead of two fills per call.  False: the separate nodes / launches of round 5 (A/B: bench.py --ops-set train_fused_nodes=0)
+    train_fused_nodes = True
     # bf16 self-attention forward: None = the library picks 32 or 64 queries per wave by grid size (sat_attention_fwd), False / True force
     # the 32- / 64-query kernel (A/B runs: bench.py --ops-set attn_q64=1; the kernel tests run both)
     attn_q64 = None
@@ -1426,6 +1437,22 @@ class SatOps:
         self._chk(self.lib.sat_cast_bf16(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), r, c, rp, int(dt == 0), int(transpose),
                                          self._stream(src)))
         return dst
+
+    def cast_bf16_dual(self, src, row_pad=8):
+        """src (R, C) fp32|bf16 -> (bf16 (R, C), bf16 transposed (C, Rp)) in one pass (sat_cast_bf16_dual), or None when the shape is outside
+        its 16-byte path (C % 8, alignment): the caller then casts twice."""
+        dt = self._dt(src)
+        if src.dim() != 2 or src.stride(1) != 1:
+            raise ValueError("cast_bf16_dual takes a 2-D tensor with a contiguous last dim")
+        r, c = src.shape
+        rp = (r + row_pad - 1) // row_pad * row_pad
+        if c % 8 or rp % 8 or src.stride(0) % (4 if dt == 0 else 8) or src.data_ptr() % 16:
+            return None
+        dst = torch.empty(r, c, dtype=torch.bfloat16, device=src.device)
+        dst_t = torch.empty(c, rp, dtype=torch.bfloat16, device=src.device)
+        self._chk(self.lib.sat_cast_bf16_dual(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), _ptr(dst_t), dst_t.stride(0), r, c, rp,
+                                              int(dt == 0), self._stream(src)))
+        return dst, dst_t
 
     def split_bf16x3(self, src, side):
         """fp32 (R, C) -> bf16 (R, 3C): side 0 (activations) [hi|hi|lo], side 1 (weights) [hi|lo|hi]."""

@@ -181,6 +181,79 @@ class _AttentionCoreFn(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+class _SelfAttnFn(torch.autograd.Function):
+    """The training path of a fused-projection self-attention as ONE autograd node (round 6): in-place rotary on the q / k thirds of
+    the (B, N, 3*H*dh) projection, head split, attention core (transformer.py:155-174, :389-441 of the reference).  As separate nodes
+    (_RopeQKFn, three slices, three permutes, _AttentionCoreFn) autograd rebuilt the projection's gradient from dq / dk / dv with three
+    zero-filled (B, N, 3*H*dh) tensors, three strided copies into their thirds, two adds and a clone for the in-place rotary — nine
+    activation-sized launches per layer; here dq / dk / dv leave the backward kernels as one (3, B, H, N, dh) buffer that ONE strided
+    copy turns into the projection's layout, and the inverse rotary runs in place on that copy.
+    `qkv` is rotated in place: it is the output of the projection GEMM, which nothing else reads (autograd raises if something saved it)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cs, heads, dh, scale):
+        ops = _ops()
+        b, n, _ = qkv.shape
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        if cs is not None:
+            ops.rope_apply_(qkv[..., 0:2 * heads * dh].unflatten(-1, (2 * heads, dh)), cs)     # q and k heads in one launch
+        q5 = qkv.view(b, n, 3, heads, dh)
+        q, k, v = (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        if ctx.needs_input_grad[0]:
+            o, lse, planes = ops.attention(q, k, v, scale, return_planes=True)
+            ctx.ops, ctx.scale, ctx.planes, ctx.meta = ops, scale, planes, (b, n, heads, dh)
+            ctx.save_for_backward(o, lse, cs)
+            return o
+        return ops.attention(q, k, v, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        o, lse, cs = ctx.saved_tensors
+        b, n, heads, dh = ctx.meta
+        buf = torch.empty(3, b, heads, n, dh, dtype=o.dtype, device=o.device)
+        ctx.ops.attention_bwd(ctx.planes, o, g.contiguous(), lse, ctx.scale, heads, n, out=(buf[0], buf[1], buf[2]))
+        dqkv = torch.empty(b, n, 3, heads, dh, dtype=o.dtype, device=o.device)
+        dqkv.copy_(buf.permute(1, 3, 0, 2, 4))
+        dqkv = dqkv.view(b, n, 3 * heads * dh)
+        if cs is not None:
+            ctx.ops.rope_apply_(dqkv[..., 0:2 * heads * dh].unflatten(-1, (2 * heads, dh)), cs, transpose=True)
+        return dqkv, None, None, None, None
+
+
+class _CrossAttnFn(torch.autograd.Function):
+    """The training path of the cross-attention core as one autograd node: q (B, N, H*dh) and the fused key / value projection
+    kv (B, M, 2*Hkv*dh) in, merged heads out; the backward assembles dkv with one strided copy (see _SelfAttnFn)."""
+
+    @staticmethod
+    def forward(ctx, q2, kv, heads, kv_heads, dh, scale):
+        ops = _ops()
+        b, n, _ = q2.shape
+        m = kv.shape[1]
+        q = q2.view(b, n, heads, dh).permute(0, 2, 1, 3)
+        kv5 = kv.contiguous().view(b, m, 2, kv_heads, dh)
+        k, v = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
+        if any(ctx.needs_input_grad[:2]):
+            o, lse, planes = ops.attention(q, k, v, scale, return_planes=True)
+            ctx.ops, ctx.scale, ctx.planes, ctx.meta = ops, scale, planes, (b, n, m, heads, kv_heads, dh)
+            ctx.save_for_backward(o, lse)
+            return o
+        return ops.attention(q, k, v, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        o, lse = ctx.saved_tensors
+        b, n, m, heads, kv_heads, dh = ctx.meta
+        buf = torch.empty(2, b, kv_heads, m, dh, dtype=o.dtype, device=o.device)
+        dq = torch.empty(b, heads, n, dh, dtype=o.dtype, device=o.device)
+        ctx.ops.attention_bwd(ctx.planes, o, g.contiguous(), lse, ctx.scale, kv_heads, m, out=(dq, buf[0], buf[1]))
+        dq2 = torch.empty(b, n, heads, dh, dtype=o.dtype, device=o.device)
+        dq2.copy_(dq.permute(0, 2, 1, 3))
+        dkv = torch.empty(b, m, 2, kv_heads, dh, dtype=o.dtype, device=o.device)
+        dkv.copy_(buf.permute(1, 3, 0, 2, 4))
+        return dq2.view(b, n, heads * dh), dkv.view(b, m, 2 * kv_heads * dh), None, None, None, None
+
+
 class _SwiGLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xin):
@@ -332,6 +405,13 @@ class Attention(nn.Module):
                 cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
                 pl = self._heads(ops, self.to_qkv, x2, cs, h, b, n, 0, 3, "self")
                 out = ops.attention_planes(pl["q"], pl["k"], pl["v_tr"], n, n, self.scale)
+            return self.to_out(out, res=res)
+        if _ops().train_fused_nodes and dh == 64:
+            if cross:
+                out = _CrossAttnFn.apply(self.to_q(x), self.to_kv(kv_input), h, kv_h, dh, self.scale)
+            else:
+                cs = rotary_pos_emb[0] if rotary_pos_emb is not None else None
+                out = _SelfAttnFn.apply(self.to_qkv(x), cs, h, dh, self.scale)     # (B, N, H*dh): heads already merged
             return self.to_out(out, res=res)
         if cross:
             q = self.to_q(x).view(b, n, h, dh).permute(0, 2, 1, 3)

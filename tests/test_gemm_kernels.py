@@ -87,6 +87,13 @@ def _prep_case(ops, dev):
     assert t.shape == (136, 128) and rel_err(t[:, :70].float(), a.t().bfloat16().float()) == 0.0 and float(t[:, 70:].abs().max()) == 0.0
     ab = a.bfloat16()
     assert rel_err(ops.cast_bf16(ab, transpose=True).float(), ab.t().float()) == 0.0
+    # both copies of a weight in one pass (sat_cast_bf16_dual): bit-equal to the two separate casts; shapes outside its 16-byte path decline
+    w = torch.randn(200, 136).to(dev)
+    plain, tr = ops.cast_bf16_dual(w)
+    assert torch.equal(plain, ops.cast_bf16(w)) and torch.equal(tr, ops.cast_bf16(w, transpose=True, row_pad=8))
+    plain, tr = ops.cast_bf16_dual(w[:70])                                   # R = 70: two zero columns pad the transposed copy to 72
+    assert tr.shape == (136, 72) and torch.equal(plain, ops.cast_bf16(w[:70])) and torch.equal(tr, ops.cast_bf16(w[:70], transpose=True, row_pad=8))
+    assert ops.cast_bf16_dual(torch.randn(16, 20).to(dev)) is None
     sa, sb = ops.split_bf16x3(a, 0).float(), ops.split_bf16x3(a, 1).float()
     c = a.shape[1]
     assert rel_err(sa[:, :c] + sa[:, 2 * c:], a) < 1e-5 and torch.equal(sa[:, :c], sa[:, c:2 * c])
