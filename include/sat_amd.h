@@ -389,7 +389,7 @@ int sat_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, 
                           long long mod_stride, void* q, float* qscale, int rows, int D, int rows_per_batch, float eps,
                           int dtype, void* stream);
 /* dx plus partial column sums part[3][sat_layernorm_bwd_nblocks()][D] = {d_gamma, d_scale, d_shift} (slabs of one
- * batch item are contiguous; reduce with sat_reduce_splits). */
+ * batch item are contiguous; reduce with sat_reduce_splits).  Without modulation (scale == NULL) only part[0] is defined. */
 int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch);
 int sat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale,
                       long long mod_stride, const float* mean, const float* rstd, void* dx, float* part, int rows, int D,
@@ -511,6 +511,11 @@ int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int 
 /* Both bf16 copies of a weight in one pass (nn.Linear under bf16 autocast, models/transformer.py:263,308,362,481: the forward GEMM reads
  * W (R, C), the data-gradient GEMM its transpose): dst (R, C) row stride ldd and dst_t (C, Rpad) row stride ldd_t, columns R..Rpad-1
  * zero.  All three tensors with 16-byte aligned rows, C % 8 == 0 (status 1 otherwise: the caller keeps two sat_cast_bf16 calls). */
+/* Two transposing casts in one launch — the operands of a weight-gradient GEMM (autograd of nn.Linear, models/transformer.py:263,308,362,481):
+ * dst_a (Ca, Rpad_a) = src_a (Ra, Ca)^T and dst_b (Cb, Rpad_b) = src_b (Rb, Cb)^T, each exactly as sat_cast_bf16(transpose = 1). */
+int sat_cast_bf16_tpair(const void* src_a, long long lds_a, void* dst_a, long long ldd_a, int Ra, int Ca, int Rpad_a, int a_f32,
+                        const void* src_b, long long lds_b, void* dst_b, long long ldd_b, int Rb, int Cb, int Rpad_b, int b_f32,
+                        void* stream);
 int sat_cast_bf16_dual(const void* src, long long lds, void* dst, long long ldd, void* dst_t, long long ldd_t, int R, int C, int Rpad,
                        int src_f32, void* stream);
 

@@ -119,6 +119,7 @@ SIGNATURES = {
     "sat_absmax_scale_blocks": (_I, [_I, _I]),
     "sat_splitk_epilogue": (_I, [_P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _P]),
     "sat_cast_bf16": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "sat_cast_bf16_tpair": (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "sat_cast_bf16_dual": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "sat_split_bf16x3": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
     # dit_ops.hip

@@ -363,6 +363,83 @@ __global__ void __launch_bounds__(256) sat_layernorm_bwd_param_kernel(SatLnParam
     p.part[((size_t)2 * nby + by) * p.D + col] = a2;
 }
 
+// Two adjacent columns per thread (one 4-byte load of a bf16 pair / one 8-byte load of an fp32 pair), four rows in flight per step — the
+// one-column kernel above is a chain of 64 dependent 2-byte loads per thread (22.7 us per launch at 4100 x 1536 bf16: 1.1 TB/s, round 6
+// profiles/r06_dit_train_b4_kernel_stats.csv).  Without adaLN modulation only part[0] is produced (the caller reads nothing else).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct SatLd2;
+template <> struct SatLd2<float> {
+    static SAT_DEVICE void ld(const void* p, long long i, float* o) { const f32x2 v = *reinterpret_cast<const f32x2*>((const float*)p + i); o[0] = v[0]; o[1] = v[1]; }
+};
+template <> struct SatLd2<short> {
+    static SAT_DEVICE void ld(const void* p, long long i, float* o) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>((const short*)p + i);
+        o[0] = __builtin_bit_cast(float, v << 16);
+        o[1] = __builtin_bit_cast(float, v & 0xffff0000u);
+    }
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sat_layernorm_bwd_param2_kernel(SatLnParams p) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int b = blockIdx.z;
+    const int r0 = b * p.rows_per_batch + blockIdx.y * SAT_LN_ROWS_PER_BLOCK;
+    int r1 = r0 + SAT_LN_ROWS_PER_BLOCK;
+    const int rend = (b + 1) * p.rows_per_batch;
+    if (r1 > rend) r1 = rend;
+    if (col >= p.D) return;                        // D is even: col + 1 < D
+    const bool mod = p.scale != nullptr;
+    float gam[2], bet[2], sc[2], a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        gam[e] = p.gamma[col + e];
+        bet[e] = p.beta ? p.beta[col + e] : 0.0f;
+        sc[e] = mod ? 1.0f + SatIO<T>::ld(p.scale, (long long)b * p.mod_stride + col + e) : 1.0f;
+    }
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        float dy[4][2], xv[4][2], mu[4], rs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            SatLd2<T>::ld(p.dy, (long long)(r + u) * p.D + col, dy[u]);
+            SatLd2<T>::ld(p.x, (long long)(r + u) * p.D + col, xv[u]);
+            mu[u] = p.mean[r + u];
+            rs[u] = p.rstd[r + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float xh = (xv[u][e] - mu[u]) * rs[u];
+                a0[e] += dy[u][e] * sc[e] * xh;
+                if (mod) {
+                    a1[e] += dy[u][e] * (xh * gam[e] + bet[e]);
+                    a2[e] += dy[u][e];
+                }
+            }
+    }
+    for (; r < r1; ++r) {
+        float dy[2], xv[2];
+        SatLd2<T>::ld(p.dy, (long long)r * p.D + col, dy);
+        SatLd2<T>::ld(p.x, (long long)r * p.D + col, xv);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float xh = (xv[e] - p.mean[r]) * p.rstd[r];
+            a0[e] += dy[e] * sc[e] * xh;
+            if (mod) {
+                a1[e] += dy[e] * (xh * gam[e] + bet[e]);
+                a2[e] += dy[e];
+            }
+        }
+    }
+    const int nby = gridDim.y * gridDim.z;
+    const int by = b * gridDim.y + blockIdx.y;
+    *reinterpret_cast<f32x2*>(p.part + ((size_t)0 * nby + by) * p.D + col) = f32x2{a0[0], a0[1]};
+    if (mod) {
+        *reinterpret_cast<f32x2*>(p.part + ((size_t)1 * nby + by) * p.D + col) = f32x2{a1[0], a1[1]};
+        *reinterpret_cast<f32x2*>(p.part + ((size_t)2 * nby + by) * p.D + col) = f32x2{a2[0], a2[1]};
+    }
+}
+
 static int sat_ln_check(int rows, int D, int rows_per_batch, int dtype, const char* who) {
     if (rows <= 0 || D <= 0 || rows_per_batch <= 0 || rows % rows_per_batch != 0) { sat_set_error(who); return 1; }
     if (dtype != 0 && dtype != 1) { sat_set_error("layernorm: dtype must be 0 (f32) or 1 (bf16)"); return 1; }
@@ -420,14 +497,19 @@ extern "C" int sat_layernorm_bwd(const void* dy, const void* x, const float* gam
     dim3 g1(sat_cdiv(rows, 4));
     dim3 g2(sat_cdiv(D, 256), sat_cdiv(rows_per_batch, SAT_LN_ROWS_PER_BLOCK), rows / rows_per_batch);
     const bool vec = sat_ln_vec_ok(p, dtype == 0 ? 4 : 2);
+    // two columns per thread: D even and 8-byte aligned rows / partial planes
+    const bool pair = (D % 2 == 0) && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)part) % 8 == 0);
+    dim3 g2p(sat_cdiv(D, 512), g2.y, g2.z);
     if (dtype == 0) {
         if (vec) SAT_LAUNCH(sat_layernorm_bwd_dx_vec_kernel<float>, g1, dim3(256), stream, p);
         else SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<float>, g1, dim3(256), stream, p);
-        SAT_LAUNCH(sat_layernorm_bwd_param_kernel<float>, g2, dim3(256), stream, p);
+        if (pair) SAT_LAUNCH(sat_layernorm_bwd_param2_kernel<float>, g2p, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_bwd_param_kernel<float>, g2, dim3(256), stream, p);
     } else {
         if (vec) SAT_LAUNCH(sat_layernorm_bwd_dx_vec_kernel<short>, g1, dim3(256), stream, p);
         else SAT_LAUNCH(sat_layernorm_bwd_dx_kernel<short>, g1, dim3(256), stream, p);
-        SAT_LAUNCH(sat_layernorm_bwd_param_kernel<short>, g2, dim3(256), stream, p);
+        if (pair) SAT_LAUNCH(sat_layernorm_bwd_param2_kernel<short>, g2p, dim3(256), stream, p);
+        else SAT_LAUNCH(sat_layernorm_bwd_param_kernel<short>, g2, dim3(256), stream, p);
     }
     return sat_check_launch("sat_layernorm_bwd");
 }

@@ -1450,27 +1450,11 @@ SAT_DEVICE u32x4 sat_cast_load8(const SatCastParams& p, int r, int c, bool vec) 
     }
     return o;
 }
-__global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
-    // 16-byte accesses need 16-byte aligned rows on both sides (checked on the host: vec flag rides in `transpose` bit 1)
+// transpose of one 64 x 64 tile (tile coordinates bx = column tile, by = row tile) through LDS; rows of the LDS tile are 66 shorts apart
+// (a column read walks 33 banks per row)
+SAT_DEVICE void sat_cast_transpose_tile(const SatCastParams& p, short (*tile)[66], int bx, int by) {
     const bool vec = (p.transpose & 2) != 0;
-    if (!(p.transpose & 1)) {
-        const int cchunks = (p.Cc + 7) >> 3;
-        const long long total = (long long)p.R * cchunks;
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-            const int r = (int)(i / cchunks), c = (int)(i % cchunks) * 8;
-            const u32x4 v = sat_cast_load8(p, r, c, vec);
-            short* d = p.dst + (long long)r * p.ldd + c;
-            if (vec && c + 8 <= p.Cc) {
-                *(u32x4*)d = v;
-            } else {
-                for (int e = 0; e < 8 && c + e < p.Cc; ++e) d[e] = (short)(v[e >> 1] >> (16 * (e & 1)));
-            }
-        }
-        return;
-    }
-    // transpose: 64 x 64 tile through LDS; rows of the tile are 66 shorts apart (a column read walks 33 banks per row)
-    __shared__ short tile[64][66];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int r0 = by * 64, c0 = bx * 64;
     for (int i = threadIdx.x; i < 64 * 8; i += 256) {
         const int rr = i >> 3, cc = (i & 7) * 8;
         const u32x4 v = sat_cast_load8(p, r0 + rr, c0 + cc, vec);
@@ -1495,6 +1479,36 @@ __global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
         }
     }
 }
+__global__ void __launch_bounds__(256) sat_cast_kernel(SatCastParams p) {
+    // 16-byte accesses need 16-byte aligned rows on both sides (checked on the host: vec flag rides in `transpose` bit 1)
+    const bool vec = (p.transpose & 2) != 0;
+    if (!(p.transpose & 1)) {
+        const int cchunks = (p.Cc + 7) >> 3;
+        const long long total = (long long)p.R * cchunks;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int r = (int)(i / cchunks), c = (int)(i % cchunks) * 8;
+            const u32x4 v = sat_cast_load8(p, r, c, vec);
+            short* d = p.dst + (long long)r * p.ldd + c;
+            if (vec && c + 8 <= p.Cc) {
+                *(u32x4*)d = v;
+            } else {
+                for (int e = 0; e < 8 && c + e < p.Cc; ++e) d[e] = (short)(v[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        return;
+    }
+    __shared__ short tile[64][66];
+    sat_cast_transpose_tile(p, tile, blockIdx.x, blockIdx.y);
+}
+// two independent transposing casts in ONE launch (blockIdx.z picks the tensor; tiles outside a tensor's range exit): the two operands of a
+// weight-gradient GEMM, dz^T and x^T, are prepared together (round 6)
+struct SatCastPairParams { SatCastParams a, b; };
+__global__ void __launch_bounds__(256) sat_cast_pair_kernel(SatCastPairParams pp) {
+    __shared__ short tile[64][66];
+    const SatCastParams& p = blockIdx.z ? pp.b : pp.a;
+    if ((int)blockIdx.x * 64 >= p.Cc || (int)blockIdx.y * 64 >= p.Rpad) return;      // block-uniform
+    sat_cast_transpose_tile(p, tile, blockIdx.x, blockIdx.y);
+}
 // src (R, C) fp32|bf16 row stride lds -> dst bf16: (R, ldd) copy/cast, or transposed (C, ldd) with rows R..Rpad-1 zero.
 extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long long ldd, int R, int C, int Rpad, int src_f32,
                              int transpose, void* stream) {
@@ -1511,6 +1525,22 @@ extern "C" int sat_cast_bf16(const void* src, long long lds, void* dst, long lon
         SAT_LAUNCH(sat_cast_kernel, dim3((unsigned)(sat_cdivll(total, 256) < 8192 ? sat_cdivll(total, 256) : 8192)), dim3(256), stream, p);
     }
     return sat_check_launch("sat_cast_bf16");
+}
+
+// dst_a (Ca, Rpad_a) <- src_a (Ra, Ca)^T and dst_b (Cb, Rpad_b) <- src_b (Rb, Cb)^T in one launch; each as sat_cast_bf16(transpose = 1).
+extern "C" int sat_cast_bf16_tpair(const void* src_a, long long lds_a, void* dst_a, long long ldd_a, int Ra, int Ca, int Rpad_a, int a_f32,
+                                   const void* src_b, long long lds_b, void* dst_b, long long ldd_b, int Rb, int Cb, int Rpad_b, int b_f32,
+                                   void* stream) {
+    if (Ra <= 0 || Ca <= 0 || Rb <= 0 || Cb <= 0 || !src_a || !dst_a || !src_b || !dst_b) { sat_set_error("sat_cast_bf16_tpair: bad arguments"); return 1; }
+    if (Rpad_a < Ra) Rpad_a = Ra;
+    if (Rpad_b < Rb) Rpad_b = Rb;
+    const bool vec_a = ((unsigned long long)src_a % 16 == 0) && ((unsigned long long)dst_a % 16 == 0) && (lds_a % (a_f32 ? 4 : 8) == 0) && (ldd_a % 8 == 0);
+    const bool vec_b = ((unsigned long long)src_b % 16 == 0) && ((unsigned long long)dst_b % 16 == 0) && (lds_b % (b_f32 ? 4 : 8) == 0) && (ldd_b % 8 == 0);
+    SatCastPairParams pp{SatCastParams{src_a, (short*)dst_a, lds_a, ldd_a, Ra, Ca, Rpad_a, a_f32, 1 | (vec_a ? 2 : 0), nullptr, 0},
+                         SatCastParams{src_b, (short*)dst_b, lds_b, ldd_b, Rb, Cb, Rpad_b, b_f32, 1 | (vec_b ? 2 : 0), nullptr, 0}};
+    const int gx = sat_cdiv(Ca > Cb ? Ca : Cb, 64), gy = sat_cdiv(Rpad_a > Rpad_b ? Rpad_a : Rpad_b, 64);
+    SAT_LAUNCH(sat_cast_pair_kernel, dim3(gx, gy, 2), dim3(256), stream, pp);
+    return sat_check_launch("sat_cast_bf16_tpair");
 }
 
 // One pass over a weight for BOTH bf16 copies a training step needs (round 6): dst (R, ldd) = cast(src) for the forward GEMM, dst_t

@@ -255,12 +255,25 @@ class LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 # dW (N, K) = dz^T (N, Mp) · x^T (K, Mp)^T, reduction over the zero-padded token dim.  The bias gradient rides in
                 # the same GEMM: one extra "activation" row of ones makes column K of the result the column sum of dz.
-                dzt = _pad_rows8(ops.cast_bf16(dzb, transpose=True, row_pad=8))          # (N8, Mp)
                 k8 = (k + 7) // 8 * 8
-                if has_bias and ops.train_fused_nodes:
-                    xt = _bias_operand(dzt.device, k, k8, dzt.shape[1], m)     # rows k.. (zero padding, the row of ones) already in place
-                    ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
+                if ops.train_fused_nodes:
+                    # both transposed operands from ONE launch (sat_cast_bf16_tpair); the rows of x^T past k (zero padding, the bias row of
+                    # ones) live in a cached buffer
+                    mp = (m + 7) // 8 * 8
+                    if has_bias:
+                        xt = _bias_operand(dzb.device, k, k8, mp, m)
+                    else:
+                        xt = torch.empty(k8, mp, dtype=torch.bfloat16, device=dzb.device)
+                        if k8 != k:
+                            xt[k:].zero_()
+                    if ops.cast_pair:
+                        dzt, _ = ops.cast_bf16_tpair(dzb, x2, row_pad=8, out_b=xt[:k])
+                    else:
+                        dzt = ops.cast_bf16(dzb, transpose=True, row_pad=8)
+                        ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
+                    dzt = _pad_rows8(dzt)                                                    # (N8, Mp)
                 else:
+                    dzt = _pad_rows8(ops.cast_bf16(dzb, transpose=True, row_pad=8))          # (N8, Mp)
                     xt = torch.empty(k8 + (8 if has_bias else 0), dzt.shape[1], dtype=torch.bfloat16, device=dzt.device)
                     ops.cast_bf16(x2, transpose=True, row_pad=8, out=xt[:k])
                     xt[k:].zero_()

@@ -1016,6 +1016,7 @@ class SatOps:
     # bf16 copies of a weight from one cast launch (sat_cast_bf16_dual), the bias row of the weight-gradient GEMM's operand kept in a cached
     # buffer instead of two fills per call.  False: the separate nodes / launches of round 5 (A/B: bench.py --ops-set train_fused_nodes=0)
     train_fused_nodes = True
+    cast_pair = True        # both transposed operands of a weight-gradient GEMM from one launch (sat_cast_bf16_tpair); False: two sat_cast_bf16 launches
     # bf16 self-attention forward: None = the library picks 32 or 64 queries per wave by grid size (sat_attention_fwd), False / True force
     # the 32- / 64-query kernel (A/B runs: bench.py --ops-set attn_q64=1; the kernel tests run both)
     attn_q64 = None
@@ -1437,6 +1438,22 @@ class SatOps:
         self._chk(self.lib.sat_cast_bf16(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), r, c, rp, int(dt == 0), int(transpose),
                                          self._stream(src)))
         return dst
+
+    def cast_bf16_tpair(self, a, b, row_pad=8, out_b=None):
+        """(a^T, b^T) as cast_bf16(transpose=True, row_pad=...) of two 2-D tensors, in ONE launch (sat_cast_bf16_tpair).  out_b: optional
+        destination for b^T (row stride free)."""
+        da, db = self._dt(a), self._dt(b)
+        if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+            raise ValueError("cast_bf16_tpair takes 2-D tensors with a contiguous last dim")
+        (ra, ca), (rb, cb) = a.shape, b.shape
+        rpa, rpb = (ra + row_pad - 1) // row_pad * row_pad, (rb + row_pad - 1) // row_pad * row_pad
+        ta = torch.empty(ca, rpa, dtype=torch.bfloat16, device=a.device)
+        tb = out_b if out_b is not None else torch.empty(cb, rpb, dtype=torch.bfloat16, device=b.device)
+        if tuple(tb.shape) != (cb, rpb) or tb.dtype != torch.bfloat16 or tb.stride(1) != 1:
+            raise ValueError("cast_bf16_tpair: bad destination")
+        self._chk(self.lib.sat_cast_bf16_tpair(_ptr(a), a.stride(0), _ptr(ta), ta.stride(0), ra, ca, rpa, int(da == 0),
+                                               _ptr(b), b.stride(0), _ptr(tb), tb.stride(0), rb, cb, rpb, int(db == 0), self._stream(a)))
+        return ta, tb
 
     def cast_bf16_dual(self, src, row_pad=8):
         """src (R, C) fp32|bf16 -> (bf16 (R, C), bf16 transposed (C, Rp)) in one pass (sat_cast_bf16_dual), or None when the shape is outside

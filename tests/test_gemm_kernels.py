@@ -94,6 +94,13 @@ def _prep_case(ops, dev):
     plain, tr = ops.cast_bf16_dual(w[:70])                                   # R = 70: two zero columns pad the transposed copy to 72
     assert tr.shape == (136, 72) and torch.equal(plain, ops.cast_bf16(w[:70])) and torch.equal(tr, ops.cast_bf16(w[:70], transpose=True, row_pad=8))
     assert ops.cast_bf16_dual(torch.randn(16, 20).to(dev)) is None
+    # two transposing casts in one launch (sat_cast_bf16_tpair): bit-equal to the separate ones, fp32 and bf16 sources, different shapes
+    xa, xb = torch.randn(70, 200).to(dev).bfloat16(), torch.randn(70, 136).to(dev)
+    ta, tb = ops.cast_bf16_tpair(xa, xb)
+    assert torch.equal(ta, ops.cast_bf16(xa, transpose=True, row_pad=8)) and torch.equal(tb, ops.cast_bf16(xb, transpose=True, row_pad=8))
+    buf = torch.full((144, 72), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.cast_bf16_tpair(xb, xa[:, :131], out_b=buf[:131])
+    assert torch.equal(buf[:131], ops.cast_bf16(xa[:, :131], transpose=True, row_pad=8)) and float(buf[131:].float().min()) == 7.0
     sa, sb = ops.split_bf16x3(a, 0).float(), ops.split_bf16x3(a, 1).float()
     c = a.shape[1]
     assert rel_err(sa[:, :c] + sa[:, 2 * c:], a) < 1e-5 and torch.equal(sa[:, :c], sa[:, c:2 * c])

@@ -93,6 +93,41 @@ def test_stft_loss_gradients_simulator(emu_modules):
     _gradients("cpu")
 
 
+def _views_consistency(ops, device):
+    """The kernels transform each CHANNEL once and form the views from the channels' bins (csrc/stft.hip, round 6): six views in one call
+    (two forward workgroup chunks of four) must give the sums of six one-view calls, and the backward with all views at once must equal the
+    sum of the one-view backwards (linearity of the gradient in the per-view coefficients); mono input takes the single-channel path."""
+    x = torch.from_numpy(seeded.seeded_array((2, 2, 3000), 510, scale=0.1)).to(device)
+    y = x + torch.from_numpy(seeded.seeded_array((2, 2, 3000), 511, scale=0.01)).to(device)
+    views = torch.tensor([[1.0, 1.0], [1.0, -1.0], [1.0, 0.0], [0.0, 1.0], [0.5, 0.25], [-0.3, 0.9]], device=device)
+    for n, h in ((512, 128), (64, 16), (1024, 256)):
+        s_all = ops.stft_sums(x, y, views, n, h)
+        s_one = torch.cat([ops.stft_sums(x, y, views[i:i + 1].contiguous(), n, h) for i in range(6)], dim=1)
+        assert rel_err(s_all, s_one) < 1e-5, n
+        coef = torch.from_numpy(seeded.seeded_array((2, 6, 3), 512 + n, scale=1e-2)).abs().to(device)
+        g_all = torch.zeros(4, 2, 2, 3000, device=device)
+        ops.stft_backward(x, y, views, coef, g_all, n, h)
+        g_sum = torch.zeros(2, 2, 3000, device=device)
+        for i in range(6):
+            g = torch.zeros(4, 2, 2, 3000, device=device)
+            ops.stft_backward(x, y, views[i:i + 1].contiguous(), coef[:, i:i + 1].contiguous(), g, n, h)
+            g_sum += g.sum(0)
+        assert rel_err(g_all.sum(0), g_sum) < 1e-4, n
+    # mono: one channel, one view
+    xm, ym = x[:, :1].contiguous(), y[:, :1].contiguous()
+    one = torch.tensor([[1.0, 0.0]], device=device)
+    assert rel_err(ops.stft_sums(xm, ym, one, 256, 64), ops.stft_sums(x, y, torch.tensor([[1.0, 0.0]], device=device), 256, 64)) < 1e-5
+
+
+def test_stft_views_from_channel_spectra_simulator(emu):
+    _views_consistency(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_stft_views_from_channel_spectra_gpu(hip):
+    _views_consistency(hip, "cuda")
+
+
 def test_unsupported_configurations_raise():
     from stable_audio_tools_amd import auraloss as al
     with pytest.raises(NotImplementedError):
