@@ -68,41 +68,40 @@ class _MRSTFTFn(torch.autograd.Function):
             xf, yf = x, y
         nres = len(fft_sizes)
         vw = _view_weights(view_w, x.device)
-        total = torch.zeros((), dtype=torch.float32, device=x.device)
-        sums_all = []
-        for n, h in zip(fft_sizes, hop_sizes):
-            sums = ops.stft_sums(xf, yf, views, n, h)              # (NI, NV, 3)
-            sums_all.append(sums)
-            cnt = float(ni * (n // 2 + 1) * (1 + t // h))
-            sc = torch.sqrt(sums[..., 0] / sums[..., 1])            # (NI, NV)
-            per_view = sc.mean(0) + sums[..., 2].sum(0) / cnt       # (NV,)
-            total = total + (per_view * vw).sum() / nres
+        # all resolutions' kernels first, then ONE pass of scalar arithmetic over the stacked sums (round 6: ten tiny launches per
+        # resolution sat between the STFT kernels before — 140 of the generator step's 233 torch launches with the backward's)
+        sums_all = torch.stack([ops.stft_sums(xf, yf, views, n, h) for n, h in zip(fft_sizes, hop_sizes)])      # (R, NI, NV, 3)
+        inv_cnt = _view_weights([1.0 / float(ni * (n // 2 + 1) * (1 + t // h)) for n, h in zip(fft_sizes, hop_sizes)], x.device).view(-1, 1)
+        sc = torch.sqrt(sums_all[..., 0] / sums_all[..., 1])        # (R, NI, NV)
+        per_view = sc.mean(1) + sums_all[..., 2].sum(1) * inv_cnt   # (R, NV)
+        total = (per_view * vw).sum() / nres
         ctx.ops = ops
         ctx.meta = (fft_sizes, hop_sizes, view_w, taps is not None)
-        ctx.save_for_backward(xf, yf, views, taps, *sums_all)
+        ctx.save_for_backward(xf, yf, views, taps, sums_all)
         return total
 
     @staticmethod
     def backward(ctx, g):
         ops = ctx.ops
         fft_sizes, hop_sizes, view_w, has_taps = ctx.meta
-        xf, yf, views, taps, *sums_all = ctx.saved_tensors
+        xf, yf, views, taps, sums_all = ctx.saved_tensors
         ni, c, t = xf.shape
         nres = len(fft_sizes)
         vw = _view_weights(view_w, xf.device)
         grads = [None, None]
+        # the three per-(item, view) coefficients of every resolution in one pass: c1 = scale / (NI sc S2), c2 = sc^2, c3 = scale / count
+        inv_cnt = _view_weights([1.0 / float(ni * (n // 2 + 1) * (1 + t // h)) for n, h in zip(fft_sizes, hop_sizes)], xf.device).view(-1, 1, 1)
+        sc = torch.sqrt(sums_all[..., 0] / sums_all[..., 1])        # (R, NI, NV)
+        scale = (g * vw / nres).view(1, 1, -1)                      # (1, 1, NV)
+        coef_all = torch.stack([scale / (ni * sc * sums_all[..., 1]), sc * sc, (scale * inv_cnt).expand_as(sc)], dim=-1).contiguous()
         for which in (0, 1):          # 0: d/dx (first argument), 1: d/dy (second argument)
             if not ctx.needs_input_grad[which]:
                 continue
             # one set of 4 write-once planes per resolution (csrc/stft.hip: no atomics), summed in a fixed order: the
             # gradient is bit-reproducible run to run
             planes = torch.zeros((nres, 4) + tuple(yf.shape), dtype=yf.dtype, device=yf.device)
-            for ri, ((n, h), sums) in enumerate(zip(zip(fft_sizes, hop_sizes), sums_all)):
-                cnt = float(ni * (n // 2 + 1) * (1 + t // h))
-                sc = torch.sqrt(sums[..., 0] / sums[..., 1])
-                scale = (g * vw / nres).view(1, -1)                 # (1, NV)
-                coef = torch.stack([scale / (ni * sc * sums[..., 1]), sc * sc, (scale / cnt).expand_as(sc)], dim=-1).contiguous()
-                ops.stft_backward(xf, yf, views, coef, planes[ri], n, h, wrt_x=(which == 0))
+            for ri, (n, h) in enumerate(zip(fft_sizes, hop_sizes)):
+                ops.stft_backward(xf, yf, views, coef_all[ri], planes[ri], n, h, wrt_x=(which == 0))
             acc = planes.sum(dim=(0, 1))
             if has_taps:
                 acc = ops.fir(acc.view(ni * c, t), taps, adjoint=True).view(ni, c, t)
