@@ -394,6 +394,11 @@ int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch);
 int sat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale,
                       long long mod_stride, const float* mean, const float* rstd, void* dx, float* part, int rows, int D,
                       int rows_per_batch, int dtype, void* stream);
+/* The same with an addend: dx = LayerNorm backward + dres, dres (rows, D) in the activation dtype (or NULL) — the gradient that reached x
+ * along the residual connection around the normalised branch (x = x + f(LN(x)), transformer.py:703-712). */
+int sat_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale,
+                          long long mod_stride, const float* mean, const float* rstd, const void* dres, void* dx, float* part,
+                          int rows, int D, int rows_per_batch, int dtype, void* stream);
 
 /* RotaryEmbedding.forward (transformer.py:125-138): cs[n][j] = {cos, sin}(pos_scale * n * inv_freq[j]), fp32. */
 int sat_rope_tables(const float* inv_freq, float* cs, int N, int half, float pos_scale, void* stream);

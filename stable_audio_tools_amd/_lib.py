@@ -127,6 +127,7 @@ SIGNATURES = {
     "sat_layernorm_fwd_fp8": (_I, [_P] * 5 + [_L] + [_P] * 2 + [_I] * 3 + [_F, _I, _P]),
     "sat_layernorm_bwd_nblocks": (_I, [_I, _I]),
     "sat_layernorm_bwd": (_I, [_P] * 5 + [_L] + [_P] * 4 + [_I] * 4 + [_P]),
+    "sat_layernorm_bwd_res": (_I, [_P] * 5 + [_L] + [_P] * 5 + [_I] * 4 + [_P]),
     "sat_rope_tables": (_I, [_P, _P, _I, _I, _F, _P]),
     "sat_rope_apply": (_I, [_P, _P, _L, _L, _L] + [_I] * 7 + [_P]),
     "sat_swiglu": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),

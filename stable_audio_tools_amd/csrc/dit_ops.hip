@@ -43,6 +43,8 @@ struct SatLnParams {
     // fp8 output (sat_layernorm_fwd_fp8): e4m3 bytes (rows, D) with one dynamic scale per row
     uint8_t* q;
     float* qscale;        // (rows): row max / 448
+    // backward: optional addend of dx, (rows, D) in the activation dtype — the gradient that reached x along the residual path
+    const void* dres;
 };
 
 template <typename T>
@@ -98,7 +100,9 @@ __global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_kernel(SatLnParams p
         if (p.scale) g *= 1.0f + SatIO<T>::ld(p.scale, mb + i);
         g *= p.gamma[i];
         const float xh = (SatIO<T>::ld(p.x, base + i) - mean) * rstd;
-        SatIO<T>::st(p.dx, base + i, rstd * (g - s1 - xh * s2));
+        float o = rstd * (g - s1 - xh * s2);
+        if (p.dres) o += SatIO<T>::ld(p.dres, base + i);
+        SatIO<T>::st(p.dx, base + i, o);
     }
 }
 
@@ -318,6 +322,12 @@ __global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_vec_kernel(SatLnPara
             float o[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) o[j] = rstd * (gs[c][j] - s1 - xh[c][j] * s2);
+            if (p.dres) {
+                float r[N];
+                SatVec<T>::ld(p.dres, base + (c * 64 + lane) * N, r);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += r[j];
+            }
             SatVec<T>::st(p.dx, base + (c * 64 + lane) * N, o);
         }
     }
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(256) sat_layernorm_bwd_dx_vec_kernel(SatLnPara
 static bool sat_ln_vec_ok(const SatLnParams& p, int elem_bytes) {
     const int n = 16 / elem_bytes, maxc = elem_bytes == 4 ? 16 : 8;
     if (p.D % (64 * n) != 0 || p.D / (64 * n) > maxc) return false;
-    const void* ptrs[] = {p.x, p.gamma, p.beta, p.scale, p.shift, p.y, p.dy, p.dx};
+    const void* ptrs[] = {p.x, p.gamma, p.beta, p.scale, p.shift, p.y, p.dy, p.dx, p.dres};
     for (const void* q : ptrs)
         if (q && ((uintptr_t)q & 15)) return false;
     return !p.scale || (p.mod_stride % n) == 0;
@@ -486,12 +496,27 @@ extern "C" int sat_layernorm_bwd_nblocks(int rows, int rows_per_batch) {
     return (rows / rows_per_batch) * sat_cdiv(rows_per_batch, SAT_LN_ROWS_PER_BLOCK);
 }
 
+// dx = LayerNorm backward [+ dres]: dres (rows, D, activation dtype) is the gradient that reached x along the residual connection around the
+// normalised branch (x = x + f(LN(x)), transformer.py:703-712) — added in the same pass instead of by an elementwise launch of autograd's.
+static int sat_layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale, long long mod_stride,
+                                  const float* mean, const float* rstd, const void* dres, void* dx, float* part, int rows, int D, int rows_per_batch,
+                                  int dtype, void* stream);
 extern "C" int sat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                  const void* scale, long long mod_stride, const float* mean, const float* rstd,
                                  void* dx, float* part, int rows, int D, int rows_per_batch, int dtype, void* stream) {
+    return sat_layernorm_bwd_impl(dy, x, gamma, beta, scale, mod_stride, mean, rstd, nullptr, dx, part, rows, D, rows_per_batch, dtype, stream);
+}
+extern "C" int sat_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale, long long mod_stride,
+                                     const float* mean, const float* rstd, const void* dres, void* dx, float* part, int rows, int D,
+                                     int rows_per_batch, int dtype, void* stream) {
+    return sat_layernorm_bwd_impl(dy, x, gamma, beta, scale, mod_stride, mean, rstd, dres, dx, part, rows, D, rows_per_batch, dtype, stream);
+}
+static int sat_layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* beta, const void* scale, long long mod_stride,
+                                  const float* mean, const float* rstd, const void* dres, void* dx, float* part, int rows, int D, int rows_per_batch,
+                                  int dtype, void* stream) {
     if (sat_ln_check(rows, D, rows_per_batch, dtype, "sat_layernorm_bwd: bad shape")) return 1;
     SatLnParams p{};
-    p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.dy = dy; p.dx = dx; p.part = part;
+    p.x = x; p.gamma = gamma; p.beta = beta; p.scale = scale; p.dy = dy; p.dx = dx; p.part = part; p.dres = dres;
     p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
     p.mod_stride = mod_stride; p.rows = rows; p.D = D; p.rows_per_batch = rows_per_batch;
     dim3 g1(sat_cdiv(rows, 4));

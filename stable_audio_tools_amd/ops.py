@@ -1016,6 +1016,7 @@ class SatOps:
     # bf16 copies of a weight from one cast launch (sat_cast_bf16_dual), the bias row of the weight-gradient GEMM's operand kept in a cached
     # buffer instead of two fills per call.  False: the separate nodes / launches of round 5 (A/B: bench.py --ops-set train_fused_nodes=0)
     train_fused_nodes = True
+    ln_residual = True      # training: the residual path's gradient is added inside the LayerNorm backward kernel (transformer.LayerNormResFn); False: autograd's add
     cast_pair = True        # both transposed operands of a weight-gradient GEMM from one launch (sat_cast_bf16_tpair); False: two sat_cast_bf16 launches
     # bf16 self-attention forward: None = the library picks 32 or 64 queries per wave by grid size (sat_attention_fwd), False / True force
     # the 32- / 64-query kernel (A/B runs: bench.py --ops-set attn_q64=1; the kernel tests run both)
@@ -1065,16 +1066,19 @@ class SatOps:
         self._chk(rc)
         return q, rs
 
-    def layernorm_bwd(self, dy, x, gamma, beta, scale, mean, rstd):
-        """Returns dx, dgamma (D,), dscale (B, D) or None, dshift (B, D) or None."""
-        dt = self._dt(dy, x, scale)
+    def layernorm_bwd(self, dy, x, gamma, beta, scale, mean, rstd, dres=None):
+        """Returns dx, dgamma (D,), dscale (B, D) or None, dshift (B, D) or None.  dres: optional (B, N, D) contiguous addend of dx in the
+        activation dtype (the gradient that reached x along the residual path: sat_layernorm_bwd_res)."""
+        dt = self._dt(dy, x, scale, dres)
+        if dres is not None and (dres.shape != x.shape or not dres.is_contiguous()):
+            raise ValueError("layernorm_bwd: dres must be contiguous with the shape of x")
         b, n, d = x.shape
         dx = torch.empty_like(x)
         nby = self.lib.sat_layernorm_bwd_nblocks(b * n, n)
         part = torch.empty(3, nby, d, dtype=torch.float32, device=x.device)
         ms = scale.stride(0) if scale is not None else 0
-        self._chk(self.lib.sat_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), ms, _ptr(mean),
-                                             _ptr(rstd), _ptr(dx), _ptr(part), b * n, d, n, dt, self._stream(x)))
+        self._chk(self.lib.sat_layernorm_bwd_res(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), ms, _ptr(mean),
+                                                 _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(part), b * n, d, n, dt, self._stream(x)))
         per_b = nby // b
         dgamma = self._reduce_rows(part[0].contiguous(), nby, d)
         if scale is None:

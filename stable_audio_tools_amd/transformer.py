@@ -65,6 +65,33 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dgamma.to(ctx.gdtype), None, dscale, dshift, None, None, None
 
 
+class LayerNormResFn(torch.autograd.Function):
+    """(LayerNorm(x), x) for a pre-norm residual branch x = x + f(LN(x)) (transformer.py:703-712): the second output is x itself, to be
+    handed to the branch's output projection as `res`.  Autograd then delivers BOTH gradients of x to this node — through the normalised
+    branch and along the residual path — and the LayerNorm backward kernel adds the latter in its own pass (sat_layernorm_bwd_res) instead
+    of autograd launching an elementwise add of two (B, N, D) tensors per norm (round 6)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, g32, b32):
+        ops = _ops()
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm(x, g32, b32, None, None, eps, save_stats=True)
+        ctx.save_for_backward(x, g32, b32, mean, rstd)
+        ctx.ops, ctx.gdtype = ops, gamma.dtype
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, g32, b32, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None, None
+        if dres is not None and dres.dtype != dy.dtype:
+            dres = dres.to(dy.dtype)
+        dx, dgamma, _, _ = ctx.ops.layernorm_bwd(dy.contiguous(), x, g32, b32, None, mean, rstd,
+                                                 dres=dres.contiguous() if dres is not None else None)
+        return dx, dgamma.to(ctx.gdtype), None, None, None, None
+
+
 class LayerNorm(nn.Module):
     def __init__(self, dim, bias=False, fix_scale=False, force_fp32=False, eps=1e-5):
         super().__init__()
@@ -107,6 +134,10 @@ class LayerNorm(nn.Module):
             if out is not None:
                 return _linear.Fp8Rows(out[0], out[1], x.shape)
         return LayerNormFn.apply(x, self.gamma, self.beta, scale, shift, self.eps, self._as_f32("gamma"), self._as_f32("beta"))
+
+    def with_residual(self, x):
+        """(LN(x), x) — see LayerNormResFn; training path of the un-modulated pre-norm branches."""
+        return LayerNormResFn.apply(x, self.gamma, self.beta, self.eps, self._as_f32("gamma"), self._as_f32("beta"))
 
 
 class RotaryEmbedding(nn.Module):
@@ -474,6 +505,15 @@ class TransformerBlock(nn.Module):
             x = _GateResidualFn.apply(h, gate_ff, x)
         else:
             # (fp8_for: each norm's only consumer — in fp8 inference the rows leave the LayerNorm kernel quantised)
+            if torch.is_grad_enabled() and x.requires_grad and _ops().train_fused_nodes and _ops().ln_residual:
+                # training: each norm also hands x through, so the residual path's gradient is added inside the LayerNorm backward kernel
+                h, xr = self.pre_norm.with_residual(x)
+                x = self.self_attn(h, rotary_pos_emb=rotary_pos_emb, res=xr)
+                if context is not None and self.cross_attend:
+                    h, xr = self.cross_attend_norm.with_residual(x)
+                    x = self.cross_attn(h, context=context, res=xr)
+                h, xr = self.ff_norm.with_residual(x)
+                return self.ff(h, res=xr)
             x = self.self_attn(self.pre_norm(x, fp8_for=self.self_attn.to_qkv), rotary_pos_emb=rotary_pos_emb, res=x)   # residual adds live in
             if context is not None and self.cross_attend:                                                                 # the output projections' epilogues
                 x = self.cross_attn(self.cross_attend_norm(x, fp8_for=self.cross_attn.to_q), context=context, res=x)

@@ -40,6 +40,11 @@ def _ln_case(ops, dev, dtype, b, n, d, ada, seed):
     if ada:
         close(dscale, sc.grad, 4.0)
         close(dshift, sh.grad, 4.0)
+    # the residual-path addend of dx (sat_layernorm_bwd_res): dx + dres in the kernel's own pass; parameter gradients unchanged
+    dres = torch.randn(b, n, d, generator=gen).to(dev).to(dtype)
+    dx2, dgamma2, _, _ = ops.layernorm_bwd(dy, x, gamma, beta, scale, mean, rstd, dres=dres)
+    close(dx2, xr.grad + dres.float())
+    assert torch.equal(dgamma2, dgamma)
 
 
 CASES = [(torch.float32, 2, 9, 1536, True), (torch.float32, 1, 7, 200, False), (torch.bfloat16, 2, 9, 1536, True),
