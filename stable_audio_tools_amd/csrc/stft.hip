@@ -20,7 +20,16 @@
 #include "sat_device.h"
 
 #define SAT_FFT_MAX 2048
+// tuning knobs (defaults = the shipped configuration; tools/stft_sweep.sh builds variants of this file alone with -D...)
+#ifndef SAT_STFT_NG
 #define SAT_STFT_NG 8  // frame groups per workgroup (consecutive frames share the LDS overlap-add buffer)
+#endif
+#ifndef SAT_STFT_FBPTS
+#define SAT_STFT_FBPTS 512  // points per channel transformed concurrently for n below this (fb = FBPTS / n frames)
+#endif
+#ifndef SAT_STFT_CCMAX
+#define SAT_STFT_CCMAX 1    // channels transformed concurrently by the n = 2048 instance
+#endif
 #define SAT_STFT_OBUF (7 * 512 + 2048)
 #define SAT_STFT_SMALL 512             // n <= 512: fb * n == 512
 #define SAT_STFT_OBUF_SMALL 1408       // (8 fb - 1) hop + n at hop = n / 4 for n <= 512 (largest at n = 512)
@@ -464,7 +473,7 @@ static int sat_stft_plan(int n, int hop, int T, SatStftParams* p) {
     p->log2n = l;
     p->hop = hop;
     p->nframes = 1 + T / hop;
-    p->fb = (n >= 512) ? 1 : 512 / n;
+    p->fb = (n >= SAT_STFT_FBPTS) ? 1 : SAT_STFT_FBPTS / n;
     const int fpb = SAT_STFT_NG * p->fb;
     if ((fpb - 1) * hop + n > SAT_STFT_OBUF) return 1;
     if (p->fb * (n / 2 + 1) > 5 * 256) return 1;
@@ -488,7 +497,7 @@ extern "C" int sat_stft_fwd(const float* x, const float* y, const float* views, 
     const int bins = p.fb * (p.n / 2 + 1);
     if (p.fb * p.n <= SAT_STFT_SMALL && bins <= 2 * 256) SAT_LAUNCH((sat_stft_fwd_kernel<SAT_STFT_SMALL, 2, 2>), grid, dim3(256), stream, p);
     else if (p.fb * p.n <= SAT_STFT_MID && bins <= 3 * 256) SAT_LAUNCH((sat_stft_fwd_kernel<SAT_STFT_MID, 3, 2>), grid, dim3(256), stream, p);
-    else SAT_LAUNCH((sat_stft_fwd_kernel<SAT_FFT_MAX, 5, 1>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_stft_fwd_kernel<SAT_FFT_MAX, 5, SAT_STFT_CCMAX>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_fwd");
 }
 
@@ -504,7 +513,7 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     const int bins = p.fb * (p.n / 2 + 1);
     if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL && bins <= 2 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL, 2, 2>), grid, dim3(256), stream, p);
     else if (p.fb * p.n <= SAT_STFT_MID && olen <= SAT_STFT_OBUF_MID && bins <= 3 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_MID, SAT_STFT_OBUF_MID, 3, 2>), grid, dim3(256), stream, p);
-    else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF, 5, 1>), grid, dim3(256), stream, p);
+    else SAT_LAUNCH((sat_stft_bwd_kernel<SAT_FFT_MAX, SAT_STFT_OBUF, 5, SAT_STFT_CCMAX>), grid, dim3(256), stream, p);
     return sat_check_launch("sat_stft_bwd");
 }
 
