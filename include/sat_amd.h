@@ -285,7 +285,9 @@ int sat_fir(const float* x, const float* taps, float* y, int N, int T, int ntaps
  * bwd writes dL/dy — or dL/dx if wrt_x — given coef[NI][NV][3] = {c1, c2, c3}: dL/d|Y| = c1*((|Y|-|X|) - c2*|Y|) +
  * c3*sign(log|Y|-log|X|)/|Y|, as FOUR planes dy[4][NI][C][T] (even / odd workgroups x direct / reflected samples; the caller
  * zero-fills them and sums them in a fixed order): plain stores, no atomics — the gradient is bit-reproducible.
- * Periodic Hann window of length n_fft, centre/reflect padding, hop, one-sided, unnormalised, power clamped at 1e-8. */
+ * Periodic Hann window of length n_fft, centre/reflect padding, hop, one-sided, unnormalised, power clamped at 1e-8.
+ * Round 6: each CHANNEL is transformed once and the views' bins are formed from the channels' (the DFT is linear); the backward needs
+ * n_fft <= (frames per workgroup + 1) * hop (every hop >= n_fft / 4; status 1 otherwise — the two-plane write-out's invariant). */
 int sat_stft_tiles(int n_fft, int hop, int T);
 int sat_stft_fwd(const float* x, const float* y, const float* views, float* partial, int NI, int C, int T, int NV,
                  int n_fft, int hop, void* stream);

@@ -22,7 +22,7 @@
 #define SAT_FFT_MAX 2048
 // tuning knobs (defaults = the shipped configuration; tools/stft_sweep.sh builds variants of this file alone with -D...)
 #ifndef SAT_STFT_NG
-#define SAT_STFT_NG 8  // frame groups per workgroup (consecutive frames share the LDS overlap-add buffer)
+#define SAT_STFT_NG 4  // frame groups per workgroup (consecutive frames share the LDS overlap-add buffer); 8 until the sweep of round 6 (profiles/r06_experiments/stft_sweep/: 2.45 -> 2.25 ms over the seven resolutions)
 #endif
 #ifndef SAT_STFT_FBPTS
 #define SAT_STFT_FBPTS 512  // points per channel transformed concurrently for n below this (fb = FBPTS / n frames)
@@ -510,6 +510,9 @@ extern "C" int sat_stft_bwd(const float* x, const float* y, const float* views, 
     p.NI = NI; p.C = C; p.T = T; p.NV = NV; p.wrt_x = wrt_x;
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI, 1);       // the views are looped inside the workgroup
     const int olen = (SAT_STFT_NG * p.fb - 1) * p.hop + p.n;
+    // the write-out's even / odd planes assume a sample is touched by at most two NEIGHBOURING workgroups: a workgroup's span (olen) must not
+    // exceed twice its stride (fpb * hop), i.e. n <= (fpb + 1) * hop — true for every hop >= n / 4 (the reference's configurations use n / 4)
+    if (olen > 2 * SAT_STFT_NG * p.fb * p.hop) { sat_set_error("sat_stft_bwd: hop too small for this n_fft (needs n_fft <= (frames per workgroup + 1) * hop)"); return 1; }
     const int bins = p.fb * (p.n / 2 + 1);
     if (p.fb * p.n <= SAT_STFT_SMALL && olen <= SAT_STFT_OBUF_SMALL && bins <= 2 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_SMALL, SAT_STFT_OBUF_SMALL, 2, 2>), grid, dim3(256), stream, p);
     else if (p.fb * p.n <= SAT_STFT_MID && olen <= SAT_STFT_OBUF_MID && bins <= 3 * 256) SAT_LAUNCH((sat_stft_bwd_kernel<SAT_STFT_MID, SAT_STFT_OBUF_MID, 3, 2>), grid, dim3(256), stream, p);
@@ -691,6 +694,8 @@ extern "C" int sat_spec_bwd(const float* dz, float* dx, int NI, int C, int T, in
     if (NI <= 0 || (C != 1 && C != 2)) { sat_set_error("sat_spec_bwd: bad shape (C must be 1 or 2)"); return 1; }
     if (sat_spec_plan(n_fft, hop, T, &p)) { sat_set_error("sat_spec_bwd: unsupported n_fft/hop/T"); return 1; }
     p.z = const_cast<float*>(dz); p.dx = dx; p.NI = NI; p.C = C; p.T = T;
+    // (the even / odd planes of the write-out: a workgroup's span must not exceed twice its stride — see sat_stft_bwd)
+    if ((SAT_STFT_NG * p.fb - 1) * p.hop + p.n > 2 * SAT_STFT_NG * p.fb * p.hop) { sat_set_error("sat_spec_bwd: hop too small for this n_fft"); return 1; }
     dim3 grid(sat_cdiv(p.nframes, SAT_STFT_NG * p.fb), NI);
     SAT_LAUNCH(sat_spec_bwd_kernel, grid, dim3(256), stream, p);
     return sat_check_launch("sat_spec_bwd");

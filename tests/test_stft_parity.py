@@ -128,6 +128,17 @@ def test_stft_views_from_channel_spectra_gpu(hip):
     _views_consistency(hip, "cuda")
 
 
+def test_backward_refuses_hops_outside_the_two_plane_invariant(emu):
+    """csrc/stft.hip's write-out lets a sample be touched by two NEIGHBOURING workgroups only: n_fft <= (frames per workgroup + 1) * hop.
+    A smaller hop used to be accepted and would have produced a wrong gradient; it is an error now (the forward has no such limit)."""
+    x = torch.from_numpy(seeded.seeded_array((1, 1, 4000), 520, scale=0.1))
+    views = torch.tensor([[1.0, 0.0]])
+    emu.stft_sums(x, x, views, 512, 32)
+    with pytest.raises(RuntimeError, match="hop too small"):
+        emu.stft_backward(x, x, views, torch.ones(1, 1, 3), torch.zeros(4, 1, 1, 4000), 512, 32)
+    emu.stft_backward(x, x, views, torch.ones(1, 1, 3), torch.zeros(4, 1, 1, 4000), 512, 128)     # hop = n / 4: always served
+
+
 def test_unsupported_configurations_raise():
     from stable_audio_tools_amd import auraloss as al
     with pytest.raises(NotImplementedError):
