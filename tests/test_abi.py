@@ -74,7 +74,7 @@ def test_argument_validation_never_launches():
     assert b"power of two" in lib.sat_last_error()
     assert lib.sat_fir(null, null, null, 1, 100, 100, 0, null) != 0
     assert lib.sat_adamw_step(null, null, null, null, 0, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1, 1.0, null, 0.0, null) != 0
-    assert lib.sat_stft_tiles(2048, 512, 2097152) == 513
+    assert lib.sat_stft_tiles(2048, 512, 2097152) == 1025     # 4097 frames, four per workgroup (eight until round 6's sweep)
     assert lib.sat_stft_tiles(2048, 512, 1000) == -1        # reflect pad needs T > n_fft/2
     assert lib.sat_convtr1d_partial_rows(1, 64, 16, 8) == -1
     # bf16x3 family: geometry rules, plan sizes and partial-plane sizes (host code only)
